@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark driver: simulation steps/s (+ PCG iterations/s, HBM roofline) of the blub fluid step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (N=1): scenes/corner_dams_256.json -- 968 688 particles on a 256^3 grid, dt = 1/120 s, solver defaults
+(tolerance 0.1, 32 iterations, check every 4), rebinning every 60 steps: the "1M particles @ 256^3" configuration of
+BASELINE.json.  A "step" is one HybridFluid::step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(kernel, N, F, P):
+    """Per-launch algorithmic HBM bytes (DESIGN.md section 4 / SURVEY.md 8(d)); F = FLUID cells, P = particles."""
+    table = {
+        "init_grid": 13 * N,               # marker N + 3 list-head volumes 4N (advect variant: 5N, averaged below)
+        "build_lists": 16 * P + 12 * P + 12 * P,
+        "gather_velocity": 5 * N + 32 * P + 4 * F,
+        "divergence": N + 28 * F,
+        "pcg_init": N + 12 * F + 4 * N,   # marker + r rw + p (read everywhere, zeroing writes only where nonzero) + s
+        "pcg_apply": N + 4 * F,
+        "pcg_update": N + 20 * F,
+        "pcg_search": N + 12 * F,
+        "divergence_remove": 13 * N + 16 * F,
+        "extrapolate": N + 8 * F,
+        "advect": 176 * P,
+        "density_gather": 5 * N + 16 * P + 4 * F,
+        "position_change": N + 4 * F + 12 * N,
+        "correct": 28 * P + 12 * P,
+    }
+    return float(table.get(kernel, 0))
+
+
+def dense_pcg_benchmark(n=256, iterations=32):
+    """M3 of BASELINE.md: SOLID shell + all-FLUID interior, b = sin*sin*sin, fixed iteration count, per-kernel HIP-event timing."""
+    import blub_amd
+    h = blub_amd.HybridFluid((n, n, n), 16, binning="off")
+    marker = np.zeros((n, n, n), np.int8)
+    marker[1:-1, 1:-1, 1:-1] = 1
+    ax = np.sin(2 * np.pi * (np.arange(n) + 0.5) / n).astype(np.float32)
+    b = (ax[:, None, None] * ax[None, :, None] * ax[None, None, :]).astype(np.float32)
+    b[marker != 1] = 0
+    h.write_volume("marker", marker)
+    h.set_solver_config(0, error_tolerance=0.0, max_num_iterations=iterations, error_check_frequency=4)
+    dt = blub_amd.default_simulation_delta()
+    N, F = n ** 3, int((marker == 1).sum())
+    for rep in range(2):   # first repetition warms up
+        h.write_volume("residual", b)
+        h.mark_pressure_initialised(0, False)
+        h.profile_enable(rep == 1)
+        h.profile_reset()
+        h.run_stage("solve_velocity", dt)
+        h.synchronize()
+    prof = h.profile_read()
+    h.profile_enable(False)
+    out = {}
+    for k in ("pcg_apply", "pcg_update", "pcg_search"):
+        avg_ms = prof[k]["total_ms"] / prof[k]["launches"]
+        gbs = algorithmic_bytes(k, N, F, 0) / (avg_ms * 1e-3) / 1e9
+        out[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": prof[k]["launches"], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    iter_us = sum(out[k]["avg_us"] for k in out)
+    err, iters = h.solver_stats(0)
+    h.close()
+    return {"grid": "%d^3" % n, "fluid_cells": F, "iterations": iters, "us_per_iteration_kernels": round(iter_us, 1),
+            "iter_bytes": 3 * N + 36 * F, "iter_GBs": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9, 1),
+            "iter_frac": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
+
+
+def cpu_baseline(scene_path, dt, budget_steps=2):
+    """The CPU oracle (a restatement of the reference, kind "port") on the same scene: bounded sample of whole steps."""
+    import blub_amd
+    from oracle.oracle import Oracle
+    sc = blub_amd.Scene.parse(path=scene_path).config
+    dim = list(sc.grid_dimension)
+    o = Oracle(dim[0], dim[1], dim[2], sc.max_num_particles)
+    scale = np.float32(sc.grid_to_world_scale)
+    for i in range(sc.num_fluid_cubes):
+        o.add_fluid_cube(np.float32(list(sc.cube_min[i])) / scale, np.float32(list(sc.cube_max[i])) / scale)
+    o.set_gravity_grid(np.float32(list(sc.gravity)) / scale)
+    o.step(dt)   # warm-up (includes the step-0 rebinning)
+    t0 = time.perf_counter()
+    it0, s0 = o.solver_totals()
+    for _ in range(budget_steps):
+        o.step(dt)
+    el = time.perf_counter() - t0
+    it1, s1 = o.solver_totals()
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(budget_steps / el, 4), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same scene after 1 warm-up step (oracle/libbluboracle.so, OpenMP, %d threads)" % (budget_steps, threads),
+            "pcg_iters_per_sec": round((it1 - it0) / max(s1 - s0, 1e-9), 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scene", default="corner_dams_256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-pcg", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    import blub_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+
+    scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
+    scene = blub_amd.Scene(path=scene_path, device=dev)
+    fluid = scene.fluid()
+    dt = blub_amd.default_simulation_delta()
+    nx, ny, nz = fluid.grid_dimension()
+    N, P = nx * ny * nz, fluid.num_particles()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        fluid.synchronize()
+
+    for _ in range(args.warmup):
+        scene.step(dt)
+    barrier()
+    it0 = fluid.total_solver_iterations()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scene.step(dt)
+    fluid.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    it1 = fluid.total_solver_iterations()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- instrumented pass: per-kernel-class HIP-event timing on the engine's own stream -----------------------------
+    fluid.profile_enable(True)
+    fluid.profile_reset()
+    for _ in range(args.profile_steps):
+        scene.step(dt)
+    fluid.synchronize()
+    prof = fluid.profile_read()
+    fluid.profile_enable(False)
+    F = int((fluid.read_volume("marker") == 1).sum())
+    total_ms = sum(v["total_ms"] for v in prof.values())
+    dominant = max(prof, key=lambda k: prof[k]["total_ms"])
+    avg_ms = prof[dominant]["total_ms"] / prof[dominant]["launches"]
+    ach = algorithmic_bytes(dominant, N, F, P) / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
+                "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F}
+    pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
+    solver_iters_prof = None
+    breakdown = {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+
+    steps_per_s = args.steps * world / elapsed   # weak scaling: every rank steps its own domain
+    result = {
+        "metric": "simulation steps/sec, 1M particles @ 256^3 grid", "value": round(steps_per_s, 3), "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.scene, "grid": [nx, ny, nz], "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4",
+                   "rebinning": 60, "parallelism": "single GPU" if world == 1 else "replicas x%d (one domain per GPU)" % world},
+        "pcg_iters_per_sec": round((it1 - it0) * world / elapsed, 1),
+        "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
+        "pcg_iters_per_sec_in_solver": round((it1 - it0) / args.steps * args.profile_steps / (pcg_ms * 1e-3), 1) if pcg_ms > 0 else None,
+        "roofline": roofline,
+        "kernel_us_per_step": breakdown,
+    }
+    if not args.no_dense_pcg:
+        scene._fluid.close()
+        scene._fluid = None
+        result["roofline_pcg_dense"] = dense_pcg_benchmark(256, 32)
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(scene_path, dt)
+    print(json.dumps(result))
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,580 @@
+// libblubhip.so -- host orchestration + C-ABI of the MI355X-native blub fluid step.
+// Mirrors src/simulation/hybrid_fluid.rs (HybridFluid) and src/simulation/pressure_solver.rs (PressureSolver /
+// PressureField) of the reference; the kernels live in blub_kernels.hip.h.  There is no CPU fallback: without a HIP
+// device every device entry point returns BLUB_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "blub_internal.h"
+#include "blub_kernels.hip.h"
+
+namespace blub {
+
+static thread_local std::string g_last_error;
+int set_error(int status, const char* msg) { g_last_error = msg ? msg : ""; return status; }
+
+#define HIP_TRY(expr)                                                                                                   \
+    do {                                                                                                                \
+        hipError_t _e = (expr);                                                                                         \
+        if (_e != hipSuccess) {                                                                                         \
+            char _b[512]; snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return set_error(_e == hipErrorOutOfMemory ? BLUB_ERR_OUT_OF_MEMORY : (_e == hipErrorNoDevice ? BLUB_ERR_NO_DEVICE : BLUB_ERR_DEVICE), _b); \
+        }                                                                                                               \
+    } while (0)
+
+using namespace blubk;
+
+enum KernelClass {
+    KC_INIT_GRID, KC_BUILD_LISTS, KC_GATHER_VELOCITY, KC_DIVERGENCE, KC_PCG_INIT, KC_PCG_APPLY, KC_PCG_UPDATE, KC_PCG_PRECOND,
+    KC_PCG_SEARCH, KC_DIVERGENCE_REMOVE, KC_EXTRAPOLATE, KC_ADVECT, KC_DENSITY_GATHER, KC_POSITION_CHANGE, KC_CORRECT,
+    KC_BIN_COUNT, KC_BIN_SCAN, KC_BIN_REWRITE, KC_COPY, KC_COUNT
+};
+static const char* kKernelClassNames[KC_COUNT] = {
+    "init_grid", "build_lists", "gather_velocity", "divergence", "pcg_init", "pcg_apply", "pcg_update", "pcg_precond",
+    "pcg_search", "divergence_remove", "extrapolate", "advect", "density_gather", "position_change", "correct",
+    "bin_count", "bin_scan", "bin_rewrite", "copy"};
+
+constexpr int PCG_GRID_MAX = 1024;   // persistent blocks of the PCG kernels (= number of dot-product partials)
+constexpr int STATS_RING = 32;       // pressure_solver.rs:49 NUM_PRESSURE_ERROR_BUFFER
+constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
+
+struct PendingStat { hipEvent_t ev; int slot; };
+
+}  // namespace blub
+
+using namespace blub;
+
+struct blub_fluid {
+    Grid g{};
+    size_t N = 0;
+    uint32_t max_particles = 0, num_particles = 0;
+    float gravity[3] = {0, 0, 0};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t precond_mode = BLUB_PRECOND_ZERO, binning_mode = BLUB_BINNING_FIXED;
+    uint32_t rebin_freq = 60;   // hybrid_fluid.rs:603-605
+    uint32_t step_counter = 0;
+    // particles (hybrid_fluid.rs:114-122)
+    float4 *pos = nullptr, *pos_tmp = nullptr, *pvel[3] = {nullptr, nullptr, nullptr};
+    uint32_t *next1 = nullptr, *next2 = nullptr;
+    // volumes (hybrid_fluid.rs:142-154; pressure_solver.rs:104-108, 332-351)
+    int8_t* marker = nullptr;
+    uint32_t* ll[3] = {nullptr, nullptr, nullptr};
+    float *vel[3] = {nullptr, nullptr, nullptr}, *pressure[2] = {nullptr, nullptr}, *residual = nullptr, *search = nullptr, *aux = nullptr, *aux_temp = nullptr;
+    float4* solid = nullptr;
+    uint32_t* scan_totals = nullptr;
+    // PCG
+    PcgGeom geom{};
+    int pcg_grid = 0;
+    float *part_sas = nullptr, *part_sigma[2] = {nullptr, nullptr}, *part_max = nullptr;
+    uint8_t* tile_flags = nullptr;
+    PcgCtrl* ctrl[2] = {nullptr, nullptr};
+    blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
+    bool pressure_initialised[2] = {false, false};
+    // statistics read-back ring (pressure_solver.rs:118-126, 148-209)
+    float* stats_host[2] = {nullptr, nullptr};   // pinned, STATS_RING x 2 floats
+    hipEvent_t stats_events[2][STATS_RING] = {};
+    int stats_head[2] = {0, 0};
+    std::deque<PendingStat> stats_pending[2];
+    std::deque<float> stats_dt[2];
+    std::deque<blub_solver_stats> stats_history[2];
+    uint64_t total_iterations = 0;
+    // profiling
+    bool prof_enabled = false;
+    struct ProfPending { hipEvent_t a, b; int kc; };
+    std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[KC_COUNT] = {};
+    uint64_t prof_launches[KC_COUNT] = {};
+};
+
+namespace blub {
+
+static int prof_flush(blub_fluid* h) {
+    if (h->prof_pending.empty()) return BLUB_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& p : h->prof_pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        h->prof_ms[p.kc] += ms; h->prof_launches[p.kc] += 1;
+        h->prof_pool.push_back(p.a); h->prof_pool.push_back(p.b);
+    }
+    h->prof_pending.clear();
+    return BLUB_OK;
+}
+struct ProfScope {
+    blub_fluid* h; int kc; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(blub_fluid* h_, int kc_) : h(h_), kc(kc_) {
+        if (!h->prof_enabled) return;
+        if (h->prof_pending.size() >= 8192) prof_flush(h);
+        auto get = [&]() { hipEvent_t e; if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, h->stream);
+        h->prof_pending.push_back({a, b, kc});
+    }
+};
+#define LAUNCH(h, kc, kernel, grid, block, ...)                                  \
+    do {                                                                         \
+        ProfScope _ps((h), (kc));                                                \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+    } while (0)
+
+static dim3 cell_grid(const Grid& g) { return dim3((g.nx + 63) / 64, (g.ny + 3) / 4, g.nz); }
+static dim3 tile9_grid(const Grid& g) { return dim3((g.nx + 7) / 8, (g.ny + 7) / 8, (g.nz + 7) / 8); }   // hybrid_fluid.rs:786
+static unsigned particle_blocks(uint32_t n) { return (n + 255) / 256; }
+static unsigned stream_blocks(size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, 2048); }
+
+template <class T>
+static int dev_alloc_zero(T** p, size_t count) {
+    HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+    HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+    return BLUB_OK;
+}
+
+// ---- stages ------------------------------------------------------------------------------------------------------
+static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-833
+    LAUNCH(h, KC_INIT_GRID, k_init_grid, dim3(stream_blocks(h->N / 4)), dim3(256), h->g, h->marker, h->solid, h->ll[0], h->ll[1], h->ll[2]);
+    if (h->num_particles)
+        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker,
+               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2);
+    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity<0>, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[0], h->pos, (const uint32_t*)nullptr, h->pvel[0], h->vel[0], h->gravity[0] * dt);
+    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity<1>, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[1], h->pos, (const uint32_t*)h->next1, h->pvel[1], h->vel[1], h->gravity[1] * dt);
+    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity<2>, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[2], h->pos, (const uint32_t*)h->next2, h->pvel[2], h->vel[2], h->gravity[2] * dt);
+    return BLUB_OK;
+}
+static int stage_divergence(blub_fluid* h) {   // :836-840
+    LAUNCH(h, KC_DIVERGENCE, k_divergence, cell_grid(h->g), dim3(256), h->g, h->marker, h->vel[0], h->vel[1], h->vel[2], h->solid, h->residual);
+    return BLUB_OK;
+}
+
+// PressureSolver::solve, pressure_solver.rs:591-729 (schedule: SURVEY Appendix D)
+static int stage_solve(blub_fluid* h, int which, float dt) {
+    float* p = h->pressure[which];
+    const blub_solver_config& c = h->cfg[which];
+    if (!h->pressure_initialised[which]) {   // :601-603
+        HIP_TRY(hipMemsetAsync(p, 0, h->N * sizeof(float), h->stream));
+        h->pressure_initialised[which] = true;
+    }
+    const float tol = c.error_tolerance / dt;   // :197
+    PcgCtrl* ctrl = h->ctrl[which];
+    HIP_TRY(hipMemsetAsync(ctrl, 0, sizeof(PcgCtrl), h->stream));
+    const dim3 grid(h->pcg_grid), block(256);
+    const int np = h->pcg_grid;
+    const bool zero_mode = h->precond_mode == BLUB_PRECOND_ZERO;
+    if (zero_mode) {
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init<true>, grid, block, h->geom, h->marker, p, h->residual, h->search, h->part_sigma[0], h->tile_flags);
+    } else {
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init<false>, grid, block, h->geom, h->marker, p, h->residual, h->search, (float*)nullptr, h->tile_flags);
+        LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
+        LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->search, (const float*)h->residual, h->part_sigma[0], h->tile_flags, ctrl);
+    }
+    const int maxit = c.max_num_iterations;
+    for (int i = 0; i <= maxit; ++i) {   // :654-723
+        float* sig_cur = h->part_sigma[i & 1];
+        float* sig_next = h->part_sigma[(i + 1) & 1];
+        LAUNCH(h, KC_PCG_APPLY, k_pcg_apply, grid, block, h->geom, h->marker, h->search, h->part_sas, h->tile_flags, ctrl);
+        const int last = (i == maxit);
+        const int check = last || (i > 0 && c.error_check_frequency > 0 && i % c.error_check_frequency == 0);   // :672-673
+        if (zero_mode) {
+            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update<true>, grid, block, h->geom, h->marker, h->search, p, h->residual, h->part_sas, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl);
+            LAUNCH(h, KC_PCG_SEARCH, k_pcg_search<true>, grid, block, h->geom, h->marker, h->residual, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
+        } else {
+            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update<false>, grid, block, h->geom, h->marker, h->search, p, h->residual, h->part_sas, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl);
+            if (!last) {
+                LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
+                LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->aux, (const float*)h->residual, sig_next, h->tile_flags, ctrl);
+            }
+            LAUNCH(h, KC_PCG_SEARCH, k_pcg_search<false>, grid, block, h->geom, h->marker, h->aux, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
+        }
+        if (last) break;
+    }
+    // enqueue_error_buffer_read, pressure_solver.rs:176-191: 8 bytes {MaxError, NumIterations}
+    if ((int)h->stats_pending[which].size() < STATS_RING) {
+        const int slot = h->stats_head[which];
+        h->stats_head[which] = (slot + 1) % STATS_RING;
+        HIP_TRY(hipMemcpyAsync(h->stats_host[which] + 2 * slot, ctrl, 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->stats_events[which][slot], h->stream));
+        h->stats_pending[which].push_back({h->stats_events[which][slot], slot});
+        h->stats_dt[which].push_back(dt);
+    }   // else: "No more error buffer available" -- the reference warns and skips the sample (:188-190)
+    return BLUB_OK;
+}
+
+static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
+    if (h->binning_mode == BLUB_BINNING_OFF || h->num_particles == 0) return BLUB_OK;
+    HIP_TRY(hipMemsetAsync(h->ll[0], 0, h->N * sizeof(uint32_t), h->stream));   // clear_texture :858
+    LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->ll[0]);
+    const int n = (int)h->N, nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    LAUNCH(h, KC_BIN_SCAN, k_scan_block_totals, dim3(nblocks), dim3(1024), (const uint32_t*)h->ll[0], n, h->scan_totals);
+    LAUNCH(h, KC_BIN_SCAN, k_scan_totals, dim3(1), dim3(1024), h->scan_totals, nblocks);
+    LAUNCH(h, KC_BIN_SCAN, k_scan_apply, dim3(nblocks), dim3(1024), h->ll[0], n, (const uint32_t*)h->scan_totals);
+    LAUNCH(h, KC_BIN_REWRITE, k_bin_rewrite, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->max_particles,
+           (const float4*)h->pos, h->pos_tmp, (const uint32_t*)h->ll[0]);
+    {
+        ProfScope ps(h, KC_COPY);   // :885-891 (only the live range; the rest of the buffer is never read)
+        HIP_TRY(hipMemcpyAsync(h->pos, h->pos_tmp, (size_t)h->num_particles * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    }
+    return BLUB_OK;
+}
+static int stage_extrapolate(blub_fluid* h) {
+    LAUNCH(h, KC_EXTRAPOLATE, k_extrapolate, cell_grid(h->g), dim3(256), h->g, h->marker, h->vel[0], h->vel[1], h->vel[2]);
+    return BLUB_OK;
+}
+static int stage_project(blub_fluid* h) {   // :906-914
+    LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove, cell_grid(h->g), dim3(256), h->g, h->marker, h->pressure[0], h->solid, h->vel[0], h->vel[1], h->vel[2]);
+    return stage_extrapolate(h);
+}
+static int stage_advect(blub_fluid* h, float dt) {   // :916-932
+    LAUNCH(h, KC_INIT_GRID, k_init_grid, dim3(stream_blocks(h->N / 4)), dim3(256), h->g, h->marker, h->solid, h->ll[0], (uint32_t*)nullptr, (uint32_t*)nullptr);
+    if (h->num_particles)
+        LAUNCH(h, KC_ADVECT, k_advect, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
+               h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, h->ll[0]);
+    return BLUB_OK;
+}
+static int stage_density_gather(blub_fluid* h, float dt) {   // :933-937
+    LAUNCH(h, KC_DENSITY_GATHER, k_density_gather, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[0], h->pos, h->residual, dt);
+    return BLUB_OK;
+}
+static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
+    LAUNCH(h, KC_POSITION_CHANGE, k_position_change, cell_grid(h->g), dim3(256), h->g, h->marker, h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
+    return stage_extrapolate(h);
+}
+static int stage_correct(blub_fluid* h) {   // :969-973
+    if (h->num_particles)
+        LAUNCH(h, KC_CORRECT, k_correct, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2]);
+    return BLUB_OK;
+}
+
+static int run_stage(blub_fluid* h, int stage, float dt) {
+    switch (stage) {
+    case BLUB_STAGE_TRANSFER: return stage_transfer(h, dt);
+    case BLUB_STAGE_DIVERGENCE: return stage_divergence(h);
+    case BLUB_STAGE_SOLVE_VELOCITY: return stage_solve(h, 0, dt);
+    case BLUB_STAGE_BINNING: return stage_binning(h);
+    case BLUB_STAGE_PROJECT: return stage_project(h);
+    case BLUB_STAGE_ADVECT: return stage_advect(h, dt);
+    case BLUB_STAGE_DENSITY_GATHER: return stage_density_gather(h, dt);
+    case BLUB_STAGE_SOLVE_DENSITY: return stage_solve(h, 1, dt);
+    case BLUB_STAGE_POSITION_CHANGE: return stage_position_change(h, dt);
+    case BLUB_STAGE_CORRECT: return stage_correct(h);
+    }
+    return set_error(BLUB_ERR_INVALID_ARGUMENT, "unknown stage");
+}
+
+static int check_launch(blub_fluid* h) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char b[256]; snprintf(b, sizeof b, "kernel launch failed: %s", hipGetErrorString(e)); return set_error(BLUB_ERR_DEVICE, b); }
+    (void)h;
+    return BLUB_OK;
+}
+
+static void destroy(blub_fluid* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->next1); F(h->next2); F(h->marker); for (auto p : h->ll) F(p);
+    for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
+    F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
+    for (int w = 0; w < 2; ++w) { if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]); for (auto e : h->stats_events[w]) if (e) (void)hipEventDestroy(e); }
+    for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : h->prof_pool) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int create(const blub_fluid_desc* d, blub_fluid** out) {
+    if (!d || !out) return set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (d->nx < 4 || d->ny < 3 || d->nz < 3) return set_error(BLUB_ERR_INVALID_ARGUMENT, "grid too small");
+    if (d->nx % 4 != 0) return set_error(BLUB_ERR_UNSUPPORTED, "grid_dimension.x must be a multiple of 4 (float4 rows)");
+    const uint64_t N64 = (uint64_t)d->nx * d->ny * d->nz;
+    if (N64 <= 16384) return set_error(BLUB_ERR_UNSUPPORTED, "grid must have more than 16384 cells (pressure_solver.rs:551)");
+    if (N64 >= (1ull << 31)) return set_error(BLUB_ERR_UNSUPPORTED, "grid must have fewer than 2^31 cells");
+    if (d->precond_mode > BLUB_PRECOND_LOD0 || (d->binning_mode != BLUB_BINNING_FIXED && d->binning_mode != BLUB_BINNING_OFF))
+        return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad quirk mode");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(BLUB_ERR_NO_DEVICE, "no HIP device (libblubhip has no CPU fallback)");
+    int dev = d->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return set_error(BLUB_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(dev));
+    blub_fluid* h = new (std::nothrow) blub_fluid();
+    if (!h) return set_error(BLUB_ERR_OUT_OF_MEMORY, "host allocation failed");
+    h->device = dev;
+    h->g = Grid{(int)d->nx, (int)d->ny, (int)d->nz};
+    h->N = (size_t)N64;
+    h->max_particles = d->max_num_particles;
+    h->precond_mode = d->precond_mode; h->binning_mode = d->binning_mode;
+    int rc = BLUB_OK;
+    auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
+    const size_t P = std::max<size_t>(h->max_particles, 1);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
+    A(dev_alloc_zero(&h->pos, P)); A(dev_alloc_zero(&h->pos_tmp, P));
+    for (int c = 0; c < 3; ++c) A(dev_alloc_zero(&h->pvel[c], P));
+    A(dev_alloc_zero(&h->next1, P)); A(dev_alloc_zero(&h->next2, P));
+    A(dev_alloc_zero(&h->marker, h->N));
+    for (int c = 0; c < 3; ++c) { A(dev_alloc_zero(&h->ll[c], h->N)); A(dev_alloc_zero(&h->vel[c], h->N)); }
+    for (int w = 0; w < 2; ++w) A(dev_alloc_zero(&h->pressure[w], h->N));
+    A(dev_alloc_zero(&h->residual, h->N)); A(dev_alloc_zero(&h->search, h->N)); A(dev_alloc_zero(&h->aux, h->N)); A(dev_alloc_zero(&h->aux_temp, h->N));
+    A(dev_alloc_zero(&h->scan_totals, (h->N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
+    PcgGeom& gm = h->geom;
+    gm.g = h->g; gm.qpr = h->g.nx / 4; gm.qpp = gm.qpr * h->g.ny; gm.plane_blocks = (gm.qpp + 255) / 256;
+    gm.z_chunks = (h->g.nz + PCG_ZC - 1) / PCG_ZC; gm.tiles = gm.plane_blocks * gm.z_chunks;
+    h->pcg_grid = std::min(PCG_GRID_MAX, gm.tiles);
+    A(dev_alloc_zero(&h->part_sas, PCG_GRID_MAX)); A(dev_alloc_zero(&h->part_sigma[0], PCG_GRID_MAX)); A(dev_alloc_zero(&h->part_sigma[1], PCG_GRID_MAX));
+    A(dev_alloc_zero(&h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(&h->tile_flags, (size_t)gm.tiles));
+    A(dev_alloc_zero(&h->ctrl[0], 1)); A(dev_alloc_zero(&h->ctrl[1], 1));
+    for (int w = 0; w < 2 && rc == BLUB_OK; ++w) {
+        if (hipHostMalloc((void**)&h->stats_host[w], STATS_RING * 2 * sizeof(float)) != hipSuccess) { rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed"); break; }
+        for (int k = 0; k < STATS_RING; ++k) if (hipEventCreateWithFlags(&h->stats_events[w][k], hipEventDisableTiming) != hipSuccess) { rc = set_error(BLUB_ERR_DEVICE, "hipEventCreate failed"); break; }
+    }
+    if (rc != BLUB_OK) { std::string keep = g_last_error; destroy(h); g_last_error = keep; return rc; }
+    *out = h;
+    return BLUB_OK;
+}
+
+static int poll_stats(blub_fluid* h, bool wait) {   // retrieve_new_error_samples, pressure_solver.rs:148-174
+    for (int w = 0; w < 2; ++w) {
+        while (!h->stats_pending[w].empty()) {
+            PendingStat ps = h->stats_pending[w].front();
+            hipError_t q = wait ? hipEventSynchronize(ps.ev) : hipEventQuery(ps.ev);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return set_error(BLUB_ERR_DEVICE, hipGetErrorString(q));
+            const float max_err = h->stats_host[w][2 * ps.slot], iters = h->stats_host[w][2 * ps.slot + 1];
+            blub_solver_stats s; s.error = max_err * h->stats_dt[w].front(); s.iteration_count = (int32_t)iters;   // :162-163
+            h->stats_history[w].push_back(s);
+            while (h->stats_history[w].size() > STATS_HISTORY) h->stats_history[w].pop_front();
+            h->total_iterations += (uint64_t)s.iteration_count;
+            h->stats_pending[w].pop_front(); h->stats_dt[w].pop_front();
+        }
+    }
+    return BLUB_OK;
+}
+
+}  // namespace blub
+
+#define REQUIRE_HANDLE(h) do { if (!(h)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); if (hipSetDevice((h)->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed"); } while (0)
+
+extern "C" {
+
+const char* blub_last_error_string(void) { return blub::g_last_error.c_str(); }
+const char* blub_version_string(void) { return "blubhip 0.1 (gfx950)"; }
+
+int blub_fluid_create(const blub_fluid_desc* desc, blub_fluid** out) { return blub::create(desc, out); }
+void blub_fluid_destroy(blub_fluid* h) { blub::destroy(h); }
+
+int blub_fluid_create_from_scene(const blub_scene_config* sc, int32_t device, blub_fluid** out) {   // scene/mod.rs:109-144
+    if (!sc || !out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    blub_fluid_desc d{};
+    d.nx = sc->grid_dimension[0]; d.ny = sc->grid_dimension[1]; d.nz = sc->grid_dimension[2];
+    d.max_num_particles = sc->max_num_particles; d.device = device;
+    int rc = blub::create(&d, out);
+    if (rc != BLUB_OK) return rc;
+    const float scale = sc->grid_to_world_scale;
+    for (uint32_t i = 0; i < sc->num_fluid_cubes && i < BLUB_SCENE_MAX_CUBES; ++i) {
+        float mn[3], mx[3];
+        for (int k = 0; k < 3; ++k) { mn[k] = sc->cube_min[i][k] / scale; mx[k] = sc->cube_max[i][k] / scale; }   // :134-137
+        rc = blub_fluid_add_fluid_cube(*out, mn, mx);
+        if (rc != BLUB_OK) { blub::destroy(*out); *out = nullptr; return rc; }
+    }
+    float gg[3]; for (int k = 0; k < 3; ++k) gg[k] = sc->gravity[k] / scale;   // :139
+    blub_fluid_set_gravity_grid(*out, gg);
+    return blub_fluid_synchronize(*out);   // :142
+}
+
+int blub_fluid_add_fluid_cube(blub_fluid* h, const float mn[3], const float mx[3]) {
+    REQUIRE_HANDLE(h);
+    if (!mn || !mx) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    const uint32_t dim[3] = {(uint32_t)h->g.nx, (uint32_t)h->g.ny, (uint32_t)h->g.nz};
+    uint32_t count = 0;
+    int rc = blub::seed_fluid_cube(dim, h->max_particles, h->num_particles, mn, mx, nullptr, 0, &count);
+    if (rc != BLUB_OK) return rc;
+    if (count == 0) return BLUB_OK;
+    std::vector<float> buf((size_t)count * 4);
+    rc = blub::seed_fluid_cube(dim, h->max_particles, h->num_particles, mn, mx, buf.data(), count, &count);
+    if (rc != BLUB_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->pos + h->num_particles, buf.data(), (size_t)count * 16, hipMemcpyHostToDevice));   // queue.write_buffer :671
+    h->num_particles += count;
+    return BLUB_OK;
+}
+int blub_fluid_set_gravity_grid(blub_fluid* h, const float g[3]) {
+    if (!h || !g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    for (int k = 0; k < 3; ++k) h->gravity[k] = g[k];
+    return BLUB_OK;
+}
+int blub_fluid_run_stage(blub_fluid* h, int stage, float dt) {
+    REQUIRE_HANDLE(h);
+    if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
+    int rc = blub::run_stage(h, stage, dt);
+    return rc != BLUB_OK ? rc : blub::check_launch(h);
+}
+int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
+    REQUIRE_HANDLE(h);
+    if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
+    static const int before_binning[] = {BLUB_STAGE_TRANSFER, BLUB_STAGE_DIVERGENCE, BLUB_STAGE_SOLVE_VELOCITY};
+    static const int after_binning[] = {BLUB_STAGE_PROJECT, BLUB_STAGE_ADVECT, BLUB_STAGE_DENSITY_GATHER, BLUB_STAGE_SOLVE_DENSITY, BLUB_STAGE_POSITION_CHANGE, BLUB_STAGE_CORRECT};
+    int rc;
+    for (int s : before_binning) if ((rc = blub::run_stage(h, s, dt)) != BLUB_OK) return rc;
+    if (h->rebin_freq != 0 && h->step_counter % h->rebin_freq == 0)   // :854-856 (Q13)
+        if ((rc = blub::run_stage(h, BLUB_STAGE_BINNING, dt)) != BLUB_OK) return rc;
+    for (int s : after_binning) if ((rc = blub::run_stage(h, s, dt)) != BLUB_OK) return rc;
+    h->step_counter += 1;   // :976
+    (void)blub::poll_stats(h, false);   // the reference polls old read-backs inside solve (:612)
+    return blub::check_launch(h);
+}
+int blub_fluid_update_statistics(blub_fluid* h) { REQUIRE_HANDLE(h); return blub::poll_stats(h, false); }
+int blub_fluid_synchronize(blub_fluid* h) {
+    REQUIRE_HANDLE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return blub::poll_stats(h, true);
+}
+int blub_fluid_set_solver_config(blub_fluid* h, int which, const blub_solver_config* cfg) {
+    if (!h || !cfg || which < 0 || which > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (cfg->max_num_iterations < 0 || !(cfg->error_tolerance >= 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad solver config");
+    h->cfg[which] = *cfg;
+    return BLUB_OK;
+}
+int blub_fluid_get_solver_config(const blub_fluid* h, int which, blub_solver_config* cfg) {
+    if (!h || !cfg || which < 0 || which > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    *cfg = h->cfg[which];
+    return BLUB_OK;
+}
+int blub_fluid_solver_stats_count(const blub_fluid* h, int which) { return (!h || which < 0 || which > 1) ? BLUB_ERR_INVALID_ARGUMENT : (int)h->stats_history[which].size(); }
+int blub_fluid_solver_stats_get(const blub_fluid* h, int which, int index, blub_solver_stats* out) {
+    if (!h || !out || which < 0 || which > 1 || index < 0 || index >= (int)h->stats_history[which].size()) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    *out = h->stats_history[which][index];
+    return BLUB_OK;
+}
+int blub_fluid_solver_stats_latest(const blub_fluid* h, int which, blub_solver_stats* out) {
+    if (!h || !out || which < 0 || which > 1 || h->stats_history[which].empty()) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "no statistics sample available");
+    *out = h->stats_history[which].back();
+    return BLUB_OK;
+}
+int blub_fluid_set_rebinning_frequency(blub_fluid* h, uint32_t f) { if (!h) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); h->rebin_freq = f; return BLUB_OK; }
+uint32_t blub_fluid_get_rebinning_frequency(const blub_fluid* h) { return h ? h->rebin_freq : 0; }
+uint32_t blub_fluid_num_particles(const blub_fluid* h) { return h ? h->num_particles : 0; }
+uint32_t blub_fluid_max_num_particles(const blub_fluid* h) { return h ? h->max_particles : 0; }
+int blub_fluid_grid_dimension(const blub_fluid* h, uint32_t d[3]) {
+    if (!h || !d) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    d[0] = h->g.nx; d[1] = h->g.ny; d[2] = h->g.nz;
+    return BLUB_OK;
+}
+uint32_t blub_fluid_step_counter(const blub_fluid* h) { return h ? h->step_counter : 0; }
+int blub_fluid_set_step_counter(blub_fluid* h, uint32_t c) { if (!h) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); h->step_counter = c; return BLUB_OK; }
+uint64_t blub_fluid_total_solver_iterations(const blub_fluid* h) { return h ? h->total_iterations : 0; }
+
+int blub_fluid_get_device_views(const blub_fluid* h, blub_device_views* v) {
+    if (!h || !v) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    v->particles_position_ll = h->pos; v->particles_velocity_x = h->pvel[0]; v->particles_velocity_y = h->pvel[1]; v->particles_velocity_z = h->pvel[2];
+    v->velocity_x = h->vel[0]; v->velocity_y = h->vel[1]; v->velocity_z = h->vel[2]; v->marker = h->marker;
+    v->pressure_from_velocity = h->pressure[0]; v->pressure_from_density = h->pressure[1]; v->stream = (void*)h->stream;
+    return BLUB_OK;
+}
+int blub_fluid_set_solid_voxels(blub_fluid* h, const float* vox) {
+    REQUIRE_HANDLE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!vox) { if (h->solid) { (void)hipFree(h->solid); h->solid = nullptr; } return BLUB_OK; }
+    if (!h->solid) HIP_TRY(hipMalloc((void**)&h->solid, h->N * sizeof(float4)));
+    HIP_TRY(hipMemcpy(h->solid, vox, h->N * sizeof(float4), hipMemcpyHostToDevice));
+    return BLUB_OK;
+}
+int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz) {
+    REQUIRE_HANDLE(h);
+    if (n > h->max_particles) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "more particles than max_num_particles");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->num_particles = n;
+    if (n == 0) return BLUB_OK;
+    if (pos_ll) HIP_TRY(hipMemcpy(h->pos, pos_ll, (size_t)n * 16, hipMemcpyHostToDevice));
+    const float* src[3] = {vx, vy, vz};
+    for (int c = 0; c < 3; ++c) {
+        if (src[c]) HIP_TRY(hipMemcpy(h->pvel[c], src[c], (size_t)n * 16, hipMemcpyHostToDevice));
+        else HIP_TRY(hipMemset(h->pvel[c], 0, (size_t)n * 16));
+    }
+    return BLUB_OK;
+}
+int blub_fluid_get_particles(blub_fluid* h, float* pos_ll, float* vx, float* vy, float* vz) {
+    REQUIRE_HANDLE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t b = (size_t)h->num_particles * 16;
+    if (b == 0) return BLUB_OK;
+    if (pos_ll) HIP_TRY(hipMemcpy(pos_ll, h->pos, b, hipMemcpyDeviceToHost));
+    float* dst[3] = {vx, vy, vz};
+    for (int c = 0; c < 3; ++c) if (dst[c]) HIP_TRY(hipMemcpy(dst[c], h->pvel[c], b, hipMemcpyDeviceToHost));
+    return BLUB_OK;
+}
+static void* volume_ptr(const blub_fluid* h, int which, size_t* bytes) {
+    const size_t N = h->N;
+    switch (which) {
+    case BLUB_VOLUME_MARKER: *bytes = N; return h->marker;
+    case BLUB_VOLUME_LINKED_LIST: *bytes = N * 4; return h->ll[0];
+    case BLUB_VOLUME_VELOCITY_X: case BLUB_VOLUME_VELOCITY_Y: case BLUB_VOLUME_VELOCITY_Z: *bytes = N * 4; return h->vel[which - BLUB_VOLUME_VELOCITY_X];
+    case BLUB_VOLUME_PRESSURE_VELOCITY: case BLUB_VOLUME_PRESSURE_DENSITY: *bytes = N * 4; return h->pressure[which - BLUB_VOLUME_PRESSURE_VELOCITY];
+    case BLUB_VOLUME_RESIDUAL: *bytes = N * 4; return h->residual;
+    case BLUB_VOLUME_SEARCH: *bytes = N * 4; return h->search;
+    case BLUB_VOLUME_AUX: *bytes = N * 4; return h->aux;
+    case BLUB_VOLUME_AUX_TEMP: *bytes = N * 4; return h->aux_temp;
+    case BLUB_VOLUME_SOLID: *bytes = N * 16; return h->solid;
+    }
+    *bytes = 0;
+    return nullptr;
+}
+size_t blub_fluid_volume_bytes(const blub_fluid* h, int which) { size_t b = 0; if (h) (void)volume_ptr(h, which, &b); return b; }
+int blub_fluid_read_volume(blub_fluid* h, int which, void* out) {
+    REQUIRE_HANDLE(h);
+    size_t b; void* p = volume_ptr(h, which, &b);
+    if (!p || !out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, p, b, hipMemcpyDeviceToHost));
+    return BLUB_OK;
+}
+int blub_fluid_write_volume(blub_fluid* h, int which, const void* in) {
+    REQUIRE_HANDLE(h);
+    if (which == BLUB_VOLUME_SOLID) return blub_fluid_set_solid_voxels(h, (const float*)in);
+    size_t b; void* p = volume_ptr(h, which, &b);
+    if (!p || !in) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(p, in, b, hipMemcpyHostToDevice));
+    return BLUB_OK;
+}
+int blub_fluid_mark_pressure_initialised(blub_fluid* h, int which, int init) {
+    if (!h || which < 0 || which > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    h->pressure_initialised[which] = init != 0;
+    return BLUB_OK;
+}
+int blub_fluid_profile_enable(blub_fluid* h, int enabled) { REQUIRE_HANDLE(h); int rc = blub::prof_flush(h); h->prof_enabled = enabled != 0; return rc; }
+int blub_fluid_profile_reset(blub_fluid* h) {
+    REQUIRE_HANDLE(h);
+    int rc = blub::prof_flush(h);
+    for (int k = 0; k < blub::KC_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_launches[k] = 0; }
+    return rc;
+}
+int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacity, int* count_out) {
+    REQUIRE_HANDLE(h);
+    if (!entries || !count_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = blub::prof_flush(h);
+    if (rc != BLUB_OK) return rc;
+    int n = 0;
+    for (int k = 0; k < blub::KC_COUNT && n < capacity; ++k) {
+        if (!h->prof_launches[k]) continue;
+        memset(&entries[n], 0, sizeof(blub_prof_entry));
+        strncpy(entries[n].name, blub::kKernelClassNames[k], sizeof(entries[n].name) - 1);
+        entries[n].launches = h->prof_launches[k]; entries[n].total_ms = h->prof_ms[k];
+        ++n;
+    }
+    *count_out = n;
+    return BLUB_OK;
+}
+}  // extern "C"

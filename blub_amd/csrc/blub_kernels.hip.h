@@ -1,0 +1,939 @@
+// Device kernels of the blub fluid step for gfx950 (MI355X, wave64).  Included by blub_fluid.hip only.
+//
+// Every kernel cites the reference shader it re-implements (paths relative to /root/reference/shader/simulation).
+// Arithmetic is written in the same operation order as the reference GLSL and compiled with -ffp-contract=off, so
+// that element-wise kernels are bit-reproducible against the CPU oracle; only summation ORDER (linked-list order,
+// dot-product trees) differs and is covered by the stated tolerances.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blubk {
+
+constexpr int CELL_SOLID = 0, CELL_FLUID = 1, CELL_AIR = -1;
+constexpr uint32_t INVALID_LL = 0xFFFFFFFFu;
+
+struct Grid { int nx, ny, nz; };
+
+__device__ __forceinline__ bool inb(const Grid& g, int x, int y, int z) {
+    return (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+}
+__device__ __forceinline__ int cidx(const Grid& g, int x, int y, int z) { return (z * g.ny + y) * g.nx + x; }
+// texelFetch / imageLoad semantics: out of bounds reads 0
+__device__ __forceinline__ int mk(const int8_t* __restrict__ m, const Grid& g, int x, int y, int z) { return inb(g, x, y, z) ? (int)m[cidx(g, x, y, z)] : CELL_SOLID; }
+__device__ __forceinline__ float fv(const float* __restrict__ v, const Grid& g, int x, int y, int z) { return inb(g, x, y, z) ? v[cidx(g, x, y, z)] : 0.0f; }
+__device__ __forceinline__ float satf(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float fractf(float v) { return v - floorf(v); }
+__device__ __forceinline__ float signf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float comp3(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
+
+// ---- wave64 / block reductions (wavefront shuffles; deterministic order) ---------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+    return v;
+}
+// Sum over a 256-thread block; result valid in every thread. `sm` needs 8 floats.
+template <bool MAX>
+__device__ __forceinline__ float block_reduce_256(float v, float* sm) {
+    v = MAX ? wave_max(v) : wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float r = sm[0];
+    if (MAX) { r = fmaxf(r, sm[1]); r = fmaxf(r, sm[2]); r = fmaxf(r, sm[3]); }
+    else { r += sm[1]; r += sm[2]; r += sm[3]; }
+    return r;
+}
+// Every block re-reduces the per-block partials of the previous kernel (n <= a few thousand floats, L2 resident):
+// no atomics, no extra launch, bit-deterministic.
+template <bool MAX>
+__device__ __forceinline__ float reduce_partials_256(const float* __restrict__ part, int n, float* sm) {
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) v = MAX ? fmaxf(v, part[i]) : v + part[i];
+    return block_reduce_256<MAX>(v, sm);
+}
+
+// =================================================================================================================
+// T1 + T3 fused: transfer_clear.comp:10-14 and transfer_set_boundary_marker.comp:11-19.
+// marker := SOLID on the domain shell / solid voxels, AIR elsewhere; the linked-list head volumes := 0.
+// (T2 then only ever turns AIR into FLUID, so the final marker equals the reference's T1 -> T2 -> T3 order.)
+// One thread = 4 x-consecutive cells (nx % 4 == 0): 4 B marker store + 16 B stores per list volume.
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_init_grid(Grid g, int8_t* __restrict__ marker, const float4* __restrict__ solid,
+                                                   uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2) {
+    const int nquads = (g.nx >> 2) * g.ny * g.nz;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < nquads; q += gridDim.x * 256) {
+        const int base = q << 2;
+        const int x0 = base % g.nx, yz = base / g.nx, y = yz % g.ny, z = yz / g.ny;
+        const bool shell_yz = (y == 0) | (z == 0) | (y == g.ny - 1) | (z == g.nz - 1);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            bool sol = shell_yz | (x == 0) | (x == g.nx - 1);
+            if (!sol && solid) sol = solid[base + j].w != 0.0f;
+            packed |= (sol ? 0u : 0xFFu) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(marker + base) = packed;
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        if (ll0) *reinterpret_cast<uint4*>(ll0 + base) = z4;
+        if (ll1) *reinterpret_cast<uint4*>(ll1 + base) = z4;
+        if (ll2) *reinterpret_cast<uint4*>(ll2 + base) = z4;
+    }
+}
+
+// =================================================================================================================
+// T2 x3 fused: transfer_build_linkedlist.comp:10-26.  One pass over the particles builds the three staggered
+// dual-grid lists (component c: dual cell = ivec3(pos - (0.5 + 0.5 e_c))) and marks FLUID cells.
+// list "next" pointers: component x lives in pos.w (as in the reference), y/z in two extra u32 arrays.
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_particles, float4* __restrict__ pos, int8_t* __restrict__ marker,
+                                                     uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
+                                                     uint32_t* __restrict__ next1, uint32_t* __restrict__ next2) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_particles) return;
+    const float4 p = pos[i];
+    {
+        const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
+        if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
+    }
+    uint32_t nxt[3];
+    uint32_t* heads[3] = {ll0, ll1, ll2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int dx = (int)(p.x - (c == 0 ? 1.0f : 0.5f)), dy = (int)(p.y - (c == 1 ? 1.0f : 0.5f)), dz = (int)(p.z - (c == 2 ? 1.0f : 0.5f));
+        uint32_t old = 0;
+        if (inb(g, dx, dy, dz)) old = atomicExch(heads[c] + cidx(g, dx, dy, dz), i + 1);
+        nxt[c] = old - 1u;
+    }
+    reinterpret_cast<uint32_t*>(pos)[4 * (size_t)i + 3] = nxt[0];
+    next1[i] = nxt[1];
+    next2[i] = nxt[2];
+}
+
+// =================================================================================================================
+// T4: transfer_gather_velocity.comp:39-127.  9x9x9 list cells per workgroup (8^3 outputs + 1 halo layer on the
+// negative sides); every thread walks ITS cell's list and publishes the current particle through LDS, the 7 other
+// lists a face needs are read from LDS (27 KiB/WG).  Differences to the reference: 768-thread blocks (12 full
+// waves) instead of 729, and the 12-round loop exits as soon as every list in the workgroup is exhausted.
+// =================================================================================================================
+__device__ __forceinline__ void add_particle(float& v, float& wsum, const float4& pp, const float4& row, float sx, float sy, float sz) {
+    const float tx = sx - pp.x, ty = sy - pp.y, tz = sz - pp.z;                       // :20
+    const float ox = satf(1.0f - fabsf(tx)), oy = satf(1.0f - fabsf(ty)), oz = satf(1.0f - fabsf(tz));
+    const float w = ox * oy * oz;                                                      // :22
+    const float d = ((row.x * tx + row.y * ty) + row.z * tz) + row.w * 1.0f;           // :24
+    v += w * d;
+    wsum += w;
+}
+
+template <int COMP>
+__global__ __launch_bounds__(768) void k_gather_velocity(Grid g, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                         const float4* __restrict__ pos, const uint32_t* __restrict__ next,
+                                                         const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
+    __shared__ float4 sPos[729];
+    __shared__ float4 sVel[729];
+    const int tid = threadIdx.x;
+    const bool live = tid < 729;
+    const int lx = tid % 9, ly = (tid / 9) % 9, lz = tid / 81;
+    const int gx = blockIdx.x * 8 + lx - 1, gy = blockIdx.y * 8 + ly - 1, gz = blockIdx.z * 8 + lz - 1;   // :41
+    const bool in = live && inb(g, gx, gy, gz);
+    const bool border = !live || lx == 0 || ly == 0 || lz == 0;
+    const int mA = in ? (int)marker[cidx(g, gx, gy, gz)] : CELL_SOLID;
+    const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
+    const bool writes = !border && in && (mA == CELL_FLUID || mB == CELL_FLUID);      // :50 (OOB stores are dropped)
+    const bool computes = !border && (mA != CELL_SOLID && mB != CELL_SOLID);           // :51
+    const float sx = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
+    const float sy = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
+    const float sz = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
+    uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+    float v = 0.0f, wsum = 0.0f;
+    const int a1 = tid - 1, a2 = tid - 9, a3 = tid - 10, a4 = tid - 81, a5 = tid - 82, a6 = tid - 90, a7 = tid - 91;   // :87-93
+    for (int round = 0; round < 12; ++round) {                                          // :61
+        const bool has = cur != INVALID_LL;
+        if (!__syncthreads_or(has)) break;   // also orders last round's LDS reads before this round's writes
+        if (has) {
+            const float4 p = pos[cur];
+            const float4 r = rows[cur];
+            cur = next ? next[cur] : __float_as_uint(p.w);
+            if (computes) add_particle(v, wsum, p, r, sx, sy, sz);
+            sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
+            sVel[tid] = r;
+        } else if (live) {
+            sPos[tid].w = 0.0f;
+        }
+        __syncthreads();
+        if (computes) {
+            float4 q;
+            q = sPos[a1]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a1], sx, sy, sz);
+            q = sPos[a2]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a2], sx, sy, sz);
+            q = sPos[a3]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a3], sx, sy, sz);
+            q = sPos[a4]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a4], sx, sy, sz);
+            q = sPos[a5]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a5], sx, sy, sz);
+            q = sPos[a6]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a6], sx, sy, sz);
+            q = sPos[a7]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a7], sx, sy, sz);
+        }
+    }
+    if (writes) {
+        if (computes) { if (wsum > 0.0f) v /= wsum; v += gravity_dt; }                 // :117-120
+        else v = 0.0f;                                                                  // :121-124
+        out[cidx(g, gx, gy, gz)] = v;
+    }
+}
+
+// =================================================================================================================
+// D1: divergence_compute.comp:28-87 -> residual volume (FLUID cells only)
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_divergence(Grid g, const int8_t* __restrict__ marker, const float* __restrict__ vx,
+                                                    const float* __restrict__ vy, const float* __restrict__ vz,
+                                                    const float4* __restrict__ solid, float* __restrict__ residual) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    const int c = cidx(g, x, y, z);
+    if (marker[c] != CELL_FLUID) return;
+    const float px = vx[c], py = vy[c], pz = vz[c];
+    const float qx = fv(vx, g, x - 1, y, z), qy = fv(vy, g, x, y - 1, z), qz = fv(vz, g, x, y, z - 1);
+    float div = px - qx;
+    div += py - qy;
+    div += pz - qz;
+    auto wall = [&](int ax, int ay, int az, float wallv, int comp) -> float {
+        if (mk(marker, g, ax, ay, az) != CELL_SOLID) return 0.0f;
+        const float sv = (solid && inb(g, ax, ay, az)) ? comp3(solid[cidx(g, ax, ay, az)], comp) : 0.0f;
+        return wallv - sv;
+    };
+    div += wall(x - 1, y, z, qx, 0); div += wall(x, y - 1, z, qy, 1); div += wall(x, y, z - 1, qz, 2);
+    div -= wall(x + 1, y, z, px, 0); div -= wall(x, y + 1, z, py, 1); div -= wall(x, y, z + 1, pz, 2);
+    residual[c] = div;
+}
+
+// =================================================================================================================
+// PCG (pressure_solver.rs:591-729, shader/simulation/pressure_solver/*; schedule in SURVEY Appendix D).
+//
+// MI355X formulation: three streaming kernels per iteration instead of the reference's ~9 dispatches
+//   K1  apply   : partial dot  s.As                                   (pressure_apply_coeff.comp + reduce level 1)
+//   K2  update  : alpha from partials; p += alpha s; r -= alpha A s; [max|r|]; z = M^-1 r; partial z.r
+//                 (pressure_update_pressure_and_residual.comp + apply_preconditioner x2 for the "zero" reading)
+//   K5  search  : beta from partials; s = z + beta s; convergence bookkeeping (pressure_update_search.comp +
+//                 pressure_reduce.comp's MAX_ERROR mode)
+// The dot products never touch a 4N-byte reduce buffer: each block writes ONE partial, the consumer kernel's blocks
+// re-reduce the <=PCG_GRID partials.  sigma is the partial array of the previous z.r (double buffered by iteration
+// parity), so no scalar needs a dedicated pass.  `done` replaces the zeroed indirect-dispatch arguments.
+//
+// Work decomposition: a tile = 256 threads x 4 x-consecutive cells (one float4 each) of a z-plane, marched over
+// PCG_ZC planes; a fixed grid of persistent blocks strides over the tiles; tiles without FLUID cells are skipped.
+// =================================================================================================================
+constexpr int PCG_ZC = 8;
+
+struct PcgCtrl {       // device-resident; [0..1] mirror the reference's MaxError / NumIterations read-back (pressure_init.comp:8-15)
+    float max_err;
+    float num_iter;
+    int done;
+    int pad;
+};
+
+struct PcgGeom {
+    Grid g;
+    int qpr;          // quads per row  = nx/4
+    int qpp;          // quads per plane
+    int plane_blocks; // ceil(qpp/256)
+    int z_chunks;
+    int tiles;
+};
+
+struct QuadMarkers { uint32_t c, ym, yp, zm, zp; int xm, xp; };
+
+__device__ __forceinline__ int mbyte(uint32_t packed, int j) { return (int)(int8_t)((packed >> (8 * j)) & 0xFFu); }
+__device__ __forceinline__ bool any_fluid4(uint32_t packed) {
+    return mbyte(packed, 0) == CELL_FLUID || mbyte(packed, 1) == CELL_FLUID || mbyte(packed, 2) == CELL_FLUID || mbyte(packed, 3) == CELL_FLUID;
+}
+__device__ __forceinline__ void load_quad_markers(const int8_t* __restrict__ M, const Grid& g, int base, int x0, int y, int z, QuadMarkers& q) {
+    const int plane = g.nx * g.ny;
+    q.xm = x0 > 0 ? (int)M[base - 1] : CELL_SOLID;
+    q.xp = x0 + 4 < g.nx ? (int)M[base + 4] : CELL_SOLID;
+    q.ym = y > 0 ? *reinterpret_cast<const uint32_t*>(M + base - g.nx) : 0u;
+    q.yp = y + 1 < g.ny ? *reinterpret_cast<const uint32_t*>(M + base + g.nx) : 0u;
+    q.zm = z > 0 ? *reinterpret_cast<const uint32_t*>(M + base - plane) : 0u;
+    q.zp = z + 1 < g.nz ? *reinterpret_cast<const uint32_t*>(M + base + plane) : 0u;
+}
+struct QuadValues { float4 c, ym, yp, zm, zp; float xm, xp; };
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void load_quad_values(const float* __restrict__ S, const Grid& g, int base, int x0, int y, int z, QuadValues& v) {
+    const int plane = g.nx * g.ny;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    v.c = ld4(S + base);
+    v.xm = x0 > 0 ? S[base - 1] : 0.0f;
+    v.xp = x0 + 4 < g.nx ? S[base + 4] : 0.0f;
+    v.ym = y > 0 ? ld4(S + base - g.nx) : zero;
+    v.yp = y + 1 < g.ny ? ld4(S + base + g.nx) : zero;
+    v.zm = z > 0 ? ld4(S + base - plane) : zero;
+    v.zp = z + 1 < g.nz ? ld4(S + base + plane) : zero;
+}
+__device__ __forceinline__ float f4(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+// MultiplyWithCoefficientMatrix (pressure.glsl:34-75) for cell j of a quad; also returns d = #non-solid neighbours.
+__device__ __forceinline__ float quad_mulA(const QuadMarkers& m, const QuadValues& v, int j, float& d) {
+    const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
+    const int mY0 = mbyte(m.ym, j), mY1 = mbyte(m.yp, j), mZ0 = mbyte(m.zm, j), mZ1 = mbyte(m.zp, j);
+    d = (float)(mX0 != 0) + (float)(mX1 != 0) + (float)(mY0 != 0) + (float)(mY1 != 0) + (float)(mZ0 != 0) + (float)(mZ1 != 0);
+    float r = 0.0f;
+    r += d * f4(v.c, j);
+    if (mX0 == CELL_FLUID) r -= (j > 0 ? f4(v.c, j - 1) : v.xm);
+    if (mX1 == CELL_FLUID) r -= (j < 3 ? f4(v.c, j + 1) : v.xp);
+    if (mY0 == CELL_FLUID) r -= f4(v.ym, j);
+    if (mY1 == CELL_FLUID) r -= f4(v.yp, j);
+    if (mZ0 == CELL_FLUID) r -= f4(v.zm, j);
+    if (mZ1 == CELL_FLUID) r -= f4(v.zp, j);
+    return r;
+}
+// "zero" reading of pressure_apply_preconditioner.comp:36-82 applied twice (pass0 then pass1): (r / d) / d
+__device__ __forceinline__ float precond_zero(float r, float d) {
+    float t = r; if (d > 0.0f) t /= d;
+    float z = t; if (d > 0.0f) z /= d;
+    return z;
+}
+__device__ __forceinline__ float eps_div(float num, float den) { return num / (den + (den < 0.0f ? -1e-10f : 1e-10f)); }   // pressure_reduce.comp:71-77
+
+#define PCG_TILE_LOOP_BEGIN(geom)                                                                            \
+    for (int tile = blockIdx.x; tile < (geom).tiles; tile += gridDim.x) {                                    \
+        const int pb = tile % (geom).plane_blocks, zc = tile / (geom).plane_blocks;                          \
+        const int q = pb * 256 + threadIdx.x;                                                                \
+        const bool qvalid = q < (geom).qpp;                                                                  \
+        const int x0 = (q % (geom).qpr) << 2, y = q / (geom).qpr;                                            \
+        const int z_begin = zc * PCG_ZC, z_end = min(z_begin + PCG_ZC, (geom).g.nz);
+#define PCG_TILE_LOOP_END }
+
+// S0 (pressure_init.comp:19-84) fused with the initial preconditioner + s.r partials (pressure_solver.rs:630-648).
+// PRECOND_ZERO: s = (r/d)/d and sigma partial here.  LOD0: only r and p are updated (generic passes follow).
+template <bool ZERO_MODE>
+__global__ __launch_bounds__(256) void k_pcg_init(PcgGeom geom, const int8_t* __restrict__ marker, float* __restrict__ p, float* __restrict__ r,
+                                                  float* __restrict__ s, float* __restrict__ part_sigma, uint8_t* __restrict__ tile_flags) {
+    __shared__ float sm[8];
+    __shared__ int s_any;
+    float acc = 0.0f;
+    PCG_TILE_LOOP_BEGIN(geom)
+        if (threadIdx.x == 0) s_any = 0;
+        __syncthreads();
+        bool any = false;
+        if (qvalid) {
+            for (int z = z_begin; z < z_end; ++z) {
+                const int base = cidx(geom.g, x0, y, z);
+                const uint32_t mc = *reinterpret_cast<const uint32_t*>(marker + base);
+                float4 pc = ld4(p + base);
+                if (any_fluid4(mc)) {
+                    any = true;
+                    QuadMarkers m; m.c = mc; load_quad_markers(marker, geom.g, base, x0, y, z, m);
+                    QuadValues pv; load_quad_values(p, geom.g, base, x0, y, z, pv);
+                    float4 rc = ld4(r + base);
+                    float rr[4] = {rc.x, rc.y, rc.z, rc.w};
+                    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (mbyte(mc, j) != CELL_FLUID) continue;
+                        const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
+                        const int mY0 = mbyte(m.ym, j), mY1 = mbyte(m.yp, j), mZ0 = mbyte(m.zm, j), mZ1 = mbyte(m.zp, j);
+                        const float d = (float)(mX0 != 0) + (float)(mX1 != 0) + (float)(mY0 != 0) + (float)(mY1 != 0) + (float)(mZ0 != 0) + (float)(mZ1 != 0);
+                        float res = rr[j];
+                        if (d > 0.0f) res -= d * f4(pv.c, j);                                   // :62-63
+                        if (mX0 == CELL_FLUID) res += (j > 0 ? f4(pv.c, j - 1) : pv.xm);          // :64-81
+                        if (mX1 == CELL_FLUID) res += (j < 3 ? f4(pv.c, j + 1) : pv.xp);
+                        if (mY0 == CELL_FLUID) res += f4(pv.ym, j);
+                        if (mY1 == CELL_FLUID) res += f4(pv.yp, j);
+                        if (mZ0 == CELL_FLUID) res += f4(pv.zm, j);
+                        if (mZ1 == CELL_FLUID) res += f4(pv.zp, j);
+                        rr[j] = res;
+                        if (ZERO_MODE) { ss[j] = precond_zero(res, d); acc += ss[j] * res; }
+                    }
+                    *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                    if (ZERO_MODE) {
+                        // the reference never writes s outside FLUID cells; keep those values untouched
+                        float4 so = ld4(s + base);
+                        if (mbyte(mc, 0) == CELL_FLUID) so.x = ss[0];
+                        if (mbyte(mc, 1) == CELL_FLUID) so.y = ss[1];
+                        if (mbyte(mc, 2) == CELL_FLUID) so.z = ss[2];
+                        if (mbyte(mc, 3) == CELL_FLUID) so.w = ss[3];
+                        *reinterpret_cast<float4*>(s + base) = so;
+                    }
+                }
+                // pressure_init.comp:45-48: p := 0 outside the fluid
+                bool dirty = false;
+                if (mbyte(mc, 0) != CELL_FLUID && pc.x != 0.0f) { pc.x = 0.0f; dirty = true; }
+                if (mbyte(mc, 1) != CELL_FLUID && pc.y != 0.0f) { pc.y = 0.0f; dirty = true; }
+                if (mbyte(mc, 2) != CELL_FLUID && pc.z != 0.0f) { pc.z = 0.0f; dirty = true; }
+                if (mbyte(mc, 3) != CELL_FLUID && pc.w != 0.0f) { pc.w = 0.0f; dirty = true; }
+                if (dirty) *reinterpret_cast<float4*>(p + base) = pc;
+            }
+        }
+        if (any) s_any = 1;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_flags[tile] = (uint8_t)s_any;
+        __syncthreads();
+    PCG_TILE_LOOP_END
+    const float tot = block_reduce_256<false>(acc, sm);
+    if (threadIdx.x == 0 && part_sigma) part_sigma[blockIdx.x] = tot;
+}
+
+// K1: pressure_apply_coeff.comp:19-30 -- partial of s.As
+__global__ __launch_bounds__(256) void k_pcg_apply(PcgGeom geom, const int8_t* __restrict__ marker, const float* __restrict__ s,
+                                                   float* __restrict__ part_sas, const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl) {
+    __shared__ float sm[8];
+    if (ctrl->done) return;
+    float acc = 0.0f;
+    PCG_TILE_LOOP_BEGIN(geom)
+        if (!tile_flags[tile] || !qvalid) continue;
+        for (int z = z_begin; z < z_end; ++z) {
+            const int base = cidx(geom.g, x0, y, z);
+            QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
+            if (!any_fluid4(m.c)) continue;
+            load_quad_markers(marker, geom.g, base, x0, y, z, m);
+            QuadValues sv; load_quad_values(s, geom.g, base, x0, y, z, sv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mbyte(m.c, j) != CELL_FLUID) continue;
+                float d; const float as = quad_mulA(m, sv, j, d);
+                acc += f4(sv.c, j) * as;
+            }
+        }
+    PCG_TILE_LOOP_END
+    const float tot = block_reduce_256<false>(acc, sm);
+    if (threadIdx.x == 0) part_sas[blockIdx.x] = tot;
+}
+
+// K2: pressure_update_pressure_and_residual.comp:23-59 (+ preconditioner and z.r partial when ZERO_MODE)
+template <bool ZERO_MODE>
+__global__ __launch_bounds__(256) void k_pcg_update(PcgGeom geom, const int8_t* __restrict__ marker, const float* __restrict__ s, float* __restrict__ p,
+                                                    float* __restrict__ r, const float* __restrict__ part_sas, const float* __restrict__ part_sigma,
+                                                    float* __restrict__ part_sigma_next, float* __restrict__ part_max, int num_part,
+                                                    const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl) {
+    __shared__ float sm[8];
+    if (ctrl->done) return;
+    const float sigma = reduce_partials_256<false>(part_sigma, num_part, sm);
+    const float sas = reduce_partials_256<false>(part_sas, num_part, sm);
+    const float alpha = eps_div(sigma, sas);                                           // RESULTMODE_ALPHA
+    float acc = 0.0f, emax = 0.0f;
+    PCG_TILE_LOOP_BEGIN(geom)
+        if (!tile_flags[tile] || !qvalid) continue;
+        for (int z = z_begin; z < z_end; ++z) {
+            const int base = cidx(geom.g, x0, y, z);
+            QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
+            if (!any_fluid4(m.c)) continue;
+            load_quad_markers(marker, geom.g, base, x0, y, z, m);
+            QuadValues sv; load_quad_values(s, geom.g, base, x0, y, z, sv);
+            float4 pc = ld4(p + base), rc = ld4(r + base);
+            float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mbyte(m.c, j) != CELL_FLUID) continue;
+                float d; const float as = quad_mulA(m, sv, j, d);
+                pp[j] = pp[j] + alpha * f4(sv.c, j);                                   // :39-40
+                float res = rr[j];
+                res -= alpha * as;                                                      // :52
+                rr[j] = res;
+                emax = fmaxf(emax, fabsf(res));                                         // :55
+                if (ZERO_MODE) acc += precond_zero(res, d) * res;
+            }
+            *reinterpret_cast<float4*>(p + base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        }
+    PCG_TILE_LOOP_END
+    const float tot = block_reduce_256<false>(acc, sm);
+    const float mx = block_reduce_256<true>(emax, sm);
+    if (threadIdx.x == 0) { if (ZERO_MODE) part_sigma_next[blockIdx.x] = tot; part_max[blockIdx.x] = mx; }
+}
+
+// Generic preconditioner pass for the LOD0 reading: pressure_apply_preconditioner.comp:36-82 (both passes use the
+// lower neighbours, Q3).  dot != nullptr => also emits the partial of out.r
+__global__ __launch_bounds__(256) void k_pcg_precond_lod0(PcgGeom geom, const int8_t* __restrict__ marker, const float* __restrict__ in,
+                                                          float* __restrict__ out, const float* __restrict__ rdot, float* __restrict__ part,
+                                                          const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl) {
+    __shared__ float sm[8];
+    if (ctrl->done) return;
+    float acc = 0.0f;
+    PCG_TILE_LOOP_BEGIN(geom)
+        if (!tile_flags[tile] || !qvalid) continue;
+        for (int z = z_begin; z < z_end; ++z) {
+            const int base = cidx(geom.g, x0, y, z);
+            QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
+            if (!any_fluid4(m.c)) continue;
+            load_quad_markers(marker, geom.g, base, x0, y, z, m);
+            QuadValues iv; load_quad_values(in, geom.g, base, x0, y, z, iv);
+            float4 oc = ld4(out + base);
+            float oo[4] = {oc.x, oc.y, oc.z, oc.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mbyte(m.c, j) != CELL_FLUID) continue;
+                const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
+                const int mY0 = mbyte(m.ym, j), mY1 = mbyte(m.yp, j), mZ0 = mbyte(m.zm, j), mZ1 = mbyte(m.zp, j);
+                float res = f4(iv.c, j);
+                if (mX0 == CELL_FLUID) res -= (j > 0 ? f4(iv.c, j - 1) : iv.xm);
+                if (mY0 == CELL_FLUID) res -= f4(iv.ym, j);
+                if (mZ0 == CELL_FLUID) res -= f4(iv.zm, j);
+                const float d = (float)(mX0 != 0) + (float)(mX1 != 0) + (float)(mY0 != 0) + (float)(mY1 != 0) + (float)(mZ0 != 0) + (float)(mZ1 != 0);
+                if (d > 0.0f) res /= d;
+                oo[j] = res;
+                if (rdot) acc += res * rdot[base + j];
+            }
+            *reinterpret_cast<float4*>(out + base) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+        }
+    PCG_TILE_LOOP_END
+    const float tot = block_reduce_256<false>(acc, sm);
+    if (threadIdx.x == 0 && part) part[blockIdx.x] = tot;
+}
+
+// K5: pressure_update_search.comp:13-24 + the MAX_ERROR / BETA modes of pressure_reduce.comp:63-95.
+// check: this iteration compared max|r| against the tolerance; last: i == max_num_iterations.
+template <bool ZERO_MODE>
+__global__ __launch_bounds__(256) void k_pcg_search(PcgGeom geom, const int8_t* __restrict__ marker, const float* __restrict__ r_or_z, float* __restrict__ s,
+                                                    const float* __restrict__ part_sigma, const float* __restrict__ part_sigma_next,
+                                                    const float* __restrict__ part_max, int num_part, const uint8_t* __restrict__ tile_flags,
+                                                    PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check, int last) {
+    __shared__ float sm[8];
+    if (ctrl->done) return;
+    if (check) {
+        const float err = reduce_partials_256<true>(part_max, num_part, sm);
+        if (last || err < tolerance) {                                                  // pressure_reduce.comp:82-94
+            if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->max_err = err; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
+            return;
+        }
+    }
+    const float sigma = reduce_partials_256<false>(part_sigma, num_part, sm);
+    const float sigma_next = reduce_partials_256<false>(part_sigma_next, num_part, sm);
+    const float beta = eps_div(sigma_next, sigma);                                      // RESULTMODE_BETA
+    PCG_TILE_LOOP_BEGIN(geom)
+        if (!tile_flags[tile] || !qvalid) continue;
+        for (int z = z_begin; z < z_end; ++z) {
+            const int base = cidx(geom.g, x0, y, z);
+            QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
+            if (!any_fluid4(m.c)) continue;
+            if (ZERO_MODE) load_quad_markers(marker, geom.g, base, x0, y, z, m);
+            const float4 zc4 = ld4(r_or_z + base);
+            float4 sc = ld4(s + base);
+            float ss[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mbyte(m.c, j) != CELL_FLUID) continue;
+                float zval = f4(zc4, j);
+                if (ZERO_MODE) {
+                    const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
+                    const float d = (float)(mX0 != 0) + (float)(mX1 != 0) + (float)(mbyte(m.ym, j) != 0) + (float)(mbyte(m.yp, j) != 0) +
+                                    (float)(mbyte(m.zm, j) != 0) + (float)(mbyte(m.zp, j) != 0);
+                    zval = precond_zero(zval, d);
+                }
+                ss[j] = zval + beta * ss[j];                                            // :23
+            }
+            *reinterpret_cast<float4*>(s + base) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+        }
+    PCG_TILE_LOOP_END
+}
+
+// =================================================================================================================
+// D2: divergence_remove.comp:19-49
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_divergence_remove(Grid g, const int8_t* __restrict__ marker, const float* __restrict__ p,
+                                                           const float4* __restrict__ solid, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    const int c = cidx(g, x, y, z);
+    const int mc = marker[c];
+    const float pc = (mc == CELL_FLUID) ? p[c] : 0.0f;
+    float* vel[3] = {vx, vy, vz};
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+        const int ax = x + (comp == 0), ay = y + (comp == 1), az = z + (comp == 2);
+        const int mn = mk(marker, g, ax, ay, az);
+        float v = 0.0f;
+        if (mc == CELL_FLUID || mn == CELL_FLUID) {
+            if (mc == CELL_SOLID) v = solid ? comp3(solid[c], comp) : 0.0f;
+            else if (mn == CELL_SOLID) v = (solid && inb(g, ax, ay, az)) ? comp3(solid[cidx(g, ax, ay, az)], comp) : 0.0f;
+            else {
+                v = vel[comp][c];
+                const float pn = (mn == CELL_FLUID) ? p[cidx(g, ax, ay, az)] : 0.0f;
+                v -= pc - pn;
+            }
+        }
+        vel[comp][c] = v;
+    }
+}
+
+// =================================================================================================================
+// D3: extrapolate_velocity.comp:9-90.  Reads only valid faces, writes only invalid ones => in place.
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_extrapolate(Grid g, const int8_t* __restrict__ marker, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    const int c = cidx(g, x, y, z);
+    if (marker[c] == CELL_FLUID) return;
+    float* vel[3] = {vx, vy, vz};
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+        if (mk(marker, g, x + (comp == 0), y + (comp == 1), z + (comp == 2)) == CELL_FLUID) continue;
+        float numV = 0.0f, avgV = 0.0f;
+        // in-plane neighbours in the reference's order: (a,b) over the two axes != comp, b-major (lines :37-44, :55-62, :73-80)
+#pragma unroll
+        for (int b = -1; b <= 1; ++b)
+#pragma unroll
+            for (int a = -1; a <= 1; ++a) {
+                if (a == 0 && b == 0) continue;
+                int ox, oy, oz;
+                if (comp == 0) { ox = 0; oy = a; oz = b; }
+                else if (comp == 1) { ox = a; oy = 0; oz = b; }
+                else { ox = a; oy = b; oz = 0; }
+                const int cx = x + ox, cy = y + oy, cz = z + oz;
+                const bool valid = mk(marker, g, cx, cy, cz) == CELL_FLUID ||
+                                   mk(marker, g, cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
+                if (valid) { numV += 1.0f; avgV += fv(vel[comp], g, cx, cy, cz); }
+            }
+        if (numV > 0.0f) vel[comp][c] = avgV / numV;
+    }
+}
+
+// ---- samplers (SamplerPointClamp / SamplerTrilinearClamp with exact f32 weights) -------------
+__device__ __forceinline__ float4 solid_point_clamp(const float4* __restrict__ solid, const Grid& g, float tx, float ty, float tz) {
+    const int x = min(max((int)floorf(tx * (float)g.nx), 0), g.nx - 1);
+    const int y = min(max((int)floorf(ty * (float)g.ny), 0), g.ny - 1);
+    const int z = min(max((int)floorf(tz * (float)g.nz), 0), g.nz - 1);
+    return solid[cidx(g, x, y, z)];
+}
+template <class Fetch>
+__device__ __forceinline__ float trilinear_clamp(const Grid& g, Fetch fetch, float tx, float ty, float tz) {
+    const float ux = tx * (float)g.nx - 0.5f, uy = ty * (float)g.ny - 0.5f, uz = tz * (float)g.nz - 0.5f;
+    const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
+    const float fx = ux - fx0, fy = uy - fy0, fz = uz - fz0;
+    const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+    const int xa = min(max(x0, 0), g.nx - 1), xb = min(max(x0 + 1, 0), g.nx - 1);
+    const int ya = min(max(y0, 0), g.ny - 1), yb = min(max(y0 + 1, 0), g.ny - 1);
+    const int za = min(max(z0, 0), g.nz - 1), zb = min(max(z0 + 1, 0), g.nz - 1);
+    const float c00 = mixf(fetch(xa, ya, za), fetch(xb, ya, za), fx), c10 = mixf(fetch(xa, yb, za), fetch(xb, yb, za), fx);
+    const float c01 = mixf(fetch(xa, ya, zb), fetch(xb, ya, zb), fx), c11 = mixf(fetch(xa, yb, zb), fetch(xb, yb, zb), fx);
+    return mixf(mixf(c00, c10, fy), mixf(c01, c11, fy), fz);
+}
+// advect_particles.comp:139-148 / density_projection_correct_particles.comp:51-60 (Q12: literal)
+__device__ __forceinline__ void truncate_step(const float* orig, const float* move, float* dir, float& max_step) {
+    const float len = sqrtf((move[0] * move[0] + move[1] * move[1]) + move[2] * move[2]) + 1e-10f;
+    float ms = len;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dir[k] = move[k] / len;
+        const float pic = fractf(orig[k]);
+        ms = fminf(ms, (dir[k] > 0.0f ? pic : 1.0f - pic) / fabsf(dir[k]) - 0.001f);
+    }
+    max_step = ms;
+}
+
+// =================================================================================================================
+// A1: advect_particles.comp:35-194 (G2P + APIC rows + RK4-in-cell + wall handling + marker / density list)
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, float dt, float4* __restrict__ pos, float4* __restrict__ pvx,
+                                                float4* __restrict__ pvy, float4* __restrict__ pvz, const float* __restrict__ vx,
+                                                const float* __restrict__ vy, const float* __restrict__ vz, const float4* __restrict__ solid,
+                                                int8_t* __restrict__ marker, uint32_t* __restrict__ heads) {
+    const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
+    if (pi >= num_particles) return;
+    const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
+    const float inv[3] = {1.0f / gs[0], 1.0f / gs[1], 1.0f / gs[2]};
+    const int dimm1[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
+    const float4 p0 = pos[pi];
+    float op[3] = {p0.x, p0.y, p0.z};
+    if (solid) {   // :46-65
+        const float4 cs = solid_point_clamp(solid, g, op[0] * inv[0], op[1] * inv[1], op[2] * inv[2]);
+        if (cs.w > 0.0f) {
+            const float ax = fabsf(cs.x), ay = fabsf(cs.y), az = fabsf(cs.z);
+            if (ax > ay) { if (ax > az) op[0] += signf(cs.x); else op[2] += signf(cs.z); }
+            else { if (ay > az) op[1] += signf(cs.y); else op[2] += signf(cs.z); }
+        }
+    }
+    float v[8][3], ipx[3], ipy[3], ipz[3];
+    const float* vel[3] = {vx, vy, vz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // :74-93
+        float o[3]; int lo[3], hi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o[k] = fmaxf(0.0f, op[k] - (k == i ? 1.0f : 0.5f)); lo[k] = (int)o[k]; hi[k] = min(lo[k] + 1, dimm1[k]); }
+        ipx[i] = fractf(o[0]); ipy[i] = fractf(o[1]); ipz[i] = fractf(o[2]);
+        const float* V = vel[i];
+        v[0][i] = fv(V, g, lo[0], lo[1], lo[2]); v[1][i] = fv(V, g, hi[0], lo[1], lo[2]);
+        v[2][i] = fv(V, g, lo[0], hi[1], lo[2]); v[3][i] = fv(V, g, hi[0], hi[1], lo[2]);
+        v[4][i] = fv(V, g, lo[0], lo[1], hi[2]); v[5][i] = fv(V, g, hi[0], lo[1], hi[2]);
+        v[6][i] = fv(V, g, lo[0], hi[1], hi[2]); v[7][i] = fv(V, g, hi[0], hi[1], hi[2]);
+    }
+    float nv[3], cx[3], cy[3], cz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // :97-112
+        const float x00 = mixf(v[0][i], v[1][i], ipx[i]), x01 = mixf(v[4][i], v[5][i], ipx[i]);
+        const float x10 = mixf(v[2][i], v[3][i], ipx[i]), x11 = mixf(v[6][i], v[7][i], ipx[i]);
+        const float xy0 = mixf(x00, x10, ipy[i]), xy1 = mixf(x01, x11, ipy[i]);
+        nv[i] = mixf(xy0, xy1, ipz[i]);
+        cx[i] = mixf(mixf(v[1][i], v[3][i], ipy[i]), mixf(v[5][i], v[7][i], ipy[i]), ipz[i]) -
+                mixf(mixf(v[0][i], v[2][i], ipy[i]), mixf(v[4][i], v[6][i], ipy[i]), ipz[i]);
+        cy[i] = mixf(x10, x11, ipz[i]) - mixf(x00, x01, ipz[i]);
+        cz[i] = xy1 - xy0;
+    }
+    auto tri = [&](const float* sx, const float* sy, const float* sz, float* out) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            out[i] = mixf(mixf(mixf(v[0][i], v[1][i], sx[i]), mixf(v[2][i], v[3][i], sx[i]), sy[i]),
+                          mixf(mixf(v[4][i], v[5][i], sx[i]), mixf(v[6][i], v[7][i], sx[i]), sy[i]), sz[i]);
+    };
+    float k2[3], k3[3], k4[3], st[3], sx[3], sy[3], sz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st[i] = dt * 0.5f * nv[i]; sx[i] = satf(ipx[i] + st[i]); sy[i] = satf(ipy[i] + st[i]); sz[i] = satf(ipz[i] + st[i]); }   // :117-119 (Q11)
+    tri(sx, sy, sz, k2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st[i] = dt * 0.5f * k2[i]; sx[i] = satf(ipx[i] + st[i]); sy[i] = satf(ipy[i] + st[i]); sz[i] = satf(ipz[i] + st[i]); }
+    tri(sx, sy, sz, k3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st[i] = dt * k3[i]; sx[i] = satf(ipx[i] + st[i]); sy[i] = satf(ipy[i] + st[i]); sz[i] = satf(ipz[i] + st[i]); }
+    tri(sx, sy, sz, k4);
+    float mv[3], np[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { mv[i] = dt * (1.0f / 6.0f) * (nv[i] + 2.0f * (k2[i] + k3[i]) + k4[i]); np[i] = op[i] + mv[i]; }   // :126-127
+    bool outside = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (clampf(np[k], 1.001f, gs[k] - 1.001f) != np[k]) outside = true;
+    const float tc[3] = {np[0] * inv[0], np[1] * inv[1], np[2] * inv[2]};
+    if (outside || (solid && solid_point_clamp(solid, g, tc[0], tc[1], tc[2]).w > 0.0f)) {   // :137-173
+        float dir[3], ms;
+        truncate_step(op, mv, dir, ms);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mv[k] = dir[k] * ms;
+        if ((int)op[0] == (int)np[0] && (int)op[1] == (int)np[1] && (int)op[2] == (int)np[2]) {   // :154
+            auto sw = [&](int ax, int ay, int az) -> float { return solid ? solid[cidx(g, ax, ay, az)].w : 0.0f; };
+            const float push[3] = {
+                trilinear_clamp(g, sw, tc[0] - inv[0], tc[1], tc[2]) - trilinear_clamp(g, sw, tc[0] + inv[0], tc[1], tc[2]),
+                trilinear_clamp(g, sw, tc[0], tc[1] - inv[1], tc[2]) - trilinear_clamp(g, sw, tc[0], tc[1] + inv[1], tc[2]),
+                trilinear_clamp(g, sw, tc[0], tc[1], tc[2] - inv[2]) - trilinear_clamp(g, sw, tc[0], tc[1], tc[2] + inv[2])};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) mv[k] += push[k] * (dt * 50.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { np[k] = op[k] + mv[k]; np[k] = clampf(np[k], 1.001f, gs[k] - 1.001f); nv[k] = (dir[k] * ms) / dt; }
+    }
+    // :176-181 marker + density list (dual cell = ivec3(pos - 0.5))
+    {
+        const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
+        if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
+    }
+    uint32_t old = 0;
+    {
+        const int dx = (int)(np[0] - 0.5f), dy = (int)(np[1] - 0.5f), dz = (int)(np[2] - 0.5f);
+        if (inb(g, dx, dy, dz)) old = atomicExch(heads + cidx(g, dx, dy, dz), pi + 1);
+    }
+    pos[pi] = make_float4(np[0], np[1], np[2], __uint_as_float(old - 1u));
+    pvx[pi] = make_float4(cx[0], cx[1], cx[2], nv[0]);   // :186-188 (Q2: literal row layout)
+    pvy[pi] = make_float4(cy[0], cy[1], cy[2], nv[1]);
+    pvz[pi] = make_float4(cz[0], cz[1], cz[2], nv[2]);
+}
+
+// =================================================================================================================
+// R1: density_projection_gather_error.comp:41-198 -- same LDS-staged 8-list walk, <=32 rounds, centre sample.
+// =================================================================================================================
+__global__ __launch_bounds__(768) void k_density_gather(Grid g, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                        const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
+    __shared__ float4 sPos[729];
+    const int tid = threadIdx.x;
+    const bool live = tid < 729;
+    const int lx = tid % 9, ly = (tid / 9) % 9, lz = tid / 81;
+    const int gx = blockIdx.x * 8 + lx - 1, gy = blockIdx.y * 8 + ly - 1, gz = blockIdx.z * 8 + lz - 1;
+    const bool in = live && inb(g, gx, gy, gz);
+    const bool border = !live || lx == 0 || ly == 0 || lz == 0;
+    const bool writes = !border && in && marker[cidx(g, gx, gy, gz)] == CELL_FLUID;   // :46
+    const float sx = (float)gx + 0.5f, sy = (float)gy + 0.5f, sz = (float)gz + 0.5f;
+    uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+    float density = 0.0f;
+    auto add = [&](const float4& p) {
+        const float ox = satf(1.0f - fabsf(sx - p.x)), oy = satf(1.0f - fabsf(sy - p.y)), oz = satf(1.0f - fabsf(sz - p.z));
+        density += ox * oy * oz;                                                          // :27-31
+    };
+    const int a1 = tid - 1, a2 = tid - 9, a3 = tid - 10, a4 = tid - 81, a5 = tid - 82, a6 = tid - 90, a7 = tid - 91;
+    for (int round = 0; round < 32; ++round) {                                            // :69
+        const bool has = cur != INVALID_LL;
+        if (!__syncthreads_or(has)) break;
+        if (has) {
+            const float4 p = pos[cur];
+            cur = __float_as_uint(p.w);
+            if (writes) add(p);
+            sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
+        } else if (live) {
+            sPos[tid].w = 0.0f;
+        }
+        __syncthreads();
+        if (writes) {
+            float4 q;
+            q = sPos[a1]; if (q.w != 0.0f) add(q);
+            q = sPos[a2]; if (q.w != 0.0f) add(q);
+            q = sPos[a3]; if (q.w != 0.0f) add(q);
+            q = sPos[a4]; if (q.w != 0.0f) add(q);
+            q = sPos[a5]; if (q.w != 0.0f) add(q);
+            q = sPos[a6]; if (q.w != 0.0f) add(q);
+            q = sPos[a7]; if (q.w != 0.0f) add(q);
+        }
+    }
+    if (!writes) return;
+    const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
+                      mk(marker, g, gx - 1, gy, gz), mk(marker, g, gx, gy - 1, gz), mk(marker, g, gx, gy, gz - 1)};   // :115-120
+    bool anyAir = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { if (m[k] == CELL_SOLID) density += 0.5625f; if (m[k] == CELL_AIR) anyAir = true; }   // :167-179
+    if (anyAir) density = fmaxf(8.0f, density);                                           // :182-184
+    density = 1.0f - density / 8.0f;                                                      // :188
+    density = clampf(density, -0.5f, 0.5f);                                               // :192
+    density /= dt;                                                                        // :196
+    residual[cidx(g, gx, gy, gz)] = density;
+}
+
+// =================================================================================================================
+// R2: density_projection_position_change.comp:18-51 (overwrites the velocity volumes with position deltas)
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_position_change(Grid g, const int8_t* __restrict__ marker, const float* __restrict__ p, float dt,
+                                                         float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    const int c = cidx(g, x, y, z);
+    const int mc = marker[c];
+    const float pc = (mc == CELL_FLUID) ? p[c] : 0.0f;
+    float* vel[3] = {vx, vy, vz};
+#pragma unroll
+    for (int comp = 0; comp < 3; ++comp) {
+        const int ax = x + (comp == 0), ay = y + (comp == 1), az = z + (comp == 2);
+        const int mn = mk(marker, g, ax, ay, az);
+        const float pn = (mn == CELL_FLUID) ? p[cidx(g, ax, ay, az)] : 0.0f;
+        float d = (pn - pc) * dt;
+        if (mc == CELL_SOLID || mn == CELL_SOLID) d = 0.0f;
+        vel[comp][c] = d;
+    }
+}
+
+// =================================================================================================================
+// R3: density_projection_correct_particles.comp:25-73
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles, float4* __restrict__ pos, const int8_t* __restrict__ marker,
+                                                 const float* __restrict__ vx, const float* __restrict__ vy, const float* __restrict__ vz) {
+    const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
+    if (pi >= num_particles) return;
+    const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
+    const float inv[3] = {1.0f / gs[0], 1.0f / gs[1], 1.0f / gs[2]};
+    const float4 p0 = pos[pi];
+    const float op[3] = {p0.x, p0.y, p0.z};
+    const float* vel[3] = {vx, vy, vz};
+    float ch[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float o[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = fmaxf(0.0f, op[k] - (k == c ? 0.5f : 0.0f));
+        const float* V = vel[c];
+        ch[c] = trilinear_clamp(g, [&](int ax, int ay, int az) -> float { return V[cidx(g, ax, ay, az)]; }, o[0] * inv[0], o[1] * inv[1], o[2] * inv[2]);
+    }
+    float np[3] = {op[0] + ch[0], op[1] + ch[1], op[2] + ch[2]};
+    bool outside = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (clampf(np[k], 1.001f, gs[k] - 1.001f) != np[k]) outside = true;
+    bool in_solid = false;
+    if (!outside) {
+        const int x = min(max((int)floorf(np[0] * inv[0] * gs[0]), 0), g.nx - 1);
+        const int y = min(max((int)floorf(np[1] * inv[1] * gs[1]), 0), g.ny - 1);
+        const int z = min(max((int)floorf(np[2] * inv[2] * gs[2]), 0), g.nz - 1);
+        in_solid = marker[cidx(g, x, y, z)] == CELL_SOLID;
+    }
+    if (outside || in_solid) {
+        float dir[3], ms;
+        truncate_step(op, ch, dir, ms);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { np[k] = op[k] + dir[k] * ms; np[k] = clampf(np[k], 1.001f, gs[k] - 1.001f); }
+    }
+    pos[pi] = make_float4(np[0], np[1], np[2], p0.w);
+}
+
+// =================================================================================================================
+// B1-B3: particle_binning_{count,prefixsum,rewrite_particles}.comp (hybrid_fluid.rs:857-893), "fixed" semantics (Q4):
+// guarded threads, 0-based destinations.  The scan is a deterministic three-phase wave-shuffle scan over the cell
+// counters (block totals -> scan of totals -> rescan + offset) instead of the reference's block scan + one global
+// atomic per block, so cells are laid out in linear-index order (a legal instance of the reference's "sloppy" order).
+// =================================================================================================================
+__global__ __launch_bounds__(256) void k_bin_count(Grid g, uint32_t num_particles, float4* __restrict__ pos, uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_particles) return;
+    const float4 p = pos[i];
+    const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
+    uint32_t slot = 0;
+    if (inb(g, x, y, z)) slot = atomicAdd(counters + cidx(g, x, y, z), 1u);
+    reinterpret_cast<uint32_t*>(pos)[4 * (size_t)i + 3] = slot;                         // particle_binning_count.comp:12
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+    return v;
+}
+constexpr int SCAN_ITEMS = 4;                 // u32 per thread (one uint4)
+constexpr int SCAN_BLOCK = 1024 * SCAN_ITEMS; // cells per 1024-thread block
+__global__ __launch_bounds__(1024) void k_scan_block_totals(const uint32_t* __restrict__ counters, int n, uint32_t* __restrict__ block_totals) {
+    __shared__ uint32_t sm[16];
+    const int base = (blockIdx.x * 1024 + threadIdx.x) * SCAN_ITEMS;
+    uint32_t v = 0;
+    if (base + 3 < n) { const uint4 c = *reinterpret_cast<const uint4*>(counters + base); v = c.x + c.y + c.z + c.w; }
+    else for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) v += counters[base + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += sm[w]; block_totals[blockIdx.x] = t; }
+}
+// single block: exclusive scan of the block totals in place (nblocks <= 1024*64)
+__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* __restrict__ block_totals, int nblocks) {
+    __shared__ uint32_t sm[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int start = 0; start < nblocks; start += 1024) {
+        const int i = start + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_totals[i] : 0u;
+        uint32_t inc = wave_inclusive_scan(v);
+        if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += sm[w];
+        const uint32_t c = carry;
+        if (i < nblocks) block_totals[i] = c + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + inc;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ counters, int n, const uint32_t* __restrict__ block_offsets) {
+    __shared__ uint32_t sm[16];
+    const int base = (blockIdx.x * 1024 + threadIdx.x) * SCAN_ITEMS;
+    uint32_t c[SCAN_ITEMS] = {0, 0, 0, 0};
+    if (base + 3 < n) { const uint4 q = *reinterpret_cast<const uint4*>(counters + base); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
+    else for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) c[k] = counters[base + k];
+    const uint32_t tsum = c[0] + c[1] + c[2] + c[3];
+    const uint32_t inc = wave_inclusive_scan(tsum);
+    if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t off = block_offsets[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += sm[w];
+    uint32_t run = off + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { run += c[k]; c[k] = run; }   // inclusive prefix (particle_binning_prefixsum.comp:35-57)
+    if (base + 3 < n) *reinterpret_cast<uint4*>(counters + base) = make_uint4(c[0], c[1], c[2], c[3]);
+    else for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) counters[base + k] = c[k];
+}
+__global__ __launch_bounds__(256) void k_bin_rewrite(Grid g, uint32_t num_particles, uint32_t max_particles, const float4* __restrict__ old_pos,
+                                                     float4* __restrict__ new_pos, const uint32_t* __restrict__ inclusive) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_particles) return;
+    const float4 p = old_pos[i];
+    const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
+    const uint32_t inc = inb(g, x, y, z) ? inclusive[cidx(g, x, y, z)] : 0u;
+    const uint32_t dst = inc - __float_as_uint(p.w) - 1u;                               // particle_binning_rewrite_particles.comp:15, 0-based (Q4)
+    if (dst < max_particles) new_pos[dst] = p;
+}
+
+}  // namespace blubk

@@ -1,0 +1,425 @@
+"""ctypes mirror of the reference's `HybridFluid` / `Scene` host surface over libblubhip.so.
+
+Names, argument meaning and error behaviour follow src/simulation/hybrid_fluid.rs and src/scene/mod.rs of the
+reference (cited per method) so that the parity tests read like tests of the reference type.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+VOLUMES = {"marker": 0, "linked_list": 1, "vel_x": 2, "vel_y": 3, "vel_z": 4, "pressure_velocity": 5,
+           "pressure_density": 6, "residual": 7, "search": 8, "aux": 9, "aux_temp": 10, "solid": 11}
+STAGES = {"transfer": 0, "divergence": 1, "solve_velocity": 2, "binning": 3, "project": 4, "advect": 5,
+          "density_gather": 6, "solve_density": 7, "position_change": 8, "correct": 9}
+STEP_ORDER = ["transfer", "divergence", "solve_velocity", "binning", "project", "advect", "density_gather",
+              "solve_density", "position_change", "correct"]
+PRECOND = {"zero": 0, "lod0": 1}
+BINNING = {"fixed": 0, "off": 2}
+SOLVER_VELOCITY, SOLVER_DENSITY = 0, 1
+MAX_CUBES = 64
+PROF_MAX = 48
+
+
+class BlubError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("blubhip error %d: %s" % (status, message))
+        self.status = status
+
+
+class _SolverConfig(C.Structure):
+    _fields_ = [("error_tolerance", C.c_float), ("max_num_iterations", C.c_int32), ("error_check_frequency", C.c_int32)]
+
+
+class _SolverStats(C.Structure):
+    _fields_ = [("error", C.c_float), ("iteration_count", C.c_int32)]
+
+
+class _FluidDesc(C.Structure):
+    _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("max_num_particles", C.c_uint32),
+                ("device", C.c_int32), ("precond_mode", C.c_uint32), ("binning_mode", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class SceneConfig(C.Structure):
+    """src/scene/mod.rs:19-43"""
+    _fields_ = [("gravity", C.c_float * 3), ("world_position", C.c_float * 3), ("grid_to_world_scale", C.c_float),
+                ("grid_dimension", C.c_uint32 * 3), ("max_num_particles", C.c_uint32), ("num_fluid_cubes", C.c_uint32),
+                ("cube_min", (C.c_float * 3) * MAX_CUBES), ("cube_max", (C.c_float * 3) * MAX_CUBES),
+                ("num_static_objects", C.c_uint32)]
+
+
+class _DeviceViews(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("particles_position_ll", "particles_velocity_x", "particles_velocity_y",
+                                          "particles_velocity_z", "velocity_x", "velocity_y", "velocity_z", "marker",
+                                          "pressure_from_velocity", "pressure_from_density", "stream")]
+
+
+class _ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class SolverConfig:
+    """pressure_solver.rs:57-62"""
+
+    def __init__(self, error_tolerance=0.1, max_num_iterations=32, error_check_frequency=4):
+        self.error_tolerance = error_tolerance
+        self.max_num_iterations = max_num_iterations
+        self.error_check_frequency = error_check_frequency
+
+
+class SolverStatisticSample:
+    """pressure_solver.rs:64-68"""
+
+    def __init__(self, error, iteration_count):
+        self.error = error
+        self.iteration_count = iteration_count
+
+    def __repr__(self):
+        return "SolverStatisticSample(error=%g, iteration_count=%d)" % (self.error, self.iteration_count)
+
+
+def default_simulation_delta(steps_per_second=120):
+    """simulation_controller.rs:33-39: Duration::from_nanos(1e9 / sps).as_secs_f32()"""
+    nanos = 1000 * 1000 * 1000 // steps_per_second
+    secs, sub = divmod(nanos, 1000 * 1000 * 1000)
+    return float(np.float32(secs) + np.float32(sub) / np.float32(1e9))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libblubhip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libblubhip.so (built in-tree by blub_amd/build.py). Raises if the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError("libblubhip.so is not built: run `python -m blub_amd.build` (there is no fallback path)")
+    L = C.CDLL(path)
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
+    sig = {
+        "blub_scene_load_json": (C.c_int, [C.c_char_p, C.POINTER(SceneConfig)]),
+        "blub_scene_parse_json": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(SceneConfig)]),
+        "blub_seed_fluid_cube": (C.c_int, [vp, u32, u32, vp, vp, vp, C.c_size_t, C.POINTER(u32)]),
+        "blub_fluid_create": (C.c_int, [C.POINTER(_FluidDesc), C.POINTER(vp)]),
+        "blub_fluid_create_from_scene": (C.c_int, [C.POINTER(SceneConfig), i32, C.POINTER(vp)]),
+        "blub_fluid_destroy": (None, [vp]),
+        "blub_last_error_string": (C.c_char_p, []),
+        "blub_version_string": (C.c_char_p, []),
+        "blub_fluid_add_fluid_cube": (C.c_int, [vp, vp, vp]),
+        "blub_fluid_set_gravity_grid": (C.c_int, [vp, vp]),
+        "blub_fluid_step": (C.c_int, [vp, f32]),
+        "blub_fluid_update_statistics": (C.c_int, [vp]),
+        "blub_fluid_synchronize": (C.c_int, [vp]),
+        "blub_fluid_set_solver_config": (C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
+        "blub_fluid_get_solver_config": (C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
+        "blub_fluid_solver_stats_count": (C.c_int, [vp, C.c_int]),
+        "blub_fluid_solver_stats_get": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(_SolverStats)]),
+        "blub_fluid_solver_stats_latest": (C.c_int, [vp, C.c_int, C.POINTER(_SolverStats)]),
+        "blub_fluid_set_rebinning_frequency": (C.c_int, [vp, u32]),
+        "blub_fluid_get_rebinning_frequency": (u32, [vp]),
+        "blub_fluid_num_particles": (u32, [vp]),
+        "blub_fluid_max_num_particles": (u32, [vp]),
+        "blub_fluid_grid_dimension": (C.c_int, [vp, vp]),
+        "blub_fluid_step_counter": (u32, [vp]),
+        "blub_fluid_set_step_counter": (C.c_int, [vp, u32]),
+        "blub_fluid_get_device_views": (C.c_int, [vp, C.POINTER(_DeviceViews)]),
+        "blub_fluid_set_solid_voxels": (C.c_int, [vp, vp]),
+        "blub_fluid_set_particles": (C.c_int, [vp, u32, vp, vp, vp, vp]),
+        "blub_fluid_get_particles": (C.c_int, [vp, vp, vp, vp, vp]),
+        "blub_fluid_volume_bytes": (C.c_size_t, [vp, C.c_int]),
+        "blub_fluid_read_volume": (C.c_int, [vp, C.c_int, vp]),
+        "blub_fluid_write_volume": (C.c_int, [vp, C.c_int, vp]),
+        "blub_fluid_mark_pressure_initialised": (C.c_int, [vp, C.c_int, C.c_int]),
+        "blub_fluid_run_stage": (C.c_int, [vp, C.c_int, f32]),
+        "blub_fluid_profile_enable": (C.c_int, [vp, C.c_int]),
+        "blub_fluid_profile_reset": (C.c_int, [vp]),
+        "blub_fluid_profile_read": (C.c_int, [vp, C.POINTER(_ProfEntry), C.c_int, C.POINTER(C.c_int)]),
+        "blub_fluid_total_solver_iterations": (C.c_uint64, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError = a symbol declared in include/blubhip.h is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = None  # filled lazily by tests from include/blubhip.h
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(L, rc):
+    if rc != 0:
+        raise BlubError(rc, L.blub_last_error_string().decode("utf-8", "replace"))
+
+
+def _vol_dtype(which):
+    return {0: np.int8, 1: np.uint32}.get(which, np.float32)
+
+
+def seed_fluid_cube(grid_dim, max_num_particles, num_particles_before, min_grid, max_grid):
+    """Host-only: the particle generator of HybridFluid::add_fluid_cube (hybrid_fluid.rs:609-678)."""
+    L = load_library()
+    dim = np.asarray(grid_dim, np.uint32)
+    mn = np.asarray(min_grid, np.float32)
+    mx = np.asarray(max_grid, np.float32)
+    cnt = C.c_uint32()
+    _check(L, L.blub_seed_fluid_cube(_ptr(dim), max_num_particles, num_particles_before, _ptr(mn), _ptr(mx), None, 0, C.byref(cnt)))
+    out = np.zeros((cnt.value, 4), np.float32)
+    if cnt.value:
+        _check(L, L.blub_seed_fluid_cube(_ptr(dim), max_num_particles, num_particles_before, _ptr(mn), _ptr(mx), _ptr(out), cnt.value, C.byref(cnt)))
+    return out
+
+
+class HybridFluid:
+    """src/simulation/hybrid_fluid.rs `HybridFluid` on an MI355X."""
+
+    PARTICLES_PER_GRID_CELL = 8  # hybrid_fluid.rs:90
+
+    def __init__(self, grid_dimension, max_num_particles, device=-1, precond="zero", binning="fixed", _handle=None):
+        """HybridFluid::new (hybrid_fluid.rs:92-100). grid_dimension = (x, y, z)."""
+        self._L = load_library()
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            d = _FluidDesc(int(grid_dimension[0]), int(grid_dimension[1]), int(grid_dimension[2]), int(max_num_particles),
+                           int(device), PRECOND[precond], BINNING[binning], 0)
+            _check(self._L, self._L.blub_fluid_create(C.byref(d), C.byref(self._h)))
+        dim = (C.c_uint32 * 3)()
+        _check(self._L, self._L.blub_fluid_grid_dimension(self._h, dim))
+        self.nx, self.ny, self.nz = int(dim[0]), int(dim[1]), int(dim[2])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.blub_fluid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference surface ------------------------------------------------------------------------------------
+    def add_fluid_cube(self, min_grid, max_grid):
+        """hybrid_fluid.rs:620 (grid space)"""
+        a = np.asarray(min_grid, np.float32)
+        b = np.asarray(max_grid, np.float32)
+        _check(self._L, self._L.blub_fluid_add_fluid_cube(self._h, _ptr(a), _ptr(b)))
+
+    def set_gravity_grid(self, gravity):
+        """hybrid_fluid.rs:692"""
+        g = np.asarray(gravity, np.float32)
+        _check(self._L, self._L.blub_fluid_set_gravity_grid(self._h, _ptr(g)))
+
+    def step(self, simulation_delta):
+        """hybrid_fluid.rs:770 -- enqueues one step (asynchronous)."""
+        _check(self._L, self._L.blub_fluid_step(self._h, float(simulation_delta)))
+
+    def update_statistics(self):
+        """hybrid_fluid.rs:765"""
+        _check(self._L, self._L.blub_fluid_update_statistics(self._h))
+
+    def synchronize(self):
+        _check(self._L, self._L.blub_fluid_synchronize(self._h))
+
+    def _get_cfg(self, which):
+        c = _SolverConfig()
+        _check(self._L, self._L.blub_fluid_get_solver_config(self._h, which, C.byref(c)))
+        return SolverConfig(c.error_tolerance, c.max_num_iterations, c.error_check_frequency)
+
+    def set_solver_config(self, which, cfg=None, **kw):
+        cur = self._get_cfg(which) if cfg is None else cfg
+        for k, v in kw.items():
+            setattr(cur, k, v)
+        c = _SolverConfig(float(cur.error_tolerance), int(cur.max_num_iterations), int(cur.error_check_frequency))
+        _check(self._L, self._L.blub_fluid_set_solver_config(self._h, which, C.byref(c)))
+
+    def pressure_solver_config_velocity(self):
+        """hybrid_fluid.rs:743"""
+        return self._get_cfg(SOLVER_VELOCITY)
+
+    def pressure_solver_config_density(self):
+        """hybrid_fluid.rs:747"""
+        return self._get_cfg(SOLVER_DENSITY)
+
+    def _stats(self, which):
+        n = self._L.blub_fluid_solver_stats_count(self._h, which)
+        out = []
+        for i in range(n):
+            s = _SolverStats()
+            _check(self._L, self._L.blub_fluid_solver_stats_get(self._h, which, i, C.byref(s)))
+            out.append(SolverStatisticSample(s.error, s.iteration_count))
+        return out
+
+    def pressure_solver_stats_velocity(self):
+        """hybrid_fluid.rs:755"""
+        return self._stats(SOLVER_VELOCITY)
+
+    def pressure_solver_stats_density(self):
+        """hybrid_fluid.rs:759"""
+        return self._stats(SOLVER_DENSITY)
+
+    @property
+    def particle_rebinning_step_frequency(self):
+        """dynamic_settings(), hybrid_fluid.rs:751"""
+        return int(self._L.blub_fluid_get_rebinning_frequency(self._h))
+
+    @particle_rebinning_step_frequency.setter
+    def particle_rebinning_step_frequency(self, v):
+        _check(self._L, self._L.blub_fluid_set_rebinning_frequency(self._h, int(v)))
+
+    def num_particles(self):
+        """hybrid_fluid.rs:696"""
+        return int(self._L.blub_fluid_num_particles(self._h))
+
+    def grid_dimension(self):
+        """hybrid_fluid.rs:727"""
+        return (self.nx, self.ny, self.nz)
+
+    def bind_group_renderer(self):
+        """hybrid_fluid.rs:723 -- device pointers instead of a wgpu bind group."""
+        v = _DeviceViews()
+        _check(self._L, self._L.blub_fluid_get_device_views(self._h, C.byref(v)))
+        return {n: getattr(v, n) for n, _ in _DeviceViews._fields_}
+
+    # ---- state exchange / test hooks ---------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return (self.nz, self.ny, self.nx)
+
+    @property
+    def step_counter(self):
+        return int(self._L.blub_fluid_step_counter(self._h))
+
+    @step_counter.setter
+    def step_counter(self, v):
+        _check(self._L, self._L.blub_fluid_set_step_counter(self._h, int(v)))
+
+    def set_particles(self, pos, vx=None, vy=None, vz=None, keep_ll=False):
+        pos = np.asarray(pos, np.float32)
+        n = pos.shape[0]
+        p4 = np.zeros((n, 4), np.float32)
+        p4[:, :3] = pos[:, :3]
+        if keep_ll:
+            p4[:, 3] = pos[:, 3]
+        else:
+            p4.view(np.uint32)[:, 3] = 0xFFFFFFFF
+        vs = [None if v is None else np.ascontiguousarray(v, np.float32) for v in (vx, vy, vz)]
+        _check(self._L, self._L.blub_fluid_set_particles(self._h, n, _ptr(p4), *[_ptr(v) for v in vs]))
+
+    def get_particles(self):
+        n = self.num_particles()
+        out = [np.zeros((n, 4), np.float32) for _ in range(4)]
+        _check(self._L, self._L.blub_fluid_get_particles(self._h, *[_ptr(o) for o in out]))
+        return out
+
+    def read_volume(self, name):
+        which = VOLUMES[name]
+        shape = self.shape + ((4,) if which == 11 else ())
+        out = np.zeros(shape, _vol_dtype(which))
+        _check(self._L, self._L.blub_fluid_read_volume(self._h, which, _ptr(out)))
+        return out
+
+    def write_volume(self, name, arr):
+        which = VOLUMES[name]
+        if arr is None:
+            _check(self._L, self._L.blub_fluid_write_volume(self._h, which, None))
+            return
+        a = np.ascontiguousarray(arr, _vol_dtype(which))
+        assert a.size == self.nx * self.ny * self.nz * (4 if which == 11 else 1)
+        _check(self._L, self._L.blub_fluid_write_volume(self._h, which, _ptr(a)))
+
+    def set_solid_voxels(self, vox):
+        self.write_volume("solid", vox)
+
+    def mark_pressure_initialised(self, which, initialised=True):
+        _check(self._L, self._L.blub_fluid_mark_pressure_initialised(self._h, which, int(bool(initialised))))
+
+    def run_stage(self, name, simulation_delta):
+        _check(self._L, self._L.blub_fluid_run_stage(self._h, STAGES[name], float(simulation_delta)))
+
+    def solver_stats(self, which):
+        """Latest completed sample as (error, iterations); blocks until the stream is idle."""
+        self.synchronize()
+        s = _SolverStats()
+        _check(self._L, self._L.blub_fluid_solver_stats_latest(self._h, which, C.byref(s)))
+        return s.error, s.iteration_count
+
+    def total_solver_iterations(self):
+        return int(self._L.blub_fluid_total_solver_iterations(self._h))
+
+    def profile_enable(self, enabled=True):
+        _check(self._L, self._L.blub_fluid_profile_enable(self._h, int(bool(enabled))))
+
+    def profile_reset(self):
+        _check(self._L, self._L.blub_fluid_profile_reset(self._h))
+
+    def profile_read(self):
+        ents = (_ProfEntry * PROF_MAX)()
+        n = C.c_int()
+        _check(self._L, self._L.blub_fluid_profile_read(self._h, ents, PROF_MAX, C.byref(n)))
+        return {ents[i].name.decode(): {"launches": int(ents[i].launches), "total_ms": float(ents[i].total_ms)} for i in range(n.value)}
+
+
+class Scene:
+    """src/scene/mod.rs `Scene` reduced to what the hot path needs: JSON -> HybridFluid (:56-144) and step (:166-213)."""
+
+    def __init__(self, path=None, text=None, device=-1, config=None):
+        self._L = load_library()
+        self.config = SceneConfig() if config is None else config
+        if path is not None:
+            _check(self._L, self._L.blub_scene_load_json(os.fsencode(path), C.byref(self.config)))
+        elif text is not None:
+            b = text.encode() if isinstance(text, str) else text
+            _check(self._L, self._L.blub_scene_parse_json(b, len(b), C.byref(self.config)))
+        self._device = device
+        self._fluid = None
+
+    @staticmethod
+    def parse(path=None, text=None):
+        """Host-only parse (no GPU needed)."""
+        s = Scene.__new__(Scene)
+        s._L = load_library()
+        s.config = SceneConfig()
+        if path is not None:
+            _check(s._L, s._L.blub_scene_load_json(os.fsencode(path), C.byref(s.config)))
+        else:
+            b = text.encode() if isinstance(text, str) else text
+            _check(s._L, s._L.blub_scene_parse_json(b, len(b), C.byref(s.config)))
+        s._device = -1
+        s._fluid = None
+        return s
+
+    def fluid(self):
+        """scene/mod.rs:216; created lazily by create_fluid_from_config (:109-144)."""
+        if self._fluid is None:
+            h = C.c_void_p()
+            _check(self._L, self._L.blub_fluid_create_from_scene(C.byref(self.config), self._device, C.byref(h)))
+            self._fluid = HybridFluid(None, None, _handle=h)
+        return self._fluid
+
+    def reset(self):
+        """scene/mod.rs:146"""
+        if self._fluid is not None:
+            self._fluid.close()
+            self._fluid = None
+        return self.fluid()
+
+    def step(self, simulation_delta):
+        """scene/mod.rs:166-213: HybridFluid::step, submit, update_statistics."""
+        f = self.fluid()
+        f.step(simulation_delta)
+        f.update_statistics()

@@ -1,0 +1,203 @@
+/* blubhip.h -- C-ABI of the MI355X-native APIC fluid-step engine (libblubhip.so).
+ *
+ * This is the drop-in boundary for blub's `HybridFluid` (reference: src/simulation/mod.rs:4-5 re-exports
+ * `HybridFluid`, `SolverConfig`, `SolverStatisticSample`).  The reference has no FFI layer -- the Rust struct is the
+ * boundary -- so every entry point below names the Rust method it replaces (file:line relative to /root/reference).
+ * A Rust `HybridFluid` shim binding these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns BLUB_OK (0) or a negative blub_status and never
+ * throws/aborts; one handle = one HIP stream = one host thread at a time (the reference type is !Send);
+ * grid space everywhere (cells), x fastest, index = (z*ny + y)*nx + x; all reals f32.
+ * `blub_fluid_step` only ENQUEUES work on the handle's stream (the reference only records into the caller's command
+ * encoder, hybrid_fluid.rs:770-977); call blub_fluid_synchronize / blub_fluid_update_statistics afterwards.
+ */
+#ifndef BLUBHIP_H
+#define BLUBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct blub_fluid blub_fluid; /* opaque; owns every particle buffer and grid volume (hybrid_fluid.rs:24-72) */
+
+typedef enum blub_status {
+    BLUB_OK = 0,
+    BLUB_ERR_INVALID_ARGUMENT = -1,
+    BLUB_ERR_UNSUPPORTED = -2,      /* e.g. nx not a multiple of 4, N <= 16384 (pressure_solver.rs:551 asserts the same) */
+    BLUB_ERR_OUT_OF_MEMORY = -3,
+    BLUB_ERR_DEVICE = -4,           /* a HIP call failed; blub_last_error_string() has the text */
+    BLUB_ERR_IO = -5,               /* scene file unreadable */
+    BLUB_ERR_PARSE = -6,            /* scene JSON malformed / missing field */
+    BLUB_ERR_NO_DEVICE = -7,        /* no HIP device: there is NO CPU fallback in this library */
+    BLUB_ERR_COMM = -8              /* RCCL failure */
+} blub_status;
+
+/* hybrid_fluid.glsl:20-22 (R8Snorm marker values) */
+enum { BLUB_CELL_SOLID = 0, BLUB_CELL_FLUID = 1, BLUB_CELL_AIR = -1 };
+/* hybrid_fluid.rs:90 */
+enum { BLUB_PARTICLES_PER_GRID_CELL = 8 };
+
+typedef enum blub_solver { BLUB_SOLVER_VELOCITY = 0, BLUB_SOLVER_DENSITY = 1 } blub_solver; /* hybrid_fluid.rs:259-260 */
+
+/* pressure_solver.rs:57-62 `SolverConfig` (defaults hybrid_fluid.rs:253-257: 0.1 / 32 / 4) */
+typedef struct blub_solver_config {
+    float error_tolerance;
+    int32_t max_num_iterations;
+    int32_t error_check_frequency;
+} blub_solver_config;
+
+/* pressure_solver.rs:64-68 `SolverStatisticSample`; error = max|r| * dt (pressure_solver.rs:162) */
+typedef struct blub_solver_stats {
+    float error;
+    int32_t iteration_count;
+} blub_solver_stats;
+
+/* Reference quirks that need an explicit switch. Zero-initialised = parity defaults. */
+typedef enum blub_precond_mode {
+    BLUB_PRECOND_ZERO = 0, /* Q1: neighbour texelFetch at lod 1 returns 0 => z = (r/d)/d   (parity default) */
+    BLUB_PRECOND_LOD0 = 1  /* Q1: neighbour fetches clamp to lod 0 (literal two-pass stencil) */
+} blub_precond_mode;
+typedef enum blub_binning_mode {
+    BLUB_BINNING_FIXED = 0, /* Q4: guarded, 0-based permutation (default) */
+    BLUB_BINNING_OFF = 2    /* never rebin */
+} blub_binning_mode;
+
+typedef struct blub_fluid_desc {
+    uint32_t nx, ny, nz;           /* grid_dimension  (hybrid_fluid.rs:94) */
+    uint32_t max_num_particles;    /* hybrid_fluid.rs:95 */
+    int32_t device;                /* HIP device ordinal; -1 = current device */
+    uint32_t precond_mode;         /* blub_precond_mode */
+    uint32_t binning_mode;         /* blub_binning_mode */
+    uint32_t reserved;
+} blub_fluid_desc;
+
+/* ---- scene JSON: src/scene/mod.rs:19-43 (SceneConfig / FluidConfig / Box) -- host only, no device needed -------- */
+enum { BLUB_SCENE_MAX_CUBES = 64 };
+typedef struct blub_scene_config {
+    float gravity[3];              /* world space */
+    float world_position[3];
+    float grid_to_world_scale;
+    uint32_t grid_dimension[3];
+    uint32_t max_num_particles;
+    uint32_t num_fluid_cubes;
+    float cube_min[BLUB_SCENE_MAX_CUBES][3]; /* world space */
+    float cube_max[BLUB_SCENE_MAX_CUBES][3];
+    uint32_t num_static_objects;   /* parsed for diagnostics only: static objects / voxelisation are out of scope */
+} blub_scene_config;
+
+int blub_scene_load_json(const char* path, blub_scene_config* out);              /* Scene::new, scene/mod.rs:64-66 */
+int blub_scene_parse_json(const char* text, size_t len, blub_scene_config* out);
+/* Host-side restatement of HybridFluid::add_fluid_cube's particle generator (hybrid_fluid.rs:609-678): writes
+ * `count` ParticlePositionLl records (x,y,z,0xFFFFFFFF) for a cube given in GRID space when the fluid already holds
+ * `num_particles_before` particles. *count_out = number generated (truncated to capacity like :627-633). */
+int blub_seed_fluid_cube(const uint32_t grid_dim[3], uint32_t max_num_particles, uint32_t num_particles_before,
+                         const float min_grid[3], const float max_grid[3], float* pos_ll_out, size_t capacity,
+                         uint32_t* count_out);
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+int blub_fluid_create(const blub_fluid_desc* desc, blub_fluid** out);             /* HybridFluid::new, hybrid_fluid.rs:92-607 */
+/* Scene::create_fluid_from_config, scene/mod.rs:109-144: new + add_fluid_cube(cube/scale) for every cube +
+ * set_gravity_grid(gravity/scale) */
+int blub_fluid_create_from_scene(const blub_scene_config* scene, int32_t device, blub_fluid** out);
+void blub_fluid_destroy(blub_fluid* h);
+const char* blub_last_error_string(void);
+const char* blub_version_string(void);
+
+/* ---- HybridFluid surface -------------------------------------------------------------------------------------- */
+int blub_fluid_add_fluid_cube(blub_fluid* h, const float min_grid[3], const float max_grid[3]);      /* hybrid_fluid.rs:620 */
+int blub_fluid_set_gravity_grid(blub_fluid* h, const float gravity_grid[3]);                         /* :692 */
+int blub_fluid_step(blub_fluid* h, float simulation_delta_seconds);                                  /* :770 (dt = Duration::as_secs_f32) */
+int blub_fluid_update_statistics(blub_fluid* h);                                                     /* :765; non-blocking poll */
+int blub_fluid_synchronize(blub_fluid* h);                                                           /* device.poll(Wait), scene/mod.rs:142 */
+int blub_fluid_set_solver_config(blub_fluid* h, int which, const blub_solver_config* cfg);           /* :743-749 */
+int blub_fluid_get_solver_config(const blub_fluid* h, int which, blub_solver_config* cfg);
+/* pressure_solver_stats_{velocity,density}(): history of <= 100 samples (pressure_solver.rs:101), oldest first */
+int blub_fluid_solver_stats_count(const blub_fluid* h, int which);                                   /* :755-761 */
+int blub_fluid_solver_stats_get(const blub_fluid* h, int which, int index, blub_solver_stats* out);
+int blub_fluid_solver_stats_latest(const blub_fluid* h, int which, blub_solver_stats* out);
+int blub_fluid_set_rebinning_frequency(blub_fluid* h, uint32_t every_n_steps);                       /* dynamic_settings(), :751, 19-22 */
+uint32_t blub_fluid_get_rebinning_frequency(const blub_fluid* h);
+uint32_t blub_fluid_num_particles(const blub_fluid* h);                                              /* :696 */
+uint32_t blub_fluid_max_num_particles(const blub_fluid* h);
+int blub_fluid_grid_dimension(const blub_fluid* h, uint32_t dim_out[3]);                             /* :727 */
+uint32_t blub_fluid_step_counter(const blub_fluid* h);
+int blub_fluid_set_step_counter(blub_fluid* h, uint32_t c);
+
+/* bind_group_renderer(), hybrid_fluid.rs:700-723 + shader/fluid_render_info.glsl:11-23: device pointers, read-only
+ * for the caller, valid until destroy. */
+typedef struct blub_device_views {
+    const void* particles_position_ll;  /* float4 {x,y,z, u32 linked_list_next} */
+    const void* particles_velocity_x;   /* float4 {C row xyz, v_x}   (particles.glsl:13-15) */
+    const void* particles_velocity_y;
+    const void* particles_velocity_z;
+    const void* velocity_x;             /* f32 volumes, staggered on the positive faces */
+    const void* velocity_y;
+    const void* velocity_z;
+    const void* marker;                 /* int8 volume */
+    const void* pressure_from_velocity; /* f32 */
+    const void* pressure_from_density;  /* f32 */
+    void* stream;                       /* hipStream_t the engine enqueues on */
+} blub_device_views;
+int blub_fluid_get_device_views(const blub_fluid* h, blub_device_views* out);
+
+/* Stand-in for the borrowed `SceneVoxelization` RGBA16F volume (scene/voxelization.rs:17, hybrid_fluid.rs:266):
+ * N float4 {solid velocity xyz, solid flag w} or NULL for the all-zero volume every BASELINE scene has. */
+int blub_fluid_set_solid_voxels(blub_fluid* h, const float* voxels_xyzw_or_null);
+
+/* ---- state exchange (parity tests, checkpoint/resume) ---------------------------------------------------------- */
+int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz);
+int blub_fluid_get_particles(blub_fluid* h, float* pos_ll, float* vx, float* vy, float* vz); /* any may be NULL; blocks */
+
+typedef enum blub_volume {
+    BLUB_VOLUME_MARKER = 0,            /* int8   */
+    BLUB_VOLUME_LINKED_LIST = 1,       /* uint32 (list heads of component x / density, or binning counters) */
+    BLUB_VOLUME_VELOCITY_X = 2, BLUB_VOLUME_VELOCITY_Y = 3, BLUB_VOLUME_VELOCITY_Z = 4,
+    BLUB_VOLUME_PRESSURE_VELOCITY = 5, BLUB_VOLUME_PRESSURE_DENSITY = 6,
+    BLUB_VOLUME_RESIDUAL = 7, BLUB_VOLUME_SEARCH = 8, BLUB_VOLUME_AUX = 9, BLUB_VOLUME_AUX_TEMP = 10,
+    BLUB_VOLUME_SOLID = 11             /* float4 */
+} blub_volume;
+size_t blub_fluid_volume_bytes(const blub_fluid* h, int which);
+int blub_fluid_read_volume(blub_fluid* h, int which, void* host_out);        /* blocks */
+int blub_fluid_write_volume(blub_fluid* h, int which, const void* host_in);  /* blocks */
+int blub_fluid_mark_pressure_initialised(blub_fluid* h, int which, int initialised); /* pressure_solver.rs:601-603 */
+
+/* The rows of HybridFluid::step in recorded order; blub_fluid_step == all of them in sequence
+ * (+ BINNING every rebinning_frequency steps).  Exposed so that each stage can be compared with the oracle on
+ * identical inputs. */
+typedef enum blub_stage {
+    BLUB_STAGE_TRANSFER = 0,        /* hybrid_fluid.rs:806-833: clear + linked lists + boundary marker + gather x/y/z */
+    BLUB_STAGE_DIVERGENCE = 1,      /* :836-840 */
+    BLUB_STAGE_SOLVE_VELOCITY = 2,  /* :843-852 */
+    BLUB_STAGE_BINNING = 3,         /* :857-893 */
+    BLUB_STAGE_PROJECT = 4,         /* :906-914 divergence_remove + extrapolate_velocity */
+    BLUB_STAGE_ADVECT = 5,          /* :916-932 clear + advect_particles + boundary marker */
+    BLUB_STAGE_DENSITY_GATHER = 6,  /* :933-937 */
+    BLUB_STAGE_SOLVE_DENSITY = 7,   /* :940-949 */
+    BLUB_STAGE_POSITION_CHANGE = 8, /* :960-967 position_change + extrapolate_velocity */
+    BLUB_STAGE_CORRECT = 9,         /* :969-973 */
+    BLUB_STAGE_COUNT = 10
+} blub_stage;
+int blub_fluid_run_stage(blub_fluid* h, int stage, float simulation_delta_seconds);
+
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+/* Per-stage / per-kernel-class device time, measured with hipEvents on the handle's own stream. When profiling is
+ * enabled every kernel class launch is bracketed by events (adds host overhead; do not time steps/s with it on). */
+enum { BLUB_PROF_MAX_ENTRIES = 48 };
+typedef struct blub_prof_entry {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} blub_prof_entry;
+int blub_fluid_profile_enable(blub_fluid* h, int enabled);
+int blub_fluid_profile_reset(blub_fluid* h);
+int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacity, int* count_out); /* blocks */
+/* Total PCG iterations executed (sum of reported iteration counts) since creation, both solvers. */
+uint64_t blub_fluid_total_solver_iterations(const blub_fluid* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLUBHIP_H */
