@@ -96,7 +96,8 @@ def cpu_baseline(scene_path, dt, budget_steps=2):
         o.step(dt)
     el = time.perf_counter() - t0
     it1, s1 = o.solver_totals()
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    from oracle.oracle import num_threads
+    threads = num_threads()
     return {"value": round(budget_steps / el, 4), "unit": "steps/s", "cores": threads, "kind": "port",
             "sample": "%d steps of the same scene after 1 warm-up step (oracle/libbluboracle.so, OpenMP, %d threads)" % (budget_steps, threads),
             "pcg_iters_per_sec": round((it1 - it0) / max(s1 - s0, 1e-9), 2)}

@@ -26,6 +26,9 @@
 #include <cstring>
 #include <deque>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace {
 
@@ -713,6 +716,19 @@ void orc_run_stage(void* h, int stage, float dt) { ((Oracle*)h)->run_stage(stage
 void orc_step(void* h, float dt) { ((Oracle*)h)->step(dt); }
 void orc_get_solver_stats(void* h, int which, float* err, int* it) { *err = ((Oracle*)h)->last_stats[which].error; *it = ((Oracle*)h)->last_stats[which].iterations; }
 void orc_get_solver_totals(void* h, uint64_t* iters, double* seconds) { *iters = ((Oracle*)h)->solver_iterations_total; *seconds = ((Oracle*)h)->solver_seconds_total; }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+    (void)n;
+}
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 // RNG known-answer hooks (tests/test_oracle_kat.py)
 void orc_rng_from_seed(const uint8_t* seed32, uint64_t* out, int n) { Oracle::SmallRng r; r.from_seed_bytes(seed32); for (int i = 0; i < n; ++i) out[i] = r.next_u64(); }
 void orc_rng_seed_from_u64(uint64_t seed, uint64_t* state4, float* out, int n) { Oracle::SmallRng r; r.seed_from_u64(seed); for (int k = 0; k < 4; ++k) state4[k] = r.s[k]; for (int i = 0; i < n; ++i) out[i] = r.gen_f32(); }

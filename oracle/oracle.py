@@ -65,8 +65,34 @@ def _load():
         L.orc_get_solver_totals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rng_from_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_rng_seed_from_u64.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_set_num_threads.restype = None
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_get_max_threads.restype = C.c_int
+        L.orc_set_num_threads(usable_cpus())
         _lib = L
     return _lib
+
+
+def usable_cpus(cap=32):
+    """CPUs this process may really use: affinity mask and cgroup quota (OpenMP's default = all logical CPUs of the host
+    oversubscribes badly inside a CPU-limited container)."""
+    if "OMP_NUM_THREADS" in os.environ:
+        try:
+            return max(1, int(os.environ["OMP_NUM_THREADS"]))
+        except ValueError:
+            pass
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def num_threads():
+    return int(_load().orc_get_max_threads())
 
 
 def _ptr(a):

@@ -1,0 +1,96 @@
+"""CPU-side checks of the product boundary: the C-ABI library loads, exports every symbol include/blubhip.h declares,
+and its host-only logic (scene JSON, particle seeding, error behaviour) matches the reference's rules. No GPU calls."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import blub_amd
+from blub_amd.hybrid_fluid import BlubError
+from oracle.oracle import Oracle
+from tests.conftest import ROOT, has_gpu
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "blubhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(blub_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    lib = ctypes.CDLL(blub_amd.lib_path())
+    names = declared_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), "libblubhip.so does not export %s" % n
+    blub_amd.load_library()
+
+
+def test_scene_json_matches_reference_schema(tmp_path):
+    s = blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", "double_dam.json")).config
+    assert list(s.grid_dimension) == [128, 64, 64] and s.max_num_particles == 2000000 and s.num_fluid_cubes == 2
+    assert np.float32(s.grid_to_world_scale) == np.float32(0.01)
+    assert np.allclose(list(s.gravity), [0, -9.81, 0]) and np.allclose(list(s.cube_min[1]), [0.96, 0, 0])
+    # static_objects is #[serde(default)]
+    txt = json.dumps({"gravity": {"x": 0, "y": -1, "z": 0}, "static_objects": [{"a": 1}, {"b": [1, 2, {"c": "d\\n"}]}],
+                      "fluid": {"world_position": {"x": 0, "y": 0, "z": 0}, "grid_to_world_scale": 1e-2, "max_num_particles": 10,
+                                "grid_dimension": {"x": 32, "y": 32, "z": 32}, "fluid_cubes": []}})
+    c = blub_amd.Scene.parse(text=txt).config
+    assert c.num_static_objects == 2 and c.num_fluid_cubes == 0
+
+
+@pytest.mark.parametrize("mutate,status", [
+    (lambda d: d.pop("gravity"), -6), (lambda d: d["fluid"].pop("grid_dimension"), -6),
+    (lambda d: d["fluid"].__setitem__("max_num_particles", -3), -6), (lambda d: d["fluid"]["fluid_cubes"].append({"min": {"x": 0}}), -6)])
+def test_scene_json_errors(mutate, status):
+    d = json.load(open(os.path.join(ROOT, "scenes", "dam_halfhalf.json")))
+    mutate(d)
+    with pytest.raises(BlubError) as e:
+        blub_amd.Scene.parse(text=json.dumps(d))
+    assert e.value.status == status
+    with pytest.raises(BlubError) as e:
+        blub_amd.Scene.parse(text="{ not json")
+    assert e.value.status == -6
+    with pytest.raises(BlubError) as e:
+        blub_amd.Scene.parse(path="/nonexistent/scene.json")
+    assert e.value.status == -5
+
+
+@pytest.mark.parametrize("scene,expect", [("single_cell_debug", 8), ("dam_halfhalf", 1218672), ("double_dam", 1199328),
+                                          ("corner_dams_128", 111600), ("corner_dams_256", 968688)])
+def test_product_seeding_equals_oracle_bitwise(scene, expect):
+    c = blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", scene + ".json")).config
+    dim = list(c.grid_dimension)
+    o = Oracle(dim[0], dim[1], dim[2], c.max_num_particles)
+    scale = np.float32(c.grid_to_world_scale)
+    parts, total = [], 0
+    for i in range(c.num_fluid_cubes):
+        mn, mx = np.float32(list(c.cube_min[i])) / scale, np.float32(list(c.cube_max[i])) / scale
+        p = blub_amd.seed_fluid_cube(dim, c.max_num_particles, total, mn, mx)
+        total += len(p)
+        parts.append(p)
+        o.add_fluid_cube(mn, mx)
+    assert total == expect == o.num_particles
+    got = np.concatenate(parts)
+    assert np.array_equal(got.view(np.uint32), o.get_particles()[0].view(np.uint32))
+
+
+def test_seeding_truncates_like_the_reference():
+    p = blub_amd.seed_fluid_cube((32, 32, 32), 100, 40, (1, 1, 1), (9, 9, 9))   # hybrid_fluid.rs:627-633
+    assert len(p) == 60
+    p = blub_amd.seed_fluid_cube((32, 32, 32), 100, 0, (-5, 40, 3), (2, 50, 3))  # clamps to [1, dim-1]; empty extent
+    assert len(p) == 0
+
+
+def test_default_simulation_delta():
+    assert blub_amd.default_simulation_delta() == float(np.float32(8333333) / np.float32(1e9))
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    with pytest.raises(BlubError) as e:
+        blub_amd.HybridFluid((32, 32, 32), 16)
+    assert e.value.status == -7

@@ -1,0 +1,378 @@
+"""Known-answer tests that pin the CPU oracle from first principles (the reference ships no tests / golden vectors:
+SURVEY.md section 4 -- "parity unpinned").  Each test states the analytic fact it checks."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle.oracle import Oracle, rng_from_seed, rng_seed_from_u64
+from tests import util
+
+DT = util.DT
+
+
+def test_xoshiro256plusplus_published_vector():
+    """xoshiro256++ reference implementation, state {1,2,3,4} (the vector the rand crate's own test uses)."""
+    seed = b"".join(int(v).to_bytes(8, "little") for v in (1, 2, 3, 4))
+    expect = [41943041, 58720359, 3588806011781223, 3591011842654386, 9228616714210784205, 9973669472204895162,
+              14011001112246962877, 12406186145184390807, 15849039046786891736, 10450023813501588000]
+    assert rng_from_seed(seed, 10).tolist() == expect
+
+
+def test_seed_from_u64_pcg32_fill_and_f32_sampling():
+    """rand_core 0.6 default seed_from_u64: PCG32 (MUL 6364136223846793005, INC 11634580027462260723) fills the seed;
+    f32 sample = 24 high bits of next_u32 * 2^-24 (re-derived here in Python integers)."""
+    MUL, INC, M = 6364136223846793005, 11634580027462260723, (1 << 64) - 1
+    state, words = 42, []
+    for _ in range(8):
+        state = (state * MUL + INC) & M
+        xs = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+        rot = state >> 59
+        words.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+    s = [words[2 * i] | (words[2 * i + 1] << 32) for i in range(4)]
+    got_state, got_f = rng_seed_from_u64(42, 6)
+    assert got_state.tolist() == s
+    rotl = lambda v, k: ((v << k) | (v >> (64 - k))) & M
+    exp = []
+    for _ in range(6):
+        res = (rotl((s[0] + s[3]) & M, 23) + s[0]) & M
+        t = (s[1] << 17) & M
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45)
+        exp.append(np.float32((res >> 32) >> 8) * np.float32(2.0 ** -24))
+    assert np.array_equal(got_f, np.array(exp, np.float32))
+    assert np.all((got_f >= 0) & (got_f < 1))
+
+
+@pytest.mark.parametrize("dim,scale,maxp,cubes,expect", [
+    ((64, 64, 128), 0.01, 1238328, [((0.319, 0.319, 0.639), (0.32, 0.32, 0.64))], 8),
+    ((128, 64, 64), 0.01, 1238328, [((0, 0, 0), (0.64, 0.4, 0.64))], 1218672),
+    ((128, 64, 64), 0.01, 2000000, [((0, 0, 0), (0.32, 0.4, 0.64)), ((0.96, 0, 0), (1.28, 0.4, 0.64))], 1199328),
+])
+def test_add_fluid_cube_counts_and_stratification(dim, scale, maxp, cubes, expect):
+    """hybrid_fluid.rs:609-678: cube clamped to cells [1, dim-1], 8 particles per cell, one per octant (stratified)."""
+    o = Oracle(*dim, maxp)
+    for mn, mx in cubes:
+        o.add_fluid_cube(np.float32(mn) / np.float32(scale), np.float32(mx) / np.float32(scale))
+    assert o.num_particles == expect
+    p = o.get_particles()[0][:, :3]
+    assert np.all(p >= 1) and np.all(p[:, 0] <= dim[0] - 1) and np.all(p[:, 1] <= dim[1] - 1) and np.all(p[:, 2] <= dim[2] - 1)
+    # groups of 8 consecutive particles share a cell; sample k of a group sits in octant (k%2, k/2%2, k/4%2).
+    # (f32 rounding of cell + offset may land exactly on the upper bound, hence the inclusive comparisons.)
+    grp = p.reshape(-1, 8, 3)
+    cell = np.floor(grp[:, 0, :])[:, None, :]
+    k = np.arange(8)
+    lo = np.stack([k % 2, k // 2 % 2, k // 4 % 2], 1)[None] * 0.5
+    off = grp - cell
+    assert np.all(off >= lo) and np.all(off <= lo + 0.5)
+
+
+def test_add_fluid_cube_truncates_at_capacity():
+    o = Oracle(32, 32, 32, 100)
+    n = o.add_fluid_cube((1, 1, 1), (9, 9, 9))
+    assert n == 100 and o.num_particles == 100   # hybrid_fluid.rs:627-633
+
+
+def _two_particle_oracle():
+    o = Oracle(16, 16, 16, 8)
+    o.set_quirks(binning="off")
+    o.set_gravity_grid((0, 0, 0))
+    return o
+
+
+def test_p2g_two_particles_hand_computed_weights():
+    """transfer_gather_velocity.comp:18-26: v = sum w*(C.(s-p) + v_p) / sum w with w = prod sat(1-|s-p|)."""
+    o = _two_particle_oracle()
+    p = np.array([[5.3, 6.6, 7.2], [5.9, 6.1, 7.7]], np.float32)
+    rows = [np.array([[0.1, -0.2, 0.3, 2.0], [0.0, 0.4, -0.1, -1.0]], np.float32) for _ in range(3)]
+    o.set_particles(p, *rows)
+    o.run_stage("transfer", DT)
+    for c, name in enumerate(("vel_x", "vel_y", "vel_z")):
+        vol = o.read_volume(name)
+        for g in [(5, 6, 7), (5, 5, 7), (4, 6, 6), (5, 6, 6)]:
+            s = np.array(g, np.float64) + 0.5
+            s[c] += 0.5
+            num = den = 0.0
+            for k in range(2):
+                d = s - p[k].astype(np.float64)
+                w = np.prod(np.clip(1 - np.abs(d), 0, 1))
+                num += w * (rows[c][k, :3].astype(np.float64) @ d + rows[c][k, 3])
+                den += w
+            m = o.read_volume("marker")
+            nb = list(g); nb[c] += 1
+            touches_fluid = m[g[2], g[1], g[0]] == 1 or m[nb[2], nb[1], nb[0]] == 1
+            expected = (num / den if den > 0 else 0.0) if touches_fluid else 0.0
+            assert abs(vol[g[2], g[1], g[0]] - expected) < 1e-5, (name, g)
+    m = o.read_volume("marker")
+    assert m[7, 6, 5] == 1 and m[0, 0, 0] == 0 and m[8, 8, 8] == -1
+
+
+def _block_particles(dim, lo, hi, seed=0):
+    rng = np.random.default_rng(seed)
+    cells = np.stack(np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]), np.arange(lo[2], hi[2]), indexing="ij"), -1).reshape(-1, 3)
+    return (cells[:, None, :] + rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
+
+
+def test_uniform_velocity_roundtrip_p2g_g2p():
+    """A uniform particle velocity survives P2G -> (zero pressure) project/extrapolate -> G2P; the APIC rows come back 0."""
+    dim = (24, 24, 24)
+    pos = _block_particles(dim, (6, 6, 6), (16, 16, 16))
+    n = pos.shape[0]
+    v = np.array([1.5, -0.75, 0.5], np.float32)
+    rows = [np.tile(np.array([0, 0, 0, v[c]], np.float32), (n, 1)) for c in range(3)]
+    o = Oracle(*dim, n)
+    o.set_quirks(binning="off")
+    o.set_gravity_grid((0, 0, 0))
+    o.set_particles(pos, *rows)
+    o.run_stage("transfer", DT)
+    o.run_stage("project", DT)      # pressure volume is zero: keeps the velocities, extrapolates one layer
+    o.run_stage("advect", DT)
+    p1, vx, vy, vz = o.get_particles()
+    for c, r in enumerate((vx, vy, vz)):
+        assert np.abs(r[:, 3] - v[c]).max() < 1e-5
+        assert np.abs(r[:, :3]).max() < 1e-5
+    assert np.abs((p1[:, :3] - pos) - v * np.float32(DT)).max() < 1e-5
+
+
+def test_apic_linear_field_exactness_and_q2_transpose():
+    """P2G with rows = gradient of a linear field reproduces the field exactly on the faces (affine exactness); G2P
+    returns rows that hold the TRANSPOSED Jacobian (Q2: advect_particles.comp:109-112 vs gather :18-26)."""
+    dim = (24, 24, 24)
+    pos = _block_particles(dim, (5, 5, 5), (18, 18, 18), seed=3)
+    n = pos.shape[0]
+    J = np.array([[0.10, 0.03, -0.02], [0.07, -0.05, 0.04], [0.01, 0.06, 0.08]], np.float64)   # J[c, k] = d v_c / d x_k (not symmetric)
+    v0 = np.array([0.3, -0.2, 0.1])
+    vel = pos.astype(np.float64) @ J.T + v0
+    rows = [np.concatenate([np.tile(J[c], (n, 1)), vel[:, c:c + 1]], 1).astype(np.float32) for c in range(3)]
+    o = Oracle(*dim, n)
+    o.set_quirks(binning="off")
+    o.set_gravity_grid((0, 0, 0))
+    o.set_particles(pos, *rows)
+    o.run_stage("transfer", DT)
+    m = o.read_volume("marker")
+    for c, name in enumerate(("vel_x", "vel_y", "vel_z")):
+        vol = o.read_volume(name)
+        zz, yy, xx = np.nonzero(m[:-1, :-1, :-1] == 1)
+        s = np.stack([xx, yy, zz], 1) + 0.5
+        s[:, c] += 0.5
+        expected = s @ J[c] + v0[c]
+        assert np.abs(vol[zz, yy, xx] - expected).max() < 2e-5
+    o.run_stage("project", DT)
+    o.run_stage("advect", DT)
+    _, vx, vy, vz = o.get_particles()
+    inner = np.all((pos > 7) & (pos < 16), axis=1)
+    got = np.stack([vx[inner, :3], vy[inner, :3], vz[inner, :3]], 1)    # got[:, c, :] = row stored for component c
+    assert np.abs(got - J.T[None]).max() < 1e-4                          # rows hold d v / d x_c, i.e. the transpose
+
+
+def _poisson_matrix(marker):
+    """A of pressure.glsl:34-75 on the FLUID cells of `marker` (z,y,x): diag = #non-solid nbrs, -1 per FLUID nbr."""
+    nz, ny, nx = marker.shape
+    fluid = np.argwhere(marker == 1)
+    index = -np.ones(marker.shape, np.int64)
+    index[marker == 1] = np.arange(len(fluid))
+    mp = np.pad(marker, 1, constant_values=0)
+    rows, cols, vals = [], [], []
+    for i, (z, y, x) in enumerate(fluid):
+        d = 0
+        for dz, dy, dx in ((0, 0, -1), (0, 0, 1), (0, -1, 0), (0, 1, 0), (-1, 0, 0), (1, 0, 0)):
+            mm = mp[z + 1 + dz, y + 1 + dy, x + 1 + dx]
+            d += mm != 0
+            if mm == 1:
+                rows.append(i); cols.append(index[z + dz, y + dy, x + dx]); vals.append(-1.0)
+        rows.append(i); cols.append(i); vals.append(float(d))
+    return sp.csr_matrix((vals, (rows, cols)), shape=(len(fluid), len(fluid))), fluid
+
+
+@pytest.mark.parametrize("precond", ["zero"])
+def test_pcg_converges_to_sparse_direct_solution(precond):
+    """Run to convergence, the solver must agree with scipy's direct solve of A p = b (7-point, Neumann at SOLID,
+    Dirichlet at AIR) on a random fluid blob."""
+    rng = np.random.default_rng(7)
+    n = 20
+    marker = -np.ones((n, n, n), np.int8)
+    marker[[0, -1], :, :] = 0; marker[:, [0, -1], :] = 0; marker[:, :, [0, -1]] = 0
+    blob = rng.random((n, n, n)) < 0.55
+    blob[:, n // 2:, :] &= rng.random((n, n // 2 + n % 2, n)) < 0.3
+    marker[(marker == -1) & blob] = 1
+    marker[8:11, 3:6, 8:11] = 0      # an interior solid block
+    b = np.where(marker == 1, rng.standard_normal((n, n, n)), 0).astype(np.float32)
+    o = Oracle(n, n, n, 8)
+    o.set_quirks(precond=precond)
+    o.write_volume("marker", marker)
+    o.write_volume("residual", b)
+    o.set_solver_config(0, error_tolerance=1e-7, max_num_iterations=600, error_check_frequency=4)
+    o.run_stage("solve_velocity", DT)
+    A, fluid = _poisson_matrix(marker)
+    x = spla.spsolve(A.tocsc(), b[marker == 1].astype(np.float64))
+    p = o.read_volume("pressure_velocity")
+    err, it = o.solver_stats(0)
+    assert it < 600
+    assert np.abs(p[marker == 1] - x).max() < 2e-4 * max(1.0, np.abs(x).max())
+    assert np.all(p[marker != 1] == 0)
+
+
+def test_pcg_residual_history_against_numpy_cg():
+    """Fixed k iterations of the scheme in SURVEY Appendix D (diagonal 'zero' preconditioner z = r/d^2) re-implemented
+    with scipy sparse matrices in f64: pressure after k steps agrees to 1e-4 of its scale for small k."""
+    rng = np.random.default_rng(11)
+    n = 18
+    marker = -np.ones((n, n, n), np.int8)
+    marker[[0, -1], :, :] = 0; marker[:, [0, -1], :] = 0; marker[:, :, [0, -1]] = 0
+    marker[1:-1, 1:10, 1:-1] = 1
+    b = np.where(marker == 1, rng.standard_normal((n, n, n)), 0).astype(np.float32)
+    A, fluid = _poisson_matrix(marker)
+    d = A.diagonal()
+    for k in (0, 1, 3, 6):
+        o = Oracle(n, n, n, 8)
+        o.write_volume("marker", marker)
+        o.write_volume("residual", b)
+        o.set_solver_config(0, error_tolerance=0.0, max_num_iterations=k, error_check_frequency=4)
+        o.run_stage("solve_velocity", DT)
+        r = b[marker == 1].astype(np.float64); p = np.zeros_like(r)
+        s = r / d / d; sigma = s @ r
+        for i in range(k + 1):
+            As = A @ s
+            alpha = sigma / (s @ As)
+            p += alpha * s; r -= alpha * As
+            if i == k:
+                break
+            z = r / d / d; sig2 = z @ r
+            s = z + (sig2 / sigma) * s; sigma = sig2
+        got = o.read_volume("pressure_velocity")[marker == 1]
+        assert np.abs(got - p).max() < 1e-4 * max(1.0, np.abs(p).max()), k
+        err, it = o.solver_stats(0)
+        assert it == k and abs(err - np.abs(r).max() * DT) < 1e-4 * np.abs(r).max() * DT + 1e-9
+
+
+def test_check_cadence_and_iteration_count_semantics():
+    """pressure_solver.rs:672-673: error checked at i = f, 2f, ... and i = max only; converged => reported i."""
+    n = 18
+    marker = -np.ones((n, n, n), np.int8)
+    marker[[0, -1], :, :] = 0; marker[:, [0, -1], :] = 0; marker[:, :, [0, -1]] = 0
+    marker[1:-1, 1:8, 1:-1] = 1
+    b = np.where(marker == 1, 1.0, 0).astype(np.float32)
+    for freq, maxit in ((4, 32), (5, 32), (7, 10)):
+        o = Oracle(n, n, n, 8)
+        o.write_volume("marker", marker); o.write_volume("residual", b)
+        o.set_solver_config(0, error_tolerance=1e-3, max_num_iterations=maxit, error_check_frequency=freq)
+        o.run_stage("solve_velocity", DT)
+        err, it = o.solver_stats(0)
+        assert it == maxit or (it > 0 and it % freq == 0)
+        if it < maxit:
+            assert err < 1e-3
+
+
+def test_hydrostatic_column_stays_at_rest():
+    """A settled tank: after the velocity projection the divergence left is below the solver tolerance and particles
+    barely move over 5 steps (SURVEY 8c KAT 4)."""
+    dim = (24, 24, 24)
+    pos = _block_particles(dim, (1, 1, 1), (23, 12, 23), seed=5)
+    o = Oracle(*dim, pos.shape[0])
+    o.set_quirks(binning="off")
+    o.set_gravity_grid((0, -981.0, 0))
+    for w in (0, 1):
+        o.set_solver_config(w, error_tolerance=1e-3, max_num_iterations=200, error_check_frequency=4)
+    o.set_particles(pos)
+    for _ in range(5):
+        o.step(DT)
+        assert o.solver_stats(0)[0] < 1e-3
+    p1 = o.get_particles()[0][:, :3]
+    d = np.abs(p1 - pos)
+    assert d.max() < 0.6 and np.median(d) < 0.05    # density projection relaxes the random jitter a little
+    assert abs(p1[:, 1].mean() - pos[:, 1].mean()) < 0.15   # ... but the column does not fall or rise (free fall would be 1.0)
+
+
+def test_projection_leaves_divergence_below_tolerance():
+    """The north-star quantity: per-step grid divergence residual. max|div| recomputed with D1's formula right after
+    divergence_remove equals the solver's own statistic max|r| (definition (ii))."""
+    dim = (32, 24, 24)
+    pos, vel, maxp = util.make_dam(*dim)
+    o = Oracle(*dim, maxp)
+    o.set_quirks(binning="off")
+    o.set_gravity_grid((0, -981.0, 0))
+    o.set_solver_config(0, error_tolerance=1e-4, max_num_iterations=300, error_check_frequency=4)
+    o.set_particles(pos, *vel)
+    for s in ("transfer", "divergence", "solve_velocity"):
+        o.run_stage(s, DT)
+    err, it = o.solver_stats(0)
+    # divergence_remove only (no extrapolation needed for FLUID cells), then D1 again
+    o.run_stage("project", DT)
+    r_after_solve = o.read_volume("residual").copy()
+    o.run_stage("divergence", DT)
+    div = o.read_volume("residual")
+    fluid = o.read_volume("marker") == 1
+    assert np.abs(div[fluid]).max() * DT < 2 * err + 1e-5
+    assert np.abs(np.abs(div[fluid]).max() - np.abs(r_after_solve[fluid]).max()) < 1e-2 * np.abs(r_after_solve[fluid]).max() + 1e-3
+
+
+def test_single_cell_debug_free_fall():
+    """scenes/single_cell_debug: 8 particles in one cell fall freely: y_n = y_0 + g dt^2 n(n+1)/2 (uniform velocity field,
+    zero divergence, density clamped at free surfaces => both pressures stay 0)."""
+    o = Oracle(64, 64, 128, 64)
+    o.set_quirks(binning="off")
+    s = np.float32(0.01)
+    o.add_fluid_cube(np.float32([0.319, 0.319, 0.639]) / s, np.float32([0.32, 0.32, 0.64]) / s)
+    g = np.float32(-9.81) / s
+    o.set_gravity_grid((0, g, 0))
+    p0 = o.get_particles()[0][:, :3].copy()
+    assert o.num_particles == 8 and np.all(np.floor(p0) == [31, 31, 63])
+    for n in range(1, 6):
+        o.step(DT)
+        p = o.get_particles()[0][:, :3]
+        assert np.abs(p[:, 1] - (p0[:, 1] + float(g) * DT * DT * n * (n + 1) / 2)).max() < 2e-4
+        assert np.abs(p[:, [0, 2]] - p0[:, [0, 2]]).max() < 1e-5
+
+
+def test_binning_fixed_is_cell_ordered_permutation_and_literal_quirk():
+    dim = (24, 20, 16)
+    pos = _block_particles(dim, (2, 2, 2), (12, 10, 9), seed=9)
+    rng = np.random.default_rng(1)
+    pos = pos[rng.permutation(len(pos))][:3003]          # not a multiple of 64
+    n = len(pos)
+    o = Oracle(*dim, n + 200)
+    o.set_quirks(binning="fixed")
+    o.set_particles(pos)
+    o.run_stage("binning", DT)
+    got = o.get_particles()[0][:, :3]
+    rec = lambda a: np.sort(np.ascontiguousarray(a).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).reshape(-1), order=("x", "y", "z"))
+    assert np.array_equal(rec(got), rec(pos))
+    c = got.astype(np.int64)
+    assert np.all(np.diff((c[:, 2] * dim[1] + c[:, 1]) * dim[0] + c[:, 0]) >= 0)
+    # literal (Q4): threads up to ceil(n/64)*64 bin zero records, destinations are 1-based => pad+1 real particles are lost
+    o2 = Oracle(*dim, n + 200)
+    o2.set_quirks(binning="literal")
+    o2.set_particles(pos)
+    o2.run_stage("binning", DT)
+    lit = o2.get_particles()[0][:, :3]
+    lost = len(rec(pos)) - np.isin(rec(pos), rec(lit)).sum()
+    pad = (n + 63) // 64 * 64 - n
+    assert lost == pad + 1
+
+
+def test_extrapolation_and_position_change_are_local_kats():
+    """extrapolate_velocity.comp: an invalid face gets the mean of its valid in-plane neighbours; position_change:
+    delta = (p_nbr - p_c) * dt, 0 next to SOLID."""
+    n = 12
+    o = Oracle(n, n, n, 8)
+    marker = -np.ones((n, n, n), np.int8)
+    marker[[0, -1], :, :] = 0; marker[:, [0, -1], :] = 0; marker[:, :, [0, -1]] = 0
+    marker[5, 5, 5] = 1
+    o.write_volume("marker", marker)
+    vx = np.zeros((n, n, n), np.float32)
+    vx[5, 5, 5] = 2.0; vx[5, 5, 4] = 4.0     # the two valid x-faces of the single fluid cell
+    o.write_volume("vel_x", vx)
+    o.run_stage("position_change", DT)        # pressure is zero: overwrites with zeros, then extrapolates zeros
+    assert np.all(o.read_volume("vel_x") == 0)
+    o.write_volume("vel_x", vx)
+    pd = np.zeros((n, n, n), np.float32); pd[5, 5, 5] = 3.0
+    o.write_volume("pressure_density", pd)
+    o.run_stage("position_change", DT)
+    out = o.read_volume("vel_x")
+    assert abs(out[5, 5, 5] - (0 - 3.0) * DT) < 1e-9 and abs(out[5, 5, 4] - (3.0 - 0) * DT) < 1e-9
+    # cell (x=5,y=6,z=5): +x neighbour (6,6,5) is AIR => invalid face; valid in-plane nbrs: (5,5,5) only -> wait for both
+    o.write_volume("vel_x", vx); o.write_volume("pressure_velocity", np.zeros((n, n, n), np.float32))
+    o.run_stage("project", DT)
+    out = o.read_volume("vel_x")
+    assert out[5, 5, 5] == 2.0 and out[5, 5, 4] == 4.0
+    assert out[5, 6, 5] == 2.0 and out[5, 6, 4] == 4.0 and out[6, 6, 5] == 2.0     # one valid neighbour each
+    assert out[5, 5, 6] == 0.0                                                       # no valid in-plane neighbour: untouched (0)
