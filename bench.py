@@ -22,23 +22,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def algorithmic_bytes(kernel, N, F, P):
-    """Per-launch algorithmic HBM bytes (DESIGN.md section 4 / SURVEY.md 8(d)); F = FLUID cells, P = particles."""
+def algorithmic_bytes(kernel, F, P, A, Fb):
+    """Per-launch algorithmic HBM bytes (derived from SURVEY.md 8(d)).
+    F = FLUID cells, P = particles, A = cells of the active bricks the kernel sweeps (N for a dense-row kernel),
+    Fb = cells of the bricks that hold fluid (N for a dense-row kernel).  f32 fields 4 B, marker / descriptor 1 B."""
     table = {
-        "init_grid": 13 * N,               # marker N + 3 list-head volumes 4N (advect variant: 5N, averaged below)
-        "build_lists": 16 * P + 12 * P + 12 * P,
-        "gather_velocity": 5 * N + 32 * P + 4 * F,
-        "divergence": N + 28 * F,
-        "pcg_init": N + 12 * F + 4 * N,   # marker + r rw + p (read everywhere, zeroing writes only where nonzero) + s
-        "pcg_apply": N + 4 * F,
-        "pcg_update": N + 20 * F,
-        "pcg_search": N + 12 * F,
-        "divergence_remove": 13 * N + 16 * F,
-        "extrapolate": N + 8 * F,
+        "reset_bricks": 13 * A,                  # marker + 3 list-head volumes (the advect variant writes 5 B/cell)
+        "build_lists": 16 * P + 12 * P + 12 * P, # pos read, 3 atomic exchanges, 3 next pointers
+        "gather_velocity": 5 * A + 32 * P + 4 * F,
+        "divergence": Fb + 28 * F,
+        "pcg_init": 6 * A + 12 * F,              # marker + descriptor + p everywhere, r rw + s on FLUID
+        "pcg_dir": Fb + 12 * F,                  # descriptor, r, s read, s write
+        "pcg_update": Fb + 20 * F,               # descriptor, s, p rw, r rw
+        "divergence_remove": 13 * A + 16 * F,
+        "extrapolate": A + 8 * F,
         "advect": 176 * P,
-        "density_gather": 5 * N + 16 * P + 4 * F,
-        "position_change": N + 4 * F + 12 * N,
-        "correct": 28 * P + 12 * P,
+        "density_gather": 5 * Fb + 16 * P + 4 * F,
+        "position_change": 13 * A + 4 * F,
+        "correct": 40 * P,
     }
     return float(table.get(kernel, 0))
 
@@ -66,16 +67,20 @@ def dense_pcg_benchmark(n=256, iterations=32):
     prof = h.profile_read()
     h.profile_enable(False)
     out = {}
-    for k in ("pcg_apply", "pcg_update", "pcg_search"):
+    for k in ("pcg_dir", "pcg_update"):
         avg_ms = prof[k]["total_ms"] / prof[k]["launches"]
-        gbs = algorithmic_bytes(k, N, F, 0) / (avg_ms * 1e-3) / 1e9
+        gbs = algorithmic_bytes(k, F, 0, N, N) / (avg_ms * 1e-3) / 1e9
         out[k] = {"avg_us": round(avg_ms * 1e3, 2), "launches": prof[k]["launches"], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     iter_us = sum(out[k]["avg_us"] for k in out)
     err, iters = h.solver_stats(0)
     h.close()
+    # one iteration = pcg_dir + pcg_update.  "iter_bytes" is SURVEY 8(d)'s figure for the UNFUSED three-phase iteration
+    # (3N + 36F); the fused pair itself only has to move 2N + 32F ("iter_bytes_fused"), both fractions are reported.
+    fused = 2 * N + 32 * F
     return {"grid": "%d^3" % n, "fluid_cells": F, "iterations": iters, "us_per_iteration_kernels": round(iter_us, 1),
             "iter_bytes": 3 * N + 36 * F, "iter_GBs": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9, 1),
-            "iter_frac": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
+            "iter_frac": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "iter_bytes_fused": fused, "iter_frac_fused": round(fused / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
 
 
 def cpu_baseline(scene_path, dt, budget_steps=2):
@@ -175,13 +180,16 @@ def main():
     prof = fluid.profile_read()
     fluid.profile_enable(False)
     F = int((fluid.read_volume("marker") == 1).sum())
+    bc = fluid.brick_counts()
+    A, Fb = bc["active"] * bc["cells_per_brick"], bc["fluid"] * bc["cells_per_brick"]
     total_ms = sum(v["total_ms"] for v in prof.values())
     dominant = max(prof, key=lambda k: prof[k]["total_ms"])
     avg_ms = prof[dominant]["total_ms"] / prof[dominant]["launches"]
-    ach = algorithmic_bytes(dominant, N, F, P) / (avg_ms * 1e-3) / 1e9
+    ach = algorithmic_bytes(dominant, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
-                "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F}
+                "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F,
+                "active_brick_cells": A, "fluid_brick_cells": Fb, "launches_per_step": round(prof[dominant]["launches"] / args.profile_steps, 1)}
     pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
     solver_iters_prof = None
     breakdown = {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}

@@ -1,0 +1,512 @@
+// Brick-sparse work decomposition for the grid kernels (MI355X-first redesign of the reference's dense dispatches).
+//
+// The reference dispatches every grid shader over all N cells (hybrid_fluid.rs:786).  At the headline operating point
+// (1 M particles in 256^3) < 1 % of the cells are FLUID, so here the volumes stay dense in HBM (the renderer contract,
+// hybrid_fluid.rs:700-721, wants plain volumes) but the WORK is driven by compact lists of 16x8x4-cell bricks:
+//   fluid list  : bricks that contain a particle (= contain a FLUID cell)
+//   active list : fluid bricks dilated by one brick (every cell within >= 4 cells of the fluid; all stencils of the
+//                 step reach at most 2 cells beyond a FLUID cell)
+//   reset list  : active bricks + "stale" bricks (touched by an earlier step, not active any more) whose velocity /
+//                 pressure / marker contents are put back to the state the reference's dense passes would leave there
+//                 (velocity 0: divergence_remove.comp:36-38, pressure 0: pressure_init.comp:45-48, marker AIR/SOLID).
+// Invariant: outside the bricks ever touched, every volume holds exactly what the dense reference would hold.
+// Lists are rebuilt on the device twice per step (before P2G, after advection) from the particle positions with a
+// deterministic scan, so kernels are launched with a fixed grid and loop `for (i = blockIdx.x; i < *count; ...)`.
+#pragma once
+#include "blub_kernels.hip.h"
+
+namespace blubk {
+
+constexpr int BX = 16, BY = 8, BZ = 4;        // brick extent in cells (x fastest): 512 cells = 128 quads
+constexpr int BRICK_THREADS = 128;            // one thread per quad (4 x-consecutive cells)
+constexpr uint32_t STALE_BIT = 0x80000000u;
+
+struct BrickGeom {
+    Grid g;
+    int nbx, nby, nbz, nb;
+};
+struct BrickCounts {        // device resident
+    uint32_t n_fluid, n_active, n_reset, n_stale;
+};
+
+__device__ __forceinline__ uint32_t brick_of_cell(const BrickGeom& bg, int x, int y, int z) {
+    return (uint32_t)(((z / BZ) * bg.nby + (y / BY)) * bg.nbx + (x / BX));
+}
+// thread -> quad of brick b; returns false if the quad lies outside the grid
+__device__ __forceinline__ bool brick_quad(const BrickGeom& bg, uint32_t b, int t, int& x0, int& y, int& z) {
+    const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+    x0 = bx * BX + ((t & 3) << 2);
+    y = by * BY + ((t >> 2) & 7);
+    z = bz * BZ + (t >> 5);
+    return x0 < bg.g.nx && y < bg.g.ny && z < bg.g.nz;
+}
+
+// ---- list construction ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bricks_mark_particles(BrickGeom bg, uint32_t num_particles, const float4* __restrict__ pos, uint8_t* __restrict__ brick_fluid) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_particles) return;
+    const float4 p = pos[i];
+    const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
+    if (inb(bg.g, x, y, z)) brick_fluid[brick_of_cell(bg, x, y, z)] = 1;
+}
+// stand-alone stage calls (test hook): derive the fluid bricks from the marker volume instead of the particles
+__global__ __launch_bounds__(BRICK_THREADS) void k_bricks_mark_from_marker(BrickGeom bg, const int8_t* __restrict__ marker, uint8_t* __restrict__ brick_fluid) {
+    const uint32_t b = blockIdx.x;
+    int x0, y, z;
+    bool any = false;
+    if (brick_quad(bg, b, threadIdx.x, x0, y, z)) any = any_fluid4(*reinterpret_cast<const uint32_t*>(marker + cidx(bg.g, x0, y, z)));
+    if (__syncthreads_or(any) && threadIdx.x == 0) brick_fluid[b] = 1;
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* sm /*17*/, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v);
+    __syncthreads();
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t s = sm[w]; if (w < wave) woff += s; tot += s; }
+    total = tot;
+    return woff + inc - v;
+}
+
+enum { COMPACT_STEP_A = 0, COMPACT_STEP_B = 1, COMPACT_ALL_ACTIVE = 2 };
+// One 1024-thread block; each thread owns ITEMS consecutive bricks per chunk => lists come out in brick (memory) order.
+constexpr int COMPACT_ITEMS = 8;
+__global__ __launch_bounds__(1024) void k_bricks_compact(BrickGeom bg, int phase, int all_touched, const uint8_t* __restrict__ brick_fluid,
+                                                         uint8_t* __restrict__ brick_active, uint8_t* __restrict__ brick_touched,
+                                                         uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
+                                                         uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts) {
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t base[3];
+    if (threadIdx.x == 0) { base[0] = base[1] = base[2] = 0; }
+    __syncthreads();
+    uint32_t n_stale = 0;
+    for (int start = 0; start < bg.nb; start += 1024 * COMPACT_ITEMS) {
+        const int b0 = start + threadIdx.x * COMPACT_ITEMS;
+        uint8_t f[COMPACT_ITEMS], a[COMPACT_ITEMS], st[COMPACT_ITEMS];
+        uint32_t cf = 0, ca = 0, cr = 0;
+#pragma unroll
+        for (int k = 0; k < COMPACT_ITEMS; ++k) {
+            const int b = b0 + k;
+            f[k] = a[k] = st[k] = 0;
+            if (b >= bg.nb) continue;
+            f[k] = brick_fluid[b];
+            bool act;
+            if (phase == COMPACT_ALL_ACTIVE) act = true;
+            else {
+                const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+                act = false;
+                for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+                    const int qx = bx + dx, qy = by + dy, qz = bz + dz;
+                    if ((unsigned)qx < (unsigned)bg.nbx && (unsigned)qy < (unsigned)bg.nby && (unsigned)qz < (unsigned)bg.nbz)
+                        act = act || brick_fluid[(qz * bg.nby + qy) * bg.nbx + qx] != 0;
+                }
+                if (phase == COMPACT_STEP_B) act = act || brick_active[b] != 0;
+            }
+            const bool touched = all_touched || brick_touched[b] != 0;
+            a[k] = act;
+            st[k] = (phase == COMPACT_STEP_A) && touched && !act;
+            cf += f[k] != 0; ca += act; cr += act || st[k];
+            n_stale += st[k];
+        }
+        uint32_t tf, ta, tr;
+        uint32_t of = block_exclusive_scan_1024(cf, sm, tf);
+        uint32_t oa = block_exclusive_scan_1024(ca, sm, ta);
+        uint32_t orr = block_exclusive_scan_1024(cr, sm, tr);
+        of += base[0]; oa += base[1]; orr += base[2];
+#pragma unroll
+        for (int k = 0; k < COMPACT_ITEMS; ++k) {
+            const int b = b0 + k;
+            if (b >= bg.nb) continue;
+            if (f[k]) list_fluid[of++] = (uint32_t)b;
+            if (a[k]) list_active[oa++] = (uint32_t)b;
+            if (a[k] || st[k]) list_reset[orr++] = (uint32_t)b | (st[k] ? STALE_BIT : 0u);
+            brick_active[b] = a[k];
+            if (phase == COMPACT_STEP_A) brick_touched[b] = a[k];
+            else if (a[k]) brick_touched[b] = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { base[0] += tf; base[1] += ta; base[2] += tr; }
+        __syncthreads();
+    }
+    uint32_t tot_stale;
+    (void)block_exclusive_scan_1024(n_stale, sm, tot_stale);
+    if (threadIdx.x == 0) { counts->n_fluid = base[0]; counts->n_active = base[1]; counts->n_reset = base[2]; counts->n_stale = tot_stale; }
+}
+
+// ---- static marker pattern: transfer_clear.comp:10-14 + transfer_set_boundary_marker.comp:11-19 --------------------
+__device__ __forceinline__ uint32_t static_marker_quad(const Grid& g, const float4* __restrict__ solid, int base, int x0, int y, int z) {
+    const bool shell_yz = (y == 0) | (z == 0) | (y == g.ny - 1) | (z == g.nz - 1);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = x0 + j;
+        bool sol = shell_yz | (x == 0) | (x == g.nx - 1);
+        if (!sol && solid) sol = solid[base + j].w != 0.0f;
+        packed |= (sol ? 0u : 0xFFu) << (8 * j);
+    }
+    return packed;
+}
+// T1 (+T3) over the reset list: marker := static pattern, list heads := 0; stale bricks additionally get velocity and
+// pressure volumes zeroed (what the reference's dense D2 / pressure_init / R2 passes would have written there).
+__global__ __launch_bounds__(BRICK_THREADS) void k_reset_bricks(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                const float4* __restrict__ solid, int8_t* __restrict__ marker,
+                                                                uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
+                                                                float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz,
+                                                                float* __restrict__ p0, float* __restrict__ p1) {
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t e = list[i];
+        int x0, y, z;
+        if (!brick_quad(bg, e & ~STALE_BIT, threadIdx.x, x0, y, z)) continue;
+        const int base = cidx(bg.g, x0, y, z);
+        *reinterpret_cast<uint32_t*>(marker + base) = static_marker_quad(bg.g, solid, base, x0, y, z);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        if (ll0) *reinterpret_cast<uint4*>(ll0 + base) = z4;
+        if (ll1) *reinterpret_cast<uint4*>(ll1 + base) = z4;
+        if (ll2) *reinterpret_cast<uint4*>(ll2 + base) = z4;
+        if ((e & STALE_BIT) && vx) {
+            const float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(vx + base) = f0; *reinterpret_cast<float4*>(vy + base) = f0; *reinterpret_cast<float4*>(vz + base) = f0;
+            *reinterpret_cast<float4*>(p0 + base) = f0; *reinterpret_cast<float4*>(p1 + base) = f0;
+        }
+    }
+}
+// Dense variant (creation, new solid voxels): every cell gets the static pattern.
+__global__ __launch_bounds__(256) void k_static_marker_dense(Grid g, const float4* __restrict__ solid, int8_t* __restrict__ marker) {
+    const int nquads = (g.nx >> 2) * g.ny * g.nz;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < nquads; q += gridDim.x * 256) {
+        const int base = q << 2;
+        const int x0 = base % g.nx, yz = base / g.nx, y = yz % g.ny, z = yz / g.ny;
+        *reinterpret_cast<uint32_t*>(marker + base) = static_marker_quad(g, solid, base, x0, y, z);
+    }
+}
+
+// ---- T4 over active bricks: transfer_gather_velocity.comp:39-127 ---------------------------------------------------
+// One workgroup per brick: (16+1)x(8+1)x(4+1) = 765 list cells (brick + one halo layer on the negative sides), each
+// thread walks its own cell's list and publishes the current particle through LDS (24 KiB); a face reads the 7 other
+// lists it needs from LDS.  768 threads = 12 full waves.  The <=12-round loop ends when every list of the tile is empty.
+constexpr int GT_X = BX + 1, GT_Y = BY + 1, GT_Z = BZ + 1, GT_N = GT_X * GT_Y * GT_Z;   // 17 x 9 x 5 = 765
+
+template <int COMP>
+__global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                           const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                           const float4* __restrict__ pos, const uint32_t* __restrict__ next,
+                                                           const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
+    __shared__ float4 sPos[GT_N];
+    __shared__ float4 sVel[GT_N];
+    const Grid g = bg.g;
+    const int tid = threadIdx.x;
+    const bool live = tid < GT_N;
+    const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
+    const int a1 = tid - 1, a2 = tid - GT_X, a3 = tid - GT_X - 1, a4 = tid - GT_X * GT_Y, a5 = a4 - 1, a6 = a4 - GT_X, a7 = a4 - GT_X - 1;   // :87-93
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t b = list[i];
+        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;      // :41
+        const bool in = live && inb(g, gx, gy, gz);
+        const bool border = !live || lx == 0 || ly == 0 || lz == 0;
+        const int mA = in ? (int)marker[cidx(g, gx, gy, gz)] : CELL_SOLID;
+        const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
+        const bool writes = !border && in && (mA == CELL_FLUID || mB == CELL_FLUID);           // :50
+        const bool computes = !border && (mA != CELL_SOLID && mB != CELL_SOLID);                // :51
+        const float sx = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
+        const float sy = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
+        const float sz = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
+        uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+        float v = 0.0f, wsum = 0.0f;
+        for (int round = 0; round < 12; ++round) {                                               // :61
+            const bool has = cur != INVALID_LL;
+            if (!__syncthreads_or(has)) break;
+            if (has) {
+                const float4 p = pos[cur];
+                const float4 r = rows[cur];
+                cur = next ? next[cur] : __float_as_uint(p.w);
+                if (computes) add_particle(v, wsum, p, r, sx, sy, sz);
+                sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
+                sVel[tid] = r;
+            } else if (live) {
+                sPos[tid].w = 0.0f;
+            }
+            __syncthreads();
+            if (computes) {
+                float4 q;
+                q = sPos[a1]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a1], sx, sy, sz);
+                q = sPos[a2]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a2], sx, sy, sz);
+                q = sPos[a3]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a3], sx, sy, sz);
+                q = sPos[a4]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a4], sx, sy, sz);
+                q = sPos[a5]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a5], sx, sy, sz);
+                q = sPos[a6]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a6], sx, sy, sz);
+                q = sPos[a7]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a7], sx, sy, sz);
+            }
+        }
+        if (writes) {
+            if (computes) { if (wsum > 0.0f) v /= wsum; v += gravity_dt; }                       // :117-120
+            else v = 0.0f;                                                                        // :121-124
+            out[cidx(g, gx, gy, gz)] = v;
+        }
+        __syncthreads();   // LDS is reused by the next brick of this block
+    }
+}
+
+// ---- R1 over fluid bricks: density_projection_gather_error.comp:41-198 -----------------------------------------------
+__global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                          const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                          const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
+    __shared__ float4 sPos[GT_N];
+    const Grid g = bg.g;
+    const int tid = threadIdx.x;
+    const bool live = tid < GT_N;
+    const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
+    const int a1 = tid - 1, a2 = tid - GT_X, a3 = tid - GT_X - 1, a4 = tid - GT_X * GT_Y, a5 = a4 - 1, a6 = a4 - GT_X, a7 = a4 - GT_X - 1;
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t b = list[i];
+        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;
+        const bool in = live && inb(g, gx, gy, gz);
+        const bool border = !live || lx == 0 || ly == 0 || lz == 0;
+        const bool writes = !border && in && marker[cidx(g, gx, gy, gz)] == CELL_FLUID;           // :46
+        const float sx = (float)gx + 0.5f, sy = (float)gy + 0.5f, sz = (float)gz + 0.5f;
+        uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+        float density = 0.0f;
+        auto add = [&](const float4& p) {
+            const float ox = satf(1.0f - fabsf(sx - p.x)), oy = satf(1.0f - fabsf(sy - p.y)), oz = satf(1.0f - fabsf(sz - p.z));
+            density += ox * oy * oz;                                                              // :27-31
+        };
+        for (int round = 0; round < 32; ++round) {                                                // :69
+            const bool has = cur != INVALID_LL;
+            if (!__syncthreads_or(has)) break;
+            if (has) {
+                const float4 p = pos[cur];
+                cur = __float_as_uint(p.w);
+                if (writes) add(p);
+                sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
+            } else if (live) {
+                sPos[tid].w = 0.0f;
+            }
+            __syncthreads();
+            if (writes) {
+                float4 q;
+                q = sPos[a1]; if (q.w != 0.0f) add(q);
+                q = sPos[a2]; if (q.w != 0.0f) add(q);
+                q = sPos[a3]; if (q.w != 0.0f) add(q);
+                q = sPos[a4]; if (q.w != 0.0f) add(q);
+                q = sPos[a5]; if (q.w != 0.0f) add(q);
+                q = sPos[a6]; if (q.w != 0.0f) add(q);
+                q = sPos[a7]; if (q.w != 0.0f) add(q);
+            }
+        }
+        if (writes) {
+            const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
+                              mk(marker, g, gx - 1, gy, gz), mk(marker, g, gx, gy - 1, gz), mk(marker, g, gx, gy, gz - 1)};   // :115-120
+            bool anyAir = false;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { if (m[k] == CELL_SOLID) density += 0.5625f; if (m[k] == CELL_AIR) anyAir = true; }   // :167-179
+            if (anyAir) density = fmaxf(8.0f, density);                                           // :182-184
+            density = 1.0f - density / 8.0f;                                                      // :188
+            density = clampf(density, -0.5f, 0.5f);                                               // :192
+            density /= dt;                                                                        // :196
+            residual[cidx(g, gx, gy, gz)] = density;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- quad-vectorised element-wise grid kernels over brick lists -------------------------------------------------------
+#define BRICK_LOOP_BEGIN(bg, list, count)                                                     \
+    const uint32_t _n = *(count);                                                             \
+    for (uint32_t _i = blockIdx.x; _i < _n; _i += gridDim.x) {                                \
+        int x0, y, z;                                                                         \
+        if (!brick_quad((bg), (list)[_i] & ~STALE_BIT, threadIdx.x, x0, y, z)) continue;      \
+        const int base = cidx((bg).g, x0, y, z);
+#define BRICK_LOOP_END }
+
+__device__ __forceinline__ float solid_comp(const float4* __restrict__ solid, const Grid& g, int x, int y, int z, int comp) {
+    return (solid && inb(g, x, y, z)) ? comp3(solid[cidx(g, x, y, z)], comp) : 0.0f;
+}
+
+// D1: divergence_compute.comp:28-87 (fluid bricks; FLUID cells only)
+__global__ __launch_bounds__(BRICK_THREADS) void k_divergence_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                const int8_t* __restrict__ marker, const float* __restrict__ vx, const float* __restrict__ vy,
+                                                                const float* __restrict__ vz, const float4* __restrict__ solid, float* __restrict__ residual) {
+    const Grid g = bg.g;
+    BRICK_LOOP_BEGIN(bg, list, count)
+        QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
+        if (!any_fluid4(m.c)) continue;
+        load_quad_markers(marker, g, base, x0, y, z, m);
+        const int plane = g.nx * g.ny;
+        const float4 px = ld4(vx + base), py = ld4(vy + base), pz = ld4(vz + base);
+        const float qx_edge = x0 > 0 ? vx[base - 1] : 0.0f;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 qy = y > 0 ? ld4(vy + base - g.nx) : zero;
+        const float4 qz = z > 0 ? ld4(vz + base - plane) : zero;
+        float4 rc = ld4(residual + base);
+        float rr[4] = {rc.x, rc.y, rc.z, rc.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (mbyte(m.c, j) != CELL_FLUID) continue;
+            const int x = x0 + j;
+            const float vpx = f4(px, j), vpy = f4(py, j), vpz = f4(pz, j);
+            const float vqx = j > 0 ? f4(px, j - 1) : qx_edge, vqy = f4(qy, j), vqz = f4(qz, j);
+            float div = vpx - vqx;
+            div += vpy - vqy;
+            div += vpz - vqz;
+            const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
+            div += (mX0 == CELL_SOLID) ? vqx - solid_comp(solid, g, x - 1, y, z, 0) : 0.0f;       // :67-75
+            div += (mbyte(m.ym, j) == CELL_SOLID) ? vqy - solid_comp(solid, g, x, y - 1, z, 1) : 0.0f;
+            div += (mbyte(m.zm, j) == CELL_SOLID) ? vqz - solid_comp(solid, g, x, y, z - 1, 2) : 0.0f;
+            div -= (mX1 == CELL_SOLID) ? vpx - solid_comp(solid, g, x + 1, y, z, 0) : 0.0f;       // :76-84
+            div -= (mbyte(m.yp, j) == CELL_SOLID) ? vpy - solid_comp(solid, g, x, y + 1, z, 1) : 0.0f;
+            div -= (mbyte(m.zp, j) == CELL_SOLID) ? vpz - solid_comp(solid, g, x, y, z + 1, 2) : 0.0f;
+            rr[j] = div;
+        }
+        *reinterpret_cast<float4*>(residual + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+    BRICK_LOOP_END
+}
+
+// D2: divergence_remove.comp:19-49 (active bricks; every cell is written: value or 0)
+__global__ __launch_bounds__(BRICK_THREADS) void k_divergence_remove_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                       const int8_t* __restrict__ marker, const float* __restrict__ p, const float4* __restrict__ solid,
+                                                                       float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
+    const Grid g = bg.g;
+    BRICK_LOOP_BEGIN(bg, list, count)
+        QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
+        load_quad_markers(marker, g, base, x0, y, z, m);
+        const bool any = any_fluid4(m.c) || m.xp == CELL_FLUID || any_fluid4(m.yp) || any_fluid4(m.zp);
+        float ox[4] = {0.f, 0.f, 0.f, 0.f}, oy[4] = {0.f, 0.f, 0.f, 0.f}, oz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (any) {
+            const int plane = g.nx * g.ny;
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 pc = ld4(p + base);
+            const float pxp = x0 + 4 < g.nx ? p[base + 4] : 0.0f;
+            const float4 pyp = y + 1 < g.ny ? ld4(p + base + g.nx) : zero, pzp = z + 1 < g.nz ? ld4(p + base + plane) : zero;
+            const float4 vxc = ld4(vx + base), vyc = ld4(vy + base), vzc = ld4(vz + base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j;
+                const int mc = mbyte(m.c, j);
+                const float pcj = (mc == CELL_FLUID) ? f4(pc, j) : 0.0f;
+                const int mn[3] = {j < 3 ? mbyte(m.c, j + 1) : m.xp, mbyte(m.yp, j), mbyte(m.zp, j)};
+                const float pn[3] = {j < 3 ? f4(pc, j + 1) : pxp, f4(pyp, j), f4(pzp, j)};
+                const float vc[3] = {f4(vxc, j), f4(vyc, j), f4(vzc, j)};
+                float res[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float v = 0.0f;
+                    if (mc == CELL_FLUID || mn[c] == CELL_FLUID) {
+                        if (mc == CELL_SOLID) v = solid_comp(solid, g, x, y, z, c);
+                        else if (mn[c] == CELL_SOLID) v = solid_comp(solid, g, x + (c == 0), y + (c == 1), z + (c == 2), c);
+                        else { v = vc[c]; v -= pcj - ((mn[c] == CELL_FLUID) ? pn[c] : 0.0f); }
+                    }
+                    res[c] = v;
+                }
+                ox[j] = res[0]; oy[j] = res[1]; oz[j] = res[2];
+            }
+        }
+        *reinterpret_cast<float4*>(vx + base) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+        *reinterpret_cast<float4*>(vy + base) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+        *reinterpret_cast<float4*>(vz + base) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+    BRICK_LOOP_END
+}
+
+// R2: density_projection_position_change.comp:18-51 (active bricks; every cell is written)
+__global__ __launch_bounds__(BRICK_THREADS) void k_position_change_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                     const int8_t* __restrict__ marker, const float* __restrict__ p, float dt,
+                                                                     float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
+    const Grid g = bg.g;
+    BRICK_LOOP_BEGIN(bg, list, count)
+        QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
+        load_quad_markers(marker, g, base, x0, y, z, m);
+        const bool any = any_fluid4(m.c) || m.xp == CELL_FLUID || any_fluid4(m.yp) || any_fluid4(m.zp);
+        float ox[4] = {0.f, 0.f, 0.f, 0.f}, oy[4] = {0.f, 0.f, 0.f, 0.f}, oz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (any) {
+            const int plane = g.nx * g.ny;
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 pc = ld4(p + base);
+            const float pxp = x0 + 4 < g.nx ? p[base + 4] : 0.0f;
+            const float4 pyp = y + 1 < g.ny ? ld4(p + base + g.nx) : zero, pzp = z + 1 < g.nz ? ld4(p + base + plane) : zero;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mc = mbyte(m.c, j);
+                const float pcj = (mc == CELL_FLUID) ? f4(pc, j) : 0.0f;
+                const int mn[3] = {j < 3 ? mbyte(m.c, j + 1) : m.xp, mbyte(m.yp, j), mbyte(m.zp, j)};
+                const float pn[3] = {j < 3 ? f4(pc, j + 1) : pxp, f4(pyp, j), f4(pzp, j)};
+                float res[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float d = (((mn[c] == CELL_FLUID) ? pn[c] : 0.0f) - pcj) * dt;
+                    if (mc == CELL_SOLID || mn[c] == CELL_SOLID) d = 0.0f;
+                    res[c] = d;
+                }
+                ox[j] = res[0]; oy[j] = res[1]; oz[j] = res[2];
+            }
+        }
+        *reinterpret_cast<float4*>(vx + base) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+        *reinterpret_cast<float4*>(vy + base) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+        *reinterpret_cast<float4*>(vz + base) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+    BRICK_LOOP_END
+}
+
+// D3: extrapolate_velocity.comp:9-90 (active bricks).  The thread caches the 3x3 rows x 6 bytes of markers around its
+// quad (9 dword + 18 byte loads) and then evaluates the reference's per-cell logic from registers.
+__global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                 const int8_t* __restrict__ marker, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
+    const Grid g = bg.g;
+    float* vel[3] = {vx, vy, vz};
+    BRICK_LOOP_BEGIN(bg, list, count)
+        // mm[dz+1][dy+1][k], k = 0..5 <-> x0-1 .. x0+4
+        int8_t mm[3][3][6];
+        bool near_fluid = false;
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy, zz = z + dz;
+                uint32_t c4 = 0; int xm = 0, xp = 0;
+                if ((unsigned)yy < (unsigned)g.ny && (unsigned)zz < (unsigned)g.nz) {
+                    const int b2 = cidx(g, x0, yy, zz);
+                    c4 = *reinterpret_cast<const uint32_t*>(marker + b2);
+                    xm = x0 > 0 ? (int)marker[b2 - 1] : 0;
+                    xp = x0 + 4 < g.nx ? (int)marker[b2 + 4] : 0;
+                }
+                mm[dz + 1][dy + 1][0] = (int8_t)xm; mm[dz + 1][dy + 1][5] = (int8_t)xp;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mm[dz + 1][dy + 1][j + 1] = (int8_t)mbyte(c4, j);
+                near_fluid = near_fluid || any_fluid4(c4) || xm == CELL_FLUID || xp == CELL_FLUID;
+            }
+        // Every marker the reference reads for these 4 cells (in-plane neighbours and their +e_c cells) lies inside the
+        // cached 6x3x3 block; without a FLUID cell in it no neighbour face is valid and nothing is written.
+        if (!near_fluid) continue;
+        auto M = [&](int x, int yy, int zz) -> int { return (int)mm[zz - z + 1][yy - y + 1][x - x0 + 1]; };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            if (M(x, y, z) == CELL_FLUID) continue;
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) {
+                if (M(x + (comp == 0), y + (comp == 1), z + (comp == 2)) == CELL_FLUID) continue;
+                float numV = 0.0f, avgV = 0.0f;
+#pragma unroll
+                for (int b2 = -1; b2 <= 1; ++b2)
+#pragma unroll
+                    for (int a = -1; a <= 1; ++a) {
+                        if (a == 0 && b2 == 0) continue;
+                        int ox, oy, oz;
+                        if (comp == 0) { ox = 0; oy = a; oz = b2; }
+                        else if (comp == 1) { ox = a; oy = 0; oz = b2; }
+                        else { ox = a; oy = b2; oz = 0; }
+                        const int cx = x + ox, cy = y + oy, cz = z + oz;
+                        const bool valid = M(cx, cy, cz) == CELL_FLUID || M(cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
+                        if (valid) { numV += 1.0f; avgV += fv(vel[comp], g, cx, cy, cz); }
+                    }
+                if (numV > 0.0f) vel[comp][base + j] = avgV / numV;
+            }
+        }
+    BRICK_LOOP_END
+}
+
+}  // namespace blubk

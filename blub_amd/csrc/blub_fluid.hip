@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "blub_internal.h"
-#include "blub_kernels.hip.h"
+#include "blub_pcg.hip.h"
 
 namespace blub {
 
@@ -32,23 +32,25 @@ int set_error(int status, const char* msg) { g_last_error = msg ? msg : ""; retu
 using namespace blubk;
 
 enum KernelClass {
-    KC_INIT_GRID, KC_BUILD_LISTS, KC_GATHER_VELOCITY, KC_DIVERGENCE, KC_PCG_INIT, KC_PCG_APPLY, KC_PCG_UPDATE, KC_PCG_PRECOND,
-    KC_PCG_SEARCH, KC_DIVERGENCE_REMOVE, KC_EXTRAPOLATE, KC_ADVECT, KC_DENSITY_GATHER, KC_POSITION_CHANGE, KC_CORRECT,
+    KC_BRICK_LISTS, KC_RESET_BRICKS, KC_BUILD_LISTS, KC_GATHER_VELOCITY, KC_DIVERGENCE, KC_PCG_INIT, KC_PCG_DIR, KC_PCG_UPDATE, KC_PCG_FINALIZE,
+    KC_PCG_LOD0, KC_DIVERGENCE_REMOVE, KC_EXTRAPOLATE, KC_ADVECT, KC_DENSITY_GATHER, KC_POSITION_CHANGE, KC_CORRECT,
     KC_BIN_COUNT, KC_BIN_SCAN, KC_BIN_REWRITE, KC_COPY, KC_COUNT
 };
 static const char* kKernelClassNames[KC_COUNT] = {
-    "init_grid", "build_lists", "gather_velocity", "divergence", "pcg_init", "pcg_apply", "pcg_update", "pcg_precond",
-    "pcg_search", "divergence_remove", "extrapolate", "advect", "density_gather", "position_change", "correct",
+    "brick_lists", "reset_bricks", "build_lists", "gather_velocity", "divergence", "pcg_init", "pcg_dir", "pcg_update", "pcg_finalize",
+    "pcg_lod0", "divergence_remove", "extrapolate", "advect", "density_gather", "position_change", "correct",
     "bin_count", "bin_scan", "bin_rewrite", "copy"};
 
 constexpr int PCG_GRID_MAX = 1024;   // persistent blocks of the PCG kernels (= number of dot-product partials)
+constexpr int BRICK_GRID_MAX = 2048; // persistent blocks of the brick-list kernels
 constexpr int STATS_RING = 32;       // pressure_solver.rs:49 NUM_PRESSURE_ERROR_BUFFER
 constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
+constexpr int COUNTS_RING = 8;
+constexpr float SPARSE_PCG_MAX_FILL = 0.30f;   // fluid bricks / bricks below which the brick-list PCG kernels are used
 
 struct PendingStat { hipEvent_t ev; int slot; };
 
 }  // namespace blub
-
 using namespace blub;
 
 struct blub_fluid {
@@ -70,7 +72,19 @@ struct blub_fluid {
     float *vel[3] = {nullptr, nullptr, nullptr}, *pressure[2] = {nullptr, nullptr}, *residual = nullptr, *search = nullptr, *aux = nullptr, *aux_temp = nullptr;
     float4* solid = nullptr;
     uint32_t* scan_totals = nullptr;
+    // brick work lists (blub_bricks.hip.h)
+    BrickGeom bg{};
+    int brick_grid = 0;
+    uint8_t *brick_fluid = nullptr, *brick_active = nullptr, *brick_touched = nullptr;
+    uint32_t *list_fluid = nullptr, *list_active = nullptr, *list_reset = nullptr;
+    BrickCounts* counts = nullptr;            // device
+    BrickCounts* counts_host = nullptr;       // pinned ring of COUNTS_RING snapshots (path selection only)
+    hipEvent_t counts_events[8] = {};
+    int counts_head = 0, counts_valid = 0;
+    bool all_touched = false;
+    int force_pcg_path = -1;                  // -1 auto, 0 dense rows, 1 brick lists
     // PCG
+    uint8_t* dvol = nullptr;
     PcgGeom geom{};
     int pcg_grid = 0;
     float *part_sas = nullptr, *part_sigma[2] = {nullptr, nullptr}, *part_max = nullptr;
@@ -130,8 +144,6 @@ struct ProfScope {
         hipLaunchKernelGGL(kernel, grid, block, 0, (h)->stream, __VA_ARGS__);    \
     } while (0)
 
-static dim3 cell_grid(const Grid& g) { return dim3((g.nx + 63) / 64, (g.ny + 3) / 4, g.nz); }
-static dim3 tile9_grid(const Grid& g) { return dim3((g.nx + 7) / 8, (g.ny + 7) / 8, (g.nz + 7) / 8); }   // hybrid_fluid.rs:786
 static unsigned particle_blocks(uint32_t n) { return (n + 255) / 256; }
 static unsigned stream_blocks(size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, 2048); }
 
@@ -142,24 +154,113 @@ static int dev_alloc_zero(T** p, size_t count) {
     return BLUB_OK;
 }
 
-// ---- stages ------------------------------------------------------------------------------------------------------
-static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-833
-    LAUNCH(h, KC_INIT_GRID, k_init_grid, dim3(stream_blocks(h->N / 4)), dim3(256), h->g, h->marker, h->solid, h->ll[0], h->ll[1], h->ll[2]);
-    if (h->num_particles)
-        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker,
-               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2);
-    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity<0>, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[0], h->pos, (const uint32_t*)nullptr, h->pvel[0], h->vel[0], h->gravity[0] * dt);
-    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity<1>, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[1], h->pos, (const uint32_t*)h->next1, h->pvel[1], h->vel[1], h->gravity[1] * dt);
-    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity<2>, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[2], h->pos, (const uint32_t*)h->next2, h->pvel[2], h->vel[2], h->gravity[2] * dt);
+// ---- brick work lists ----------------------------------------------------------------------------------------------
+static int snapshot_counts(blub_fluid* h) {
+    const int slot = h->counts_head;
+    h->counts_head = (slot + 1) % COUNTS_RING;
+    HIP_TRY(hipMemcpyAsync(&h->counts_host[slot], h->counts, sizeof(BrickCounts), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->counts_events[slot], h->stream));
+    h->counts_valid = std::min(h->counts_valid + 1, COUNTS_RING);
     return BLUB_OK;
 }
-static int stage_divergence(blub_fluid* h) {   // :836-840
-    LAUNCH(h, KC_DIVERGENCE, k_divergence, cell_grid(h->g), dim3(256), h->g, h->marker, h->vel[0], h->vel[1], h->vel[2], h->solid, h->residual);
+// phase: COMPACT_STEP_A (before P2G) / COMPACT_STEP_B (after advection), from the particle positions
+static int build_lists_from_particles(blub_fluid* h, int phase) {
+    ProfScope ps(h, KC_BRICK_LISTS);
+    HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
+    if (h->num_particles)
+        hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles)), dim3(256), 0, h->stream, h->bg, h->num_particles, (const float4*)h->pos, h->brick_fluid);
+    hipLaunchKernelGGL(k_bricks_compact, dim3(1), dim3(1024), 0, h->stream, h->bg, phase, (int)h->all_touched, (const uint8_t*)h->brick_fluid, h->brick_active,
+                       h->brick_touched, h->list_fluid, h->list_active, h->list_reset, h->counts);
+    if (phase == COMPACT_STEP_A) h->all_touched = false;
+    return snapshot_counts(h);
+}
+// stand-alone stage calls: FLUID bricks from the marker volume, every brick active (dense semantics for the test hook)
+static int build_lists_from_marker(blub_fluid* h) {
+    ProfScope ps(h, KC_BRICK_LISTS);
+    HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
+    hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
+    hipLaunchKernelGGL(k_bricks_compact, dim3(1), dim3(1024), 0, h->stream, h->bg, (int)COMPACT_ALL_ACTIVE, 1, (const uint8_t*)h->brick_fluid, h->brick_active,
+                       h->brick_touched, h->list_fluid, h->list_active, h->list_reset, h->counts);
+    return snapshot_counts(h);
+}
+// latest completed snapshot of the brick counts (never waits unless `block`): only steers a performance choice
+static int latest_counts(blub_fluid* h, bool block, BrickCounts* out, bool* have) {
+    *have = false;
+    for (int k = 0; k < h->counts_valid; ++k) {
+        const int slot = (h->counts_head - 1 - k + 2 * COUNTS_RING) % COUNTS_RING;
+        hipError_t q = (block && k == 0) ? hipEventSynchronize(h->counts_events[slot]) : hipEventQuery(h->counts_events[slot]);
+        if (q == hipSuccess) { *out = h->counts_host[slot]; *have = true; return BLUB_OK; }
+        if (q != hipErrorNotReady) return set_error(BLUB_ERR_DEVICE, hipGetErrorString(q));
+    }
     return BLUB_OK;
 }
 
-// PressureSolver::solve, pressure_solver.rs:591-729 (schedule: SURVEY Appendix D)
-static int stage_solve(blub_fluid* h, int which, float dt) {
+#define LIST(h, which) (const uint32_t*)(h)->list_##which, (const uint32_t*)&(h)->counts->n_##which
+
+// ---- stages ------------------------------------------------------------------------------------------------------
+static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-833
+    int rc = build_lists_from_particles(h, COMPACT_STEP_A);
+    if (rc != BLUB_OK) return rc;
+    const dim3 bgrid(h->brick_grid);
+    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, bgrid, dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0], h->ll[1], h->ll[2],
+           h->vel[0], h->vel[1], h->vel[2], h->pressure[0], h->pressure[1]);
+    if (h->num_particles)
+        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker,
+               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2);
+    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<0>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[0], (const float4*)h->pos, (const uint32_t*)nullptr, (const float4*)h->pvel[0], h->vel[0], h->gravity[0] * dt);
+    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<1>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[1], (const float4*)h->pos, (const uint32_t*)h->next1, (const float4*)h->pvel[1], h->vel[1], h->gravity[1] * dt);
+    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<2>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[2], (const float4*)h->pos, (const uint32_t*)h->next2, (const float4*)h->pvel[2], h->vel[2], h->gravity[2] * dt);
+    return BLUB_OK;
+}
+static int stage_divergence(blub_fluid* h) {   // :836-840
+    LAUNCH(h, KC_DIVERGENCE, k_divergence_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const float*)h->vel[0],
+           (const float*)h->vel[1], (const float*)h->vel[2], (const float4*)h->solid, h->residual);
+    return BLUB_OK;
+}
+
+static int enqueue_stats_readback(blub_fluid* h, int which, float dt) {   // enqueue_error_buffer_read, pressure_solver.rs:176-191
+    if ((int)h->stats_pending[which].size() < STATS_RING) {
+        const int slot = h->stats_head[which];
+        h->stats_head[which] = (slot + 1) % STATS_RING;
+        HIP_TRY(hipMemcpyAsync(h->stats_host[which] + 2 * slot, h->ctrl[which], 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->stats_events[which][slot], h->stream));
+        h->stats_pending[which].push_back({h->stats_events[which][slot], slot});
+        h->stats_dt[which].push_back(dt);
+    }   // else: "No more error buffer available" -- the reference warns and skips the sample (:188-190)
+    return BLUB_OK;
+}
+
+// PressureSolver::solve for the LOD0 preconditioner reading: the literal kernel sequence (dense rows, marker based).
+static int stage_solve_lod0(blub_fluid* h, int which, float dt) {
+    float* p = h->pressure[which];
+    const blub_solver_config& c = h->cfg[which];
+    const float tol = c.error_tolerance / dt;
+    PcgCtrl* ctrl = h->ctrl[which];
+    const dim3 grid(h->pcg_grid), block(256);
+    const int np = h->pcg_grid;
+    LAUNCH(h, KC_PCG_LOD0, k_pcg_init<false>, grid, block, h->geom, h->marker, p, h->residual, h->search, (float*)nullptr, h->tile_flags);
+    LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
+    LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->search, (const float*)h->residual, h->part_sigma[0], h->tile_flags, ctrl);
+    const int maxit = c.max_num_iterations;
+    for (int i = 0; i <= maxit; ++i) {   // :654-723
+        float* sig_cur = h->part_sigma[i & 1];
+        float* sig_next = h->part_sigma[(i + 1) & 1];
+        LAUNCH(h, KC_PCG_LOD0, k_pcg_apply, grid, block, h->geom, h->marker, h->search, h->part_sas, h->tile_flags, ctrl);
+        const int last = (i == maxit);
+        const int check = last || (i > 0 && c.error_check_frequency > 0 && i % c.error_check_frequency == 0);   // :672-673
+        LAUNCH(h, KC_PCG_LOD0, k_pcg_update<false>, grid, block, h->geom, h->marker, h->search, p, h->residual, h->part_sas, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl);
+        if (!last) {
+            LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
+            LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->aux, (const float*)h->residual, sig_next, h->tile_flags, ctrl);
+        }
+        LAUNCH(h, KC_PCG_LOD0, k_pcg_search<false>, grid, block, h->geom, h->marker, h->aux, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
+        if (last) break;
+    }
+    return BLUB_OK;
+}
+
+// PressureSolver::solve, pressure_solver.rs:591-729 (schedule: SURVEY Appendix D), fused two-kernel iteration (blub_pcg.hip.h)
+static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float* p = h->pressure[which];
     const blub_solver_config& c = h->cfg[which];
     if (!h->pressure_initialised[which]) {   // :601-603
@@ -169,46 +270,59 @@ static int stage_solve(blub_fluid* h, int which, float dt) {
     const float tol = c.error_tolerance / dt;   // :197
     PcgCtrl* ctrl = h->ctrl[which];
     HIP_TRY(hipMemsetAsync(ctrl, 0, sizeof(PcgCtrl), h->stream));
-    const dim3 grid(h->pcg_grid), block(256);
-    const int np = h->pcg_grid;
-    const bool zero_mode = h->precond_mode == BLUB_PRECOND_ZERO;
-    if (zero_mode) {
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init<true>, grid, block, h->geom, h->marker, p, h->residual, h->search, h->part_sigma[0], h->tile_flags);
-    } else {
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init<false>, grid, block, h->geom, h->marker, p, h->residual, h->search, (float*)nullptr, h->tile_flags);
-        LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
-        LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->search, (const float*)h->residual, h->part_sigma[0], h->tile_flags, ctrl);
+    int rc;
+    if (h->precond_mode != BLUB_PRECOND_ZERO) {
+        if ((rc = stage_solve_lod0(h, which, dt)) != BLUB_OK) return rc;
+        return enqueue_stats_readback(h, which, dt);
+    }
+    // work mapping: brick lists when the fluid is sparse, dense rows otherwise (a performance choice only)
+    bool sparse;
+    if (h->force_pcg_path >= 0) sparse = h->force_pcg_path == 1;
+    else {
+        BrickCounts bc{}; bool have = false;
+        if ((rc = latest_counts(h, standalone || h->counts_valid <= 1, &bc, &have)) != BLUB_OK) return rc;
+        sparse = have && (float)bc.n_fluid < SPARSE_PCG_MAX_FILL * (float)h->bg.nb;
     }
     const int maxit = c.max_num_iterations;
-    for (int i = 0; i <= maxit; ++i) {   // :654-723
-        float* sig_cur = h->part_sigma[i & 1];
-        float* sig_next = h->part_sigma[(i + 1) & 1];
-        LAUNCH(h, KC_PCG_APPLY, k_pcg_apply, grid, block, h->geom, h->marker, h->search, h->part_sas, h->tile_flags, ctrl);
-        const int last = (i == maxit);
-        const int check = last || (i > 0 && c.error_check_frequency > 0 && i % c.error_check_frequency == 0);   // :672-673
-        if (zero_mode) {
-            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update<true>, grid, block, h->geom, h->marker, h->search, p, h->residual, h->part_sas, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl);
-            LAUNCH(h, KC_PCG_SEARCH, k_pcg_search<true>, grid, block, h->geom, h->marker, h->residual, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
-        } else {
-            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update<false>, grid, block, h->geom, h->marker, h->search, p, h->residual, h->part_sas, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl);
-            if (!last) {
-                LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
-                LAUNCH(h, KC_PCG_PRECOND, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->aux, (const float*)h->residual, sig_next, h->tile_flags, ctrl);
-            }
-            LAUNCH(h, KC_PCG_SEARCH, k_pcg_search<false>, grid, block, h->geom, h->marker, h->aux, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
+    const int freq = c.error_check_frequency;
+    auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };   // :672-673 (the i == max case is k_pcg_finalize)
+    float* sbuf[2] = {h->search, h->aux};
+    if (sparse) {
+        const int np = std::min(h->bg.nb, PCG_GRID_MAX);
+        const dim3 grid(np), block(BRICK_THREADS);
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], h->part_sigma[0]);
+        for (int i = 0; i <= maxit; ++i) {
+            float *sig_prev = h->part_sigma[(i + 1) & 1], *sig_cur = h->part_sigma[i & 1], *sig_next = h->part_sigma[(i + 1) & 1];
+            if (i == 0)
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
+                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, ctrl, tol, i, 0);
+            else
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<false>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
+                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, ctrl, tol, i, (int)is_check(i - 1));
+            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
+                   (const float*)h->part_sas, (const float*)sig_cur, sig_next, h->part_max, np, (const PcgCtrl*)ctrl);
         }
-        if (last) break;
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float*)h->part_max, np, maxit);
+    } else {
+        const int np = h->pcg_grid;
+        const dim3 grid(np), block(256);
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_d, grid, block, h->geom, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], h->part_sigma[0], h->tile_flags);
+        for (int i = 0; i <= maxit; ++i) {
+            float *sig_prev = h->part_sigma[(i + 1) & 1], *sig_cur = h->part_sigma[i & 1], *sig_next = h->part_sigma[(i + 1) & 1];
+            if (i == 0)
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_d<true>, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
+                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);
+            else
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_d<false>, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
+                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));
+            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_d, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
+                   (const float*)h->part_sas, (const float*)sig_cur, sig_next, h->part_max, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl);
+        }
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float*)h->part_max, np, maxit);
     }
-    // enqueue_error_buffer_read, pressure_solver.rs:176-191: 8 bytes {MaxError, NumIterations}
-    if ((int)h->stats_pending[which].size() < STATS_RING) {
-        const int slot = h->stats_head[which];
-        h->stats_head[which] = (slot + 1) % STATS_RING;
-        HIP_TRY(hipMemcpyAsync(h->stats_host[which] + 2 * slot, ctrl, 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipEventRecord(h->stats_events[which][slot], h->stream));
-        h->stats_pending[which].push_back({h->stats_events[which][slot], slot});
-        h->stats_dt[which].push_back(dt);
-    }   // else: "No more error buffer available" -- the reference warns and skips the sample (:188-190)
-    return BLUB_OK;
+    // the search direction of a full-length solve ends in sbuf[maxit & 1]; keep BLUB_VOLUME_SEARCH pointing at it
+    if (maxit & 1) std::swap(h->search, h->aux);
+    return enqueue_stats_readback(h, which, dt);
 }
 
 static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
@@ -228,26 +342,30 @@ static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
     return BLUB_OK;
 }
 static int stage_extrapolate(blub_fluid* h) {
-    LAUNCH(h, KC_EXTRAPOLATE, k_extrapolate, cell_grid(h->g), dim3(256), h->g, h->marker, h->vel[0], h->vel[1], h->vel[2]);
+    LAUNCH(h, KC_EXTRAPOLATE, k_extrapolate_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker, h->vel[0], h->vel[1], h->vel[2]);
     return BLUB_OK;
 }
 static int stage_project(blub_fluid* h) {   // :906-914
-    LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove, cell_grid(h->g), dim3(256), h->g, h->marker, h->pressure[0], h->solid, h->vel[0], h->vel[1], h->vel[2]);
+    LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+           (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
     return stage_extrapolate(h);
 }
 static int stage_advect(blub_fluid* h, float dt) {   // :916-932
-    LAUNCH(h, KC_INIT_GRID, k_init_grid, dim3(stream_blocks(h->N / 4)), dim3(256), h->g, h->marker, h->solid, h->ll[0], (uint32_t*)nullptr, (uint32_t*)nullptr);
+    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const float4*)h->solid, h->marker, h->ll[0],
+           (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     if (h->num_particles)
         LAUNCH(h, KC_ADVECT, k_advect, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
                h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, h->ll[0]);
-    return BLUB_OK;
+    return build_lists_from_particles(h, COMPACT_STEP_B);
 }
 static int stage_density_gather(blub_fluid* h, float dt) {   // :933-937
-    LAUNCH(h, KC_DENSITY_GATHER, k_density_gather, tile9_grid(h->g), dim3(768), h->g, h->marker, h->ll[0], h->pos, h->residual, dt);
+    LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_b, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
+           (const float4*)h->pos, h->residual, dt);
     return BLUB_OK;
 }
 static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
-    LAUNCH(h, KC_POSITION_CHANGE, k_position_change, cell_grid(h->g), dim3(256), h->g, h->marker, h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
+    LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+           (const float*)h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
     return stage_extrapolate(h);
 }
 static int stage_correct(blub_fluid* h) {   // :969-973
@@ -256,16 +374,21 @@ static int stage_correct(blub_fluid* h) {   // :969-973
     return BLUB_OK;
 }
 
-static int run_stage(blub_fluid* h, int stage, float dt) {
+// `standalone`: called through blub_fluid_run_stage (test hook) -- the brick lists are then derived from the marker
+// volume with every brick active, i.e. the stage has the reference's dense semantics on whatever state was written.
+static int run_stage(blub_fluid* h, int stage, float dt, bool standalone) {
+    int rc;
+    if (standalone && stage != BLUB_STAGE_TRANSFER && stage != BLUB_STAGE_BINNING)
+        if ((rc = build_lists_from_marker(h)) != BLUB_OK) return rc;
     switch (stage) {
     case BLUB_STAGE_TRANSFER: return stage_transfer(h, dt);
     case BLUB_STAGE_DIVERGENCE: return stage_divergence(h);
-    case BLUB_STAGE_SOLVE_VELOCITY: return stage_solve(h, 0, dt);
+    case BLUB_STAGE_SOLVE_VELOCITY: return stage_solve(h, 0, dt, standalone);
     case BLUB_STAGE_BINNING: return stage_binning(h);
     case BLUB_STAGE_PROJECT: return stage_project(h);
     case BLUB_STAGE_ADVECT: return stage_advect(h, dt);
     case BLUB_STAGE_DENSITY_GATHER: return stage_density_gather(h, dt);
-    case BLUB_STAGE_SOLVE_DENSITY: return stage_solve(h, 1, dt);
+    case BLUB_STAGE_SOLVE_DENSITY: return stage_solve(h, 1, dt, standalone);
     case BLUB_STAGE_POSITION_CHANGE: return stage_position_change(h, dt);
     case BLUB_STAGE_CORRECT: return stage_correct(h);
     }
@@ -286,6 +409,9 @@ static void destroy(blub_fluid* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->next1); F(h->next2); F(h->marker); for (auto p : h->ll) F(p);
     for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
+    F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
+    if (h->counts_host) (void)hipHostFree(h->counts_host);
+    for (auto e : h->counts_events) if (e) (void)hipEventDestroy(e);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
     for (int w = 0; w < 2; ++w) { if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]); for (auto e : h->stats_events[w]) if (e) (void)hipEventDestroy(e); }
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -336,11 +462,23 @@ static int create(const blub_fluid_desc* d, blub_fluid** out) {
     A(dev_alloc_zero(&h->part_sas, PCG_GRID_MAX)); A(dev_alloc_zero(&h->part_sigma[0], PCG_GRID_MAX)); A(dev_alloc_zero(&h->part_sigma[1], PCG_GRID_MAX));
     A(dev_alloc_zero(&h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(&h->tile_flags, (size_t)gm.tiles));
     A(dev_alloc_zero(&h->ctrl[0], 1)); A(dev_alloc_zero(&h->ctrl[1], 1));
+    A(dev_alloc_zero(&h->dvol, h->N));
+    BrickGeom& bg = h->bg;
+    bg.g = h->g; bg.nbx = (h->g.nx + BX - 1) / BX; bg.nby = (h->g.ny + BY - 1) / BY; bg.nbz = (h->g.nz + BZ - 1) / BZ; bg.nb = bg.nbx * bg.nby * bg.nbz;
+    h->brick_grid = std::min(bg.nb, BRICK_GRID_MAX);
+    A(dev_alloc_zero(&h->brick_fluid, (size_t)bg.nb)); A(dev_alloc_zero(&h->brick_active, (size_t)bg.nb)); A(dev_alloc_zero(&h->brick_touched, (size_t)bg.nb));
+    A(dev_alloc_zero(&h->list_fluid, (size_t)bg.nb)); A(dev_alloc_zero(&h->list_active, (size_t)bg.nb)); A(dev_alloc_zero(&h->list_reset, (size_t)bg.nb));
+    A(dev_alloc_zero(&h->counts, 1));
+    if (rc == BLUB_OK && hipHostMalloc((void**)&h->counts_host, COUNTS_RING * sizeof(BrickCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    for (int k = 0; k < COUNTS_RING && rc == BLUB_OK; ++k) if (hipEventCreateWithFlags(&h->counts_events[k], hipEventDisableTiming) != hipSuccess) rc = set_error(BLUB_ERR_DEVICE, "hipEventCreate failed");
     for (int w = 0; w < 2 && rc == BLUB_OK; ++w) {
         if (hipHostMalloc((void**)&h->stats_host[w], STATS_RING * 2 * sizeof(float)) != hipSuccess) { rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed"); break; }
         for (int k = 0; k < STATS_RING; ++k) if (hipEventCreateWithFlags(&h->stats_events[w][k], hipEventDisableTiming) != hipSuccess) { rc = set_error(BLUB_ERR_DEVICE, "hipEventCreate failed"); break; }
     }
     if (rc != BLUB_OK) { std::string keep = g_last_error; destroy(h); g_last_error = keep; return rc; }
+    // the marker volume starts in its static pattern (AIR + SOLID shell): the brick kernels only maintain it locally
+    hipLaunchKernelGGL(k_static_marker_dense, dim3(stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)nullptr, h->marker);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "marker initialisation failed"); }
     *out = h;
     return BLUB_OK;
 }
@@ -418,7 +556,7 @@ int blub_fluid_set_gravity_grid(blub_fluid* h, const float g[3]) {
 int blub_fluid_run_stage(blub_fluid* h, int stage, float dt) {
     REQUIRE_HANDLE(h);
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
-    int rc = blub::run_stage(h, stage, dt);
+    int rc = blub::run_stage(h, stage, dt, true);
     return rc != BLUB_OK ? rc : blub::check_launch(h);
 }
 int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
@@ -427,10 +565,10 @@ int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
     static const int before_binning[] = {BLUB_STAGE_TRANSFER, BLUB_STAGE_DIVERGENCE, BLUB_STAGE_SOLVE_VELOCITY};
     static const int after_binning[] = {BLUB_STAGE_PROJECT, BLUB_STAGE_ADVECT, BLUB_STAGE_DENSITY_GATHER, BLUB_STAGE_SOLVE_DENSITY, BLUB_STAGE_POSITION_CHANGE, BLUB_STAGE_CORRECT};
     int rc;
-    for (int s : before_binning) if ((rc = blub::run_stage(h, s, dt)) != BLUB_OK) return rc;
+    for (int s : before_binning) if ((rc = blub::run_stage(h, s, dt, false)) != BLUB_OK) return rc;
     if (h->rebin_freq != 0 && h->step_counter % h->rebin_freq == 0)   // :854-856 (Q13)
-        if ((rc = blub::run_stage(h, BLUB_STAGE_BINNING, dt)) != BLUB_OK) return rc;
-    for (int s : after_binning) if ((rc = blub::run_stage(h, s, dt)) != BLUB_OK) return rc;
+        if ((rc = blub::run_stage(h, BLUB_STAGE_BINNING, dt, false)) != BLUB_OK) return rc;
+    for (int s : after_binning) if ((rc = blub::run_stage(h, s, dt, false)) != BLUB_OK) return rc;
     h->step_counter += 1;   // :976
     (void)blub::poll_stats(h, false);   // the reference polls old read-backs inside solve (:612)
     return blub::check_launch(h);
@@ -486,9 +624,15 @@ int blub_fluid_get_device_views(const blub_fluid* h, blub_device_views* v) {
 int blub_fluid_set_solid_voxels(blub_fluid* h, const float* vox) {
     REQUIRE_HANDLE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!vox) { if (h->solid) { (void)hipFree(h->solid); h->solid = nullptr; } return BLUB_OK; }
-    if (!h->solid) HIP_TRY(hipMalloc((void**)&h->solid, h->N * sizeof(float4)));
-    HIP_TRY(hipMemcpy(h->solid, vox, h->N * sizeof(float4), hipMemcpyHostToDevice));
+    if (!vox) { if (h->solid) { (void)hipFree(h->solid); h->solid = nullptr; } }
+    else {
+        if (!h->solid) HIP_TRY(hipMalloc((void**)&h->solid, h->N * sizeof(float4)));
+        HIP_TRY(hipMemcpy(h->solid, vox, h->N * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    // the static marker pattern changed everywhere; every brick may now differ from it
+    hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker);
+    h->all_touched = true;
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return BLUB_OK;
 }
 int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz) {
@@ -547,11 +691,26 @@ int blub_fluid_write_volume(blub_fluid* h, int which, const void* in) {
     if (!p || !in) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(p, in, b, hipMemcpyHostToDevice));
+    h->all_touched = true;   // arbitrary data may now sit outside the active bricks: the next step re-establishes the invariant
     return BLUB_OK;
 }
 int blub_fluid_mark_pressure_initialised(blub_fluid* h, int which, int init) {
     if (!h || which < 0 || which > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
     h->pressure_initialised[which] = init != 0;
+    return BLUB_OK;
+}
+int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode) {
+    if (!h || mode < -1 || mode > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    h->force_pcg_path = mode;
+    return BLUB_OK;
+}
+int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]) {
+    REQUIRE_HANDLE(h);
+    if (!out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    blubk::BrickCounts bc{};
+    HIP_TRY(hipMemcpy(&bc, h->counts, sizeof(bc), hipMemcpyDeviceToHost));
+    out[0] = bc.n_fluid; out[1] = bc.n_active; out[2] = bc.n_reset; out[3] = bc.n_stale; out[4] = (uint32_t)h->bg.nb; out[5] = blubk::BX * blubk::BY * blubk::BZ;
     return BLUB_OK;
 }
 int blub_fluid_profile_enable(blub_fluid* h, int enabled) { REQUIRE_HANDLE(h); int rc = blub::prof_flush(h); h->prof_enabled = enabled != 0; return rc; }

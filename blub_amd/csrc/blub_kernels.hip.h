@@ -63,35 +63,6 @@ __device__ __forceinline__ float reduce_partials_256(const float* __restrict__ p
 }
 
 // =================================================================================================================
-// T1 + T3 fused: transfer_clear.comp:10-14 and transfer_set_boundary_marker.comp:11-19.
-// marker := SOLID on the domain shell / solid voxels, AIR elsewhere; the linked-list head volumes := 0.
-// (T2 then only ever turns AIR into FLUID, so the final marker equals the reference's T1 -> T2 -> T3 order.)
-// One thread = 4 x-consecutive cells (nx % 4 == 0): 4 B marker store + 16 B stores per list volume.
-// =================================================================================================================
-__global__ __launch_bounds__(256) void k_init_grid(Grid g, int8_t* __restrict__ marker, const float4* __restrict__ solid,
-                                                   uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2) {
-    const int nquads = (g.nx >> 2) * g.ny * g.nz;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < nquads; q += gridDim.x * 256) {
-        const int base = q << 2;
-        const int x0 = base % g.nx, yz = base / g.nx, y = yz % g.ny, z = yz / g.ny;
-        const bool shell_yz = (y == 0) | (z == 0) | (y == g.ny - 1) | (z == g.nz - 1);
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = x0 + j;
-            bool sol = shell_yz | (x == 0) | (x == g.nx - 1);
-            if (!sol && solid) sol = solid[base + j].w != 0.0f;
-            packed |= (sol ? 0u : 0xFFu) << (8 * j);
-        }
-        *reinterpret_cast<uint32_t*>(marker + base) = packed;
-        const uint4 z4 = make_uint4(0, 0, 0, 0);
-        if (ll0) *reinterpret_cast<uint4*>(ll0 + base) = z4;
-        if (ll1) *reinterpret_cast<uint4*>(ll1 + base) = z4;
-        if (ll2) *reinterpret_cast<uint4*>(ll2 + base) = z4;
-    }
-}
-
-// =================================================================================================================
 // T2 x3 fused: transfer_build_linkedlist.comp:10-26.  One pass over the particles builds the three staggered
 // dual-grid lists (component c: dual cell = ivec3(pos - (0.5 + 0.5 e_c))) and marks FLUID cells.
 // list "next" pointers: component x lives in pos.w (as in the reference), y/z in two extra u32 arrays.
@@ -120,12 +91,7 @@ __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_partic
     next2[i] = nxt[2];
 }
 
-// =================================================================================================================
-// T4: transfer_gather_velocity.comp:39-127.  9x9x9 list cells per workgroup (8^3 outputs + 1 halo layer on the
-// negative sides); every thread walks ITS cell's list and publishes the current particle through LDS, the 7 other
-// lists a face needs are read from LDS (27 KiB/WG).  Differences to the reference: 768-thread blocks (12 full
-// waves) instead of 729, and the 12-round loop exits as soon as every list in the workgroup is exhausted.
-// =================================================================================================================
+// ---- shared by the P2G gather (blub_bricks.hip.h): transfer_gather_velocity.comp:18-26 ----
 __device__ __forceinline__ void add_particle(float& v, float& wsum, const float4& pp, const float4& row, float sx, float sy, float sz) {
     const float tx = sx - pp.x, ty = sy - pp.y, tz = sz - pp.z;                       // :20
     const float ox = satf(1.0f - fabsf(tx)), oy = satf(1.0f - fabsf(ty)), oz = satf(1.0f - fabsf(tz));
@@ -133,85 +99,6 @@ __device__ __forceinline__ void add_particle(float& v, float& wsum, const float4
     const float d = ((row.x * tx + row.y * ty) + row.z * tz) + row.w * 1.0f;           // :24
     v += w * d;
     wsum += w;
-}
-
-template <int COMP>
-__global__ __launch_bounds__(768) void k_gather_velocity(Grid g, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
-                                                         const float4* __restrict__ pos, const uint32_t* __restrict__ next,
-                                                         const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
-    __shared__ float4 sPos[729];
-    __shared__ float4 sVel[729];
-    const int tid = threadIdx.x;
-    const bool live = tid < 729;
-    const int lx = tid % 9, ly = (tid / 9) % 9, lz = tid / 81;
-    const int gx = blockIdx.x * 8 + lx - 1, gy = blockIdx.y * 8 + ly - 1, gz = blockIdx.z * 8 + lz - 1;   // :41
-    const bool in = live && inb(g, gx, gy, gz);
-    const bool border = !live || lx == 0 || ly == 0 || lz == 0;
-    const int mA = in ? (int)marker[cidx(g, gx, gy, gz)] : CELL_SOLID;
-    const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
-    const bool writes = !border && in && (mA == CELL_FLUID || mB == CELL_FLUID);      // :50 (OOB stores are dropped)
-    const bool computes = !border && (mA != CELL_SOLID && mB != CELL_SOLID);           // :51
-    const float sx = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
-    const float sy = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
-    const float sz = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
-    uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
-    float v = 0.0f, wsum = 0.0f;
-    const int a1 = tid - 1, a2 = tid - 9, a3 = tid - 10, a4 = tid - 81, a5 = tid - 82, a6 = tid - 90, a7 = tid - 91;   // :87-93
-    for (int round = 0; round < 12; ++round) {                                          // :61
-        const bool has = cur != INVALID_LL;
-        if (!__syncthreads_or(has)) break;   // also orders last round's LDS reads before this round's writes
-        if (has) {
-            const float4 p = pos[cur];
-            const float4 r = rows[cur];
-            cur = next ? next[cur] : __float_as_uint(p.w);
-            if (computes) add_particle(v, wsum, p, r, sx, sy, sz);
-            sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
-            sVel[tid] = r;
-        } else if (live) {
-            sPos[tid].w = 0.0f;
-        }
-        __syncthreads();
-        if (computes) {
-            float4 q;
-            q = sPos[a1]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a1], sx, sy, sz);
-            q = sPos[a2]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a2], sx, sy, sz);
-            q = sPos[a3]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a3], sx, sy, sz);
-            q = sPos[a4]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a4], sx, sy, sz);
-            q = sPos[a5]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a5], sx, sy, sz);
-            q = sPos[a6]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a6], sx, sy, sz);
-            q = sPos[a7]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a7], sx, sy, sz);
-        }
-    }
-    if (writes) {
-        if (computes) { if (wsum > 0.0f) v /= wsum; v += gravity_dt; }                 // :117-120
-        else v = 0.0f;                                                                  // :121-124
-        out[cidx(g, gx, gy, gz)] = v;
-    }
-}
-
-// =================================================================================================================
-// D1: divergence_compute.comp:28-87 -> residual volume (FLUID cells only)
-// =================================================================================================================
-__global__ __launch_bounds__(256) void k_divergence(Grid g, const int8_t* __restrict__ marker, const float* __restrict__ vx,
-                                                    const float* __restrict__ vy, const float* __restrict__ vz,
-                                                    const float4* __restrict__ solid, float* __restrict__ residual) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
-    if (x >= g.nx || y >= g.ny) return;
-    const int c = cidx(g, x, y, z);
-    if (marker[c] != CELL_FLUID) return;
-    const float px = vx[c], py = vy[c], pz = vz[c];
-    const float qx = fv(vx, g, x - 1, y, z), qy = fv(vy, g, x, y - 1, z), qz = fv(vz, g, x, y, z - 1);
-    float div = px - qx;
-    div += py - qy;
-    div += pz - qz;
-    auto wall = [&](int ax, int ay, int az, float wallv, int comp) -> float {
-        if (mk(marker, g, ax, ay, az) != CELL_SOLID) return 0.0f;
-        const float sv = (solid && inb(g, ax, ay, az)) ? comp3(solid[cidx(g, ax, ay, az)], comp) : 0.0f;
-        return wallv - sv;
-    };
-    div += wall(x - 1, y, z, qx, 0); div += wall(x, y - 1, z, qy, 1); div += wall(x, y, z - 1, qz, 2);
-    div -= wall(x + 1, y, z, px, 0); div -= wall(x, y + 1, z, py, 1); div -= wall(x, y, z + 1, pz, 2);
-    residual[c] = div;
 }
 
 // =================================================================================================================
@@ -533,67 +420,6 @@ __global__ __launch_bounds__(256) void k_pcg_search(PcgGeom geom, const int8_t* 
     PCG_TILE_LOOP_END
 }
 
-// =================================================================================================================
-// D2: divergence_remove.comp:19-49
-// =================================================================================================================
-__global__ __launch_bounds__(256) void k_divergence_remove(Grid g, const int8_t* __restrict__ marker, const float* __restrict__ p,
-                                                           const float4* __restrict__ solid, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
-    if (x >= g.nx || y >= g.ny) return;
-    const int c = cidx(g, x, y, z);
-    const int mc = marker[c];
-    const float pc = (mc == CELL_FLUID) ? p[c] : 0.0f;
-    float* vel[3] = {vx, vy, vz};
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp) {
-        const int ax = x + (comp == 0), ay = y + (comp == 1), az = z + (comp == 2);
-        const int mn = mk(marker, g, ax, ay, az);
-        float v = 0.0f;
-        if (mc == CELL_FLUID || mn == CELL_FLUID) {
-            if (mc == CELL_SOLID) v = solid ? comp3(solid[c], comp) : 0.0f;
-            else if (mn == CELL_SOLID) v = (solid && inb(g, ax, ay, az)) ? comp3(solid[cidx(g, ax, ay, az)], comp) : 0.0f;
-            else {
-                v = vel[comp][c];
-                const float pn = (mn == CELL_FLUID) ? p[cidx(g, ax, ay, az)] : 0.0f;
-                v -= pc - pn;
-            }
-        }
-        vel[comp][c] = v;
-    }
-}
-
-// =================================================================================================================
-// D3: extrapolate_velocity.comp:9-90.  Reads only valid faces, writes only invalid ones => in place.
-// =================================================================================================================
-__global__ __launch_bounds__(256) void k_extrapolate(Grid g, const int8_t* __restrict__ marker, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
-    if (x >= g.nx || y >= g.ny) return;
-    const int c = cidx(g, x, y, z);
-    if (marker[c] == CELL_FLUID) return;
-    float* vel[3] = {vx, vy, vz};
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp) {
-        if (mk(marker, g, x + (comp == 0), y + (comp == 1), z + (comp == 2)) == CELL_FLUID) continue;
-        float numV = 0.0f, avgV = 0.0f;
-        // in-plane neighbours in the reference's order: (a,b) over the two axes != comp, b-major (lines :37-44, :55-62, :73-80)
-#pragma unroll
-        for (int b = -1; b <= 1; ++b)
-#pragma unroll
-            for (int a = -1; a <= 1; ++a) {
-                if (a == 0 && b == 0) continue;
-                int ox, oy, oz;
-                if (comp == 0) { ox = 0; oy = a; oz = b; }
-                else if (comp == 1) { ox = a; oy = 0; oz = b; }
-                else { ox = a; oy = b; oz = 0; }
-                const int cx = x + ox, cy = y + oy, cz = z + oz;
-                const bool valid = mk(marker, g, cx, cy, cz) == CELL_FLUID ||
-                                   mk(marker, g, cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
-                if (valid) { numV += 1.0f; avgV += fv(vel[comp], g, cx, cy, cz); }
-            }
-        if (numV > 0.0f) vel[comp][c] = avgV / numV;
-    }
-}
-
 // ---- samplers (SamplerPointClamp / SamplerTrilinearClamp with exact f32 weights) -------------
 __device__ __forceinline__ float4 solid_point_clamp(const float4* __restrict__ solid, const Grid& g, float tx, float ty, float tz) {
     const int x = min(max((int)floorf(tx * (float)g.nx), 0), g.nx - 1);
@@ -729,85 +555,6 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
     pvx[pi] = make_float4(cx[0], cx[1], cx[2], nv[0]);   // :186-188 (Q2: literal row layout)
     pvy[pi] = make_float4(cy[0], cy[1], cy[2], nv[1]);
     pvz[pi] = make_float4(cz[0], cz[1], cz[2], nv[2]);
-}
-
-// =================================================================================================================
-// R1: density_projection_gather_error.comp:41-198 -- same LDS-staged 8-list walk, <=32 rounds, centre sample.
-// =================================================================================================================
-__global__ __launch_bounds__(768) void k_density_gather(Grid g, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
-                                                        const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
-    __shared__ float4 sPos[729];
-    const int tid = threadIdx.x;
-    const bool live = tid < 729;
-    const int lx = tid % 9, ly = (tid / 9) % 9, lz = tid / 81;
-    const int gx = blockIdx.x * 8 + lx - 1, gy = blockIdx.y * 8 + ly - 1, gz = blockIdx.z * 8 + lz - 1;
-    const bool in = live && inb(g, gx, gy, gz);
-    const bool border = !live || lx == 0 || ly == 0 || lz == 0;
-    const bool writes = !border && in && marker[cidx(g, gx, gy, gz)] == CELL_FLUID;   // :46
-    const float sx = (float)gx + 0.5f, sy = (float)gy + 0.5f, sz = (float)gz + 0.5f;
-    uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
-    float density = 0.0f;
-    auto add = [&](const float4& p) {
-        const float ox = satf(1.0f - fabsf(sx - p.x)), oy = satf(1.0f - fabsf(sy - p.y)), oz = satf(1.0f - fabsf(sz - p.z));
-        density += ox * oy * oz;                                                          // :27-31
-    };
-    const int a1 = tid - 1, a2 = tid - 9, a3 = tid - 10, a4 = tid - 81, a5 = tid - 82, a6 = tid - 90, a7 = tid - 91;
-    for (int round = 0; round < 32; ++round) {                                            // :69
-        const bool has = cur != INVALID_LL;
-        if (!__syncthreads_or(has)) break;
-        if (has) {
-            const float4 p = pos[cur];
-            cur = __float_as_uint(p.w);
-            if (writes) add(p);
-            sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
-        } else if (live) {
-            sPos[tid].w = 0.0f;
-        }
-        __syncthreads();
-        if (writes) {
-            float4 q;
-            q = sPos[a1]; if (q.w != 0.0f) add(q);
-            q = sPos[a2]; if (q.w != 0.0f) add(q);
-            q = sPos[a3]; if (q.w != 0.0f) add(q);
-            q = sPos[a4]; if (q.w != 0.0f) add(q);
-            q = sPos[a5]; if (q.w != 0.0f) add(q);
-            q = sPos[a6]; if (q.w != 0.0f) add(q);
-            q = sPos[a7]; if (q.w != 0.0f) add(q);
-        }
-    }
-    if (!writes) return;
-    const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
-                      mk(marker, g, gx - 1, gy, gz), mk(marker, g, gx, gy - 1, gz), mk(marker, g, gx, gy, gz - 1)};   // :115-120
-    bool anyAir = false;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { if (m[k] == CELL_SOLID) density += 0.5625f; if (m[k] == CELL_AIR) anyAir = true; }   // :167-179
-    if (anyAir) density = fmaxf(8.0f, density);                                           // :182-184
-    density = 1.0f - density / 8.0f;                                                      // :188
-    density = clampf(density, -0.5f, 0.5f);                                               // :192
-    density /= dt;                                                                        // :196
-    residual[cidx(g, gx, gy, gz)] = density;
-}
-
-// =================================================================================================================
-// R2: density_projection_position_change.comp:18-51 (overwrites the velocity volumes with position deltas)
-// =================================================================================================================
-__global__ __launch_bounds__(256) void k_position_change(Grid g, const int8_t* __restrict__ marker, const float* __restrict__ p, float dt,
-                                                         float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
-    if (x >= g.nx || y >= g.ny) return;
-    const int c = cidx(g, x, y, z);
-    const int mc = marker[c];
-    const float pc = (mc == CELL_FLUID) ? p[c] : 0.0f;
-    float* vel[3] = {vx, vy, vz};
-#pragma unroll
-    for (int comp = 0; comp < 3; ++comp) {
-        const int ax = x + (comp == 0), ay = y + (comp == 1), az = z + (comp == 2);
-        const int mn = mk(marker, g, ax, ay, az);
-        const float pn = (mn == CELL_FLUID) ? p[cidx(g, ax, ay, az)] : 0.0f;
-        float d = (pn - pc) * dt;
-        if (mc == CELL_SOLID || mn == CELL_SOLID) d = 0.0f;
-        vel[comp][c] = d;
-    }
 }
 
 // =================================================================================================================

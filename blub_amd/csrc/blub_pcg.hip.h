@@ -1,0 +1,316 @@
+// Fused PCG iteration for the parity-default ("zero") preconditioner reading -- two streaming kernels per iteration.
+//
+// Reference schedule per iteration (pressure_solver.rs:654-723): apply_coeff, reduce x2, update p/r, [reduce_max x2],
+// preconditioner pass 0, pass 1, reduce x2, update_search  (9-11 dispatches, 4N-byte reduce buffers).  Here:
+//   KD "direction": [max|r| test of the previous iteration]  beta = sigma'/sigma;  s = M^-1 r + beta s  (own cell AND,
+//                   redundantly, its 6 neighbours -- identical f32 ops, so every copy is bit-identical; s is double
+//                   buffered because neighbours still need the old value);  partial s.As
+//   KU "update"   : alpha = sigma / s.As;  p += alpha s;  r -= alpha A s;  partial max|r|;  partial (M^-1 r).r
+// M^-1 r = (r/d)/d is pointwise (SURVEY Appendix B, Q1 reading "zero"), d = number of non-solid neighbours.
+// All marker logic is folded once per solve into a stencil-descriptor byte volume `dvol`:
+//   dvol[c] = 0x80 | d  for FLUID cells,  0 otherwise        (bit 7 = "is FLUID", bits 0-2 = diagonal of A)
+// so the iteration kernels read 1 byte per cell + the f32 fields, never the marker.
+// Dot products: one partial per block, re-reduced (<=1024 floats, L2 resident) by every block of the consumer kernel:
+// no atomics, no reduce dispatch, bit-deterministic.  sigma is double-buffered by iteration parity.
+//
+// Two work mappings share the per-quad device functions:
+//   *_d : dense rows  -- a tile = 256 threads x 4 x-consecutive cells of a z-plane, marched over PCG_ZC planes,
+//                        persistent grid striding over tiles, tiles without FLUID skipped (high fill ratios)
+//   *_b : brick lists -- one 128-thread block per FLUID brick (16x8x4 cells), low fill ratios (the 1M @ 256^3 scene)
+#pragma once
+#include "blub_bricks.hip.h"
+
+namespace blubk {
+
+__device__ __forceinline__ int dbyte(uint32_t packed, int j) { return (int)((packed >> (8 * j)) & 0xFFu); }
+__device__ __forceinline__ bool any_fluid_d(uint32_t packed) { return (packed & 0x80808080u) != 0u; }
+
+struct QuadD { uint32_t c, ym, yp, zm, zp; int xm, xp; };
+__device__ __forceinline__ void load_quad_d(const uint8_t* __restrict__ D, const Grid& g, int base, int x0, int y, int z, QuadD& q) {
+    const int plane = g.nx * g.ny;
+    q.xm = x0 > 0 ? (int)D[base - 1] : 0;
+    q.xp = x0 + 4 < g.nx ? (int)D[base + 4] : 0;
+    q.ym = y > 0 ? *reinterpret_cast<const uint32_t*>(D + base - g.nx) : 0u;
+    q.yp = y + 1 < g.ny ? *reinterpret_cast<const uint32_t*>(D + base + g.nx) : 0u;
+    q.zm = z > 0 ? *reinterpret_cast<const uint32_t*>(D + base - plane) : 0u;
+    q.zp = z + 1 < g.nz ? *reinterpret_cast<const uint32_t*>(D + base + plane) : 0u;
+}
+
+template <int NT, bool MAX>
+__device__ __forceinline__ float block_reduce(float v, float* sm) {
+    v = MAX ? wave_max(v) : wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float r = sm[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = MAX ? fmaxf(r, sm[w]) : r + sm[w];
+    return r;
+}
+template <int NT, bool MAX>
+__device__ __forceinline__ float reduce_partials(const float* __restrict__ part, int n, float* sm) {
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < n; i += NT) v = MAX ? fmaxf(v, part[i]) : v + part[i];
+    return block_reduce<NT, MAX>(v, sm);
+}
+
+// ---- per-quad bodies ---------------------------------------------------------------------------------------------
+// S0 (pressure_init.comp:19-84) + dvol + initial preconditioner/sigma (pressure_solver.rs:636-648)
+__device__ __forceinline__ bool pcg_init_quad(const Grid& g, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
+                                              float* __restrict__ r, float* __restrict__ s, int base, int x0, int y, int z, float& acc) {
+    const uint32_t mc = *reinterpret_cast<const uint32_t*>(marker + base);
+    float4 pc = ld4(p + base);
+    uint32_t dq = 0;
+    const bool anyf = any_fluid4(mc);
+    if (anyf) {
+        QuadMarkers m; m.c = mc; load_quad_markers(marker, g, base, x0, y, z, m);
+        QuadValues pv; load_quad_values(p, g, base, x0, y, z, pv);
+        const float4 rc = ld4(r + base);
+        float4 so = ld4(s + base);
+        float rr[4] = {rc.x, rc.y, rc.z, rc.w}, ss[4] = {so.x, so.y, so.z, so.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (mbyte(mc, j) != CELL_FLUID) continue;
+            const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
+            const int mY0 = mbyte(m.ym, j), mY1 = mbyte(m.yp, j), mZ0 = mbyte(m.zm, j), mZ1 = mbyte(m.zp, j);
+            const int di = (mX0 != 0) + (mX1 != 0) + (mY0 != 0) + (mY1 != 0) + (mZ0 != 0) + (mZ1 != 0);
+            const float d = (float)di;
+            dq |= (uint32_t)(0x80 | di) << (8 * j);
+            float res = rr[j];
+            if (d > 0.0f) res -= d * f4(pv.c, j);                                   // :62-63
+            if (mX0 == CELL_FLUID) res += (j > 0 ? f4(pv.c, j - 1) : pv.xm);          // :64-81
+            if (mX1 == CELL_FLUID) res += (j < 3 ? f4(pv.c, j + 1) : pv.xp);
+            if (mY0 == CELL_FLUID) res += f4(pv.ym, j);
+            if (mY1 == CELL_FLUID) res += f4(pv.yp, j);
+            if (mZ0 == CELL_FLUID) res += f4(pv.zm, j);
+            if (mZ1 == CELL_FLUID) res += f4(pv.zp, j);
+            rr[j] = res;
+            ss[j] = precond_zero(res, d);
+            acc += ss[j] * res;
+        }
+        *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        *reinterpret_cast<float4*>(s + base) = make_float4(ss[0], ss[1], ss[2], ss[3]);   // non-FLUID lanes keep their old value
+    }
+    *reinterpret_cast<uint32_t*>(dvol + base) = dq;
+    bool dirty = false;   // pressure_init.comp:45-48: p := 0 outside the fluid
+    if (mbyte(mc, 0) != CELL_FLUID && pc.x != 0.0f) { pc.x = 0.0f; dirty = true; }
+    if (mbyte(mc, 1) != CELL_FLUID && pc.y != 0.0f) { pc.y = 0.0f; dirty = true; }
+    if (mbyte(mc, 2) != CELL_FLUID && pc.z != 0.0f) { pc.z = 0.0f; dirty = true; }
+    if (mbyte(mc, 3) != CELL_FLUID && pc.w != 0.0f) { pc.w = 0.0f; dirty = true; }
+    if (dirty) *reinterpret_cast<float4*>(p + base) = pc;
+    return anyf;
+}
+
+// A s for cell j from descriptor bytes (pressure.glsl:34-75: diag * s - sum over FLUID neighbours)
+__device__ __forceinline__ float quad_mulA_d(const QuadD& m, const QuadValues& v, int j) {
+    const int bX0 = j > 0 ? dbyte(m.c, j - 1) : m.xm, bX1 = j < 3 ? dbyte(m.c, j + 1) : m.xp;
+    float r = 0.0f;
+    r += (float)(dbyte(m.c, j) & 7) * f4(v.c, j);
+    if (bX0 & 0x80) r -= (j > 0 ? f4(v.c, j - 1) : v.xm);
+    if (bX1 & 0x80) r -= (j < 3 ? f4(v.c, j + 1) : v.xp);
+    if (dbyte(m.ym, j) & 0x80) r -= f4(v.ym, j);
+    if (dbyte(m.yp, j) & 0x80) r -= f4(v.yp, j);
+    if (dbyte(m.zm, j) & 0x80) r -= f4(v.zm, j);
+    if (dbyte(m.zp, j) & 0x80) r -= f4(v.zp, j);
+    return r;
+}
+__device__ __forceinline__ float snew_of(int dv, float r, float sold, float beta) {   // pressure_update_search.comp:23 on top of M^-1 r
+    return (dv & 0x80) ? precond_zero(r, (float)(dv & 7)) + beta * sold : 0.0f;
+}
+__device__ __forceinline__ float4 snew4(uint32_t dq, const float4& r, const float4& s, float beta) {
+    return make_float4(snew_of(dbyte(dq, 0), r.x, s.x, beta), snew_of(dbyte(dq, 1), r.y, s.y, beta),
+                       snew_of(dbyte(dq, 2), r.z, s.z, beta), snew_of(dbyte(dq, 3), r.w, s.w, beta));
+}
+
+// KD body.  FIRST: s comes from the init kernel, only s.As is computed (pressure_apply_coeff.comp:19-30).
+template <bool FIRST>
+__device__ __forceinline__ void pcg_dir_quad(const Grid& g, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
+                                             float* __restrict__ s_out, float beta, int base, int x0, int y, int z, float& acc) {
+    QuadD m; m.c = *reinterpret_cast<const uint32_t*>(dvol + base);
+    if (!any_fluid_d(m.c)) return;
+    load_quad_d(dvol, g, base, x0, y, z, m);
+    QuadValues sv; load_quad_values(s_in, g, base, x0, y, z, sv);
+    if (!FIRST) {
+        QuadValues rv; load_quad_values(r, g, base, x0, y, z, rv);
+        const float4 sold = sv.c;
+        sv.c = snew4(m.c, rv.c, sv.c, beta);
+        sv.ym = snew4(m.ym, rv.ym, sv.ym, beta); sv.yp = snew4(m.yp, rv.yp, sv.yp, beta);
+        sv.zm = snew4(m.zm, rv.zm, sv.zm, beta); sv.zp = snew4(m.zp, rv.zp, sv.zp, beta);
+        sv.xm = snew_of(m.xm, rv.xm, sv.xm, beta); sv.xp = snew_of(m.xp, rv.xp, sv.xp, beta);
+        // the reference only writes s on FLUID cells: other lanes keep their old value
+        float4 so = sv.c;
+        if (!(dbyte(m.c, 0) & 0x80)) so.x = sold.x;
+        if (!(dbyte(m.c, 1) & 0x80)) so.y = sold.y;
+        if (!(dbyte(m.c, 2) & 0x80)) so.z = sold.z;
+        if (!(dbyte(m.c, 3) & 0x80)) so.w = sold.w;
+        *reinterpret_cast<float4*>(s_out + base) = so;   // s is double buffered: neighbours still read the OLD s of this cell
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (dbyte(m.c, j) & 0x80) acc += f4(sv.c, j) * quad_mulA_d(m, sv, j);
+}
+
+// KU body: pressure_update_pressure_and_residual.comp:23-59 + M^-1 r and its dot with r
+__device__ __forceinline__ void pcg_update_quad(const Grid& g, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+                                                float* __restrict__ r, float alpha, int base, int x0, int y, int z, float& acc, float& emax) {
+    QuadD m; m.c = *reinterpret_cast<const uint32_t*>(dvol + base);
+    if (!any_fluid_d(m.c)) return;
+    load_quad_d(dvol, g, base, x0, y, z, m);
+    QuadValues sv; load_quad_values(s, g, base, x0, y, z, sv);
+    const float4 pc = ld4(p + base), rc = ld4(r + base);
+    float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dv = dbyte(m.c, j);
+        if (!(dv & 0x80)) continue;
+        const float as = quad_mulA_d(m, sv, j);
+        pp[j] = pp[j] + alpha * f4(sv.c, j);                                           // :39-40
+        float res = rr[j];
+        res -= alpha * as;                                                              // :52
+        rr[j] = res;
+        emax = fmaxf(emax, fabsf(res));                                                 // :55
+        acc += precond_zero(res, (float)(dv & 7)) * res;
+    }
+    *reinterpret_cast<float4*>(p + base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+}
+
+// ---- shared prologues ----------------------------------------------------------------------------------------------
+// KD prologue: convergence test of the previous iteration (pressure_reduce.comp:82-94) and beta (RESULTMODE_BETA).
+// Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
+template <int NT>
+__device__ __forceinline__ bool pcg_dir_prologue(PcgCtrl* __restrict__ ctrl, const float* __restrict__ part_sigma_prev, const float* __restrict__ part_sigma,
+                                                 const float* __restrict__ part_max, int num_part, float tolerance, int iteration, int check_prev,
+                                                 float* sm, float& beta) {
+    if (ctrl->done) return false;
+    beta = 0.0f;
+    if (iteration == 0) return true;
+    if (check_prev) {
+        const float err = reduce_partials<NT, true>(part_max, num_part, sm);
+        if (err < tolerance) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->max_err = err; ctrl->num_iter = (float)(iteration - 1); ctrl->done = 1; }
+            return false;
+        }
+    }
+    const float sigma_prev = reduce_partials<NT, false>(part_sigma_prev, num_part, sm);
+    const float sigma = reduce_partials<NT, false>(part_sigma, num_part, sm);
+    beta = eps_div(sigma, sigma_prev);
+    return true;
+}
+template <int NT>
+__device__ __forceinline__ float pcg_alpha(const float* __restrict__ part_sigma, const float* __restrict__ part_sas, int num_part, float* sm) {
+    const float sigma = reduce_partials<NT, false>(part_sigma, num_part, sm);
+    const float sas = reduce_partials<NT, false>(part_sas, num_part, sm);
+    return eps_div(sigma, sas);                                                         // RESULTMODE_ALPHA
+}
+
+// ---- dense-row wrappers ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pcg_init_d(PcgGeom geom, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
+                                                    float* __restrict__ r, float* __restrict__ s, float* __restrict__ part_sigma, uint8_t* __restrict__ tile_flags) {
+    __shared__ float sm[8];
+    float acc = 0.0f;
+    PCG_TILE_LOOP_BEGIN(geom)
+        bool any = false;
+        if (qvalid) for (int z = z_begin; z < z_end; ++z) any |= pcg_init_quad(geom.g, marker, dvol, p, r, s, cidx(geom.g, x0, y, z), x0, y, z, acc);
+        const int tile_any = __syncthreads_or(any);
+        if (threadIdx.x == 0) tile_flags[tile] = (uint8_t)(tile_any != 0);
+    PCG_TILE_LOOP_END
+    const float tot = block_reduce<256, false>(acc, sm);
+    if (threadIdx.x == 0) part_sigma[blockIdx.x] = tot;
+}
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_pcg_dir_d(PcgGeom geom, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
+                                                   const float* __restrict__ part_sigma_prev, const float* __restrict__ part_sigma, const float* __restrict__ part_max,
+                                                   float* __restrict__ part_sas, int num_part, const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl,
+                                                   float tolerance, int iteration, int check_prev) {
+    __shared__ float sm[8];
+    float beta;
+    if (!pcg_dir_prologue<256>(ctrl, part_sigma_prev, part_sigma, part_max, num_part, tolerance, iteration, check_prev, sm, beta)) return;
+    float acc = 0.0f;
+    PCG_TILE_LOOP_BEGIN(geom)
+        if (!tile_flags[tile] || !qvalid) continue;
+        for (int z = z_begin; z < z_end; ++z) pcg_dir_quad<FIRST>(geom.g, dvol, r, s_in, s_out, beta, cidx(geom.g, x0, y, z), x0, y, z, acc);
+    PCG_TILE_LOOP_END
+    const float tot = block_reduce<256, false>(acc, sm);
+    if (threadIdx.x == 0) part_sas[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_pcg_update_d(PcgGeom geom, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+                                                      float* __restrict__ r, const float* __restrict__ part_sas, const float* __restrict__ part_sigma,
+                                                      float* __restrict__ part_sigma_next, float* __restrict__ part_max, int num_part,
+                                                      const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl) {
+    __shared__ float sm[8];
+    if (ctrl->done) return;
+    const float alpha = pcg_alpha<256>(part_sigma, part_sas, num_part, sm);
+    float acc = 0.0f, emax = 0.0f;
+    PCG_TILE_LOOP_BEGIN(geom)
+        if (!tile_flags[tile] || !qvalid) continue;
+        for (int z = z_begin; z < z_end; ++z) pcg_update_quad(geom.g, dvol, s, p, r, alpha, cidx(geom.g, x0, y, z), x0, y, z, acc, emax);
+    PCG_TILE_LOOP_END
+    const float tot = block_reduce<256, false>(acc, sm);
+    const float mx = block_reduce<256, true>(emax, sm);
+    if (threadIdx.x == 0) { part_sigma_next[blockIdx.x] = tot; part_max[blockIdx.x] = mx; }
+}
+
+// ---- brick-list wrappers ---------------------------------------------------------------------------------------------
+// init runs over the ACTIVE list (dvol / p must be valid on every neighbour of a FLUID brick), KD / KU over the FLUID list
+__global__ __launch_bounds__(BRICK_THREADS) void k_pcg_init_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                              const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
+                                                              float* __restrict__ r, float* __restrict__ s, float* __restrict__ part_sigma) {
+    __shared__ float sm[8];
+    float acc = 0.0f;
+    {
+        BRICK_LOOP_BEGIN(bg, list, count)
+            (void)pcg_init_quad(bg.g, marker, dvol, p, r, s, base, x0, y, z, acc);
+        BRICK_LOOP_END
+    }
+    const float tot = block_reduce<BRICK_THREADS, false>(acc, sm);
+    if (threadIdx.x == 0) part_sigma[blockIdx.x] = tot;
+}
+template <bool FIRST>
+__global__ __launch_bounds__(BRICK_THREADS) void k_pcg_dir_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                             const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
+                                                             const float* __restrict__ part_sigma_prev, const float* __restrict__ part_sigma,
+                                                             const float* __restrict__ part_max, float* __restrict__ part_sas, int num_part,
+                                                             PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
+    __shared__ float sm[8];
+    float beta;
+    if (!pcg_dir_prologue<BRICK_THREADS>(ctrl, part_sigma_prev, part_sigma, part_max, num_part, tolerance, iteration, check_prev, sm, beta)) return;
+    float acc = 0.0f;
+    {
+        BRICK_LOOP_BEGIN(bg, list, count)
+            pcg_dir_quad<FIRST>(bg.g, dvol, r, s_in, s_out, beta, base, x0, y, z, acc);
+        BRICK_LOOP_END
+    }
+    const float tot = block_reduce<BRICK_THREADS, false>(acc, sm);
+    if (threadIdx.x == 0) part_sas[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(BRICK_THREADS) void k_pcg_update_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+                                                                float* __restrict__ r, const float* __restrict__ part_sas, const float* __restrict__ part_sigma,
+                                                                float* __restrict__ part_sigma_next, float* __restrict__ part_max, int num_part,
+                                                                const PcgCtrl* __restrict__ ctrl) {
+    __shared__ float sm[8];
+    if (ctrl->done) return;
+    const float alpha = pcg_alpha<BRICK_THREADS>(part_sigma, part_sas, num_part, sm);
+    float acc = 0.0f, emax = 0.0f;
+    {
+        BRICK_LOOP_BEGIN(bg, list, count)
+            pcg_update_quad(bg.g, dvol, s, p, r, alpha, base, x0, y, z, acc, emax);
+        BRICK_LOOP_END
+    }
+    const float tot = block_reduce<BRICK_THREADS, false>(acc, sm);
+    const float mx = block_reduce<BRICK_THREADS, true>(emax, sm);
+    if (threadIdx.x == 0) { part_sigma_next[blockIdx.x] = tot; part_max[blockIdx.x] = mx; }
+}
+
+// After the last update (i == max_num_iterations): statistics are written unconditionally if nothing converged before
+// (pressure_reduce.comp:84: MaxNumSolverIterations == iterationIdx).
+__global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float* __restrict__ part_max, int num_part, int iteration) {
+    __shared__ float sm[8];
+    if (ctrl->done) return;
+    const float err = reduce_partials<256, true>(part_max, num_part, sm);
+    if (threadIdx.x == 0) { ctrl->max_err = err; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
+}
+
+}  // namespace blubk

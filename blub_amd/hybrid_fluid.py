@@ -143,6 +143,8 @@ def load_library():
         "blub_fluid_profile_reset": (C.c_int, [vp]),
         "blub_fluid_profile_read": (C.c_int, [vp, C.POINTER(_ProfEntry), C.c_int, C.POINTER(C.c_int)]),
         "blub_fluid_total_solver_iterations": (C.c_uint64, [vp]),
+        "blub_fluid_set_pcg_work_mapping": (C.c_int, [vp, C.c_int]),
+        "blub_fluid_get_brick_counts": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError = a symbol declared in include/blubhip.h is not exported
@@ -357,6 +359,15 @@ class HybridFluid:
         s = _SolverStats()
         _check(self._L, self._L.blub_fluid_solver_stats_latest(self._h, which, C.byref(s)))
         return s.error, s.iteration_count
+
+    def set_pcg_work_mapping(self, mode):
+        """"auto" | "rows" | "bricks" -- performance knob, see include/blubhip.h"""
+        _check(self._L, self._L.blub_fluid_set_pcg_work_mapping(self._h, {"auto": -1, "rows": 0, "bricks": 1}[mode]))
+
+    def brick_counts(self):
+        out = (C.c_uint32 * 6)()
+        _check(self._L, self._L.blub_fluid_get_brick_counts(self._h, out))
+        return dict(zip(("fluid", "active", "reset", "stale", "total", "cells_per_brick"), [int(v) for v in out]))
 
     def total_solver_iterations(self):
         return int(self._L.blub_fluid_total_solver_iterations(self._h))

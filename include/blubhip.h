@@ -194,6 +194,12 @@ typedef struct blub_prof_entry {
 int blub_fluid_profile_enable(blub_fluid* h, int enabled);
 int blub_fluid_profile_reset(blub_fluid* h);
 int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacity, int* count_out); /* blocks */
+/* Work mapping of the PCG kernels: -1 = automatic (brick lists when < 30 % of the bricks hold fluid, dense rows otherwise),
+ * 0 = dense rows, 1 = brick lists.  A performance knob only: both mappings run the same per-cell arithmetic (the
+ * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise). */
+int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
+/* {fluid bricks, active bricks, reset-list entries, stale bricks, total bricks, cells per brick} of the latest list build; blocks. */
+int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]);
 /* Total PCG iterations executed (sum of reported iteration counts) since creation, both solvers. */
 uint64_t blub_fluid_total_solver_iterations(const blub_fluid* h);
 

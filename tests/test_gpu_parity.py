@@ -62,11 +62,13 @@ def test_elementwise_grid_stage_bit_exact(pair, stage, outputs):
     assert any(np.abs(o.read_volume(v)).max() > 0 for v in outputs)
 
 
-@pytest.mark.parametrize("iters", [0, 1, 4, 8])
-def test_pcg_fixed_iterations(pair, iters):
+@pytest.mark.parametrize("mapping", ["rows", "bricks"])
+@pytest.mark.parametrize("iters", [0, 1, 4, 7, 8])
+def test_pcg_fixed_iterations(pair, iters, mapping):
     """Fixed iteration count (tolerance 0): p, r, s after k iterations. Only the dot-product summation order differs;
     before the rounding noise is amplified by many unconverged CG iterations the fields agree to 1e-4 of their scale."""
     o, h = pair
+    h.set_pcg_work_mapping(mapping)
     for f in (o, h):
         f.set_solver_config(0, error_tolerance=0.0, max_num_iterations=iters, error_check_frequency=4)
     run_until(o, "solve_velocity")
@@ -86,13 +88,15 @@ def test_pcg_fixed_iterations(pair, iters):
     assert abs(eh - eo) <= 1e-4 * abs(eo) + 1e-9
 
 
+@pytest.mark.parametrize("mapping", ["rows", "bricks"])
 @pytest.mark.parametrize("which,stage", [(0, "solve_velocity"), (1, "solve_density")])
-def test_pcg_default_config(pair, which, stage):
+def test_pcg_default_config(pair, which, stage, mapping):
     """Defaults (tol 0.1, 32 iterations, check every 4): the solve stops far from convergence (max|r| ~ 12), where the
     CG iterate is sensitive to the rounding of the dot products (the oracle itself moves by 2 % when its dots are
     accumulated in f32 instead of f64).  So: residual norms within 5 %, pressure within 3 % in relative L2, and the
     reported state must be self-consistent: r == b - A p recomputed in f64."""
     o, h = pair
+    h.set_pcg_work_mapping(mapping)
     run_until(o, stage)
     util.copy_state(o, h)
     b = o.read_volume("residual").astype(np.float64)
@@ -189,10 +193,12 @@ def test_binning_is_cell_ordered_permutation(pair):
             h2.close()
 
 
-def test_full_step_converged_solver(pair):
+@pytest.mark.parametrize("mapping", ["auto", "rows"])
+def test_full_step_converged_solver(pair, mapping):
     """With both pressure solves run to convergence the solution no longer depends on CG rounding: one whole step
     (binning off, identical particle order) reproduces the oracle's particle positions to 1e-4 cells."""
     o, h = pair
+    h.set_pcg_work_mapping(mapping)
     cfg = dict(error_tolerance=2e-6, max_num_iterations=400, error_check_frequency=8)
     for f in (o, h):
         f.set_solver_config(0, **cfg)
@@ -336,5 +342,35 @@ def test_solid_voxels_and_scene_single_cell():
         print("solid scene deviation: median %.3g p99 %.3g max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
         assert (d > 1e-4).mean() < 1e-3 and d.max() < 0.05
         assert np.array_equal(h.read_volume("marker"), o.read_volume("marker")) or (h.read_volume("marker") != o.read_volume("marker")).mean() < 1e-4
+    finally:
+        h.close()
+
+
+def test_sparse_bricks_track_moving_fluid():
+    """A blob falling through a tall domain leaves its bricks behind: every volume the renderer can see must still equal
+    the dense reference's (velocity / pressure 0 and marker AIR where the fluid used to be) -- this exercises the
+    stale-brick clearing of the brick-sparse work lists (blub_bricks.hip.h)."""
+    dim = (32, 64, 32)
+    rng = np.random.default_rng(3)
+    cells = np.stack(np.meshgrid(np.arange(10, 20), np.arange(48, 58), np.arange(10, 20), indexing="ij"), -1).reshape(-1, 3)
+    pos = (cells[:, None, :] + rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
+    o, h = util.new_pair(*dim, pos.shape[0], solver=dict(error_tolerance=2e-6, max_num_iterations=300, error_check_frequency=8))
+    try:
+        o.set_particles(pos)
+        h.set_particles(pos)
+        for step in range(30):
+            o.step(util.DT)
+            h.step(util.DT)
+            if step in (0, 14, 29):
+                assert np.array_equal(h.read_volume("marker"), o.read_volume("marker")), step
+                for v in ("vel_x", "vel_y", "vel_z", "pressure_velocity", "pressure_density"):
+                    a, b = h.read_volume(v), o.read_volume(v)
+                    util.assert_close("%s after step %d" % (v, step), a, b, abs_=2e-3 * max(1.0, np.abs(b).max()))
+                    assert np.array_equal(a != 0, b != 0) or ((a != 0) != (b != 0)).mean() < 1e-4, (v, step)
+        bc = h.brick_counts()
+        assert 0 < bc["fluid"] < bc["active"] < bc["total"]
+        po, ph = o.get_particles()[0][:, :3], h.get_particles()[0][:, :3]
+        assert po[:, 1].mean() < 40          # it really fell out of its initial bricks (8 cells high)
+        assert np.abs(ph - po).max() < 5e-3
     finally:
         h.close()
