@@ -72,68 +72,79 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 }
 
 enum { COMPACT_STEP_A = 0, COMPACT_STEP_B = 1, COMPACT_ALL_ACTIVE = 2 };
-// One 1024-thread block; each thread owns ITEMS consecutive bricks per chunk => lists come out in brick (memory) order.
-constexpr int COMPACT_ITEMS = 8;
-__global__ __launch_bounds__(1024) void k_bricks_compact(BrickGeom bg, int phase, int all_touched, const uint8_t* __restrict__ brick_fluid,
-                                                         uint8_t* __restrict__ brick_active, uint8_t* __restrict__ brick_touched,
+enum { BF_FLUID = 1, BF_ACTIVE = 2, BF_STALE = 4 };
+// Pass 1 (one thread per brick, 1024 bricks per block): dilate the fluid flags, classify each brick, count per block.
+__global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phase, int all_touched, const uint8_t* __restrict__ brick_fluid,
+                                                          uint8_t* __restrict__ brick_active, uint8_t* __restrict__ brick_touched,
+                                                          uint8_t* __restrict__ brick_flags, uint4* __restrict__ block_counts) {
+    __shared__ uint32_t sm[17];
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    uint32_t fl = 0;
+    if (b < bg.nb) {
+        const bool f = brick_fluid[b] != 0;
+        bool act;
+        if (phase == COMPACT_ALL_ACTIVE) act = true;
+        else {
+            const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+            act = false;
+#pragma unroll
+            for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int qx = bx + dx, qy = by + dy, qz = bz + dz;
+                        if ((unsigned)qx < (unsigned)bg.nbx && (unsigned)qy < (unsigned)bg.nby && (unsigned)qz < (unsigned)bg.nbz)
+                            act = act || brick_fluid[(qz * bg.nby + qy) * bg.nbx + qx] != 0;
+                    }
+            if (phase == COMPACT_STEP_B) act = act || brick_active[b] != 0;
+        }
+        const bool touched = all_touched || brick_touched[b] != 0;
+        const bool stale = (phase == COMPACT_STEP_A) && touched && !act;
+        fl = (f ? BF_FLUID : 0) | (act ? BF_ACTIVE : 0) | (stale ? BF_STALE : 0);
+        brick_flags[b] = (uint8_t)fl;
+        brick_active[b] = act;
+        if (phase == COMPACT_STEP_A) brick_touched[b] = act;
+        else if (act) brick_touched[b] = 1;
+    }
+    uint32_t tf, ta, tr, ts;
+    (void)block_exclusive_scan_1024((fl & BF_FLUID) != 0, sm, tf);
+    (void)block_exclusive_scan_1024((fl & BF_ACTIVE) != 0, sm, ta);
+    (void)block_exclusive_scan_1024((fl & (BF_ACTIVE | BF_STALE)) != 0, sm, tr);
+    (void)block_exclusive_scan_1024((fl & BF_STALE) != 0, sm, ts);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = make_uint4(tf, ta, tr, ts);
+}
+// Pass 2: every block adds up the counts of the blocks before it (<= 256 of them) and scatters its bricks: the lists
+// come out in brick (= memory) order, deterministically.
+__global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uint8_t* __restrict__ brick_flags, const uint4* __restrict__ block_counts, int nblocks,
                                                          uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
                                                          uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts) {
     __shared__ uint32_t sm[17];
-    __shared__ uint32_t base[3];
-    if (threadIdx.x == 0) { base[0] = base[1] = base[2] = 0; }
-    __syncthreads();
-    uint32_t n_stale = 0;
-    for (int start = 0; start < bg.nb; start += 1024 * COMPACT_ITEMS) {
-        const int b0 = start + threadIdx.x * COMPACT_ITEMS;
-        uint8_t f[COMPACT_ITEMS], a[COMPACT_ITEMS], st[COMPACT_ITEMS];
-        uint32_t cf = 0, ca = 0, cr = 0;
-#pragma unroll
-        for (int k = 0; k < COMPACT_ITEMS; ++k) {
-            const int b = b0 + k;
-            f[k] = a[k] = st[k] = 0;
-            if (b >= bg.nb) continue;
-            f[k] = brick_fluid[b];
-            bool act;
-            if (phase == COMPACT_ALL_ACTIVE) act = true;
-            else {
-                const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
-                act = false;
-                for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
-                    const int qx = bx + dx, qy = by + dy, qz = bz + dz;
-                    if ((unsigned)qx < (unsigned)bg.nbx && (unsigned)qy < (unsigned)bg.nby && (unsigned)qz < (unsigned)bg.nbz)
-                        act = act || brick_fluid[(qz * bg.nby + qy) * bg.nbx + qx] != 0;
-                }
-                if (phase == COMPACT_STEP_B) act = act || brick_active[b] != 0;
-            }
-            const bool touched = all_touched || brick_touched[b] != 0;
-            a[k] = act;
-            st[k] = (phase == COMPACT_STEP_A) && touched && !act;
-            cf += f[k] != 0; ca += act; cr += act || st[k];
-            n_stale += st[k];
+    __shared__ uint32_t base[4], total[4];
+    if (threadIdx.x < 64) {   // one wave sums the block counts: lanes stride over the blocks in order
+        uint32_t before[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};
+        for (int k = threadIdx.x; k < nblocks; k += 64) {
+            const uint4 c = block_counts[k];
+            all[0] += c.x; all[1] += c.y; all[2] += c.z; all[3] += c.w;
+            if (k < (int)blockIdx.x) { before[0] += c.x; before[1] += c.y; before[2] += c.z; before[3] += c.w; }
         }
-        uint32_t tf, ta, tr;
-        uint32_t of = block_exclusive_scan_1024(cf, sm, tf);
-        uint32_t oa = block_exclusive_scan_1024(ca, sm, ta);
-        uint32_t orr = block_exclusive_scan_1024(cr, sm, tr);
-        of += base[0]; oa += base[1]; orr += base[2];
 #pragma unroll
-        for (int k = 0; k < COMPACT_ITEMS; ++k) {
-            const int b = b0 + k;
-            if (b >= bg.nb) continue;
-            if (f[k]) list_fluid[of++] = (uint32_t)b;
-            if (a[k]) list_active[oa++] = (uint32_t)b;
-            if (a[k] || st[k]) list_reset[orr++] = (uint32_t)b | (st[k] ? STALE_BIT : 0u);
-            brick_active[b] = a[k];
-            if (phase == COMPACT_STEP_A) brick_touched[b] = a[k];
-            else if (a[k]) brick_touched[b] = 1;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { base[0] += tf; base[1] += ta; base[2] += tr; }
-        __syncthreads();
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { before[q] += __shfl_down(before[q], off, 64); all[q] += __shfl_down(all[q], off, 64); }
+        if (threadIdx.x == 0) for (int q = 0; q < 4; ++q) { base[q] = before[q]; total[q] = all[q]; }
     }
-    uint32_t tot_stale;
-    (void)block_exclusive_scan_1024(n_stale, sm, tot_stale);
-    if (threadIdx.x == 0) { counts->n_fluid = base[0]; counts->n_active = base[1]; counts->n_reset = base[2]; counts->n_stale = tot_stale; }
+    __syncthreads();
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t fl = b < bg.nb ? brick_flags[b] : 0u;
+    uint32_t t;
+    const uint32_t of = block_exclusive_scan_1024((fl & BF_FLUID) != 0, sm, t);
+    const uint32_t oa = block_exclusive_scan_1024((fl & BF_ACTIVE) != 0, sm, t);
+    const uint32_t orr = block_exclusive_scan_1024((fl & (BF_ACTIVE | BF_STALE)) != 0, sm, t);
+    if (fl & BF_FLUID) list_fluid[base[0] + of] = (uint32_t)b;
+    if (fl & BF_ACTIVE) list_active[base[1] + oa] = (uint32_t)b;
+    if (fl & (BF_ACTIVE | BF_STALE)) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counts->n_fluid = total[0]; counts->n_active = total[1]; counts->n_reset = total[2]; counts->n_stale = total[3]; }
 }
 
 // ---- static marker pattern: transfer_clear.comp:10-14 + transfer_set_boundary_marker.comp:11-19 --------------------

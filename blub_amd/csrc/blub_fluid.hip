@@ -77,6 +77,8 @@ struct blub_fluid {
     int brick_grid = 0;
     uint8_t *brick_fluid = nullptr, *brick_active = nullptr, *brick_touched = nullptr;
     uint32_t *list_fluid = nullptr, *list_active = nullptr, *list_reset = nullptr;
+    uint8_t* brick_flags = nullptr;
+    uint4* brick_block_counts = nullptr;
     BrickCounts* counts = nullptr;            // device
     BrickCounts* counts_host = nullptr;       // pinned ring of COUNTS_RING snapshots (path selection only)
     hipEvent_t counts_events[8] = {};
@@ -147,10 +149,17 @@ struct ProfScope {
 static unsigned particle_blocks(uint32_t n) { return (n + 255) / 256; }
 static unsigned stream_blocks(size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, 2048); }
 
+// NOTE: the handle's stream is non-blocking, i.e. NOT ordered against the null stream: every memset / copy of this
+// library is issued on the handle's stream (a null-stream hipMemset may still be in flight when a kernel starts).
 template <class T>
-static int dev_alloc_zero(T** p, size_t count) {
+static int dev_alloc_zero(hipStream_t stream, T** p, size_t count) {
     HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
-    HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+    HIP_TRY(hipMemsetAsync(*p, 0, count * sizeof(T), stream));
+    return BLUB_OK;
+}
+static int copy_sync(blub_fluid* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return BLUB_OK;
 }
 
@@ -169,8 +178,11 @@ static int build_lists_from_particles(blub_fluid* h, int phase) {
     HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
     if (h->num_particles)
         hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles)), dim3(256), 0, h->stream, h->bg, h->num_particles, (const float4*)h->pos, h->brick_fluid);
-    hipLaunchKernelGGL(k_bricks_compact, dim3(1), dim3(1024), 0, h->stream, h->bg, phase, (int)h->all_touched, (const uint8_t*)h->brick_fluid, h->brick_active,
-                       h->brick_touched, h->list_fluid, h->list_active, h->list_reset, h->counts);
+    const int nblk = (h->bg.nb + 1023) / 1024;
+    hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, (int)h->all_touched, (const uint8_t*)h->brick_fluid, h->brick_active,
+                       h->brick_touched, h->brick_flags, h->brick_block_counts);
+    hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
+                       h->list_fluid, h->list_active, h->list_reset, h->counts);
     if (phase == COMPACT_STEP_A) h->all_touched = false;
     return snapshot_counts(h);
 }
@@ -179,8 +191,11 @@ static int build_lists_from_marker(blub_fluid* h) {
     ProfScope ps(h, KC_BRICK_LISTS);
     HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
     hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
-    hipLaunchKernelGGL(k_bricks_compact, dim3(1), dim3(1024), 0, h->stream, h->bg, (int)COMPACT_ALL_ACTIVE, 1, (const uint8_t*)h->brick_fluid, h->brick_active,
-                       h->brick_touched, h->list_fluid, h->list_active, h->list_reset, h->counts);
+    const int nblk = (h->bg.nb + 1023) / 1024;
+    hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (int)COMPACT_ALL_ACTIVE, 1, (const uint8_t*)h->brick_fluid, h->brick_active,
+                       h->brick_touched, h->brick_flags, h->brick_block_counts);
+    hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
+                       h->list_fluid, h->list_active, h->list_reset, h->counts);
     return snapshot_counts(h);
 }
 // latest completed snapshot of the brick counts (never waits unless `block`): only steers a performance choice
@@ -287,38 +302,38 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     const int freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };   // :672-673 (the i == max case is k_pcg_finalize)
     float* sbuf[2] = {h->search, h->aux};
+    float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
+    float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
     if (sparse) {
-        const int np = std::min(h->bg.nb, PCG_GRID_MAX);
-        const dim3 grid(np), block(BRICK_THREADS);
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], h->part_sigma[0]);
+        const int np = std::min((h->bg.nb + 1) / 2, PCG_GRID_MAX);
+        const dim3 grid(np), block(PCG_B_THREADS);
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd);
         for (int i = 0; i <= maxit; ++i) {
-            float *sig_prev = h->part_sigma[(i + 1) & 1], *sig_cur = h->part_sigma[i & 1], *sig_next = h->part_sigma[(i + 1) & 1];
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
-                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, ctrl, tol, i, 0);
+                       (const float2*)part_upd, part_dir, np, ctrl, tol, i, 0);
             else
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<false>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
-                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, ctrl, tol, i, (int)is_check(i - 1));
+                       (const float2*)part_upd, part_dir, np, ctrl, tol, i, (int)is_check(i - 1));
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
-                   (const float*)h->part_sas, (const float*)sig_cur, sig_next, h->part_max, np, (const PcgCtrl*)ctrl);
+                   (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
         }
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float*)h->part_max, np, maxit);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit);
     } else {
         const int np = h->pcg_grid;
         const dim3 grid(np), block(256);
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_d, grid, block, h->geom, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], h->part_sigma[0], h->tile_flags);
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_d, grid, block, h->geom, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags);
         for (int i = 0; i <= maxit; ++i) {
-            float *sig_prev = h->part_sigma[(i + 1) & 1], *sig_cur = h->part_sigma[i & 1], *sig_next = h->part_sigma[(i + 1) & 1];
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_d<true>, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
-                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);
+                       (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);
             else
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_d<false>, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
-                       (const float*)sig_prev, (const float*)sig_cur, (const float*)h->part_max, h->part_sas, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));
+                       (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_d, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
-                   (const float*)h->part_sas, (const float*)sig_cur, sig_next, h->part_max, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl);
+                   (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);
         }
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float*)h->part_max, np, maxit);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit);
     }
     // the search direction of a full-length solve ends in sbuf[maxit & 1]; keep BLUB_VOLUME_SEARCH pointing at it
     if (maxit & 1) std::swap(h->search, h->aux);
@@ -409,7 +424,7 @@ static void destroy(blub_fluid* h) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->next1); F(h->next2); F(h->marker); for (auto p : h->ll) F(p);
     for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
-    F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
+    F(h->brick_flags); F(h->brick_block_counts); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
     for (auto e : h->counts_events) if (e) (void)hipEventDestroy(e);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
@@ -447,28 +462,29 @@ static int create(const blub_fluid_desc* d, blub_fluid** out) {
     auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
     const size_t P = std::max<size_t>(h->max_particles, 1);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
-    A(dev_alloc_zero(&h->pos, P)); A(dev_alloc_zero(&h->pos_tmp, P));
-    for (int c = 0; c < 3; ++c) A(dev_alloc_zero(&h->pvel[c], P));
-    A(dev_alloc_zero(&h->next1, P)); A(dev_alloc_zero(&h->next2, P));
-    A(dev_alloc_zero(&h->marker, h->N));
-    for (int c = 0; c < 3; ++c) { A(dev_alloc_zero(&h->ll[c], h->N)); A(dev_alloc_zero(&h->vel[c], h->N)); }
-    for (int w = 0; w < 2; ++w) A(dev_alloc_zero(&h->pressure[w], h->N));
-    A(dev_alloc_zero(&h->residual, h->N)); A(dev_alloc_zero(&h->search, h->N)); A(dev_alloc_zero(&h->aux, h->N)); A(dev_alloc_zero(&h->aux_temp, h->N));
-    A(dev_alloc_zero(&h->scan_totals, (h->N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
+    A(dev_alloc_zero(h->stream, &h->pos, P)); A(dev_alloc_zero(h->stream, &h->pos_tmp, P));
+    for (int c = 0; c < 3; ++c) A(dev_alloc_zero(h->stream, &h->pvel[c], P));
+    A(dev_alloc_zero(h->stream, &h->next1, P)); A(dev_alloc_zero(h->stream, &h->next2, P));
+    A(dev_alloc_zero(h->stream, &h->marker, h->N));
+    for (int c = 0; c < 3; ++c) { A(dev_alloc_zero(h->stream, &h->ll[c], h->N)); A(dev_alloc_zero(h->stream, &h->vel[c], h->N)); }
+    for (int w = 0; w < 2; ++w) A(dev_alloc_zero(h->stream, &h->pressure[w], h->N));
+    A(dev_alloc_zero(h->stream, &h->residual, h->N)); A(dev_alloc_zero(h->stream, &h->search, h->N)); A(dev_alloc_zero(h->stream, &h->aux, h->N)); A(dev_alloc_zero(h->stream, &h->aux_temp, h->N));
+    A(dev_alloc_zero(h->stream, &h->scan_totals, (h->N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
     PcgGeom& gm = h->geom;
     gm.g = h->g; gm.qpr = h->g.nx / 4; gm.qpp = gm.qpr * h->g.ny; gm.plane_blocks = (gm.qpp + 255) / 256;
     gm.z_chunks = (h->g.nz + PCG_ZC - 1) / PCG_ZC; gm.tiles = gm.plane_blocks * gm.z_chunks;
     h->pcg_grid = std::min(PCG_GRID_MAX, gm.tiles);
-    A(dev_alloc_zero(&h->part_sas, PCG_GRID_MAX)); A(dev_alloc_zero(&h->part_sigma[0], PCG_GRID_MAX)); A(dev_alloc_zero(&h->part_sigma[1], PCG_GRID_MAX));
-    A(dev_alloc_zero(&h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(&h->tile_flags, (size_t)gm.tiles));
-    A(dev_alloc_zero(&h->ctrl[0], 1)); A(dev_alloc_zero(&h->ctrl[1], 1));
-    A(dev_alloc_zero(&h->dvol, h->N));
+    A(dev_alloc_zero(h->stream, &h->part_sas, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[0], 2 * PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[1], PCG_GRID_MAX));
+    A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, (size_t)gm.tiles));
+    A(dev_alloc_zero(h->stream, &h->ctrl[0], 1)); A(dev_alloc_zero(h->stream, &h->ctrl[1], 1));
+    A(dev_alloc_zero(h->stream, &h->dvol, h->N));
     BrickGeom& bg = h->bg;
     bg.g = h->g; bg.nbx = (h->g.nx + BX - 1) / BX; bg.nby = (h->g.ny + BY - 1) / BY; bg.nbz = (h->g.nz + BZ - 1) / BZ; bg.nb = bg.nbx * bg.nby * bg.nbz;
     h->brick_grid = std::min(bg.nb, BRICK_GRID_MAX);
-    A(dev_alloc_zero(&h->brick_fluid, (size_t)bg.nb)); A(dev_alloc_zero(&h->brick_active, (size_t)bg.nb)); A(dev_alloc_zero(&h->brick_touched, (size_t)bg.nb));
-    A(dev_alloc_zero(&h->list_fluid, (size_t)bg.nb)); A(dev_alloc_zero(&h->list_active, (size_t)bg.nb)); A(dev_alloc_zero(&h->list_reset, (size_t)bg.nb));
-    A(dev_alloc_zero(&h->counts, 1));
+    A(dev_alloc_zero(h->stream, &h->brick_fluid, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_active, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_touched, (size_t)bg.nb));
+    A(dev_alloc_zero(h->stream, &h->list_fluid, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_active, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_reset, (size_t)bg.nb));
+    A(dev_alloc_zero(h->stream, &h->counts, 1));
+    A(dev_alloc_zero(h->stream, &h->brick_flags, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_block_counts, (size_t)(bg.nb + 1023) / 1024));
     if (rc == BLUB_OK && hipHostMalloc((void**)&h->counts_host, COUNTS_RING * sizeof(BrickCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     for (int k = 0; k < COUNTS_RING && rc == BLUB_OK; ++k) if (hipEventCreateWithFlags(&h->counts_events[k], hipEventDisableTiming) != hipSuccess) rc = set_error(BLUB_ERR_DEVICE, "hipEventCreate failed");
     for (int w = 0; w < 2 && rc == BLUB_OK; ++w) {
@@ -543,8 +559,7 @@ int blub_fluid_add_fluid_cube(blub_fluid* h, const float mn[3], const float mx[3
     std::vector<float> buf((size_t)count * 4);
     rc = blub::seed_fluid_cube(dim, h->max_particles, h->num_particles, mn, mx, buf.data(), count, &count);
     if (rc != BLUB_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(h->pos + h->num_particles, buf.data(), (size_t)count * 16, hipMemcpyHostToDevice));   // queue.write_buffer :671
+    { int rc2 = blub::copy_sync(h, h->pos + h->num_particles, buf.data(), (size_t)count * 16, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }   // queue.write_buffer :671
     h->num_particles += count;
     return BLUB_OK;
 }
@@ -627,7 +642,7 @@ int blub_fluid_set_solid_voxels(blub_fluid* h, const float* vox) {
     if (!vox) { if (h->solid) { (void)hipFree(h->solid); h->solid = nullptr; } }
     else {
         if (!h->solid) HIP_TRY(hipMalloc((void**)&h->solid, h->N * sizeof(float4)));
-        HIP_TRY(hipMemcpy(h->solid, vox, h->N * sizeof(float4), hipMemcpyHostToDevice));
+        { int rc2 = blub::copy_sync(h, h->solid, vox, h->N * sizeof(float4), hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
     }
     // the static marker pattern changed everywhere; every brick may now differ from it
     hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker);
@@ -641,11 +656,11 @@ int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, con
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->num_particles = n;
     if (n == 0) return BLUB_OK;
-    if (pos_ll) HIP_TRY(hipMemcpy(h->pos, pos_ll, (size_t)n * 16, hipMemcpyHostToDevice));
+    if (pos_ll) { int rc2 = blub::copy_sync(h, h->pos, pos_ll, (size_t)n * 16, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
     const float* src[3] = {vx, vy, vz};
     for (int c = 0; c < 3; ++c) {
-        if (src[c]) HIP_TRY(hipMemcpy(h->pvel[c], src[c], (size_t)n * 16, hipMemcpyHostToDevice));
-        else HIP_TRY(hipMemset(h->pvel[c], 0, (size_t)n * 16));
+        if (src[c]) { int rc2 = blub::copy_sync(h, h->pvel[c], src[c], (size_t)n * 16, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
+        else { HIP_TRY(hipMemsetAsync(h->pvel[c], 0, (size_t)n * 16, h->stream)); HIP_TRY(hipStreamSynchronize(h->stream)); }
     }
     return BLUB_OK;
 }
@@ -654,9 +669,9 @@ int blub_fluid_get_particles(blub_fluid* h, float* pos_ll, float* vx, float* vy,
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t b = (size_t)h->num_particles * 16;
     if (b == 0) return BLUB_OK;
-    if (pos_ll) HIP_TRY(hipMemcpy(pos_ll, h->pos, b, hipMemcpyDeviceToHost));
+    if (pos_ll) { int rc2 = blub::copy_sync(h, pos_ll, h->pos, b, hipMemcpyDeviceToHost); if (rc2 != BLUB_OK) return rc2; }
     float* dst[3] = {vx, vy, vz};
-    for (int c = 0; c < 3; ++c) if (dst[c]) HIP_TRY(hipMemcpy(dst[c], h->pvel[c], b, hipMemcpyDeviceToHost));
+    for (int c = 0; c < 3; ++c) if (dst[c]) { int rc2 = blub::copy_sync(h, dst[c], h->pvel[c], b, hipMemcpyDeviceToHost); if (rc2 != BLUB_OK) return rc2; }
     return BLUB_OK;
 }
 static void* volume_ptr(const blub_fluid* h, int which, size_t* bytes) {
@@ -680,17 +695,14 @@ int blub_fluid_read_volume(blub_fluid* h, int which, void* out) {
     REQUIRE_HANDLE(h);
     size_t b; void* p = volume_ptr(h, which, &b);
     if (!p || !out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(out, p, b, hipMemcpyDeviceToHost));
-    return BLUB_OK;
+    return blub::copy_sync(h, out, p, b, hipMemcpyDeviceToHost);
 }
 int blub_fluid_write_volume(blub_fluid* h, int which, const void* in) {
     REQUIRE_HANDLE(h);
     if (which == BLUB_VOLUME_SOLID) return blub_fluid_set_solid_voxels(h, (const float*)in);
     size_t b; void* p = volume_ptr(h, which, &b);
     if (!p || !in) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(p, in, b, hipMemcpyHostToDevice));
+    { int rc2 = blub::copy_sync(h, p, in, b, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
     h->all_touched = true;   // arbitrary data may now sit outside the active bricks: the next step re-establishes the invariant
     return BLUB_OK;
 }
@@ -709,7 +721,7 @@ int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]) {
     if (!out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipStreamSynchronize(h->stream));
     blubk::BrickCounts bc{};
-    HIP_TRY(hipMemcpy(&bc, h->counts, sizeof(bc), hipMemcpyDeviceToHost));
+    { int rc2 = blub::copy_sync(h, &bc, h->counts, sizeof(bc), hipMemcpyDeviceToHost); if (rc2 != BLUB_OK) return rc2; }
     out[0] = bc.n_fluid; out[1] = bc.n_active; out[2] = bc.n_reset; out[3] = bc.n_stale; out[4] = (uint32_t)h->bg.nb; out[5] = blubk::BX * blubk::BY * blubk::BZ;
     return BLUB_OK;
 }

@@ -124,6 +124,8 @@ struct PcgCtrl {       // device-resident; [0..1] mirror the reference's MaxErro
     float num_iter;
     int done;
     int pad;
+    float sigma[2];    // sigma of iteration i in slot i & 1 (the reference keeps it in PcgScalars.Sigma, pressure.glsl:24-28)
+    float pad2[2];
 };
 
 struct PcgGeom {

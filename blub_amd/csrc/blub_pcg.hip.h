@@ -176,38 +176,120 @@ __device__ __forceinline__ void pcg_update_quad(const Grid& g, const uint8_t* __
     *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
 }
 
+// ---- load / compute split of the KD and KU bodies (brick mapping): all global loads of a quad are issued up front,
+// unconditionally, so that they overlap the partial-reduction prologue; the sparse regime is latency- not byte-bound.
+struct DirLoad { QuadD m; QuadValues sv, rv; int base; bool valid; };
+template <bool FIRST>
+__device__ __forceinline__ void dir_load(const Grid& g, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
+                                         int base, int x0, int y, int z, DirLoad& L) {
+    L.base = base;
+    L.m.c = *reinterpret_cast<const uint32_t*>(dvol + base);
+    load_quad_d(dvol, g, base, x0, y, z, L.m);
+    load_quad_values(s_in, g, base, x0, y, z, L.sv);
+    if (!FIRST) load_quad_values(r, g, base, x0, y, z, L.rv);
+}
+template <bool FIRST>
+__device__ __forceinline__ void dir_compute(DirLoad& L, float* __restrict__ s_out, float beta, float& acc) {
+    if (!L.valid || !any_fluid_d(L.m.c)) return;
+    QuadValues& sv = L.sv;
+    const QuadD& m = L.m;
+    if (!FIRST) {
+        const QuadValues& rv = L.rv;
+        const float4 sold = sv.c;
+        sv.c = snew4(m.c, rv.c, sv.c, beta);
+        sv.ym = snew4(m.ym, rv.ym, sv.ym, beta); sv.yp = snew4(m.yp, rv.yp, sv.yp, beta);
+        sv.zm = snew4(m.zm, rv.zm, sv.zm, beta); sv.zp = snew4(m.zp, rv.zp, sv.zp, beta);
+        sv.xm = snew_of(m.xm, rv.xm, sv.xm, beta); sv.xp = snew_of(m.xp, rv.xp, sv.xp, beta);
+        float4 so = sv.c;
+        if (!(dbyte(m.c, 0) & 0x80)) so.x = sold.x;
+        if (!(dbyte(m.c, 1) & 0x80)) so.y = sold.y;
+        if (!(dbyte(m.c, 2) & 0x80)) so.z = sold.z;
+        if (!(dbyte(m.c, 3) & 0x80)) so.w = sold.w;
+        *reinterpret_cast<float4*>(s_out + L.base) = so;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (dbyte(m.c, j) & 0x80) acc += f4(sv.c, j) * quad_mulA_d(m, sv, j);
+}
+struct UpdLoad { QuadD m; QuadValues sv; float4 pc, rc; int base; bool valid; };
+__device__ __forceinline__ void upd_load(const Grid& g, const uint8_t* __restrict__ dvol, const float* __restrict__ s, const float* __restrict__ p,
+                                         const float* __restrict__ r, int base, int x0, int y, int z, UpdLoad& L) {
+    L.base = base;
+    L.m.c = *reinterpret_cast<const uint32_t*>(dvol + base);
+    load_quad_d(dvol, g, base, x0, y, z, L.m);
+    load_quad_values(s, g, base, x0, y, z, L.sv);
+    L.pc = ld4(p + base); L.rc = ld4(r + base);
+}
+__device__ __forceinline__ void upd_compute(const UpdLoad& L, float* __restrict__ p, float* __restrict__ r, float alpha, float& acc, float& emax) {
+    if (!L.valid || !any_fluid_d(L.m.c)) return;
+    float pp[4] = {L.pc.x, L.pc.y, L.pc.z, L.pc.w}, rr[4] = {L.rc.x, L.rc.y, L.rc.z, L.rc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dv = dbyte(L.m.c, j);
+        if (!(dv & 0x80)) continue;
+        const float as = quad_mulA_d(L.m, L.sv, j);
+        pp[j] = pp[j] + alpha * f4(L.sv.c, j);
+        float res = rr[j];
+        res -= alpha * as;
+        rr[j] = res;
+        emax = fmaxf(emax, fabsf(res));
+        acc += precond_zero(res, (float)(dv & 7)) * res;
+    }
+    *reinterpret_cast<float4*>(p + L.base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4*>(r + L.base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+}
+
 // ---- shared prologues ----------------------------------------------------------------------------------------------
-// KD prologue: convergence test of the previous iteration (pressure_reduce.comp:82-94) and beta (RESULTMODE_BETA).
-// Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
+// Partials: the update kernel (and init) emit float2 {partial of (M^-1 r).r, partial of max|r|} per block, the
+// direction kernel a float {partial of s.As}.  sigma_i is additionally stashed as a scalar by block 0 of KD(i), so each
+// kernel re-reduces exactly ONE partial array.
 template <int NT>
-__device__ __forceinline__ bool pcg_dir_prologue(PcgCtrl* __restrict__ ctrl, const float* __restrict__ part_sigma_prev, const float* __restrict__ part_sigma,
-                                                 const float* __restrict__ part_max, int num_part, float tolerance, int iteration, int check_prev,
-                                                 float* sm, float& beta) {
-    if (ctrl->done) return false;
+__device__ __forceinline__ float2 reduce_partials2(const float2* __restrict__ part, int n, float2* sm2) {
+    float sx = 0.0f, mx = 0.0f;
+    for (int i = threadIdx.x; i < n; i += NT) { const float2 p = part[i]; sx += p.x; mx = fmaxf(mx, p.y); }
+    sx = wave_sum(sx); mx = wave_max(mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm2[wave] = make_float2(sx, mx);
+    __syncthreads();
+    float2 r = sm2[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) { r.x += sm2[w].x; r.y = fmaxf(r.y, sm2[w].y); }
+    return r;
+}
+// KD prologue: sigma_i and the max|r| of iteration i-1 from the update partials, convergence test
+// (pressure_reduce.comp:82-94), beta (RESULTMODE_BETA).  Returns false when the solve is finished; every block takes the
+// same branch because the reductions are deterministic.
+template <int NT>
+__device__ __forceinline__ bool pcg_dir_prologue(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, float tolerance,
+                                                 int iteration, int check_prev, float2* sm2, float& beta) {
+    const int done = ctrl->done;
+    const float sigma_prev = ctrl->sigma[(iteration + 1) & 1];
+    const float2 red = reduce_partials2<NT>(part_upd, num_part, sm2);
+    if (done) return false;
     beta = 0.0f;
-    if (iteration == 0) return true;
-    if (check_prev) {
-        const float err = reduce_partials<NT, true>(part_max, num_part, sm);
-        if (err < tolerance) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->max_err = err; ctrl->num_iter = (float)(iteration - 1); ctrl->done = 1; }
+    if (iteration > 0) {
+        if (check_prev && red.y < tolerance) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->max_err = red.y; ctrl->num_iter = (float)(iteration - 1); ctrl->done = 1; }
             return false;
         }
+        beta = eps_div(red.x, sigma_prev);
     }
-    const float sigma_prev = reduce_partials<NT, false>(part_sigma_prev, num_part, sm);
-    const float sigma = reduce_partials<NT, false>(part_sigma, num_part, sm);
-    beta = eps_div(sigma, sigma_prev);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->sigma[iteration & 1] = red.x;
     return true;
 }
 template <int NT>
-__device__ __forceinline__ float pcg_alpha(const float* __restrict__ part_sigma, const float* __restrict__ part_sas, int num_part, float* sm) {
-    const float sigma = reduce_partials<NT, false>(part_sigma, num_part, sm);
-    const float sas = reduce_partials<NT, false>(part_sas, num_part, sm);
-    return eps_div(sigma, sas);                                                         // RESULTMODE_ALPHA
+__device__ __forceinline__ bool pcg_upd_prologue(const PcgCtrl* __restrict__ ctrl, const float* __restrict__ part_dir, int num_part, int iteration, float* sm, float& alpha) {
+    const int done = ctrl->done;
+    const float sigma = ctrl->sigma[iteration & 1];
+    const float sas = reduce_partials<NT, false>(part_dir, num_part, sm);
+    alpha = eps_div(sigma, sas);                                                        // RESULTMODE_ALPHA
+    return !done;
 }
 
 // ---- dense-row wrappers ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pcg_init_d(PcgGeom geom, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
-                                                    float* __restrict__ r, float* __restrict__ s, float* __restrict__ part_sigma, uint8_t* __restrict__ tile_flags) {
+                                                    float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, uint8_t* __restrict__ tile_flags) {
     __shared__ float sm[8];
     float acc = 0.0f;
     PCG_TILE_LOOP_BEGIN(geom)
@@ -217,31 +299,30 @@ __global__ __launch_bounds__(256) void k_pcg_init_d(PcgGeom geom, const int8_t* 
         if (threadIdx.x == 0) tile_flags[tile] = (uint8_t)(tile_any != 0);
     PCG_TILE_LOOP_END
     const float tot = block_reduce<256, false>(acc, sm);
-    if (threadIdx.x == 0) part_sigma[blockIdx.x] = tot;
+    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, 0.0f);
 }
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_pcg_dir_d(PcgGeom geom, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
-                                                   const float* __restrict__ part_sigma_prev, const float* __restrict__ part_sigma, const float* __restrict__ part_max,
-                                                   float* __restrict__ part_sas, int num_part, const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl,
-                                                   float tolerance, int iteration, int check_prev) {
+                                                   const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
+                                                   const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
     __shared__ float sm[8];
+    __shared__ float2 sm2[4];
     float beta;
-    if (!pcg_dir_prologue<256>(ctrl, part_sigma_prev, part_sigma, part_max, num_part, tolerance, iteration, check_prev, sm, beta)) return;
+    if (!pcg_dir_prologue<256>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     float acc = 0.0f;
     PCG_TILE_LOOP_BEGIN(geom)
         if (!tile_flags[tile] || !qvalid) continue;
         for (int z = z_begin; z < z_end; ++z) pcg_dir_quad<FIRST>(geom.g, dvol, r, s_in, s_out, beta, cidx(geom.g, x0, y, z), x0, y, z, acc);
     PCG_TILE_LOOP_END
     const float tot = block_reduce<256, false>(acc, sm);
-    if (threadIdx.x == 0) part_sas[blockIdx.x] = tot;
+    if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(256) void k_pcg_update_d(PcgGeom geom, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
-                                                      float* __restrict__ r, const float* __restrict__ part_sas, const float* __restrict__ part_sigma,
-                                                      float* __restrict__ part_sigma_next, float* __restrict__ part_max, int num_part,
-                                                      const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl) {
+                                                      float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
+                                                      const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[8];
-    if (ctrl->done) return;
-    const float alpha = pcg_alpha<256>(part_sigma, part_sas, num_part, sm);
+    float alpha;
+    if (!pcg_upd_prologue<256>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
     float acc = 0.0f, emax = 0.0f;
     PCG_TILE_LOOP_BEGIN(geom)
         if (!tile_flags[tile] || !qvalid) continue;
@@ -249,68 +330,85 @@ __global__ __launch_bounds__(256) void k_pcg_update_d(PcgGeom geom, const uint8_
     PCG_TILE_LOOP_END
     const float tot = block_reduce<256, false>(acc, sm);
     const float mx = block_reduce<256, true>(emax, sm);
-    if (threadIdx.x == 0) { part_sigma_next[blockIdx.x] = tot; part_max[blockIdx.x] = mx; }
+    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, mx);
 }
 
 // ---- brick-list wrappers ---------------------------------------------------------------------------------------------
-// init runs over the ACTIVE list (dvol / p must be valid on every neighbour of a FLUID brick), KD / KU over the FLUID list
-__global__ __launch_bounds__(BRICK_THREADS) void k_pcg_init_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+// 256-thread blocks work on two bricks at a time (one per 128-thread half).  init runs over the ACTIVE list (dvol / p
+// must be valid on every neighbour of a FLUID brick), KD / KU over the FLUID list.
+constexpr int PCG_B_THREADS = 2 * BRICK_THREADS;
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                               const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
-                                                              float* __restrict__ r, float* __restrict__ s, float* __restrict__ part_sigma) {
+                                                              float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd) {
     __shared__ float sm[8];
     float acc = 0.0f;
-    {
-        BRICK_LOOP_BEGIN(bg, list, count)
-            (void)pcg_init_quad(bg.g, marker, dvol, p, r, s, base, x0, y, z, acc);
-        BRICK_LOOP_END
+    const uint32_t n = *count;
+    const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    for (uint32_t i = blockIdx.x * 2 + half; i < n; i += gridDim.x * 2) {
+        int x0, y, z;
+        if (!brick_quad(bg, list[i], t, x0, y, z)) continue;
+        (void)pcg_init_quad(bg.g, marker, dvol, p, r, s, cidx(bg.g, x0, y, z), x0, y, z, acc);
     }
-    const float tot = block_reduce<BRICK_THREADS, false>(acc, sm);
-    if (threadIdx.x == 0) part_sigma[blockIdx.x] = tot;
+    const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
+    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, 0.0f);
 }
 template <bool FIRST>
-__global__ __launch_bounds__(BRICK_THREADS) void k_pcg_dir_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                              const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
-                                                             const float* __restrict__ part_sigma_prev, const float* __restrict__ part_sigma,
-                                                             const float* __restrict__ part_max, float* __restrict__ part_sas, int num_part,
+                                                             const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
                                                              PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
     __shared__ float sm[8];
+    __shared__ float2 sm2[4];
+    const uint32_t n = *count;
+    const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    uint32_t i = blockIdx.x * 2 + half;
+    DirLoad L; L.valid = false;
+    if (i < n) { int x0, y, z; L.valid = brick_quad(bg, list[i], t, x0, y, z); if (L.valid) dir_load<FIRST>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L); }
     float beta;
-    if (!pcg_dir_prologue<BRICK_THREADS>(ctrl, part_sigma_prev, part_sigma, part_max, num_part, tolerance, iteration, check_prev, sm, beta)) return;
+    if (!pcg_dir_prologue<PCG_B_THREADS>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     float acc = 0.0f;
-    {
-        BRICK_LOOP_BEGIN(bg, list, count)
-            pcg_dir_quad<FIRST>(bg.g, dvol, r, s_in, s_out, beta, base, x0, y, z, acc);
-        BRICK_LOOP_END
+    dir_compute<FIRST>(L, s_out, beta, acc);
+    for (i += gridDim.x * 2; i < n; i += gridDim.x * 2) {
+        int x0, y, z;
+        L.valid = brick_quad(bg, list[i], t, x0, y, z);
+        if (L.valid) dir_load<FIRST>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L);
+        dir_compute<FIRST>(L, s_out, beta, acc);
     }
-    const float tot = block_reduce<BRICK_THREADS, false>(acc, sm);
-    if (threadIdx.x == 0) part_sas[blockIdx.x] = tot;
+    const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
+    if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(BRICK_THREADS) void k_pcg_update_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                 const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
-                                                                float* __restrict__ r, const float* __restrict__ part_sas, const float* __restrict__ part_sigma,
-                                                                float* __restrict__ part_sigma_next, float* __restrict__ part_max, int num_part,
-                                                                const PcgCtrl* __restrict__ ctrl) {
+                                                                float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
+                                                                const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[8];
-    if (ctrl->done) return;
-    const float alpha = pcg_alpha<BRICK_THREADS>(part_sigma, part_sas, num_part, sm);
+    const uint32_t n = *count;
+    const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    uint32_t i = blockIdx.x * 2 + half;
+    UpdLoad L; L.valid = false;
+    if (i < n) { int x0, y, z; L.valid = brick_quad(bg, list[i], t, x0, y, z); if (L.valid) upd_load(bg.g, dvol, s, p, r, cidx(bg.g, x0, y, z), x0, y, z, L); }
+    float alpha;
+    if (!pcg_upd_prologue<PCG_B_THREADS>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
     float acc = 0.0f, emax = 0.0f;
-    {
-        BRICK_LOOP_BEGIN(bg, list, count)
-            pcg_update_quad(bg.g, dvol, s, p, r, alpha, base, x0, y, z, acc, emax);
-        BRICK_LOOP_END
+    upd_compute(L, p, r, alpha, acc, emax);
+    for (i += gridDim.x * 2; i < n; i += gridDim.x * 2) {
+        int x0, y, z;
+        L.valid = brick_quad(bg, list[i], t, x0, y, z);
+        if (L.valid) upd_load(bg.g, dvol, s, p, r, cidx(bg.g, x0, y, z), x0, y, z, L);
+        upd_compute(L, p, r, alpha, acc, emax);
     }
-    const float tot = block_reduce<BRICK_THREADS, false>(acc, sm);
-    const float mx = block_reduce<BRICK_THREADS, true>(emax, sm);
-    if (threadIdx.x == 0) { part_sigma_next[blockIdx.x] = tot; part_max[blockIdx.x] = mx; }
+    const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
+    const float mx = block_reduce<PCG_B_THREADS, true>(emax, sm);
+    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, mx);
 }
 
 // After the last update (i == max_num_iterations): statistics are written unconditionally if nothing converged before
 // (pressure_reduce.comp:84: MaxNumSolverIterations == iterationIdx).
-__global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float* __restrict__ part_max, int num_part, int iteration) {
-    __shared__ float sm[8];
-    if (ctrl->done) return;
-    const float err = reduce_partials<256, true>(part_max, num_part, sm);
-    if (threadIdx.x == 0) { ctrl->max_err = err; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
+__global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, int iteration) {
+    __shared__ float2 sm2[4];
+    const int done = ctrl->done;
+    const float2 red = reduce_partials2<256>(part_upd, num_part, sm2);
+    if (!done && threadIdx.x == 0) { ctrl->max_err = red.y; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
 }
 
 }  // namespace blubk
