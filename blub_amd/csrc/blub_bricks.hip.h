@@ -25,8 +25,9 @@ struct BrickGeom {
     Grid g;
     int nbx, nby, nbz, nb;
 };
-struct BrickCounts {        // device resident
+struct BrickCounts {        // device resident; `seq` tags the asynchronous host read-back of this list build
     uint32_t n_fluid, n_active, n_reset, n_stale;
+    uint32_t seq, pad0, pad1, seq_check;
 };
 
 __device__ __forceinline__ uint32_t brick_of_cell(const BrickGeom& bg, int x, int y, int z) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
 // come out in brick (= memory) order, deterministically.
 __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uint8_t* __restrict__ brick_flags, const uint4* __restrict__ block_counts, int nblocks,
                                                          uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
-                                                         uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts) {
+                                                         uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq) {
     __shared__ uint32_t sm[17];
     __shared__ uint32_t base[4], total[4];
     if (threadIdx.x < 64) {   // one wave sums the block counts: lanes stride over the blocks in order
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uin
     if (fl & BF_FLUID) list_fluid[base[0] + of] = (uint32_t)b;
     if (fl & BF_ACTIVE) list_active[base[1] + oa] = (uint32_t)b;
     if (fl & (BF_ACTIVE | BF_STALE)) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { counts->n_fluid = total[0]; counts->n_active = total[1]; counts->n_reset = total[2]; counts->n_stale = total[3]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counts->n_fluid = total[0]; counts->n_active = total[1]; counts->n_reset = total[2]; counts->n_stale = total[3]; counts->seq = seq; counts->seq_check = seq; }
 }
 
 // ---- static marker pattern: transfer_clear.comp:10-14 + transfer_set_boundary_marker.comp:11-19 --------------------

@@ -4,8 +4,11 @@
 // device every device entry point returns BLUB_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <time.h>
+
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <new>
@@ -48,7 +51,7 @@ constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
 constexpr int COUNTS_RING = 8;
 constexpr float SPARSE_PCG_MAX_FILL = 0.30f;   // fluid bricks / bricks below which the brick-list PCG kernels are used
 
-struct PendingStat { hipEvent_t ev; int slot; };
+struct PendingStat { uint32_t seq; int slot; };
 
 }  // namespace blub
 using namespace blub;
@@ -80,9 +83,13 @@ struct blub_fluid {
     uint8_t* brick_flags = nullptr;
     uint4* brick_block_counts = nullptr;
     BrickCounts* counts = nullptr;            // device
-    BrickCounts* counts_host = nullptr;       // pinned ring of COUNTS_RING snapshots (path selection only)
-    hipEvent_t counts_events[8] = {};
-    int counts_head = 0, counts_valid = 0;
+    BrickCounts* counts_host = nullptr;       // pinned ring of COUNTS_RING snapshots (path selection only), tagged by seq
+    uint32_t counts_seq = 0;                  // number of list builds enqueued so far
+    // run-ahead throttle: the device writes the number of the last finished step into pinned host memory
+    volatile uint32_t* steps_done_host = nullptr;
+    uint32_t* steps_done_dev = nullptr;
+    uint32_t steps_enqueued = 0;
+    uint32_t max_steps_in_flight = 4;
     bool all_touched = false;
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, 1 brick lists
     // PCG
@@ -95,9 +102,8 @@ struct blub_fluid {
     blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
     bool pressure_initialised[2] = {false, false};
     // statistics read-back ring (pressure_solver.rs:118-126, 148-209)
-    float* stats_host[2] = {nullptr, nullptr};   // pinned, STATS_RING x 2 floats
-    hipEvent_t stats_events[2][STATS_RING] = {};
-    int stats_head[2] = {0, 0};
+    PcgCtrl* stats_host[2] = {nullptr, nullptr};   // pinned ring of STATS_RING control-block snapshots, tagged by seq
+    uint32_t solve_seq[2] = {0, 0};                // number of solves enqueued so far
     std::deque<PendingStat> stats_pending[2];
     std::deque<float> stats_dt[2];
     std::deque<blub_solver_stats> stats_history[2];
@@ -164,48 +170,46 @@ static int copy_sync(blub_fluid* h, void* dst, const void* src, size_t bytes, hi
 }
 
 // ---- brick work lists ----------------------------------------------------------------------------------------------
+// Asynchronous read-backs never use hipEvents: querying a pending event makes the runtime push marker packets into the
+// stream, which costs milliseconds per step once the host runs ahead of the GPU.  Instead every snapshot carries the
+// sequence number of the enqueue that produced it and the host simply polls the pinned (coherent) ring.
 static int snapshot_counts(blub_fluid* h) {
-    const int slot = h->counts_head;
-    h->counts_head = (slot + 1) % COUNTS_RING;
+    const int slot = (int)(h->counts_seq % COUNTS_RING);
     HIP_TRY(hipMemcpyAsync(&h->counts_host[slot], h->counts, sizeof(BrickCounts), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(h->counts_events[slot], h->stream));
-    h->counts_valid = std::min(h->counts_valid + 1, COUNTS_RING);
     return BLUB_OK;
 }
-// phase: COMPACT_STEP_A (before P2G) / COMPACT_STEP_B (after advection), from the particle positions
-static int build_lists_from_particles(blub_fluid* h, int phase) {
+// phase: COMPACT_STEP_A (before P2G) / COMPACT_STEP_B (after advection) from the particle positions;
+// COMPACT_ALL_ACTIVE (stand-alone stage calls): FLUID bricks from the marker volume, every brick active
+static int build_lists(blub_fluid* h, int phase) {
     ProfScope ps(h, KC_BRICK_LISTS);
     HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
-    if (h->num_particles)
+    if (phase == COMPACT_ALL_ACTIVE)
+        hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
+    else if (h->num_particles)
         hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles)), dim3(256), 0, h->stream, h->bg, h->num_particles, (const float4*)h->pos, h->brick_fluid);
     const int nblk = (h->bg.nb + 1023) / 1024;
-    hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, (int)h->all_touched, (const uint8_t*)h->brick_fluid, h->brick_active,
+    const int all_touched = (phase == COMPACT_ALL_ACTIVE) ? 1 : (int)h->all_touched;
+    h->counts_seq += 1;
+    hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, (const uint8_t*)h->brick_fluid, h->brick_active,
                        h->brick_touched, h->brick_flags, h->brick_block_counts);
     hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
-                       h->list_fluid, h->list_active, h->list_reset, h->counts);
+                       h->list_fluid, h->list_active, h->list_reset, h->counts, h->counts_seq);
     if (phase == COMPACT_STEP_A) h->all_touched = false;
     return snapshot_counts(h);
 }
-// stand-alone stage calls: FLUID bricks from the marker volume, every brick active (dense semantics for the test hook)
-static int build_lists_from_marker(blub_fluid* h) {
-    ProfScope ps(h, KC_BRICK_LISTS);
-    HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
-    hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
-    const int nblk = (h->bg.nb + 1023) / 1024;
-    hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (int)COMPACT_ALL_ACTIVE, 1, (const uint8_t*)h->brick_fluid, h->brick_active,
-                       h->brick_touched, h->brick_flags, h->brick_block_counts);
-    hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
-                       h->list_fluid, h->list_active, h->list_reset, h->counts);
-    return snapshot_counts(h);
-}
-// latest completed snapshot of the brick counts (never waits unless `block`): only steers a performance choice
+static int build_lists_from_particles(blub_fluid* h, int phase) { return build_lists(h, phase); }
+static int build_lists_from_marker(blub_fluid* h) { return build_lists(h, COMPACT_ALL_ACTIVE); }
+// newest snapshot of the brick counts that has landed (never waits unless `block`): only steers a performance choice
 static int latest_counts(blub_fluid* h, bool block, BrickCounts* out, bool* have) {
     *have = false;
-    for (int k = 0; k < h->counts_valid; ++k) {
-        const int slot = (h->counts_head - 1 - k + 2 * COUNTS_RING) % COUNTS_RING;
-        hipError_t q = (block && k == 0) ? hipEventSynchronize(h->counts_events[slot]) : hipEventQuery(h->counts_events[slot]);
-        if (q == hipSuccess) { *out = h->counts_host[slot]; *have = true; return BLUB_OK; }
-        if (q != hipErrorNotReady) return set_error(BLUB_ERR_DEVICE, hipGetErrorString(q));
+    if (h->counts_seq == 0) return BLUB_OK;
+    if (block) HIP_TRY(hipStreamSynchronize(h->stream));
+    for (uint32_t k = 0; k < COUNTS_RING && k < h->counts_seq; ++k) {
+        const uint32_t seq = h->counts_seq - k;
+        const volatile BrickCounts* c = &h->counts_host[seq % COUNTS_RING];
+        BrickCounts snap;
+        snap.n_fluid = c->n_fluid; snap.n_active = c->n_active; snap.n_reset = c->n_reset; snap.n_stale = c->n_stale; snap.seq = c->seq; snap.seq_check = c->seq_check;
+        if (snap.seq == seq && snap.seq_check == seq) { *out = snap; *have = true; return BLUB_OK; }
     }
     return BLUB_OK;
 }
@@ -235,11 +239,10 @@ static int stage_divergence(blub_fluid* h) {   // :836-840
 
 static int enqueue_stats_readback(blub_fluid* h, int which, float dt) {   // enqueue_error_buffer_read, pressure_solver.rs:176-191
     if ((int)h->stats_pending[which].size() < STATS_RING) {
-        const int slot = h->stats_head[which];
-        h->stats_head[which] = (slot + 1) % STATS_RING;
-        HIP_TRY(hipMemcpyAsync(h->stats_host[which] + 2 * slot, h->ctrl[which], 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipEventRecord(h->stats_events[which][slot], h->stream));
-        h->stats_pending[which].push_back({h->stats_events[which][slot], slot});
+        const uint32_t seq = h->solve_seq[which];
+        const int slot = (int)(seq % STATS_RING);
+        HIP_TRY(hipMemcpyAsync(&h->stats_host[which][slot], h->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, h->stream));
+        h->stats_pending[which].push_back({seq, slot});
         h->stats_dt[which].push_back(dt);
     }   // else: "No more error buffer available" -- the reference warns and skips the sample (:188-190)
     return BLUB_OK;
@@ -271,6 +274,7 @@ static int stage_solve_lod0(blub_fluid* h, int which, float dt) {
         LAUNCH(h, KC_PCG_LOD0, k_pcg_search<false>, grid, block, h->geom, h->marker, h->aux, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
         if (last) break;
     }
+    LAUNCH(h, KC_PCG_LOD0, k_pcg_tag, dim3(1), dim3(1), ctrl, h->solve_seq[which]);
     return BLUB_OK;
 }
 
@@ -285,6 +289,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     const float tol = c.error_tolerance / dt;   // :197
     PcgCtrl* ctrl = h->ctrl[which];
     HIP_TRY(hipMemsetAsync(ctrl, 0, sizeof(PcgCtrl), h->stream));
+    h->solve_seq[which] += 1;
     int rc;
     if (h->precond_mode != BLUB_PRECOND_ZERO) {
         if ((rc = stage_solve_lod0(h, which, dt)) != BLUB_OK) return rc;
@@ -295,7 +300,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     if (h->force_pcg_path >= 0) sparse = h->force_pcg_path == 1;
     else {
         BrickCounts bc{}; bool have = false;
-        if ((rc = latest_counts(h, standalone || h->counts_valid <= 1, &bc, &have)) != BLUB_OK) return rc;
+        if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
         sparse = have && (float)bc.n_fluid < SPARSE_PCG_MAX_FILL * (float)h->bg.nb;
     }
     const int maxit = c.max_num_iterations;
@@ -318,7 +323,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
                    (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
         }
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which]);
     } else {
         const int np = h->pcg_grid;
         const dim3 grid(np), block(256);
@@ -333,7 +338,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_d, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
                    (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);
         }
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which]);
     }
     // the search direction of a full-length solve ends in sbuf[maxit & 1]; keep BLUB_VOLUME_SEARCH pointing at it
     if (maxit & 1) std::swap(h->search, h->aux);
@@ -426,9 +431,9 @@ static void destroy(blub_fluid* h) {
     for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
-    for (auto e : h->counts_events) if (e) (void)hipEventDestroy(e);
+    if (h->steps_done_host) (void)hipHostFree((void*)h->steps_done_host);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
-    for (int w = 0; w < 2; ++w) { if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]); for (auto e : h->stats_events[w]) if (e) (void)hipEventDestroy(e); }
+    for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -485,11 +490,18 @@ static int create(const blub_fluid_desc* d, blub_fluid** out) {
     A(dev_alloc_zero(h->stream, &h->list_fluid, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_active, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_reset, (size_t)bg.nb));
     A(dev_alloc_zero(h->stream, &h->counts, 1));
     A(dev_alloc_zero(h->stream, &h->brick_flags, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_block_counts, (size_t)(bg.nb + 1023) / 1024));
-    if (rc == BLUB_OK && hipHostMalloc((void**)&h->counts_host, COUNTS_RING * sizeof(BrickCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
-    for (int k = 0; k < COUNTS_RING && rc == BLUB_OK; ++k) if (hipEventCreateWithFlags(&h->counts_events[k], hipEventDisableTiming) != hipSuccess) rc = set_error(BLUB_ERR_DEVICE, "hipEventCreate failed");
+    if (rc == BLUB_OK) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&h->steps_done_dev, hp, 0) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+        else { memset(hp, 0, 64); h->steps_done_host = (volatile uint32_t*)hp; }
+    }
+    if (rc == BLUB_OK) {
+        if (hipHostMalloc((void**)&h->counts_host, COUNTS_RING * sizeof(BrickCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+        else memset(h->counts_host, 0, COUNTS_RING * sizeof(BrickCounts));
+    }
     for (int w = 0; w < 2 && rc == BLUB_OK; ++w) {
-        if (hipHostMalloc((void**)&h->stats_host[w], STATS_RING * 2 * sizeof(float)) != hipSuccess) { rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed"); break; }
-        for (int k = 0; k < STATS_RING; ++k) if (hipEventCreateWithFlags(&h->stats_events[w][k], hipEventDisableTiming) != hipSuccess) { rc = set_error(BLUB_ERR_DEVICE, "hipEventCreate failed"); break; }
+        if (hipHostMalloc((void**)&h->stats_host[w], STATS_RING * sizeof(PcgCtrl)) != hipSuccess) { rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed"); break; }
+        memset(h->stats_host[w], 0, STATS_RING * sizeof(PcgCtrl));
     }
     if (rc != BLUB_OK) { std::string keep = g_last_error; destroy(h); g_last_error = keep; return rc; }
     // the marker volume starts in its static pattern (AIR + SOLID shell): the brick kernels only maintain it locally
@@ -500,13 +512,18 @@ static int create(const blub_fluid_desc* d, blub_fluid** out) {
 }
 
 static int poll_stats(blub_fluid* h, bool wait) {   // retrieve_new_error_samples, pressure_solver.rs:148-174
+    if (wait) HIP_TRY(hipStreamSynchronize(h->stream));
     for (int w = 0; w < 2; ++w) {
         while (!h->stats_pending[w].empty()) {
-            PendingStat ps = h->stats_pending[w].front();
-            hipError_t q = wait ? hipEventSynchronize(ps.ev) : hipEventQuery(ps.ev);
-            if (q == hipErrorNotReady) break;
-            if (q != hipSuccess) return set_error(BLUB_ERR_DEVICE, hipGetErrorString(q));
-            const float max_err = h->stats_host[w][2 * ps.slot], iters = h->stats_host[w][2 * ps.slot + 1];
+            const PendingStat ps = h->stats_pending[w].front();
+            const volatile PcgCtrl* c = &h->stats_host[w][ps.slot];
+            const uint32_t landed = c->seq;
+            if (landed != ps.seq) {
+                if ((int32_t)(landed - ps.seq) > 0) { h->stats_pending[w].pop_front(); h->stats_dt[w].pop_front(); continue; }   // slot reused by a newer solve: sample lost
+                break;   // this snapshot has not landed yet (samples arrive in order)
+            }
+            const float max_err = c->max_err, iters = c->num_iter;
+            if (c->seq != ps.seq) continue;
             blub_solver_stats s; s.error = max_err * h->stats_dt[w].front(); s.iteration_count = (int32_t)iters;   // :162-163
             h->stats_history[w].push_back(s);
             while (h->stats_history[w].size() > STATS_HISTORY) h->stats_history[w].pop_front();
@@ -577,6 +594,20 @@ int blub_fluid_run_stage(blub_fluid* h, int stage, float dt) {
 int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
     REQUIRE_HANDLE(h);
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
+    // Bounded run-ahead ("steps in flight"): on ROCm 7.2 / gfx950 a stream with more than ~1000 queued kernel launches
+    // executes 3x slower (measured: 1.38 ms/step with <= 4 steps = 692 launches queued, 4.35 ms/step with 6), so the host waits here
+    // until step n - max_steps_in_flight has finished.  The wait polls a counter the device writes into pinned host
+    // memory: no HIP call, hence no marker packets in the stream.
+    if (h->max_steps_in_flight > 0) {
+        // keep the launches in flight below ~700 (the cliff sits at ~1024): a step is ~40 launches + 2 per PCG iteration
+        const uint32_t est_launches = 40u + 2u * (uint32_t)(h->cfg[0].max_num_iterations + h->cfg[1].max_num_iterations + 2) * (h->precond_mode == BLUB_PRECOND_ZERO ? 1u : 3u);
+        const uint32_t allowed = std::max(1u, std::min(h->max_steps_in_flight, 700u / est_launches));
+        unsigned spins = 0;
+        while ((int32_t)(h->steps_enqueued - *h->steps_done_host) >= (int32_t)allowed) {
+            if (++spins > 2000) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+            if (spins > 50000000u) return blub::set_error(BLUB_ERR_DEVICE, "timed out waiting for an earlier step");
+        }
+    }
     static const int before_binning[] = {BLUB_STAGE_TRANSFER, BLUB_STAGE_DIVERGENCE, BLUB_STAGE_SOLVE_VELOCITY};
     static const int after_binning[] = {BLUB_STAGE_PROJECT, BLUB_STAGE_ADVECT, BLUB_STAGE_DENSITY_GATHER, BLUB_STAGE_SOLVE_DENSITY, BLUB_STAGE_POSITION_CHANGE, BLUB_STAGE_CORRECT};
     int rc;
@@ -585,6 +616,8 @@ int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
         if ((rc = blub::run_stage(h, BLUB_STAGE_BINNING, dt, false)) != BLUB_OK) return rc;
     for (int s : after_binning) if ((rc = blub::run_stage(h, s, dt, false)) != BLUB_OK) return rc;
     h->step_counter += 1;   // :976
+    h->steps_enqueued += 1;
+    hipLaunchKernelGGL(blubk::k_step_done, dim3(1), dim3(1), 0, h->stream, (volatile uint32_t*)h->steps_done_dev, h->steps_enqueued);
     (void)blub::poll_stats(h, false);   // the reference polls old read-backs inside solve (:612)
     return blub::check_launch(h);
 }
@@ -716,6 +749,7 @@ int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode) {
     h->force_pcg_path = mode;
     return BLUB_OK;
 }
+int blub_fluid_set_max_steps_in_flight(blub_fluid* h, uint32_t m) { if (!h) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); h->max_steps_in_flight = m; return BLUB_OK; }
 int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]) {
     REQUIRE_HANDLE(h);
     if (!out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");

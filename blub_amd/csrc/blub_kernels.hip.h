@@ -125,7 +125,8 @@ struct PcgCtrl {       // device-resident; [0..1] mirror the reference's MaxErro
     int done;
     int pad;
     float sigma[2];    // sigma of iteration i in slot i & 1 (the reference keeps it in PcgScalars.Sigma, pressure.glsl:24-28)
-    float pad2[2];
+    uint32_t seq;      // host-assigned solve number, written by the last kernel of the solve: tags the asynchronous read-back
+    uint32_t pad2;
 };
 
 struct PcgGeom {

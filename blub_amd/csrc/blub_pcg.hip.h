@@ -404,11 +404,18 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_b(BrickGeom bg, co
 
 // After the last update (i == max_num_iterations): statistics are written unconditionally if nothing converged before
 // (pressure_reduce.comp:84: MaxNumSolverIterations == iterationIdx).
-__global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, int iteration) {
+__global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, int iteration, uint32_t seq) {
     __shared__ float2 sm2[4];
     const int done = ctrl->done;
     const float2 red = reduce_partials2<256>(part_upd, num_part, sm2);
-    if (!done && threadIdx.x == 0) { ctrl->max_err = red.y; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
+    if (threadIdx.x == 0) {
+        if (!done) { ctrl->max_err = red.y; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
+        ctrl->seq = seq;
+    }
 }
+// end-of-step marker written straight into pinned host memory (run-ahead throttle, see blub_fluid_step)
+__global__ void k_step_done(volatile uint32_t* host_counter, uint32_t step_number) { *host_counter = step_number; }
+// LOD0 path: its own kernels already wrote the statistics; only the read-back tag is missing
+__global__ void k_pcg_tag(PcgCtrl* __restrict__ ctrl, uint32_t seq) { ctrl->seq = seq; }
 
 }  // namespace blubk

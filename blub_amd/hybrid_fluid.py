@@ -145,6 +145,7 @@ def load_library():
         "blub_fluid_total_solver_iterations": (C.c_uint64, [vp]),
         "blub_fluid_set_pcg_work_mapping": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_brick_counts": (C.c_int, [vp, vp]),
+        "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError = a symbol declared in include/blubhip.h is not exported
@@ -363,6 +364,9 @@ class HybridFluid:
     def set_pcg_work_mapping(self, mode):
         """"auto" | "rows" | "bricks" -- performance knob, see include/blubhip.h"""
         _check(self._L, self._L.blub_fluid_set_pcg_work_mapping(self._h, {"auto": -1, "rows": 0, "bricks": 1}[mode]))
+
+    def set_max_steps_in_flight(self, n):
+        _check(self._L, self._L.blub_fluid_set_max_steps_in_flight(self._h, int(n)))
 
     def brick_counts(self):
         out = (C.c_uint32 * 6)()

@@ -198,6 +198,9 @@ int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacit
  * 0 = dense rows, 1 = brick lists.  A performance knob only: both mappings run the same per-cell arithmetic (the
  * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise). */
 int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
+/* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks
+ * (polling pinned memory) until step n - max has finished. */
+int blub_fluid_set_max_steps_in_flight(blub_fluid* h, uint32_t max_steps);
 /* {fluid bricks, active bricks, reset-list entries, stale bricks, total bricks, cells per brick} of the latest list build; blocks. */
 int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]);
 /* Total PCG iterations executed (sum of reported iteration counts) since creation, both solvers. */
