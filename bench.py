@@ -117,10 +117,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-pcg", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--dense-only", action="store_true", help="only run the dense 256^3 PCG micro-benchmark (tuning)")
     args = ap.parse_args()
 
     import torch
     import blub_amd
+
+    if args.dense_only:
+        print(json.dumps(dense_pcg_benchmark(256, 32)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -16,7 +16,7 @@
 #include <vector>
 
 #include "blub_internal.h"
-#include "blub_pcg.hip.h"
+#include "blub_pcg_dense.hip.h"
 
 namespace blub {
 
@@ -44,7 +44,9 @@ static const char* kKernelClassNames[KC_COUNT] = {
     "pcg_lod0", "divergence_remove", "extrapolate", "advect", "density_gather", "position_change", "correct",
     "bin_count", "bin_scan", "bin_rewrite", "copy"};
 
-constexpr int PCG_GRID_MAX = 1024;   // persistent blocks of the PCG kernels (= number of dot-product partials)
+constexpr int PCG_GRID_MAX = 4096;   // upper bound of persistent blocks of the PCG kernels (= number of dot-product partials)
+constexpr int PCG_GRID_DENSE = 2048; // dense rows: 8 blocks of 256 threads per CU
+constexpr int PCG_GRID_BRICKS = 1024;
 constexpr int BRICK_GRID_MAX = 2048; // persistent blocks of the brick-list kernels
 constexpr int STATS_RING = 32;       // pressure_solver.rs:49 NUM_PRESSURE_ERROR_BUFFER
 constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
@@ -96,6 +98,8 @@ struct blub_fluid {
     uint8_t* dvol = nullptr;
     PcgGeom geom{};
     int pcg_grid = 0;
+    PcgGeomZ gz{};            // 2.5-D dense mapping (blub_pcg_dense.hip.h)
+    int pcg_grid_z = 0;
     float *part_sas = nullptr, *part_sigma[2] = {nullptr, nullptr}, *part_max = nullptr;
     uint8_t* tile_flags = nullptr;
     PcgCtrl* ctrl[2] = {nullptr, nullptr};
@@ -310,7 +314,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
     float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
     if (sparse) {
-        const int np = std::min((h->bg.nb + 1) / 2, PCG_GRID_MAX);
+        const int np = std::min((h->bg.nb + 1) / 2, PCG_GRID_BRICKS);
         const dim3 grid(np), block(PCG_B_THREADS);
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd);
         for (int i = 0; i <= maxit; ++i) {
@@ -325,19 +329,25 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         }
         LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which]);
     } else {
-        const int np = h->pcg_grid;
-        const dim3 grid(np), block(256);
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_d, grid, block, h->geom, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags);
-        for (int i = 0; i <= maxit; ++i) {
-            if (i == 0)
-                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_d<true>, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
-                       (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);
-            else
-                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_d<false>, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
-                       (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));
-            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_d, grid, block, h->geom, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
-                   (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);
+        const int np = h->pcg_grid_z;
+        const dim3 grid(np);
+#define BLUB_LAUNCH_Z(TT)                                                                                                                                       \
+        {                                                                                                                                                       \
+            const dim3 block(TT);                                                                                                                               \
+            LAUNCH(h, KC_PCG_INIT, k_pcg_init_z<TT>, grid, block, h->gz, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags);   \
+            for (int i = 0; i <= maxit; ++i) {                                                                                                                  \
+                if (i == 0)                                                                                                                                     \
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
+                           (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);                                              \
+                else                                                                                                                                            \
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
+                           (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));                           \
+                LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_z<TT>, grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,             \
+                       (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
+            }                                                                                                                                                   \
         }
+        if (h->gz.T == 256) BLUB_LAUNCH_Z(256) else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024) else BLUB_LAUNCH_Z(512)
+#undef BLUB_LAUNCH_Z
         LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which]);
     }
     // the search direction of a full-length solve ends in sbuf[maxit & 1]; keep BLUB_VOLUME_SEARCH pointing at it
@@ -477,10 +487,25 @@ static int create(const blub_fluid_desc* d, blub_fluid** out) {
     A(dev_alloc_zero(h->stream, &h->scan_totals, (h->N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
     PcgGeom& gm = h->geom;
     gm.g = h->g; gm.qpr = h->g.nx / 4; gm.qpp = gm.qpr * h->g.ny; gm.plane_blocks = (gm.qpp + 255) / 256;
-    gm.z_chunks = (h->g.nz + PCG_ZC - 1) / PCG_ZC; gm.tiles = gm.plane_blocks * gm.z_chunks;
-    h->pcg_grid = std::min(PCG_GRID_MAX, gm.tiles);
+    {   // tile depth / grid size: tuning knobs (environment overrides exist for sweeps only)
+        int zc = 8, grid = PCG_GRID_DENSE;
+        if (const char* e = getenv("BLUB_PCG_ZC")) zc = std::max(1, atoi(e));
+        if (const char* e = getenv("BLUB_PCG_GRID")) grid = std::min(PCG_GRID_MAX, std::max(1, atoi(e)));
+        gm.zc = zc;
+        gm.z_chunks = (h->g.nz + zc - 1) / zc; gm.tiles = gm.plane_blocks * gm.z_chunks;
+        h->pcg_grid = std::min(grid, gm.tiles);
+        PcgGeomZ& gz = h->gz;
+        int T = 256, zcz = 16, gridz = 2048;   // measured on MI355X at 256^3 (profiles/r01_dense_pcg_sweep.txt)
+        if (const char* e = getenv("BLUB_PCGZ_T")) T = atoi(e);
+        if (T != 256 && T != 512 && T != 1024) T = 512;
+        if (const char* e = getenv("BLUB_PCGZ_ZC")) zcz = std::max(1, atoi(e));
+        if (const char* e = getenv("BLUB_PCGZ_GRID")) gridz = std::min(PCG_GRID_MAX, std::max(1, atoi(e)));
+        gz.g = h->g; gz.qpr = gm.qpr; gz.qpp = gm.qpp; gz.T = T; gz.plane_tiles = (gm.qpp + T - 1) / T; gz.zc = zcz;
+        gz.z_chunks = (h->g.nz + zcz - 1) / zcz; gz.tiles = gz.plane_tiles * gz.z_chunks;
+        h->pcg_grid_z = std::min(gridz, ((gz.tiles + 7) / 8) * 8);
+    }
     A(dev_alloc_zero(h->stream, &h->part_sas, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[0], 2 * PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[1], PCG_GRID_MAX));
-    A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, (size_t)gm.tiles));
+    A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, (size_t)std::max(gm.tiles, h->gz.tiles) + 8));
     A(dev_alloc_zero(h->stream, &h->ctrl[0], 1)); A(dev_alloc_zero(h->stream, &h->ctrl[1], 1));
     A(dev_alloc_zero(h->stream, &h->dvol, h->N));
     BrickGeom& bg = h->bg;

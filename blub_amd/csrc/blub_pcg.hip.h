@@ -13,10 +13,11 @@
 // Dot products: one partial per block, re-reduced (<=1024 floats, L2 resident) by every block of the consumer kernel:
 // no atomics, no reduce dispatch, bit-deterministic.  sigma is double-buffered by iteration parity.
 //
-// Two work mappings share the per-quad device functions:
-//   *_d : dense rows  -- a tile = 256 threads x 4 x-consecutive cells of a z-plane, marched over PCG_ZC planes,
-//                        persistent grid striding over tiles, tiles without FLUID skipped (high fill ratios)
-//   *_b : brick lists -- one 128-thread block per FLUID brick (16x8x4 cells), low fill ratios (the 1M @ 256^3 scene)
+// Two work mappings share the per-cell device functions:
+//   *_z : dense, 2.5-D -- blub_pcg_dense.hip.h: tiles of T quads marched in z with register/LDS neighbour exchange
+//                         (high fill ratios; the HBM-roofline path)
+//   *_b : brick lists  -- here: 256-thread blocks, two FLUID bricks (16x8x4 cells) at a time, low fill ratios
+//                         (the 1M @ 256^3 scene; latency- not byte-bound)
 #pragma once
 #include "blub_bricks.hip.h"
 
@@ -121,59 +122,6 @@ __device__ __forceinline__ float snew_of(int dv, float r, float sold, float beta
 __device__ __forceinline__ float4 snew4(uint32_t dq, const float4& r, const float4& s, float beta) {
     return make_float4(snew_of(dbyte(dq, 0), r.x, s.x, beta), snew_of(dbyte(dq, 1), r.y, s.y, beta),
                        snew_of(dbyte(dq, 2), r.z, s.z, beta), snew_of(dbyte(dq, 3), r.w, s.w, beta));
-}
-
-// KD body.  FIRST: s comes from the init kernel, only s.As is computed (pressure_apply_coeff.comp:19-30).
-template <bool FIRST>
-__device__ __forceinline__ void pcg_dir_quad(const Grid& g, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
-                                             float* __restrict__ s_out, float beta, int base, int x0, int y, int z, float& acc) {
-    QuadD m; m.c = *reinterpret_cast<const uint32_t*>(dvol + base);
-    if (!any_fluid_d(m.c)) return;
-    load_quad_d(dvol, g, base, x0, y, z, m);
-    QuadValues sv; load_quad_values(s_in, g, base, x0, y, z, sv);
-    if (!FIRST) {
-        QuadValues rv; load_quad_values(r, g, base, x0, y, z, rv);
-        const float4 sold = sv.c;
-        sv.c = snew4(m.c, rv.c, sv.c, beta);
-        sv.ym = snew4(m.ym, rv.ym, sv.ym, beta); sv.yp = snew4(m.yp, rv.yp, sv.yp, beta);
-        sv.zm = snew4(m.zm, rv.zm, sv.zm, beta); sv.zp = snew4(m.zp, rv.zp, sv.zp, beta);
-        sv.xm = snew_of(m.xm, rv.xm, sv.xm, beta); sv.xp = snew_of(m.xp, rv.xp, sv.xp, beta);
-        // the reference only writes s on FLUID cells: other lanes keep their old value
-        float4 so = sv.c;
-        if (!(dbyte(m.c, 0) & 0x80)) so.x = sold.x;
-        if (!(dbyte(m.c, 1) & 0x80)) so.y = sold.y;
-        if (!(dbyte(m.c, 2) & 0x80)) so.z = sold.z;
-        if (!(dbyte(m.c, 3) & 0x80)) so.w = sold.w;
-        *reinterpret_cast<float4*>(s_out + base) = so;   // s is double buffered: neighbours still read the OLD s of this cell
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (dbyte(m.c, j) & 0x80) acc += f4(sv.c, j) * quad_mulA_d(m, sv, j);
-}
-
-// KU body: pressure_update_pressure_and_residual.comp:23-59 + M^-1 r and its dot with r
-__device__ __forceinline__ void pcg_update_quad(const Grid& g, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
-                                                float* __restrict__ r, float alpha, int base, int x0, int y, int z, float& acc, float& emax) {
-    QuadD m; m.c = *reinterpret_cast<const uint32_t*>(dvol + base);
-    if (!any_fluid_d(m.c)) return;
-    load_quad_d(dvol, g, base, x0, y, z, m);
-    QuadValues sv; load_quad_values(s, g, base, x0, y, z, sv);
-    const float4 pc = ld4(p + base), rc = ld4(r + base);
-    float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int dv = dbyte(m.c, j);
-        if (!(dv & 0x80)) continue;
-        const float as = quad_mulA_d(m, sv, j);
-        pp[j] = pp[j] + alpha * f4(sv.c, j);                                           // :39-40
-        float res = rr[j];
-        res -= alpha * as;                                                              // :52
-        rr[j] = res;
-        emax = fmaxf(emax, fabsf(res));                                                 // :55
-        acc += precond_zero(res, (float)(dv & 7)) * res;
-    }
-    *reinterpret_cast<float4*>(p + base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-    *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
 }
 
 // ---- load / compute split of the KD and KU bodies (brick mapping): all global loads of a quad are issued up front,
@@ -285,52 +233,6 @@ __device__ __forceinline__ bool pcg_upd_prologue(const PcgCtrl* __restrict__ ctr
     const float sas = reduce_partials<NT, false>(part_dir, num_part, sm);
     alpha = eps_div(sigma, sas);                                                        // RESULTMODE_ALPHA
     return !done;
-}
-
-// ---- dense-row wrappers ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pcg_init_d(PcgGeom geom, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
-                                                    float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, uint8_t* __restrict__ tile_flags) {
-    __shared__ float sm[8];
-    float acc = 0.0f;
-    PCG_TILE_LOOP_BEGIN(geom)
-        bool any = false;
-        if (qvalid) for (int z = z_begin; z < z_end; ++z) any |= pcg_init_quad(geom.g, marker, dvol, p, r, s, cidx(geom.g, x0, y, z), x0, y, z, acc);
-        const int tile_any = __syncthreads_or(any);
-        if (threadIdx.x == 0) tile_flags[tile] = (uint8_t)(tile_any != 0);
-    PCG_TILE_LOOP_END
-    const float tot = block_reduce<256, false>(acc, sm);
-    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, 0.0f);
-}
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_pcg_dir_d(PcgGeom geom, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
-                                                   const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
-                                                   const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
-    __shared__ float sm[8];
-    __shared__ float2 sm2[4];
-    float beta;
-    if (!pcg_dir_prologue<256>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
-    float acc = 0.0f;
-    PCG_TILE_LOOP_BEGIN(geom)
-        if (!tile_flags[tile] || !qvalid) continue;
-        for (int z = z_begin; z < z_end; ++z) pcg_dir_quad<FIRST>(geom.g, dvol, r, s_in, s_out, beta, cidx(geom.g, x0, y, z), x0, y, z, acc);
-    PCG_TILE_LOOP_END
-    const float tot = block_reduce<256, false>(acc, sm);
-    if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(256) void k_pcg_update_d(PcgGeom geom, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
-                                                      float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
-                                                      const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
-    __shared__ float sm[8];
-    float alpha;
-    if (!pcg_upd_prologue<256>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
-    float acc = 0.0f, emax = 0.0f;
-    PCG_TILE_LOOP_BEGIN(geom)
-        if (!tile_flags[tile] || !qvalid) continue;
-        for (int z = z_begin; z < z_end; ++z) pcg_update_quad(geom.g, dvol, s, p, r, alpha, cidx(geom.g, x0, y, z), x0, y, z, acc, emax);
-    PCG_TILE_LOOP_END
-    const float tot = block_reduce<256, false>(acc, sm);
-    const float mx = block_reduce<256, true>(emax, sm);
-    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, mx);
 }
 
 // ---- brick-list wrappers ---------------------------------------------------------------------------------------------

@@ -1,0 +1,252 @@
+// Dense-row PCG kernels, 2.5-D formulation for gfx950 (the HBM-roofline path: high fluid fill ratios).
+//
+// A tile = T consecutive quads (4 x-cells each) of one z-plane in memory order (T = 512: 8 rows of a 256-wide grid =
+// 8 KiB contiguous per f32 volume), marched over `zc` planes by one T-thread block:
+//   * z-neighbours never touch memory: every thread keeps its quad of planes z-1, z, z+1 in registers and rotates them;
+//   * y- and x-neighbours of plane z are other threads' centre registers: exchanged through a double-buffered LDS row
+//     buffer (one barrier per plane); only the two halo rows of the tile edge and the row-continuation cells come from
+//     global memory (L2 hits when the neighbouring tile runs on the same XCD: tiles are handed out XCD-contiguously);
+//   * the loads of plane z+2 (and of the next plane's p, r) are issued before plane z is computed (software prefetch).
+// Every f32 field is therefore fetched ~(1 + 2/rows)(1 + 2/zc) times instead of 3-5 times.
+// The direction kernel computes s_new = M^-1 r + beta s ONCE per cell per tile (plus the halo ring) instead of 5.5x.
+// Arithmetic per cell is identical to the brick mapping (same device functions), only the work mapping differs.
+#pragma once
+#include "blub_pcg.hip.h"
+
+namespace blubk {
+
+struct PcgGeomZ {
+    Grid g;
+    int qpr, qpp;         // quads per row / per plane
+    int T;                // threads (= quads) per tile
+    int plane_tiles;      // ceil(qpp / T)
+    int zc, z_chunks;
+    int tiles;
+};
+
+// XCD-contiguous tile order: block b runs on XCD b % 8 (observed dispatch order, a speed hint only), so give XCD k the
+// contiguous tile range [k*tiles/8, (k+1)*tiles/8): y-adjacent tiles then share an L2 for their halo rows.
+__device__ __forceinline__ int xcd_tile(int i, int tiles) {
+    const int per = (tiles + 7) >> 3;
+    const int t = (i & 7) * per + (i >> 3);
+    return t;   // may be >= tiles for the padded tail: callers skip those
+}
+
+__device__ __forceinline__ float4 sel4(uint32_t dq, const float4& a, const float4& fallback) {   // FLUID lanes take a, others fallback
+    return make_float4((dbyte(dq, 0) & 0x80) ? a.x : fallback.x, (dbyte(dq, 1) & 0x80) ? a.y : fallback.y,
+                       (dbyte(dq, 2) & 0x80) ? a.z : fallback.z, (dbyte(dq, 3) & 0x80) ? a.w : fallback.w);
+}
+
+// ---- KU: p += alpha s; r -= alpha A s; partial (M^-1 r).r and max|r|  (pressure_update_pressure_and_residual.comp:23-59)
+template <int T>
+__global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+                                                    float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
+                                                    const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
+    __shared__ float sm[T / 64 + 1];
+    __shared__ float4 ls[2][T];
+    __shared__ uint32_t ld[2][T];
+    float alpha;
+    if (!pcg_upd_prologue<T>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
+    const Grid g = gz.g;
+    const int t = threadIdx.x, plane = g.nx * g.ny, qpr = gz.qpr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc = 0.0f, emax = 0.0f;
+    const int padded = ((gz.tiles + 7) >> 3) << 3;
+    for (int it = blockIdx.x; it < padded; it += gridDim.x) {
+        const int tile = xcd_tile(it, gz.tiles);
+        if (tile >= gz.tiles || !tile_flags[tile]) continue;
+        const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
+        const int q = pt * T + t;
+        const bool valid = q < gz.qpp;
+        const int x0 = (q % qpr) << 2, y = q / qpr;
+        const int z_begin = zci * gz.zc, z_end = min(z_begin + gz.zc, g.nz);
+        const int row_base = valid ? (y * g.nx + x0) : 0;
+        const bool edge_lo = valid && (t < qpr) && y > 0, edge_hi = valid && (t >= T - qpr || q + qpr >= gz.qpp) && y + 1 < g.ny;
+        const bool in_lo = t >= qpr, in_hi = (t + qpr < T) && (q + qpr < gz.qpp);
+        const bool xm_glob = valid && x0 > 0 && t == 0, xp_glob = valid && x0 + 4 < g.nx && (t == T - 1);
+        // planes z_begin-1 (m), z_begin (c), z_begin+1 (p) in registers; plane z+2 and the next plane's p, r are in flight
+        float4 s_m = zero4, s_c = zero4, s_p = zero4, s_n = zero4, pc = zero4, rc = zero4, pn = zero4, rn = zero4;
+        uint32_t d_m = 0, d_c = 0, d_p = 0, d_n = 0;
+        if (valid) {
+            const int b0 = z_begin * plane + row_base;
+            s_c = ld4(s + b0); d_c = *reinterpret_cast<const uint32_t*>(dvol + b0);
+            if (z_begin > 0) { s_m = ld4(s + b0 - plane); d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); }
+            if (z_begin + 1 < g.nz) { s_p = ld4(s + b0 + plane); d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane); }
+            if (any_fluid_d(d_c)) { pc = ld4(p + b0); rc = ld4(r + b0); }
+        }
+        for (int z = z_begin; z < z_end; ++z) {
+            const int base = z * plane + row_base;
+            const int buf = z & 1;
+            // issue the loads of the planes ahead: they are consumed after this plane's compute
+            if (valid && z + 2 < g.nz && z + 1 < z_end) { s_n = ld4(s + base + 2 * plane); d_n = *reinterpret_cast<const uint32_t*>(dvol + base + 2 * plane); }
+            else { s_n = zero4; d_n = 0; }
+            const bool work_next = valid && z + 1 < z_end && any_fluid_d(d_p);
+            if (work_next) { pn = ld4(p + base + plane); rn = ld4(r + base + plane); }
+            float4 h_lo = zero4, h_hi = zero4;
+            uint32_t hd_lo = 0, hd_hi = 0;
+            float gxm = 0.f, gxp = 0.f; int gdxm = 0, gdxp = 0;
+            const bool work = valid && any_fluid_d(d_c);
+            if (work) {
+                if (edge_lo && !in_lo) { h_lo = ld4(s + base - g.nx); hd_lo = *reinterpret_cast<const uint32_t*>(dvol + base - g.nx); }
+                if (edge_hi && !in_hi) { h_hi = ld4(s + base + g.nx); hd_hi = *reinterpret_cast<const uint32_t*>(dvol + base + g.nx); }
+                if (xm_glob) { gxm = s[base - 1]; gdxm = dvol[base - 1]; }
+                if (xp_glob) { gxp = s[base + 4]; gdxp = dvol[base + 4]; }
+            }
+            ls[buf][t] = s_c; ld[buf][t] = d_c;
+            __syncthreads();
+            if (work) {
+                QuadD m; QuadValues sv;
+                m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
+                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hd_lo; sv.ym = h_lo; } } else { m.ym = 0; sv.ym = zero4; }
+                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hd_hi; sv.yp = h_hi; } } else { m.yp = 0; sv.yp = zero4; }
+                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = gdxm; sv.xm = gxm; } } else { m.xm = 0; sv.xm = 0.f; }
+                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = gdxp; sv.xp = gxp; } } else { m.xp = 0; sv.xp = 0.f; }
+                float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int dv = dbyte(d_c, j);
+                    if (!(dv & 0x80)) continue;
+                    const float as = quad_mulA_d(m, sv, j);
+                    pp[j] = pp[j] + alpha * f4(s_c, j);
+                    float res = rr[j];
+                    res -= alpha * as;
+                    rr[j] = res;
+                    emax = fmaxf(emax, fabsf(res));
+                    acc += precond_zero(res, (float)(dv & 7)) * res;
+                }
+                *reinterpret_cast<float4*>(p + base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+            }
+            s_m = s_c; s_c = s_p; s_p = s_n; d_m = d_c; d_c = d_p; d_p = d_n; pc = pn; rc = rn;
+        }
+        __syncthreads();   // the LDS buffers are reused by the next tile
+    }
+    const float tot = block_reduce<T, false>(acc, sm);
+    const float mx = block_reduce<T, true>(emax, sm);
+    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, mx);
+}
+
+// ---- KD: [convergence test] beta; s = M^-1 r + beta s; partial s.As  (pressure_update_search.comp + pressure_apply_coeff.comp)
+// Registers hold s_new of planes z-1, z, z+1; s_new of a plane is computed (and written to s_out) when the plane enters.
+template <int T, bool FIRST>
+__global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
+                                                 float* __restrict__ s_out, const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
+                                                 const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
+    __shared__ float sm[T / 64 + 1];
+    __shared__ float2 sm2[T / 64 + 1];
+    __shared__ float4 ls[2][T];
+    __shared__ uint32_t ld[2][T];
+    float beta;
+    if (!pcg_dir_prologue<T>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
+    const Grid g = gz.g;
+    const int t = threadIdx.x, plane = g.nx * g.ny, qpr = gz.qpr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc = 0.0f;
+    // s_new of a quad from global memory (no write)
+    auto snew_quad = [&](int b, uint32_t dq) -> float4 {
+        if (FIRST) return ld4(s_in + b);
+        return any_fluid_d(dq) ? snew4(dq, ld4(r + b), ld4(s_in + b), beta) : zero4;
+    };
+    const int padded = ((gz.tiles + 7) >> 3) << 3;
+    for (int it = blockIdx.x; it < padded; it += gridDim.x) {
+        const int tile = xcd_tile(it, gz.tiles);
+        if (tile >= gz.tiles || !tile_flags[tile]) continue;
+        const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
+        const int q = pt * T + t;
+        const bool valid = q < gz.qpp;
+        const int x0 = (q % qpr) << 2, y = q / qpr;
+        const int z_begin = zci * gz.zc, z_end = min(z_begin + gz.zc, g.nz);
+        const int row_base = valid ? (y * g.nx + x0) : 0;
+        const bool edge_lo = valid && (t < qpr) && y > 0, edge_hi = valid && (t >= T - qpr || q + qpr >= gz.qpp) && y + 1 < g.ny;
+        const bool in_lo = t >= qpr, in_hi = (t + qpr < T) && (q + qpr < gz.qpp);
+        const bool xm_glob = valid && x0 > 0 && t == 0, xp_glob = valid && x0 + 4 < g.nx && (t == T - 1);
+        float4 n_m = zero4, n_c = zero4, n_p = zero4;   // s_new of planes z-1, z, z+1 (own quad)
+        uint32_t d_m = 0, d_c = 0, d_p = 0;
+        // s_new of an owned plane from its raw loads; written to s_out (FLUID lanes only) when `own`
+        auto enter_plane = [&](int b, uint32_t dq, const float4& rr, const float4& so, bool own) -> float4 {
+            if (FIRST) return so;
+            if (!any_fluid_d(dq)) return zero4;
+            const float4 n = snew4(dq, rr, so, beta);
+            if (own) *reinterpret_cast<float4*>(s_out + b) = sel4(dq, n, so);
+            return n;
+        };
+        if (valid) {
+            const int b0 = z_begin * plane + row_base;
+            d_c = *reinterpret_cast<const uint32_t*>(dvol + b0);
+            n_c = enter_plane(b0, d_c, FIRST ? zero4 : ld4(r + b0), ld4(s_in + b0), true);
+            if (z_begin > 0) { d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); n_m = snew_quad(b0 - plane, d_m); }   // halo plane: not written
+            if (z_begin + 1 < g.nz) {
+                d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane);
+                n_p = enter_plane(b0 + plane, d_p, FIRST ? zero4 : ld4(r + b0 + plane), ld4(s_in + b0 + plane), z_begin + 1 < z_end);
+            }
+        }
+        for (int z = z_begin; z < z_end; ++z) {
+            const int base = z * plane + row_base;
+            const int buf = z & 1;
+            // raw loads of plane z+2 are issued now and consumed after this plane's compute
+            const bool fetch = valid && z + 1 < z_end && z + 2 < g.nz;
+            uint32_t d_n = 0; float4 r_n = zero4, so_n = zero4;
+            if (fetch) {
+                d_n = *reinterpret_cast<const uint32_t*>(dvol + base + 2 * plane);
+                so_n = ld4(s_in + base + 2 * plane);
+                if (!FIRST) r_n = ld4(r + base + 2 * plane);
+            }
+            const bool work = valid && any_fluid_d(d_c);
+            float4 h_lo = zero4, h_hi = zero4, hr_lo = zero4, hr_hi = zero4;
+            uint32_t hd_lo = 0, hd_hi = 0;
+            float gxm = 0.f, gxp = 0.f, grxm = 0.f, grxp = 0.f; int gdxm = 0, gdxp = 0;
+            if (work) {   // raw halo values (converted to s_new after the barrier)
+                if (edge_lo && !in_lo) { hd_lo = *reinterpret_cast<const uint32_t*>(dvol + base - g.nx); h_lo = ld4(s_in + base - g.nx); if (!FIRST) hr_lo = ld4(r + base - g.nx); }
+                if (edge_hi && !in_hi) { hd_hi = *reinterpret_cast<const uint32_t*>(dvol + base + g.nx); h_hi = ld4(s_in + base + g.nx); if (!FIRST) hr_hi = ld4(r + base + g.nx); }
+                if (xm_glob) { gdxm = dvol[base - 1]; gxm = s_in[base - 1]; if (!FIRST) grxm = r[base - 1]; }
+                if (xp_glob) { gdxp = dvol[base + 4]; gxp = s_in[base + 4]; if (!FIRST) grxp = r[base + 4]; }
+            }
+            ls[buf][t] = n_c; ld[buf][t] = d_c;
+            __syncthreads();
+            if (work) {
+                QuadD m; QuadValues sv;
+                m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
+                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hd_lo; sv.ym = FIRST ? h_lo : snew4(hd_lo, hr_lo, h_lo, beta); } } else { m.ym = 0; sv.ym = zero4; }
+                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hd_hi; sv.yp = FIRST ? h_hi : snew4(hd_hi, hr_hi, h_hi, beta); } } else { m.yp = 0; sv.yp = zero4; }
+                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = gdxm; sv.xm = FIRST ? gxm : snew_of(gdxm, grxm, gxm, beta); } } else { m.xm = 0; sv.xm = 0.f; }
+                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = gdxp; sv.xp = FIRST ? gxp : snew_of(gdxp, grxp, gxp, beta); } } else { m.xp = 0; sv.xp = 0.f; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (dbyte(d_c, j) & 0x80) acc += f4(n_c, j) * quad_mulA_d(m, sv, j);
+            }
+            // plane z+2 enters (its loads have been in flight during the compute above)
+            float4 n_n = zero4;
+            if (fetch) n_n = enter_plane(base + 2 * plane, d_n, r_n, so_n, z + 2 < z_end);
+            n_m = n_c; n_c = n_p; n_p = n_n; d_m = d_c; d_c = d_p; d_p = d_n;
+        }
+        __syncthreads();
+    }
+    const float tot = block_reduce<T, false>(acc, sm);
+    if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
+}
+
+// init for this mapping: same per-quad body as the row kernel, tile flags indexed by the z-march tiles
+template <int T>
+__global__ __launch_bounds__(T) void k_pcg_init_z(PcgGeomZ gz, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
+                                                  float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, uint8_t* __restrict__ tile_flags) {
+    __shared__ float sm[T / 64 + 1];
+    float acc = 0.0f;
+    const Grid g = gz.g;
+    const int padded = ((gz.tiles + 7) >> 3) << 3;
+    for (int it = blockIdx.x; it < padded; it += gridDim.x) {
+        const int tile = xcd_tile(it, gz.tiles);
+        if (tile >= gz.tiles) continue;
+        const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
+        const int q = pt * T + threadIdx.x;
+        const int x0 = (q % gz.qpr) << 2, y = q / gz.qpr;
+        const int z_begin = zci * gz.zc, z_end = min(z_begin + gz.zc, g.nz);
+        bool any = false;
+        if (q < gz.qpp) for (int z = z_begin; z < z_end; ++z) any |= pcg_init_quad(g, marker, dvol, p, r, s, cidx(g, x0, y, z), x0, y, z, acc);
+        const int tile_any = __syncthreads_or(any);
+        if (threadIdx.x == 0) tile_flags[tile] = (uint8_t)(tile_any != 0);
+    }
+    const float tot = block_reduce<T, false>(acc, sm);
+    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, 0.0f);
+}
+
+}  // namespace blubk
