@@ -74,6 +74,14 @@ def dense_pcg_benchmark(n=256, iterations=32):
     iter_us = sum(out[k]["avg_us"] for k in out)
     err, iters = h.solver_stats(0)
     h.close()
+    pmc = {}
+    try:   # HBM bytes per launch from the committed PMC capture of this same benchmark (rocprofv3 cannot run inside bench.py)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_pcg_256.json")))
+    except (OSError, ValueError):
+        pass
+    for k in out:
+        out[k]["traffic_bytes_pmc"] = pmc.get(k, {}).get("traffic") if n == 256 else None
+        out[k]["algorithmic_bytes"] = algorithmic_bytes(k, F, 0, N, N)
     # one iteration = pcg_dir + pcg_update.  "iter_bytes" is SURVEY 8(d)'s figure for the UNFUSED three-phase iteration
     # (3N + 36F); the fused pair itself only has to move 2N + 32F ("iter_bytes_fused"), both fractions are reported.
     fused = 2 * N + 32 * F
@@ -191,7 +199,7 @@ def main():
     dominant = max(prof, key=lambda k: prof[k]["total_ms"])
     avg_ms = prof[dominant]["total_ms"] / prof[dominant]["launches"]
     ach = algorithmic_bytes(dominant, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline_workload = {"bound": "launch latency (see DESIGN.md 6): < 1 MB per launch", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
                 "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F,
                 "active_brick_cells": A, "fluid_brick_cells": Fb, "launches_per_step": round(prof[dominant]["launches"] / args.profile_steps, 1)}
@@ -209,13 +217,22 @@ def main():
         "pcg_iters_per_sec": round((it1 - it0) * world / elapsed, 1),
         "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
         "pcg_iters_per_sec_in_solver": round((it1 - it0) / args.steps * args.profile_steps / (pcg_ms * 1e-3), 1) if pcg_ms > 0 else None,
-        "roofline": roofline,
+        "roofline": None,
+        "roofline_workload": roofline_workload,
         "kernel_us_per_step": breakdown,
     }
     if not args.no_dense_pcg:
+        # The HBM roofline is defined on the PCG stencil at 256^3: dense fill, every byte from HBM/MALL.
+        # Dominant kernel of an iteration = the update kernel (N + 20F algorithmic bytes of the 2N + 32F the fused pair moves).
         scene._fluid.close()
         scene._fluid = None
-        result["roofline_pcg_dense"] = dense_pcg_benchmark(256, 32)
+        dense = dense_pcg_benchmark(256, 32)
+        result["roofline_pcg_dense"] = dense
+        ku = dense["kernels"]["pcg_update"]
+        result["roofline"] = {"bound": "hbm", "kernel": "k_pcg_update_z (PCG stencil update, dense 256^3 micro-benchmark M3, same process)",
+                              "achieved": ku["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"],
+                              "traffic": ku["traffic_bytes_pmc"], "algorithmic_bytes": ku["algorithmic_bytes"], "avg_us": ku["avg_us"],
+                              "launches": ku["launches"]}
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene_path, dt)
     print(json.dumps(result))
