@@ -4,5 +4,5 @@ The product is `libblubhip.so` (hand-written HIP for gfx950 behind the C-ABI of 
 only the Python mirror of the reference's host surface (src/simulation/hybrid_fluid.rs, src/scene/mod.rs) used by the
 tests and the benchmark driver.  There is no CPU fallback: constructing a HybridFluid without a GPU raises.
 """
-from .hybrid_fluid import (BlubError, HybridFluid, Scene, SceneConfig, SolverConfig, SolverStatisticSample, STAGES,  # noqa: F401
+from .hybrid_fluid import (BlubError, HybridFluid, Scene, SceneConfig, SlabGroup, SolverConfig, SolverStatisticSample, STAGES,  # noqa: F401
                            VOLUMES, default_simulation_delta, lib_path, load_library, seed_fluid_cube)

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libblubhip.so")
 SOURCES = [os.path.join(CSRC, "blub_fluid.hip"), os.path.join(CSRC, "scene_host.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "blub_kernels.hip.h"), os.path.join(CSRC, "blub_internal.h"), os.path.join(ROOT, "include", "blubhip.h")]
+DEPS = SOURCES + [os.path.join(CSRC, n) for n in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "blubhip.h")]
 # -ffp-contract=off: element-wise kernels must round exactly like the (unfused) reference arithmetic / the oracle.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-gpu-rdc",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-x", "hip"] + SOURCES + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + ["-x", "hip"] + SOURCES + ["-o", LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -73,9 +73,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 }
 
 enum { COMPACT_STEP_A = 0, COMPACT_STEP_B = 1, COMPACT_ALL_ACTIVE = 2 };
-enum { BF_FLUID = 1, BF_ACTIVE = 2, BF_STALE = 4 };
+enum { BF_FLUID = 1, BF_ACTIVE = 2, BF_STALE = 4, BF_RESET = 8 };   // FLUID / ACTIVE only for bricks of the own z-slab
 // Pass 1 (one thread per brick, 1024 bricks per block): dilate the fluid flags, classify each brick, count per block.
-__global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phase, int all_touched, const uint8_t* __restrict__ brick_fluid,
+__global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phase, int all_touched, int own_bz_lo, int own_bz_hi, const uint8_t* __restrict__ brick_fluid,
                                                           uint8_t* __restrict__ brick_active, uint8_t* __restrict__ brick_touched,
                                                           uint8_t* __restrict__ brick_flags, uint4* __restrict__ block_counts) {
     __shared__ uint32_t sm[17];
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
         }
         const bool touched = all_touched || brick_touched[b] != 0;
         const bool stale = (phase == COMPACT_STEP_A) && touched && !act;
-        fl = (f ? BF_FLUID : 0) | (act ? BF_ACTIVE : 0) | (stale ? BF_STALE : 0);
+        const int bz_own = b / (bg.nbx * bg.nby);
+        const bool own = bz_own >= own_bz_lo && bz_own < own_bz_hi;   // z-slab decomposition: lists of work hold own bricks only
+        fl = ((f && own) ? BF_FLUID : 0) | ((act && own) ? BF_ACTIVE : 0) | (stale ? BF_STALE : 0) | ((act || stale) ? BF_RESET : 0);
         brick_flags[b] = (uint8_t)fl;
         brick_active[b] = act;
         if (phase == COMPACT_STEP_A) brick_touched[b] = act;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
     uint32_t tf, ta, tr, ts;
     (void)block_exclusive_scan_1024((fl & BF_FLUID) != 0, sm, tf);
     (void)block_exclusive_scan_1024((fl & BF_ACTIVE) != 0, sm, ta);
-    (void)block_exclusive_scan_1024((fl & (BF_ACTIVE | BF_STALE)) != 0, sm, tr);
+    (void)block_exclusive_scan_1024((fl & BF_RESET) != 0, sm, tr);
     (void)block_exclusive_scan_1024((fl & BF_STALE) != 0, sm, ts);
     if (threadIdx.x == 0) block_counts[blockIdx.x] = make_uint4(tf, ta, tr, ts);
 }
@@ -141,10 +143,10 @@ __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uin
     uint32_t t;
     const uint32_t of = block_exclusive_scan_1024((fl & BF_FLUID) != 0, sm, t);
     const uint32_t oa = block_exclusive_scan_1024((fl & BF_ACTIVE) != 0, sm, t);
-    const uint32_t orr = block_exclusive_scan_1024((fl & (BF_ACTIVE | BF_STALE)) != 0, sm, t);
+    const uint32_t orr = block_exclusive_scan_1024((fl & BF_RESET) != 0, sm, t);
     if (fl & BF_FLUID) list_fluid[base[0] + of] = (uint32_t)b;
     if (fl & BF_ACTIVE) list_active[base[1] + oa] = (uint32_t)b;
-    if (fl & (BF_ACTIVE | BF_STALE)) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);
+    if (fl & BF_RESET) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);
     if (blockIdx.x == 0 && threadIdx.x == 0) { counts->n_fluid = total[0]; counts->n_active = total[1]; counts->n_reset = total[2]; counts->n_stale = total[3]; counts->seq = seq; counts->seq_check = seq; }
 }
 

@@ -17,6 +17,7 @@
 
 #include "blub_internal.h"
 #include "blub_pcg_dense.hip.h"
+#include "blub_slab.hip.h"
 
 namespace blub {
 
@@ -62,9 +63,13 @@ struct blub_fluid {
     Grid g{};
     size_t N = 0;
     uint32_t max_particles = 0, num_particles = 0;
+    // z-slab decomposition (blub_slab.hip): own planes [slab_z0, slab_z1), ghost particles live at [num_particles, +num_ghost)
+    int slab_z0 = 0, slab_z1 = 0;
+    uint32_t num_ghost = 0;
     float gravity[3] = {0, 0, 0};
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     uint32_t precond_mode = BLUB_PRECOND_ZERO, binning_mode = BLUB_BINNING_FIXED;
     uint32_t rebin_freq = 60;   // hybrid_fluid.rs:603-605
     uint32_t step_counter = 0;
@@ -189,12 +194,12 @@ static int build_lists(blub_fluid* h, int phase) {
     HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
     if (phase == COMPACT_ALL_ACTIVE)
         hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
-    else if (h->num_particles)
-        hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles)), dim3(256), 0, h->stream, h->bg, h->num_particles, (const float4*)h->pos, h->brick_fluid);
+    else if (h->num_particles + h->num_ghost)
+        hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), 0, h->stream, h->bg, h->num_particles + h->num_ghost, (const float4*)h->pos, h->brick_fluid);
     const int nblk = (h->bg.nb + 1023) / 1024;
     const int all_touched = (phase == COMPACT_ALL_ACTIVE) ? 1 : (int)h->all_touched;
     h->counts_seq += 1;
-    hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, (const uint8_t*)h->brick_fluid, h->brick_active,
+    hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, (const uint8_t*)h->brick_fluid, h->brick_active,
                        h->brick_touched, h->brick_flags, h->brick_block_counts);
     hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
                        h->list_fluid, h->list_active, h->list_reset, h->counts, h->counts_seq);
@@ -227,8 +232,8 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     const dim3 bgrid(h->brick_grid);
     LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, bgrid, dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0], h->ll[1], h->ll[2],
            h->vel[0], h->vel[1], h->vel[2], h->pressure[0], h->pressure[1]);
-    if (h->num_particles)
-        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker,
+    if (h->num_particles + h->num_ghost)
+        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), h->g, h->num_particles + h->num_ghost, h->pos, h->marker,
                h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2);
     LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<0>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[0], (const float4*)h->pos, (const uint32_t*)nullptr, (const float4*)h->pvel[0], h->vel[0], h->gravity[0] * dt);
     LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<1>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[1], (const float4*)h->pos, (const uint32_t*)h->next1, (const float4*)h->pvel[1], h->vel[1], h->gravity[1] * dt);
@@ -380,13 +385,18 @@ static int stage_project(blub_fluid* h) {   // :906-914
            (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
     return stage_extrapolate(h);
 }
-static int stage_advect(blub_fluid* h, float dt) {   // :916-932
-    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const float4*)h->solid, h->marker, h->ll[0],
+static int stage_advect_particles(blub_fluid* h, float dt, bool insert_lists) {   // :916-926
+    // the reset list (active + stale bricks of this step, own AND ghost bricks) is a superset of the active list
+    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0],
            (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     if (h->num_particles)
         LAUNCH(h, KC_ADVECT, k_advect, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
-               h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, h->ll[0]);
-    return build_lists_from_particles(h, COMPACT_STEP_B);
+               h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, insert_lists ? h->ll[0] : (uint32_t*)nullptr);
+    return BLUB_OK;
+}
+static int stage_advect(blub_fluid* h, float dt) {   // :916-932
+    int rc = stage_advect_particles(h, dt, true);
+    return rc != BLUB_OK ? rc : build_lists_from_particles(h, COMPACT_STEP_B);
 }
 static int stage_density_gather(blub_fluid* h, float dt) {   // :933-937
     LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_b, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
@@ -446,11 +456,11 @@ static void destroy(blub_fluid* h) {
     for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
-static int create(const blub_fluid_desc* d, blub_fluid** out) {
+static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared_stream = nullptr) {
     if (!d || !out) return set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (d->nx < 4 || d->ny < 3 || d->nz < 3) return set_error(BLUB_ERR_INVALID_ARGUMENT, "grid too small");
@@ -470,13 +480,15 @@ static int create(const blub_fluid_desc* d, blub_fluid** out) {
     if (!h) return set_error(BLUB_ERR_OUT_OF_MEMORY, "host allocation failed");
     h->device = dev;
     h->g = Grid{(int)d->nx, (int)d->ny, (int)d->nz};
+    h->slab_z0 = 0; h->slab_z1 = (int)d->nz + BZ;   // everything is "own" unless a slab group narrows it
     h->N = (size_t)N64;
     h->max_particles = d->max_num_particles;
     h->precond_mode = d->precond_mode; h->binning_mode = d->binning_mode;
     int rc = BLUB_OK;
     auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
     const size_t P = std::max<size_t>(h->max_particles, 1);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
+    if (shared_stream) { h->stream = shared_stream; h->owns_stream = false; }
+    else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     A(dev_alloc_zero(h->stream, &h->pos, P)); A(dev_alloc_zero(h->stream, &h->pos_tmp, P));
     for (int c = 0; c < 3; ++c) A(dev_alloc_zero(h->stream, &h->pvel[c], P));
     A(dev_alloc_zero(h->stream, &h->next1, P)); A(dev_alloc_zero(h->stream, &h->next2, P));
@@ -560,6 +572,8 @@ static int poll_stats(blub_fluid* h, bool wait) {   // retrieve_new_error_sample
 }
 
 }  // namespace blub
+
+#include "blub_slab.inc.hip"
 
 #define REQUIRE_HANDLE(h) do { if (!(h)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); if (hipSetDevice((h)->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed"); } while (0)
 

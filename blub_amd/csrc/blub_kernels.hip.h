@@ -547,13 +547,12 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
 #pragma unroll
         for (int k = 0; k < 3; ++k) { np[k] = op[k] + mv[k]; np[k] = clampf(np[k], 1.001f, gs[k] - 1.001f); nv[k] = (dir[k] * ms) / dt; }
     }
-    // :176-181 marker + density list (dual cell = ivec3(pos - 0.5))
-    {
+    // :176-181 marker + density list (dual cell = ivec3(pos - 0.5)).  heads == nullptr: a z-slab group inserts the
+    // particles after migration instead (blub_slab.hip.h: k_slab_insert_density_ghosts)
+    uint32_t old = 0;
+    if (heads) {
         const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
         if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
-    }
-    uint32_t old = 0;
-    {
         const int dx = (int)(np[0] - 0.5f), dy = (int)(np[1] - 0.5f), dz = (int)(np[2] - 0.5f);
         if (inb(g, dx, dy, dz)) old = atomicExch(heads + cidx(g, dx, dy, dz), pi + 1);
     }

@@ -1,0 +1,458 @@
+// z-slab domain decomposition of the fluid step -- protocol + transports.  Included by blub_fluid.hip.
+//
+// One protocol, two transports:
+//   loopback : all slabs live in this process on one GPU and share one stream (validation of the protocol on a 1-GPU box);
+//              halo / particle transfers are device-to-device copies, the all-reduce is a tiny kernel
+//   RCCL     : one slab per process / GPU; halo planes and particles travel as grouped ncclSend/ncclRecv between
+//              z-neighbours (point-to-point over xGMI), the PCG scalars as ncclAllReduce on the slab's stream
+// Per step (defaults: 2 x 33 PCG iterations): 3 particle exchanges, 5 three-volume halo exchanges, 2 x (descriptor + r + s
+// + p) halos and per PCG iteration 2 one-plane halos + 2 (+1 on check iterations) scalar all-reduces.
+#include <rccl/rccl.h>
+
+#include <functional>
+
+struct blub_slab_group {
+    std::vector<blub_fluid*> slabs;   // local slabs, ascending z
+    int nranks = 1, first = 0;        // total number of slabs / global index of slabs[0]
+    bool rccl = false;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    uint32_t capacity = 0;            // particle capacity of every slab and of the transfer buffers
+    struct Extra {
+        float4 *pos_new = nullptr, *pvel_new[3] = {nullptr, nullptr, nullptr};
+        float4 *up[4] = {nullptr, nullptr, nullptr, nullptr}, *dn[4] = {nullptr, nullptr, nullptr, nullptr};   // send buffers: pos, vx, vy, vz
+        blubk::SlabCounts* counts = nullptr;     // device
+        uint32_t* recv_counts = nullptr;         // device: {from below, from above}
+        float* red = nullptr;                    // device: [0] s.As  [1] sigma  [2] max|r|
+        float2* packed = nullptr;                // device: {sigma, max|r|} as a 1-element partial array
+    };
+    std::vector<Extra> ex;
+    blubk::SlabCounts* counts_host = nullptr;    // pinned, one per local slab
+    uint32_t* recv_host = nullptr;               // pinned, two per local slab
+};
+
+namespace blub {
+
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t _r = (expr);                                                                               \
+        if (_r != ncclSuccess) { char _b[256]; snprintf(_b, sizeof _b, "%s failed: %s", #expr, ncclGetErrorString(_r)); return set_error(BLUB_ERR_COMM, _b); } \
+    } while (0)
+
+enum { XFER_GHOST_FULL = 0, XFER_GHOST_POS = 1, XFER_MIGRATE = 2 };
+
+static bool has_up(const blub_slab_group* G, int i) { return G->first + i + 1 < G->nranks; }
+static bool has_down(const blub_slab_group* G, int i) { return G->first + i > 0; }
+static bool up_local(const blub_slab_group* G, int i) { return i + 1 < (int)G->slabs.size(); }
+static bool down_local(const blub_slab_group* G, int i) { return i > 0; }
+
+// One z-plane of a volume from each z-neighbour: plane z1-1 goes up, plane z0 goes down; the receiver stores it at the
+// same global z (ghost planes z0-1 and z1).
+static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(blub_fluid*)>>& fields, size_t elem) {
+    const blub_fluid* h0 = G->slabs[0];
+    const size_t pb = (size_t)h0->g.nx * h0->g.ny * elem;
+    if (G->rccl) NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < (int)G->slabs.size(); ++i) {
+        blub_fluid* h = G->slabs[i];
+        for (auto& f : fields) {
+            char* base = (char*)f(h);
+            if (has_up(G, i)) {
+                if (up_local(G, i)) {
+                    char* nb = (char*)f(G->slabs[i + 1]);
+                    HIP_TRY(hipMemcpyAsync(nb + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb, hipMemcpyDeviceToDevice, G->stream));
+                    HIP_TRY(hipMemcpyAsync(base + (size_t)h->slab_z1 * pb, nb + (size_t)h->slab_z1 * pb, pb, hipMemcpyDeviceToDevice, G->stream));
+                } else {
+                    NCCL_TRY(ncclSend(base + (size_t)(h->slab_z1 - 1) * pb, pb, ncclChar, G->first + i + 1, G->comm, G->stream));
+                    NCCL_TRY(ncclRecv(base + (size_t)h->slab_z1 * pb, pb, ncclChar, G->first + i + 1, G->comm, G->stream));
+                }
+            }
+            if (has_down(G, i) && !down_local(G, i)) {
+                NCCL_TRY(ncclSend(base + (size_t)h->slab_z0 * pb, pb, ncclChar, G->first + i - 1, G->comm, G->stream));
+                NCCL_TRY(ncclRecv(base + (size_t)(h->slab_z0 - 1) * pb, pb, ncclChar, G->first + i - 1, G->comm, G->stream));
+            }
+        }
+    }
+    if (G->rccl) NCCL_TRY(ncclGroupEnd());
+    return BLUB_OK;
+}
+static int slab_halo_velocity(blub_slab_group* G) {
+    return slab_halo(G, {[](blub_fluid* h) { return (void*)h->vel[0]; }, [](blub_fluid* h) { return (void*)h->vel[1]; }, [](blub_fluid* h) { return (void*)h->vel[2]; }}, 4);
+}
+
+// sum / max of `count` floats at red[offset] across all slabs
+static int slab_allreduce(blub_slab_group* G, int offset, int count, bool op_max) {
+    if (G->nranks == 1) return BLUB_OK;
+    if (!G->rccl) {
+        blubk::SlabPtrs ptrs{};
+        for (size_t i = 0; i < G->slabs.size(); ++i) ptrs.p[i] = G->ex[i].red + offset;
+        hipLaunchKernelGGL(blubk::k_slab_allreduce_local, dim3(1), dim3(64), 0, G->stream, ptrs, (int)G->slabs.size(), count, (int)op_max);
+        return BLUB_OK;
+    }
+    float* p = G->ex[0].red + offset;
+    NCCL_TRY(ncclAllReduce(p, p, (size_t)count, ncclFloat, op_max ? ncclMax : ncclSum, G->comm, G->stream));
+    return BLUB_OK;
+}
+
+// Ghost copies / migration of particles between z-neighbours.
+static int slab_exchange_particles(blub_slab_group* G, int mode) {
+    const int S = (int)G->slabs.size();
+    const bool with_rows = mode != XFER_GHOST_POS;
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        auto& e = G->ex[i];
+        HIP_TRY(hipMemsetAsync(e.counts, 0, sizeof(blubk::SlabCounts), G->stream));
+        const uint32_t n = h->num_particles;
+        if (!n) continue;
+        if (mode == XFER_MIGRATE) {
+            hipLaunchKernelGGL(blubk::k_slab_partition, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                               (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.pos_new, e.pvel_new[0], e.pvel_new[1], e.pvel_new[2],
+                               e.up[0], e.up[1], e.up[2], e.up[3], e.dn[0], e.dn[1], e.dn[2], e.dn[3]);
+        } else {
+            if (has_up(G, i))
+                hipLaunchKernelGGL(blubk::k_slab_select, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                                   (const float4*)h->pvel[2], (float)h->slab_z1 - blubk::GHOST_MARGIN, (float)h->slab_z1, G->capacity, &e.counts->n_up, e.up[0],
+                                   with_rows ? e.up[1] : nullptr, e.up[2], e.up[3]);
+            if (has_down(G, i))
+                hipLaunchKernelGGL(blubk::k_slab_select, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                                   (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z0 + blubk::GHOST_MARGIN, G->capacity, &e.counts->n_down, e.dn[0],
+                                   with_rows ? e.dn[1] : nullptr, e.dn[2], e.dn[3]);
+        }
+    }
+    // counts to the host (the payload sizes of the transfers below are host-side arguments)
+    for (int i = 0; i < S; ++i) HIP_TRY(hipMemcpyAsync(&G->counts_host[i], G->ex[i].counts, sizeof(blubk::SlabCounts), hipMemcpyDeviceToHost, G->stream));
+    if (G->rccl) {   // neighbours' counts
+        NCCL_TRY(ncclGroupStart());
+        for (int i = 0; i < S; ++i) {
+            auto& e = G->ex[i];
+            if (has_up(G, i) && !up_local(G, i)) { NCCL_TRY(ncclSend(&e.counts->n_up, 1, ncclUint32, G->first + i + 1, G->comm, G->stream)); NCCL_TRY(ncclRecv(e.recv_counts + 1, 1, ncclUint32, G->first + i + 1, G->comm, G->stream)); }
+            if (has_down(G, i) && !down_local(G, i)) { NCCL_TRY(ncclSend(&e.counts->n_down, 1, ncclUint32, G->first + i - 1, G->comm, G->stream)); NCCL_TRY(ncclRecv(e.recv_counts + 0, 1, ncclUint32, G->first + i - 1, G->comm, G->stream)); }
+        }
+        NCCL_TRY(ncclGroupEnd());
+        for (int i = 0; i < S; ++i) HIP_TRY(hipMemcpyAsync(&G->recv_host[2 * i], G->ex[i].recv_counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, G->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    for (int i = 0; i < S; ++i)
+        if (G->counts_host[i].n_up > G->capacity || G->counts_host[i].n_down > G->capacity) return set_error(BLUB_ERR_OUT_OF_MEMORY, "slab transfer buffer overflow");
+    if (mode == XFER_MIGRATE)
+        for (int i = 0; i < S; ++i) {
+            blub_fluid* h = G->slabs[i];
+            auto& e = G->ex[i];
+            if (!h->num_particles) continue;
+            std::swap(h->pos, e.pos_new);
+            for (int c = 0; c < 3; ++c) std::swap(h->pvel[c], e.pvel_new[c]);
+            h->num_particles = G->counts_host[i].n_stay;
+        }
+    // payload
+    const int narr = with_rows ? 4 : 1;
+    std::vector<uint32_t> from_below(S, 0), from_above(S, 0);
+    for (int i = 0; i < S; ++i) {
+        if (has_down(G, i)) from_below[i] = down_local(G, i) ? G->counts_host[i - 1].n_up : G->recv_host[2 * i + 0];
+        if (has_up(G, i)) from_above[i] = up_local(G, i) ? G->counts_host[i + 1].n_down : G->recv_host[2 * i + 1];
+        if ((uint64_t)G->slabs[i]->num_particles + from_below[i] + from_above[i] > G->capacity) return set_error(BLUB_ERR_OUT_OF_MEMORY, "slab particle capacity exceeded");
+    }
+    if (G->rccl) NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        auto& e = G->ex[i];
+        float4* dst[4] = {h->pos, h->pvel[0], h->pvel[1], h->pvel[2]};
+        const size_t at_below = h->num_particles, at_above = (size_t)h->num_particles + from_below[i];
+        for (int k = 0; k < narr; ++k) {
+            if (has_down(G, i)) {
+                if (down_local(G, i)) { if (from_below[i]) HIP_TRY(hipMemcpyAsync(dst[k] + at_below, G->ex[i - 1].up[k], (size_t)from_below[i] * 16, hipMemcpyDeviceToDevice, G->stream)); }
+                else {
+                    NCCL_TRY(ncclSend(e.dn[k], (size_t)G->counts_host[i].n_down * 16, ncclChar, G->first + i - 1, G->comm, G->stream));
+                    NCCL_TRY(ncclRecv(dst[k] + at_below, (size_t)from_below[i] * 16, ncclChar, G->first + i - 1, G->comm, G->stream));
+                }
+            }
+            if (has_up(G, i)) {
+                if (up_local(G, i)) { if (from_above[i]) HIP_TRY(hipMemcpyAsync(dst[k] + at_above, G->ex[i + 1].dn[k], (size_t)from_above[i] * 16, hipMemcpyDeviceToDevice, G->stream)); }
+                else {
+                    NCCL_TRY(ncclSend(e.up[k], (size_t)G->counts_host[i].n_up * 16, ncclChar, G->first + i + 1, G->comm, G->stream));
+                    NCCL_TRY(ncclRecv(dst[k] + at_above, (size_t)from_above[i] * 16, ncclChar, G->first + i + 1, G->comm, G->stream));
+                }
+            }
+        }
+    }
+    if (G->rccl) NCCL_TRY(ncclGroupEnd());
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        if (mode == XFER_MIGRATE) { h->num_particles += from_below[i] + from_above[i]; h->num_ghost = 0; }
+        else h->num_ghost = from_below[i] + from_above[i];
+    }
+    return BLUB_OK;
+}
+
+// PressureSolver::solve on all slabs in lock step (brick mapping; blub_pcg.hip.h kernels with 1-element "partials")
+static int slab_solve(blub_slab_group* G, int which, float dt) {
+    const int S = (int)G->slabs.size();
+    blub_fluid* h0 = G->slabs[0];
+    if (h0->precond_mode != BLUB_PRECOND_ZERO) return set_error(BLUB_ERR_UNSUPPORTED, "z-slab groups support the default preconditioner reading only");
+    const blub_solver_config c = h0->cfg[which];
+    const float tol = c.error_tolerance / dt;
+    const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
+    auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };
+    const int np = std::min((h0->bg.nb + 1) / 2, PCG_GRID_BRICKS);
+    const dim3 grid(np), block(PCG_B_THREADS);
+    int rc;
+    auto reduce_upd = [&]() -> int {   // local partials -> {sigma, max} scalars -> all-reduce -> 1-element partial
+        for (int i = 0; i < S; ++i)
+            hipLaunchKernelGGL(k_slab_reduce_upd, dim3(1), dim3(256), 0, G->stream, (const float2*)reinterpret_cast<float2*>(G->slabs[i]->part_sigma[0]), np, G->ex[i].red + 1, G->ex[i].red + 2);
+        if ((rc = slab_allreduce(G, 1, 1, false)) != BLUB_OK) return rc;
+        if ((rc = slab_allreduce(G, 2, 1, true)) != BLUB_OK) return rc;
+        for (int i = 0; i < S; ++i) hipLaunchKernelGGL(k_slab_pack_upd, dim3(1), dim3(1), 0, G->stream, (const float*)(G->ex[i].red + 1), (const float*)(G->ex[i].red + 2), G->ex[i].packed);
+        return BLUB_OK;
+    };
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
+        HIP_TRY(hipMemsetAsync(h->ctrl[which], 0, sizeof(PcgCtrl), G->stream));
+        h->solve_seq[which] += 1;
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
+               reinterpret_cast<float2*>(h->part_sigma[0]));
+    }
+    if ((rc = reduce_upd()) != BLUB_OK) return rc;
+    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1)) != BLUB_OK) return rc;
+    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }, [](blub_fluid* h) { return (void*)h->search; }}, 4)) != BLUB_OK) return rc;
+    for (int it = 0; it <= maxit; ++it) {
+        for (int i = 0; i < S; ++i) {
+            blub_fluid* h = G->slabs[i];
+            float* sbuf[2] = {h->search, h->aux};
+            if (it == 0)
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
+                       (const float2*)G->ex[i].packed, h->part_sas, 1, h->ctrl[which], tol, it, 0);
+            else
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<false>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(it - 1) & 1], sbuf[it & 1],
+                       (const float2*)G->ex[i].packed, h->part_sas, 1, h->ctrl[which], tol, it, (int)is_check(it - 1));
+        }
+        const int cur = it & 1;
+        if (it > 0 && (rc = slab_halo(G, {[cur](blub_fluid* h) { return (void*)(cur ? h->aux : h->search); }}, 4)) != BLUB_OK) return rc;
+        for (int i = 0; i < S; ++i) hipLaunchKernelGGL(k_slab_reduce_dir, dim3(1), dim3(256), 0, G->stream, (const float*)G->slabs[i]->part_sas, np, G->ex[i].red + 0);
+        if ((rc = slab_allreduce(G, 0, 1, false)) != BLUB_OK) return rc;
+        for (int i = 0; i < S; ++i) {
+            blub_fluid* h = G->slabs[i];
+            float* sbuf[2] = {h->search, h->aux};
+            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[it & 1], h->pressure[which], h->residual,
+                   (const float*)(G->ex[i].red + 0), reinterpret_cast<float2*>(h->part_sigma[0]), 1, (const PcgCtrl*)h->ctrl[which], it);
+        }
+        if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }}, 4)) != BLUB_OK) return rc;
+        if ((rc = reduce_upd()) != BLUB_OK) return rc;
+    }
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), h->ctrl[which], (const float2*)G->ex[i].packed, 1, maxit, h->solve_seq[which]);
+        if (maxit & 1) std::swap(h->search, h->aux);
+        if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
+    }
+    const int w = which;
+    return slab_halo(G, {[w](blub_fluid* h) { return (void*)h->pressure[w]; }}, 4);
+}
+
+// HybridFluid::step (hybrid_fluid.rs:770-977) over all slabs in lock step
+static int slab_step(blub_slab_group* G, float dt) {
+    int rc;
+    const int S = (int)G->slabs.size();
+#define FOR_SLABS(call) for (int i = 0; i < S; ++i) { blub_fluid* h = G->slabs[i]; (void)h; if ((rc = (call)) != BLUB_OK) return rc; }
+    if ((rc = slab_exchange_particles(G, XFER_GHOST_FULL)) != BLUB_OK) return rc;
+    FOR_SLABS(stage_transfer(h, dt))
+    for (int i = 0; i < S; ++i) G->slabs[i]->num_ghost = 0;   // the velocity ghosts are only needed by the P2G gather
+    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+    FOR_SLABS(stage_divergence(h))
+    if ((rc = slab_solve(G, 0, dt)) != BLUB_OK) return rc;
+    blub_fluid* h0 = G->slabs[0];
+    if (h0->rebin_freq != 0 && h0->step_counter % h0->rebin_freq == 0) FOR_SLABS(stage_binning(h))
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+               (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
+    }
+    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+    FOR_SLABS(stage_extrapolate(h))
+    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+    FOR_SLABS(stage_advect_particles(h, dt, false))
+    if ((rc = slab_exchange_particles(G, XFER_MIGRATE)) != BLUB_OK) return rc;
+    if ((rc = slab_exchange_particles(G, XFER_GHOST_POS)) != BLUB_OK) return rc;
+    for (int i = 0; i < S; ++i) {   // marker + density list for own and ghost particles (advect_particles.comp:176-181)
+        blub_fluid* h = G->slabs[i];
+        const uint32_t n = h->num_particles + h->num_ghost;
+        if (n) hipLaunchKernelGGL(k_slab_insert_density_ghosts, dim3(particle_blocks(n)), dim3(256), 0, G->stream, h->g, 0u, n, h->pos, h->marker, h->ll[0]);
+    }
+    FOR_SLABS(build_lists_from_particles(h, COMPACT_STEP_B))
+    FOR_SLABS(stage_density_gather(h, dt))
+    for (int i = 0; i < S; ++i) G->slabs[i]->num_ghost = 0;
+    if ((rc = slab_solve(G, 1, dt)) != BLUB_OK) return rc;
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+               (const float*)h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
+    }
+    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+    FOR_SLABS(stage_extrapolate(h))
+    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+    FOR_SLABS(stage_correct(h))
+    if ((rc = slab_exchange_particles(G, XFER_MIGRATE)) != BLUB_OK) return rc;
+    for (int i = 0; i < S; ++i) { G->slabs[i]->step_counter += 1; (void)poll_stats(G->slabs[i], false); }
+#undef FOR_SLABS
+    return check_launch(h0);
+}
+
+static void slab_group_destroy(blub_slab_group* G) {
+    if (!G) return;
+    (void)hipSetDevice(G->device);
+    if (G->stream) (void)hipStreamSynchronize(G->stream);
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    for (auto& e : G->ex) {
+        F(e.pos_new); for (auto p : e.pvel_new) F(p); for (auto p : e.up) F(p); for (auto p : e.dn) F(p);
+        F(e.counts); F(e.recv_counts); F(e.red); F(e.packed);
+    }
+    for (auto h : G->slabs) destroy(h);
+    if (G->counts_host) (void)hipHostFree(G->counts_host);
+    if (G->recv_host) (void)hipHostFree(G->recv_host);
+    if (G->comm) (void)ncclCommDestroy(G->comm);
+    if (G->stream) (void)hipStreamDestroy(G->stream);
+    delete G;
+}
+
+// z-range of slab `index` of `nranks`: whole bricks, as even as possible
+static void slab_range(int nz, int nranks, int index, int* z0, int* z1) {
+    const int nbz = (nz + BZ - 1) / BZ;
+    const int lo = (int)((int64_t)nbz * index / nranks), hi = (int)((int64_t)nbz * (index + 1) / nranks);
+    *z0 = lo * BZ;
+    *z1 = std::min(hi * BZ, index + 1 == nranks ? nz + BZ : hi * BZ);
+}
+
+static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, int nlocal, const void* nccl_id, blub_slab_group** out) {
+    if (!d || !out || nranks < 1 || nlocal < 1 || first < 0 || first + nlocal > nranks || nlocal > 8) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad slab group arguments");
+    *out = nullptr;
+    if ((int)((d->nz + BZ - 1) / BZ) < nranks) return set_error(BLUB_ERR_INVALID_ARGUMENT, "more slabs than brick layers in z");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(BLUB_ERR_NO_DEVICE, "no HIP device (libblubhip has no CPU fallback)");
+    int dev = d->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipSetDevice(dev));
+    blub_slab_group* G = new (std::nothrow) blub_slab_group();
+    if (!G) return set_error(BLUB_ERR_OUT_OF_MEMORY, "host allocation failed");
+    G->nranks = nranks; G->first = first; G->device = dev; G->capacity = std::max<uint32_t>(d->max_num_particles, 1);
+    G->rccl = nccl_id != nullptr;
+    int rc = BLUB_OK;
+    if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) { delete G; return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
+    blub_fluid_desc dd = *d; dd.device = dev;
+    for (int i = 0; i < nlocal && rc == BLUB_OK; ++i) {
+        blub_fluid* h = nullptr;
+        rc = create(&dd, &h, G->stream);
+        if (rc != BLUB_OK) break;
+        slab_range((int)d->nz, nranks, first + i, &h->slab_z0, &h->slab_z1);
+        h->max_steps_in_flight = 0;   // every particle exchange synchronises the host anyway
+        G->slabs.push_back(h);
+        blub_slab_group::Extra e;
+        auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
+        const size_t P = G->capacity;
+        A(dev_alloc_zero(G->stream, &e.pos_new, P));
+        for (int c = 0; c < 3; ++c) A(dev_alloc_zero(G->stream, &e.pvel_new[c], P));
+        for (int k = 0; k < 4; ++k) { A(dev_alloc_zero(G->stream, &e.up[k], P)); A(dev_alloc_zero(G->stream, &e.dn[k], P)); }
+        A(dev_alloc_zero(G->stream, &e.counts, 1)); A(dev_alloc_zero(G->stream, &e.recv_counts, 2)); A(dev_alloc_zero(G->stream, &e.red, 4)); A(dev_alloc_zero(G->stream, &e.packed, 1));
+        G->ex.push_back(e);
+    }
+    if (rc == BLUB_OK && hipHostMalloc((void**)&G->counts_host, nlocal * sizeof(blubk::SlabCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK && hipHostMalloc((void**)&G->recv_host, 2 * nlocal * sizeof(uint32_t)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK) { memset(G->counts_host, 0, nlocal * sizeof(blubk::SlabCounts)); memset(G->recv_host, 0, 2 * nlocal * sizeof(uint32_t)); }
+    if (rc == BLUB_OK && G->rccl) {
+        if (nlocal != 1) rc = set_error(BLUB_ERR_INVALID_ARGUMENT, "RCCL slab groups hold exactly one slab per process");
+        else {
+            ncclUniqueId id; memcpy(&id, nccl_id, sizeof(id));
+            ncclResult_t r = ncclCommInitRank(&G->comm, nranks, id, first);
+            if (r != ncclSuccess) rc = set_error(BLUB_ERR_COMM, ncclGetErrorString(r));
+        }
+    }
+    if (rc == BLUB_OK && hipStreamSynchronize(G->stream) != hipSuccess) rc = set_error(BLUB_ERR_DEVICE, "slab group initialisation failed");
+    if (rc != BLUB_OK) { std::string keep = g_last_error; slab_group_destroy(G); g_last_error = keep; return rc; }
+    *out = G;
+    return BLUB_OK;
+}
+
+}  // namespace blub
+
+extern "C" {
+int blub_rccl_unique_id(void* out128) {
+    if (!out128) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return blub::set_error(BLUB_ERR_COMM, ncclGetErrorString(r));
+    memcpy(out128, &id, sizeof(id));
+    return BLUB_OK;
+}
+int blub_slab_range(uint32_t nz, int num_slabs, int index, int32_t* z0, int32_t* z1) {   // host only
+    if (!z0 || !z1 || num_slabs < 1 || index < 0 || index >= num_slabs) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    int a, b; blub::slab_range((int)nz, num_slabs, index, &a, &b);
+    *z0 = a; *z1 = std::min<int>(b, (int)nz);
+    return BLUB_OK;
+}
+int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out) { return blub::slab_group_create(desc, num_slabs, 0, num_slabs, nullptr, out); }
+int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out) {
+    if (!unique_id_128) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null unique id");
+    return blub::slab_group_create(desc, num_ranks, rank, 1, unique_id_128, out);
+}
+void blub_slab_group_destroy(blub_slab_group* g) { blub::slab_group_destroy(g); }
+int blub_slab_group_num_local(const blub_slab_group* g) { return g ? (int)g->slabs.size() : 0; }
+blub_fluid* blub_slab_group_local_fluid(blub_slab_group* g, int i) { return (g && i >= 0 && i < (int)g->slabs.size()) ? g->slabs[i] : nullptr; }
+int blub_slab_group_local_range(const blub_slab_group* g, int i, int32_t* z0, int32_t* z1) {
+    if (!g || !z0 || !z1 || i < 0 || i >= (int)g->slabs.size()) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    *z0 = g->slabs[i]->slab_z0; *z1 = std::min(g->slabs[i]->slab_z1, g->slabs[i]->g.nz);
+    return BLUB_OK;
+}
+// Every rank passes the SAME global particle arrays; each local slab keeps the particles whose z lies in its range.
+int blub_slab_group_set_particles(blub_slab_group* g, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz) {
+    if (!g || (n && !pos_ll)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    for (size_t s = 0; s < g->slabs.size(); ++s) {
+        blub_fluid* h = g->slabs[s];
+        std::vector<float> p, a, b, c;
+        const bool last = g->first + (int)s + 1 == g->nranks, firsts = g->first + (int)s == 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float z = pos_ll[4 * (size_t)i + 2];
+            if ((z >= (float)h->slab_z0 || firsts) && (z < (float)h->slab_z1 || last)) {
+                p.insert(p.end(), pos_ll + 4 * (size_t)i, pos_ll + 4 * (size_t)i + 4);
+                if (vx) a.insert(a.end(), vx + 4 * (size_t)i, vx + 4 * (size_t)i + 4);
+                if (vy) b.insert(b.end(), vy + 4 * (size_t)i, vy + 4 * (size_t)i + 4);
+                if (vz) c.insert(c.end(), vz + 4 * (size_t)i, vz + 4 * (size_t)i + 4);
+            }
+        }
+        int rc = blub_fluid_set_particles(h, (uint32_t)(p.size() / 4), p.data(), vx ? a.data() : nullptr, vy ? b.data() : nullptr, vz ? c.data() : nullptr);
+        if (rc != BLUB_OK) return rc;
+        h->num_ghost = 0;
+    }
+    return BLUB_OK;
+}
+uint32_t blub_slab_group_num_particles(const blub_slab_group* g) { uint32_t n = 0; if (g) for (auto h : g->slabs) n += h->num_particles; return n; }
+// Own particles of all LOCAL slabs, concatenated in slab order (any pointer may be NULL); blocks.
+int blub_slab_group_get_particles(blub_slab_group* g, float* pos_ll, float* vx, float* vy, float* vz) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    size_t off = 0;
+    for (auto h : g->slabs) {
+        int rc = blub_fluid_get_particles(h, pos_ll ? pos_ll + off : nullptr, vx ? vx + off : nullptr, vy ? vy + off : nullptr, vz ? vz + off : nullptr);
+        if (rc != BLUB_OK) return rc;
+        off += (size_t)h->num_particles * 4;
+    }
+    return BLUB_OK;
+}
+int blub_slab_group_set_gravity_grid(blub_slab_group* g, const float gr[3]) { if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); for (auto h : g->slabs) blub_fluid_set_gravity_grid(h, gr); return BLUB_OK; }
+int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_solver_config* cfg) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    for (auto h : g->slabs) { int rc = blub_fluid_set_solver_config(h, which, cfg); if (rc != BLUB_OK) return rc; }
+    return BLUB_OK;
+}
+int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t f) { if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); for (auto h : g->slabs) h->rebin_freq = f; return BLUB_OK; }
+int blub_slab_group_step(blub_slab_group* g, float dt) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    return blub::slab_step(g, dt);
+}
+int blub_slab_group_synchronize(blub_slab_group* g) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    for (auto h : g->slabs) { int rc = blub_fluid_synchronize(h); if (rc != BLUB_OK) return rc; }
+    return BLUB_OK;
+}
+}  // extern "C"

@@ -438,3 +438,127 @@ class Scene:
         f = self.fluid()
         f.step(simulation_delta)
         f.update_statistics()
+
+
+class SlabGroup:
+    """z-slab domain decomposition (include/blubhip.h, blub_slab_group_*): `HybridFluid::step` over several slabs.
+
+    local=S      : S slabs in this process on one GPU (loopback transport; validates the protocol on a single GPU)
+    rank, world  : one slab per process, RCCL transport; the 128-byte RCCL id is created on rank 0 and broadcast through
+                   torch.distributed by `SlabGroup.from_torch_distributed`.
+    """
+
+    def __init__(self, grid_dimension, max_num_particles, local=None, rank=None, world=None, unique_id=None, device=-1, binning="fixed"):
+        self._L = load_library()
+        L = self._L
+        vp = C.c_void_p
+        for name, res, args in [
+                ("blub_rccl_unique_id", C.c_int, [vp]), ("blub_slab_range", C.c_int, [C.c_uint32, C.c_int, C.c_int, vp, vp]),
+                ("blub_slab_group_create_local", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.POINTER(vp)]),
+                ("blub_slab_group_create_rccl", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, C.POINTER(vp)]),
+                ("blub_slab_group_destroy", None, [vp]), ("blub_slab_group_num_local", C.c_int, [vp]),
+                ("blub_slab_group_local_fluid", vp, [vp, C.c_int]), ("blub_slab_group_local_range", C.c_int, [vp, C.c_int, vp, vp]),
+                ("blub_slab_group_set_particles", C.c_int, [vp, C.c_uint32, vp, vp, vp, vp]), ("blub_slab_group_num_particles", C.c_uint32, [vp]),
+                ("blub_slab_group_get_particles", C.c_int, [vp, vp, vp, vp, vp]), ("blub_slab_group_set_gravity_grid", C.c_int, [vp, vp]),
+                ("blub_slab_group_set_solver_config", C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
+                ("blub_slab_group_set_rebinning_frequency", C.c_int, [vp, C.c_uint32]),
+                ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp])]:
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        self.grid = tuple(int(v) for v in grid_dimension)
+        d = _FluidDesc(self.grid[0], self.grid[1], self.grid[2], int(max_num_particles), int(device), 0, BINNING[binning], 0)
+        self._g = vp()
+        if local is not None:
+            _check(L, L.blub_slab_group_create_local(C.byref(d), int(local), C.byref(self._g)))
+        else:
+            buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+            _check(L, L.blub_slab_group_create_rccl(C.byref(d), int(rank), int(world), buf, C.byref(self._g)))
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        L.blub_rccl_unique_id.restype, L.blub_rccl_unique_id.argtypes = C.c_int, [C.c_void_p]
+        buf = (C.c_uint8 * 128)()
+        _check(L, L.blub_rccl_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def slab_range(nz, num_slabs, index):
+        """Host-only: the z-range [z0, z1) of slab `index` (whole 4-cell brick layers, as even as possible)."""
+        L = load_library()
+        L.blub_slab_range.restype, L.blub_slab_range.argtypes = C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        a, b = C.c_int32(), C.c_int32()
+        _check(L, L.blub_slab_range(int(nz), int(num_slabs), int(index), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @staticmethod
+    def from_torch_distributed(grid_dimension, max_num_particles, device=-1, binning="fixed"):
+        """One slab per rank of the default process group; rank 0's RCCL id is broadcast (works over gloo or nccl)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        payload = [SlabGroup.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=0)
+        return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._L.blub_slab_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_local(self):
+        return int(self._L.blub_slab_group_num_local(self._g))
+
+    def local_range(self, i):
+        a, b = C.c_int32(), C.c_int32()
+        _check(self._L, self._L.blub_slab_group_local_range(self._g, i, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def local_fluid(self, i):
+        """Borrowed HybridFluid view of local slab i (do not close it)."""
+        h = self._L.blub_slab_group_local_fluid(self._g, i)
+        f = HybridFluid(None, None, _handle=C.c_void_p(h))
+        f.close = lambda: None
+        return f
+
+    def set_particles(self, pos, vx=None, vy=None, vz=None):
+        pos = np.asarray(pos, np.float32)
+        n = pos.shape[0]
+        p4 = np.zeros((n, 4), np.float32)
+        p4[:, :3] = pos[:, :3]
+        p4.view(np.uint32)[:, 3] = 0xFFFFFFFF
+        vs = [None if v is None else np.ascontiguousarray(v, np.float32) for v in (vx, vy, vz)]
+        _check(self._L, self._L.blub_slab_group_set_particles(self._g, n, _ptr(p4), *[_ptr(v) for v in vs]))
+
+    def num_particles(self):
+        return int(self._L.blub_slab_group_num_particles(self._g))
+
+    def get_particles(self):
+        self.synchronize()
+        n = self.num_particles()
+        out = [np.zeros((n, 4), np.float32) for _ in range(4)]
+        _check(self._L, self._L.blub_slab_group_get_particles(self._g, *[_ptr(o) for o in out]))
+        return out
+
+    def set_gravity_grid(self, g):
+        a = np.asarray(g, np.float32)
+        _check(self._L, self._L.blub_slab_group_set_gravity_grid(self._g, _ptr(a)))
+
+    def set_solver_config(self, which, error_tolerance=0.1, max_num_iterations=32, error_check_frequency=4):
+        c = _SolverConfig(float(error_tolerance), int(max_num_iterations), int(error_check_frequency))
+        _check(self._L, self._L.blub_slab_group_set_solver_config(self._g, which, C.byref(c)))
+
+    def set_rebinning_frequency(self, f):
+        _check(self._L, self._L.blub_slab_group_set_rebinning_frequency(self._g, int(f)))
+
+    def step(self, simulation_delta):
+        _check(self._L, self._L.blub_slab_group_step(self._g, float(simulation_delta)))
+
+    def synchronize(self):
+        _check(self._L, self._L.blub_slab_group_synchronize(self._g))

@@ -206,6 +206,32 @@ int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]);
 /* Total PCG iterations executed (sum of reported iteration counts) since creation, both solvers. */
 uint64_t blub_fluid_total_solver_iterations(const blub_fluid* h);
 
+/* ---- z-slab domain decomposition over up to 8 GPUs (not part of the reference, which is single-GPU) ---- */
+/* The global grid is cut into `num_slabs` z-ranges of whole 16x8x4-cell bricks.  Every slab keeps its volumes in GLOBAL
+ * grid coordinates but only works on its own planes; neighbours exchange ghost particles, halo planes (RCCL
+ * send/recv between z-neighbours), the PCG scalars (all-reduce) and migrating particles.  Two transports:
+ *   create_local : all slabs in THIS process on one device (validation of the protocol on a single GPU),
+ *   create_rccl  : one slab per process / GPU; `unique_id_128` comes from blub_rccl_unique_id() on rank 0 and is
+ *                  distributed by the caller (e.g. torch.distributed broadcast). */
+typedef struct blub_slab_group blub_slab_group;
+int blub_rccl_unique_id(void* out128);
+int blub_slab_range(uint32_t nz, int num_slabs, int index, int32_t* z0, int32_t* z1);   /* host only */
+int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out);
+int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out);
+void blub_slab_group_destroy(blub_slab_group* g);
+int blub_slab_group_num_local(const blub_slab_group* g);
+blub_fluid* blub_slab_group_local_fluid(blub_slab_group* g, int local_index);   /* for read_volume / statistics of one slab */
+int blub_slab_group_local_range(const blub_slab_group* g, int local_index, int32_t* z0, int32_t* z1);
+/* every rank passes the same global arrays; each slab keeps the particles of its z-range */
+int blub_slab_group_set_particles(blub_slab_group* g, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz);
+uint32_t blub_slab_group_num_particles(const blub_slab_group* g);   /* own particles of the local slabs */
+int blub_slab_group_get_particles(blub_slab_group* g, float* pos_ll, float* vx, float* vy, float* vz);
+int blub_slab_group_set_gravity_grid(blub_slab_group* g, const float gravity_grid[3]);
+int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_solver_config* cfg);
+int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t every_n_steps);
+int blub_slab_group_step(blub_slab_group* g, float simulation_delta_seconds);
+int blub_slab_group_synchronize(blub_slab_group* g);
+
 #ifdef __cplusplus
 }
 #endif
