@@ -149,34 +149,90 @@ def main():
     dev = torch.cuda.current_device()
 
     scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
-    scene = blub_amd.Scene(path=scene_path, device=dev)
-    fluid = scene.fluid()
     dt = blub_amd.default_simulation_delta()
-    nx, ny, nz = fluid.grid_dimension()
-    N, P = nx * ny * nz, fluid.num_particles()
+    parallelism = "single GPU"
+    group = None
+    if world > 1 and not os.environ.get("BLUB_BENCH_REPLICAS"):
+        # z-slab decomposition, weak scaling: rank k owns slab k of a (nx, ny, N*nz) domain made of N stacked
+        # copies of the scene (the dams of neighbouring slabs meet at the interfaces, so ghosts / halos / migration carry data)
+        from blub_amd import slab_scene
+        ok = torch.ones(1, device="cuda")
+        try:
+            cfg = blub_amd.Scene.parse(path=scene_path).config
+            dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, world)
+            pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
+            group = blub_amd.SlabGroup.from_torch_distributed(dim, len(pos) + 64, device=dev)
+            group.set_gravity_grid(gravity)
+            group.set_particles(pos)
+            del pos
+        except Exception as e:   # all ranks must take the same path
+            sys.stderr.write("rank %d: z-slab group unavailable (%s)\n" % (rank, e))
+            ok.zero_()
+            group = None
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            if group is not None:
+                group.close()
+            group = None
+    if group is not None:
+        parallelism = "z-slab decomposition over RCCL: %d slabs of %dx%dx%d (weak scaling), 1 rank per GPU" % (world, dim[0], dim[1], dim[2] // world)
+        fluid = group.local_fluid(0)
+        step, sync = (lambda: group.step(dt)), group.synchronize
+        nx, ny, nz = dim
+        P = int(maxp)   # global particle count is reported below from the seeded set
+    else:
+        if world > 1:
+            parallelism = "replicas x%d (one independent domain per GPU; z-slab group unavailable or disabled)" % world
+        scene = blub_amd.Scene(path=scene_path, device=dev)
+        fluid = scene.fluid()
+        step, sync = (lambda: scene.step(dt)), fluid.synchronize
+        nx, ny, nz = fluid.grid_dimension()
+    N = nx * ny * nz
+    P = fluid.num_particles() if group is None else None
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        fluid.synchronize()
+        sync()
 
     for _ in range(args.warmup):
-        scene.step(dt)
+        step()
     barrier()
     it0 = fluid.total_solver_iterations()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        scene.step(dt)
-    fluid.synchronize()
+        step()
+    sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if group is not None:
+            cnt = torch.tensor([group.num_particles()], dtype=torch.float64, device="cuda")
+            dist.all_reduce(cnt)
+            P = int(cnt.item())
         dist.barrier()
     it1 = fluid.total_solver_iterations()
+
+    if group is not None:
+        # weak scaling: one global step advances `world` slabs of the single-GPU workload size
+        if rank == 0:
+            print(json.dumps({
+                "metric": "simulation steps/sec, 1M particles @ 256^3 grid", "value": round(args.steps * world / elapsed, 3),
+                "unit": "steps/s (256^3-slab steps: one global step advances n_gpus slabs)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic", "config": {"workload": "%s stacked x%d along z" % (args.scene, world), "grid": [nx, ny, nz], "particles": P, "dt": dt,
+                                                "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60, "parallelism": parallelism},
+                "global_steps_per_sec": round(args.steps / elapsed, 3), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
+                "roofline": None, "cpu_baseline": None}))
+            sys.stdout.flush()
+        dist.barrier()
+        group.close()
+        dist.destroy_process_group()
+        return
 
     if rank != 0:
         if dist is not None:
@@ -188,7 +244,7 @@ def main():
     fluid.profile_enable(True)
     fluid.profile_reset()
     for _ in range(args.profile_steps):
-        scene.step(dt)
+        step()
     fluid.synchronize()
     prof = fluid.profile_read()
     fluid.profile_enable(False)
@@ -213,7 +269,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.scene, "grid": [nx, ny, nz], "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4",
-                   "rebinning": 60, "parallelism": "single GPU" if world == 1 else "replicas x%d (one domain per GPU)" % world},
+                   "rebinning": 60, "parallelism": parallelism},
         "pcg_iters_per_sec": round((it1 - it0) * world / elapsed, 1),
         "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
         "pcg_iters_per_sec_in_solver": round((it1 - it0) / args.steps * args.profile_steps / (pcg_ms * 1e-3), 1) if pcg_ms > 0 else None,

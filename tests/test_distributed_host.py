@@ -1,0 +1,76 @@
+"""N > 1 path, host side, as two real processes over gloo (no GPU): slab ranges, the weak-scaling scene, particle
+ownership, and the RCCL-id hand-out mechanism (broadcast_object_list) used by SlabGroup.from_torch_distributed."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from tests.conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    import blub_amd
+    from blub_amd import slab_scene
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% sys.argv[1], rank=int(sys.argv[2]), world_size=2)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cfg = blub_amd.Scene.parse(path=os.path.join(%r, "scenes", "corner_dams_128.json")).config
+    dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, world)
+    assert dim == (128, 128, 256) and len(cubes) == 4 and maxp == 2 * cfg.max_num_particles
+    pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
+    # (the upper dam of slab 0 is no longer clamped by the domain end, so slightly more than 2 x 111 600 particles)
+    assert 2 * 111600 <= len(pos) <= maxp and len(pos) %% 8 == 0
+    lens = [None, None]
+    dist.all_gather_object(lens, (len(pos), float(pos[:, :3].sum())))
+    assert lens[0] == lens[1]            # both ranks seeded the identical particle set
+    own, (z0, z1) = slab_scene.partition_particles(pos, dim[2], world, rank)
+    # ranges tile [0, nz) in whole 4-cell brick layers
+    ranges = [None, None]
+    dist.all_gather_object(ranges, (z0, z1))
+    assert ranges[0][0] == 0 and ranges[1][1] == dim[2] and ranges[0][1] == ranges[1][0] and ranges[0][1] %% 4 == 0
+    # every particle has exactly one owner
+    counts = torch.tensor([len(own)], dtype=torch.int64)
+    dist.all_reduce(counts)
+    assert int(counts) == len(pos), (int(counts), len(pos))
+    mask = torch.zeros(len(pos), dtype=torch.int32); mask[torch.from_numpy(own)] = 1
+    dist.all_reduce(mask)
+    assert int(mask.min()) == 1 and int(mask.max()) == 1
+    # both dams next to the interface (upper dam of slab 0, lower dam of slab 1) supply ghost candidates to the other rank
+    z = pos[:, 2]
+    near = np.count_nonzero((z >= z1 - 2) & (z < z1)) if rank == 0 else np.count_nonzero((z >= z0) & (z < z0 + 2))
+    assert near > 0
+    # the RCCL unique id is created on rank 0 only and handed out through the process group
+    payload = [bytes(range(128)) if rank == 0 else None]
+    dist.broadcast_object_list(payload, src=0)
+    assert payload[0] == bytes(range(128))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %%d ok" %% rank)
+""")
+
+
+def test_two_rank_gloo_host_logic(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, ROOT))
+    port = str(29500 + os.getpid() % 2000)
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\\n%s" % (r, o)
+        assert "rank %d ok" % r in o
+
+
+def test_slab_ranges_are_whole_brick_layers():
+    import blub_amd
+    for nz, n in ((256, 1), (256, 2), (256, 8), (64, 3), (48, 5), (2048, 8)):
+        r = [blub_amd.SlabGroup.slab_range(nz, n, i) for i in range(n)]
+        assert r[0][0] == 0 and r[-1][1] == nz
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(a[0] % 4 == 0 and a[1] > a[0] for a in r)
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 4
