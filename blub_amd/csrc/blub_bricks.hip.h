@@ -465,62 +465,74 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_position_change_b(BrickGeom b
     BRICK_LOOP_END
 }
 
-// D3: extrapolate_velocity.comp:9-90 (active bricks).  The thread caches the 3x3 rows x 6 bytes of markers around its
-// quad (9 dword + 18 byte loads) and then evaluates the reference's per-cell logic from registers.
+// D3: extrapolate_velocity.comp:9-90 (active bricks).  The block stages the marker tile of its brick plus a one-cell ring
+// (18 x 10 x 6 cells, padded to 24 bytes per row) in LDS with ~3 dword loads per thread; every thread then reads the
+// 6 x 3 x 3 marker neighbourhood of its quad from LDS.  Bricks whose tile holds no FLUID cell are skipped after the load
+// (most of the dilated ring); the reference's per-cell logic is evaluated from registers.
+constexpr int ET_ROW = 24;                                   // bytes per staged row: x0-4 .. x0+19 (6 dwords)
+constexpr int ET_ROWS = (BY + 2) * (BZ + 2);                 // 60 rows
 __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                  const int8_t* __restrict__ marker, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
+    __shared__ uint32_t tile[ET_ROWS * (ET_ROW / 4)];
     const Grid g = bg.g;
     float* vel[3] = {vx, vy, vz};
-    BRICK_LOOP_BEGIN(bg, list, count)
-        // mm[dz+1][dy+1][k], k = 0..5 <-> x0-1 .. x0+4
-        int8_t mm[3][3][6];
-        bool near_fluid = false;
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t b = list[i] & ~STALE_BIT;
+        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        const int tx0 = bx * BX - 4, ty0 = by * BY - 1, tz0 = bz * BZ - 1;     // tile origin (x is dword aligned)
+        bool any = false;
+        for (int w = threadIdx.x; w < ET_ROWS * (ET_ROW / 4); w += BRICK_THREADS) {
+            const int row = w / (ET_ROW / 4), dw = w % (ET_ROW / 4);
+            const int yy = ty0 + row % (BY + 2), zz = tz0 + row / (BY + 2), xx = tx0 + dw * 4;
+            uint32_t v = 0;   // out of bounds reads SOLID (0)
+            if ((unsigned)yy < (unsigned)g.ny && (unsigned)zz < (unsigned)g.nz && xx >= 0 && xx < g.nx) v = *reinterpret_cast<const uint32_t*>(marker + cidx(g, xx, yy, zz));
+            tile[w] = v;
+            any = any || any_fluid4(v);
+        }
+        if (!__syncthreads_or(any)) continue;     // (the barrier also publishes the tile)
+        int x0, y, z;
+        const bool valid = brick_quad(bg, b, threadIdx.x, x0, y, z);
+        if (valid) {
+            const int8_t* t8 = reinterpret_cast<const int8_t*>(tile);
+            auto M = [&](int x, int yy, int zz) -> int { return (int)t8[((zz - tz0) * (BY + 2) + (yy - ty0)) * ET_ROW + (x - tx0)]; };
+            bool near_fluid = false;
 #pragma unroll
-        for (int dz = -1; dz <= 1; ++dz)
+            for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int yy = y + dy, zz = z + dz;
-                uint32_t c4 = 0; int xm = 0, xp = 0;
-                if ((unsigned)yy < (unsigned)g.ny && (unsigned)zz < (unsigned)g.nz) {
-                    const int b2 = cidx(g, x0, yy, zz);
-                    c4 = *reinterpret_cast<const uint32_t*>(marker + b2);
-                    xm = x0 > 0 ? (int)marker[b2 - 1] : 0;
-                    xp = x0 + 4 < g.nx ? (int)marker[b2 + 4] : 0;
-                }
-                mm[dz + 1][dy + 1][0] = (int8_t)xm; mm[dz + 1][dy + 1][5] = (int8_t)xp;
+                for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mm[dz + 1][dy + 1][j + 1] = (int8_t)mbyte(c4, j);
-                near_fluid = near_fluid || any_fluid4(c4) || xm == CELL_FLUID || xp == CELL_FLUID;
-            }
-        // Every marker the reference reads for these 4 cells (in-plane neighbours and their +e_c cells) lies inside the
-        // cached 6x3x3 block; without a FLUID cell in it no neighbour face is valid and nothing is written.
-        if (!near_fluid) continue;
-        auto M = [&](int x, int yy, int zz) -> int { return (int)mm[zz - z + 1][yy - y + 1][x - x0 + 1]; };
+                    for (int k = -1; k <= 4; ++k) near_fluid = near_fluid || M(x0 + k, y + dy, z + dz) == CELL_FLUID;
+            if (near_fluid) {
+                const int base = cidx(g, x0, y, z);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = x0 + j;
-            if (M(x, y, z) == CELL_FLUID) continue;
+                for (int j = 0; j < 4; ++j) {
+                    const int x = x0 + j;
+                    if (M(x, y, z) == CELL_FLUID) continue;
 #pragma unroll
-            for (int comp = 0; comp < 3; ++comp) {
-                if (M(x + (comp == 0), y + (comp == 1), z + (comp == 2)) == CELL_FLUID) continue;
-                float numV = 0.0f, avgV = 0.0f;
+                    for (int comp = 0; comp < 3; ++comp) {
+                        if (M(x + (comp == 0), y + (comp == 1), z + (comp == 2)) == CELL_FLUID) continue;
+                        float numV = 0.0f, avgV = 0.0f;
 #pragma unroll
-                for (int b2 = -1; b2 <= 1; ++b2)
+                        for (int b2 = -1; b2 <= 1; ++b2)
 #pragma unroll
-                    for (int a = -1; a <= 1; ++a) {
-                        if (a == 0 && b2 == 0) continue;
-                        int ox, oy, oz;
-                        if (comp == 0) { ox = 0; oy = a; oz = b2; }
-                        else if (comp == 1) { ox = a; oy = 0; oz = b2; }
-                        else { ox = a; oy = b2; oz = 0; }
-                        const int cx = x + ox, cy = y + oy, cz = z + oz;
-                        const bool valid = M(cx, cy, cz) == CELL_FLUID || M(cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
-                        if (valid) { numV += 1.0f; avgV += fv(vel[comp], g, cx, cy, cz); }
+                            for (int a = -1; a <= 1; ++a) {
+                                if (a == 0 && b2 == 0) continue;
+                                int ox, oy, oz;
+                                if (comp == 0) { ox = 0; oy = a; oz = b2; }
+                                else if (comp == 1) { ox = a; oy = 0; oz = b2; }
+                                else { ox = a; oy = b2; oz = 0; }
+                                const int cx = x + ox, cy = y + oy, cz = z + oz;
+                                const bool ok = M(cx, cy, cz) == CELL_FLUID || M(cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
+                                if (ok) { numV += 1.0f; avgV += fv(vel[comp], g, cx, cy, cz); }
+                            }
+                        if (numV > 0.0f) vel[comp][base + j] = avgV / numV;
                     }
-                if (numV > 0.0f) vel[comp][base + j] = avgV / numV;
+                }
             }
         }
-    BRICK_LOOP_END
+        __syncthreads();   // the tile is rewritten for the next brick
+    }
 }
 
 }  // namespace blubk

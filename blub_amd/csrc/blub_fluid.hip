@@ -306,12 +306,10 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     }
     // work mapping: brick lists when the fluid is sparse, dense rows otherwise (a performance choice only)
     bool sparse;
+    BrickCounts bc{}; bool have = false;
+    if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
     if (h->force_pcg_path >= 0) sparse = h->force_pcg_path == 1;
-    else {
-        BrickCounts bc{}; bool have = false;
-        if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
-        sparse = have && (float)bc.n_fluid < SPARSE_PCG_MAX_FILL * (float)h->bg.nb;
-    }
+    else sparse = have && (float)bc.n_fluid < SPARSE_PCG_MAX_FILL * (float)h->bg.nb;
     const int maxit = c.max_num_iterations;
     const int freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };   // :672-673 (the i == max case is k_pcg_finalize)
@@ -319,7 +317,10 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
     float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
     if (sparse) {
-        const int np = std::min((h->bg.nb + 1) / 2, PCG_GRID_BRICKS);
+        // grid (= number of dot-product partials) sized from the newest landed brick count with 50 % head room: the kernels
+        // stride over the device-side list, so a stale count only costs speed, never correctness
+        int np = std::min((h->bg.nb + 1) / 2, PCG_GRID_BRICKS);
+        if (have) np = std::max(64, std::min(np, (int)((bc.n_active * 3u / 2u + 1u) / 2u)));
         const dim3 grid(np), block(PCG_B_THREADS);
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd);
         for (int i = 0; i <= maxit; ++i) {

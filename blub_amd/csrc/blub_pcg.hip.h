@@ -211,10 +211,9 @@ __device__ __forceinline__ float2 reduce_partials2(const float2* __restrict__ pa
 template <int NT>
 __device__ __forceinline__ bool pcg_dir_prologue(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, float tolerance,
                                                  int iteration, int check_prev, float2* sm2, float& beta) {
-    const int done = ctrl->done;
+    if (ctrl->done) return false;     // uniform: finished solves cost one load, not a reduction
     const float sigma_prev = ctrl->sigma[(iteration + 1) & 1];
     const float2 red = reduce_partials2<NT>(part_upd, num_part, sm2);
-    if (done) return false;
     beta = 0.0f;
     if (iteration > 0) {
         if (check_prev && red.y < tolerance) {
@@ -228,11 +227,11 @@ __device__ __forceinline__ bool pcg_dir_prologue(PcgCtrl* __restrict__ ctrl, con
 }
 template <int NT>
 __device__ __forceinline__ bool pcg_upd_prologue(const PcgCtrl* __restrict__ ctrl, const float* __restrict__ part_dir, int num_part, int iteration, float* sm, float& alpha) {
-    const int done = ctrl->done;
+    if (ctrl->done) { alpha = 0.0f; return false; }
     const float sigma = ctrl->sigma[iteration & 1];
     const float sas = reduce_partials<NT, false>(part_dir, num_part, sm);
     alpha = eps_div(sigma, sas);                                                        // RESULTMODE_ALPHA
-    return !done;
+    return true;
 }
 
 // ---- brick-list wrappers ---------------------------------------------------------------------------------------------
