@@ -1,0 +1,84 @@
+"""Error behaviour and bookkeeping of the C-ABI on a real device (the reference's unwrap()/assert!/error! paths)."""
+import numpy as np
+import pytest
+
+from tests import util
+from tests.conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def test_create_rejects_unsupported_grids():
+    import blub_amd
+    from blub_amd.hybrid_fluid import BlubError
+    for dim, status in (((30, 32, 32), -2),      # x not a multiple of 4 (float4 rows)
+                        ((16, 16, 16), -2),      # <= 16384 cells: pressure_solver.rs:551 asserts the same
+                        ((2, 64, 64), -1)):
+        with pytest.raises(BlubError) as e:
+            blub_amd.HybridFluid(dim, 16)
+        assert e.value.status == status, dim
+
+
+def test_add_fluid_cube_truncates_and_counts_like_the_reference():
+    import blub_amd
+    f = blub_amd.HybridFluid((32, 32, 32), 1000)
+    try:
+        f.add_fluid_cube((1, 1, 1), (5, 5, 5))            # 4*4*4*8 = 512
+        assert f.num_particles() == 512
+        f.add_fluid_cube((8, 8, 8), (16, 16, 16))         # would be 4096: truncated to the 488 left (hybrid_fluid.rs:627-633)
+        assert f.num_particles() == 1000
+        p = f.get_particles()[0]
+        assert np.all(p[:512, :3] >= 1) and np.all(p[:512, :3] <= 5) and np.all(p[512:, :3] >= 8)
+        assert np.all(p.view(np.uint32)[:, 3] == 0xFFFFFFFF)
+    finally:
+        f.close()
+
+
+def test_step_argument_checks_and_statistics_ring():
+    import blub_amd
+    from blub_amd.hybrid_fluid import BlubError
+    f = blub_amd.HybridFluid((32, 32, 32), 4096)
+    try:
+        with pytest.raises(BlubError) as e:
+            f.step(0.0)
+        assert e.value.status == -1
+        with pytest.raises(BlubError):
+            f.set_particles(np.zeros((5000, 3), np.float32))
+        f.add_fluid_cube((4, 4, 4), (12, 8, 12))
+        f.set_gravity_grid((0, -981.0, 0))
+        assert f.pressure_solver_config_velocity().max_num_iterations == 32 and abs(f.pressure_solver_config_density().error_tolerance - 0.1) < 1e-7
+        assert f.particle_rebinning_step_frequency == 60
+        for _ in range(130):                                # more than the 100-sample history (pressure_solver.rs:101)
+            f.step(util.DT)
+            f.update_statistics()
+        f.synchronize()
+        sv, sd = f.pressure_solver_stats_velocity(), f.pressure_solver_stats_density()
+        assert len(sv) == 100 and len(sd) == 100
+        assert all(0 < s.iteration_count <= 32 for s in sv)
+        assert f.step_counter == 130
+        views = f.bind_group_renderer()
+        assert all(views[k] for k in ("particles_position_ll", "velocity_x", "marker", "pressure_from_density", "stream"))
+    finally:
+        f.close()
+
+
+def test_scene_json_to_fluid_matches_manual_construction():
+    import os
+    import blub_amd
+    from tests.conftest import ROOT
+    scene = blub_amd.Scene(path=os.path.join(ROOT, "scenes", "single_cell_debug.json"))
+    f = scene.fluid()
+    try:
+        assert f.grid_dimension() == (64, 64, 128) and f.num_particles() == 8
+        p0 = f.get_particles()[0][:, :3].copy()
+        g = float(np.float32(-9.81) / np.float32(0.01))
+        for n in range(1, 4):                               # free fall: y_n = y_0 + g dt^2 n(n+1)/2 (tests/test_oracle_kat.py)
+            scene.step(util.DT)
+        f.synchronize()
+        p = f.get_particles()[0][:, :3]
+        # step 0 rebins (Q13): compare as sets, sorted by x (x and z do not change)
+        a, b = p[np.argsort(p[:, 0])], p0[np.argsort(p0[:, 0])]
+        assert np.abs(a[:, 1] - (b[:, 1] + g * util.DT * util.DT * 6)).max() < 2e-4
+        assert np.abs(a[:, [0, 2]] - b[:, [0, 2]]).max() < 1e-5
+    finally:
+        f.close()
