@@ -201,8 +201,13 @@ __global__ __launch_bounds__(256) void k_static_marker_dense(Grid g, const float
 // ---- T4 over active bricks: transfer_gather_velocity.comp:39-127 ---------------------------------------------------
 // One workgroup per brick: (16+1)x(8+1)x(4+1) = 765 list cells (brick + one halo layer on the negative sides), each
 // thread walks its own cell's list and publishes the current particle through LDS (24 KiB); a face reads the 7 other
-// lists it needs from LDS.  768 threads = 12 full waves.  The <=12-round loop ends when every list of the tile is empty.
+// lists it needs from LDS.  768 threads = 12 full waves.  The <=12-round loop ends when every list of the tile is empty;
+// the node of round k+1 is fetched from global memory while round k is exchanged through LDS (pointer-chase pipelining).
 constexpr int GT_X = BX + 1, GT_Y = BY + 1, GT_Z = BZ + 1, GT_N = GT_X * GT_Y * GT_Z;   // 17 x 9 x 5 = 765
+
+// LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its outstanding global loads, so a prefetched
+// list node stays in flight across the exchange (a __syncthreads() would drain vmcnt first).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int COMP>
 __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
@@ -211,8 +216,9 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
                                                            const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
     __shared__ float4 sPos[GT_N];
     __shared__ float4 sVel[GT_N];
+    __shared__ int sAny[12];
     const Grid g = bg.g;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool live = tid < GT_N;
     const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
     const int a1 = tid - 1, a2 = tid - GT_X, a3 = tid - GT_X - 1, a4 = tid - GT_X * GT_Y, a5 = a4 - 1, a6 = a4 - GT_X, a7 = a4 - GT_X - 1;   // :87-93
@@ -230,23 +236,32 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
         const float sx = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
         const float sy = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
         const float sz = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
+        // node of round 0
         uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+        bool has = cur != INVALID_LL;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), r = p;
+        uint32_t nxt = INVALID_LL;
+        if (has) { p = pos[cur]; r = rows[cur]; nxt = next ? next[cur] : __float_as_uint(p.w); }
         float v = 0.0f, wsum = 0.0f;
         for (int round = 0; round < 12; ++round) {                                               // :61
-            const bool has = cur != INVALID_LL;
-            if (!__syncthreads_or(has)) break;
             if (has) {
-                const float4 p = pos[cur];
-                const float4 r = rows[cur];
-                cur = next ? next[cur] : __float_as_uint(p.w);
                 if (computes) add_particle(v, wsum, p, r, sx, sy, sz);
                 sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
                 sVel[tid] = r;
             } else if (live) {
                 sPos[tid].w = 0.0f;
             }
-            __syncthreads();
-            if (computes) {
+            const unsigned long long wave_has = __ballot(has);
+            if (lane == 0) sAny[wave] = wave_has != 0ull;
+            // prefetch the node of the next round: its latency overlaps the LDS exchange below
+            const bool has_n = has && nxt != INVALID_LL && round + 1 < 12;
+            float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
+            if (has_n) { pn = pos[nxt]; rn = rows[nxt]; nn = next ? next[nxt] : __float_as_uint(pn.w); }
+            lds_barrier();
+            int any = 0;
+#pragma unroll
+            for (int w = 0; w < 12; ++w) any |= sAny[w];
+            if (any && computes) {
                 float4 q;
                 q = sPos[a1]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a1], sx, sy, sz);
                 q = sPos[a2]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a2], sx, sy, sz);
@@ -256,13 +271,15 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
                 q = sPos[a6]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a6], sx, sy, sz);
                 q = sPos[a7]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a7], sx, sy, sz);
             }
+            lds_barrier();   // reads (and the sAny poll) are done before the next round rewrites LDS
+            if (!any) break;
+            has = has_n; p = pn; r = rn; nxt = nn;
         }
         if (writes) {
             if (computes) { if (wsum > 0.0f) v /= wsum; v += gravity_dt; }                       // :117-120
             else v = 0.0f;                                                                        // :121-124
             out[cidx(g, gx, gy, gz)] = v;
         }
-        __syncthreads();   // LDS is reused by the next brick of this block
     }
 }
 
@@ -271,8 +288,9 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
                                                           const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
                                                           const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
     __shared__ float4 sPos[GT_N];
+    __shared__ int sAny[12];
     const Grid g = bg.g;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool live = tid < GT_N;
     const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
     const int a1 = tid - 1, a2 = tid - GT_X, a3 = tid - GT_X - 1, a4 = tid - GT_X * GT_Y, a5 = a4 - 1, a6 = a4 - GT_X, a7 = a4 - GT_X - 1;
@@ -286,24 +304,33 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
         const bool writes = !border && in && marker[cidx(g, gx, gy, gz)] == CELL_FLUID;           // :46
         const float sx = (float)gx + 0.5f, sy = (float)gy + 0.5f, sz = (float)gz + 0.5f;
         uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+        bool has = cur != INVALID_LL;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has) p = pos[cur];
         float density = 0.0f;
-        auto add = [&](const float4& p) {
-            const float ox = satf(1.0f - fabsf(sx - p.x)), oy = satf(1.0f - fabsf(sy - p.y)), oz = satf(1.0f - fabsf(sz - p.z));
+        auto add = [&](const float4& q) {
+            const float ox = satf(1.0f - fabsf(sx - q.x)), oy = satf(1.0f - fabsf(sy - q.y)), oz = satf(1.0f - fabsf(sz - q.z));
             density += ox * oy * oz;                                                              // :27-31
         };
         for (int round = 0; round < 32; ++round) {                                                // :69
-            const bool has = cur != INVALID_LL;
-            if (!__syncthreads_or(has)) break;
+            uint32_t nxt = INVALID_LL;
             if (has) {
-                const float4 p = pos[cur];
-                cur = __float_as_uint(p.w);
+                nxt = __float_as_uint(p.w);
                 if (writes) add(p);
                 sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
             } else if (live) {
                 sPos[tid].w = 0.0f;
             }
-            __syncthreads();
-            if (writes) {
+            const unsigned long long wave_has = __ballot(has);
+            if (lane == 0) sAny[wave] = wave_has != 0ull;
+            const bool has_n = has && nxt != INVALID_LL && round + 1 < 32;
+            float4 pn = p;
+            if (has_n) pn = pos[nxt];          // prefetch: overlaps the LDS exchange
+            lds_barrier();
+            int any = 0;
+#pragma unroll
+            for (int w = 0; w < 12; ++w) any |= sAny[w];
+            if (any && writes) {
                 float4 q;
                 q = sPos[a1]; if (q.w != 0.0f) add(q);
                 q = sPos[a2]; if (q.w != 0.0f) add(q);
@@ -313,6 +340,9 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
                 q = sPos[a6]; if (q.w != 0.0f) add(q);
                 q = sPos[a7]; if (q.w != 0.0f) add(q);
             }
+            lds_barrier();
+            if (!any) break;
+            has = has_n; p = pn;
         }
         if (writes) {
             const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
@@ -326,7 +356,6 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
             density /= dt;                                                                        // :196
             residual[cidx(g, gx, gy, gz)] = density;
         }
-        __syncthreads();
     }
 }
 

@@ -309,7 +309,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     BrickCounts bc{}; bool have = false;
     if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
     if (h->force_pcg_path >= 0) sparse = h->force_pcg_path == 1;
-    else sparse = have && (float)bc.n_fluid < SPARSE_PCG_MAX_FILL * (float)h->bg.nb;
+    else sparse = (have && (float)bc.n_fluid < SPARSE_PCG_MAX_FILL * (float)h->bg.nb) || h->gz.tiles < 256;   // tiny grids: too few dense tiles to fill the chip
     const int maxit = c.max_num_iterations;
     const int freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };   // :672-673 (the i == max case is k_pcg_finalize)
@@ -513,7 +513,11 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
         if (T != 256 && T != 512 && T != 1024) T = 512;
         if (const char* e = getenv("BLUB_PCGZ_ZC")) zcz = std::max(1, atoi(e));
         if (const char* e = getenv("BLUB_PCGZ_GRID")) gridz = std::min(PCG_GRID_MAX, std::max(1, atoi(e)));
-        gz.g = h->g; gz.qpr = gm.qpr; gz.qpp = gm.qpp; gz.T = T; gz.plane_tiles = (gm.qpp + T - 1) / T; gz.zc = zcz;
+        gz.g = h->g; gz.qpr = gm.qpr; gz.qpp = gm.qpp; gz.T = T; gz.plane_tiles = (gm.qpp + T - 1) / T;
+        // Tile depth: 16 planes amortise the z-halo best (profiles/r01_dense_pcg_sweep.txt), but the chip needs >= ~1000
+        // tiles in flight (256 CUs x 4 blocks): smaller grids march fewer planes per tile (128x64x64 at zc = 16 has 32 tiles).
+        if (!getenv("BLUB_PCGZ_ZC")) while (zcz > 2 && gz.plane_tiles * ((h->g.nz + zcz - 1) / zcz) < 1024) zcz >>= 1;
+        gz.zc = zcz;
         gz.z_chunks = (h->g.nz + zcz - 1) / zcz; gz.tiles = gz.plane_tiles * gz.z_chunks;
         h->pcg_grid_z = std::min(gridz, ((gz.tiles + 7) / 8) * 8);
     }

@@ -67,13 +67,36 @@ __device__ __forceinline__ float reduce_partials_256(const float* __restrict__ p
 // dual-grid lists (component c: dual cell = ivec3(pos - (0.5 + 0.5 e_c))) and marks FLUID cells.
 // list "next" pointers: component x lives in pos.w (as in the reference), y/z in two extra u32 arrays.
 // =================================================================================================================
+// Wave-aggregated list insertion.  Particles are (re)binned by cell, so neighbouring lanes mostly insert into the SAME
+// list and a per-lane atomicExch serialises on one address.  Instead, every run of adjacent lanes with the same cell
+// is chained in registers (lane -> previous lane of the run) and only the run's LAST lane exchanges the list head; the
+// old head becomes the `next` of the run's FIRST lane.  The result is a valid insertion order of the reference's
+// atomic-exchange list (transfer_build_linkedlist.comp:25) with 1 atomic per run instead of 1 per particle.
+// key < 0: the particle is outside the grid (no insertion, next = invalid).  All 64 lanes must call this.
+__device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ heads, int key, uint32_t particle) {
+    const int lane = threadIdx.x & 63;
+    const int prev_key = __shfl_up(key, 1, 64), next_key = __shfl_down(key, 1, 64);
+    const uint32_t prev_particle = __shfl_up(particle, 1, 64);
+    const bool is_start = lane == 0 || key != prev_key, is_end = lane == 63 || key != next_key;
+    const unsigned long long starts = __ballot(is_start);
+    uint32_t old = 0;
+    if (is_end && key >= 0) old = atomicExch(heads + key, particle + 1);
+    // the run's last lane = (next run start) - 1
+    const unsigned long long above = lane == 63 ? 0ull : (starts >> (lane + 1));
+    const int end_lane = above ? lane + __builtin_ctzll(above) : 63;
+    const uint32_t old_of_run = __shfl(old, end_lane, 64);
+    if (key < 0) return INVALID_LL;
+    return is_start ? old_of_run - 1u : prev_particle;
+}
+
 __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_particles, float4* __restrict__ pos, int8_t* __restrict__ marker,
                                                      uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
                                                      uint32_t* __restrict__ next1, uint32_t* __restrict__ next2) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= num_particles) return;
-    const float4 p = pos[i];
-    {
+    const bool live = i < num_particles;          // no early return: the wave-level insertion needs every lane
+    float4 p = make_float4(-8.f, -8.f, -8.f, 0.f);
+    if (live) {
+        p = pos[i];
         const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
         if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
     }
@@ -82,10 +105,10 @@ __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_partic
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int dx = (int)(p.x - (c == 0 ? 1.0f : 0.5f)), dy = (int)(p.y - (c == 1 ? 1.0f : 0.5f)), dz = (int)(p.z - (c == 2 ? 1.0f : 0.5f));
-        uint32_t old = 0;
-        if (inb(g, dx, dy, dz)) old = atomicExch(heads[c] + cidx(g, dx, dy, dz), i + 1);
-        nxt[c] = old - 1u;
+        const int key = (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1;
+        nxt[c] = wave_list_insert(heads[c], key, i);
     }
+    if (!live) return;
     reinterpret_cast<uint32_t*>(pos)[4 * (size_t)i + 3] = nxt[0];
     next1[i] = nxt[1];
     next2[i] = nxt[2];
@@ -467,11 +490,11 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
                                                 const float* __restrict__ vy, const float* __restrict__ vz, const float4* __restrict__ solid,
                                                 int8_t* __restrict__ marker, uint32_t* __restrict__ heads) {
     const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
-    if (pi >= num_particles) return;
+    const bool live = pi < num_particles;          // dead lanes run the (cheap) arithmetic on a dummy particle: the wave-level list insertion needs all lanes
     const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
     const float inv[3] = {1.0f / gs[0], 1.0f / gs[1], 1.0f / gs[2]};
     const int dimm1[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
-    const float4 p0 = pos[pi];
+    const float4 p0 = live ? pos[pi] : make_float4(1.5f, 1.5f, 1.5f, 0.0f);
     float op[3] = {p0.x, p0.y, p0.z};
     if (solid) {   // :46-65
         const float4 cs = solid_point_clamp(solid, g, op[0] * inv[0], op[1] * inv[1], op[2] * inv[2]);
@@ -549,14 +572,17 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
     }
     // :176-181 marker + density list (dual cell = ivec3(pos - 0.5)).  heads == nullptr: a z-slab group inserts the
     // particles after migration instead (blub_slab.hip.h: k_slab_insert_density_ghosts)
-    uint32_t old = 0;
+    uint32_t nxt = INVALID_LL;
     if (heads) {
-        const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
-        if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
+        if (live) {
+            const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
+            if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
+        }
         const int dx = (int)(np[0] - 0.5f), dy = (int)(np[1] - 0.5f), dz = (int)(np[2] - 0.5f);
-        if (inb(g, dx, dy, dz)) old = atomicExch(heads + cidx(g, dx, dy, dz), pi + 1);
+        nxt = wave_list_insert(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, pi);
     }
-    pos[pi] = make_float4(np[0], np[1], np[2], __uint_as_float(old - 1u));
+    if (!live) return;
+    pos[pi] = make_float4(np[0], np[1], np[2], __uint_as_float(nxt));
     pvx[pi] = make_float4(cx[0], cx[1], cx[2], nv[0]);   // :186-188 (Q2: literal row layout)
     pvy[pi] = make_float4(cy[0], cy[1], cy[2], nv[1]);
     pvz[pi] = make_float4(cz[0], cz[1], cz[2], nv[2]);
