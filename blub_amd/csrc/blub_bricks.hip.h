@@ -541,7 +541,8 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, c
 #pragma unroll
                     for (int comp = 0; comp < 3; ++comp) {
                         if (M(x + (comp == 0), y + (comp == 1), z + (comp == 2)) == CELL_FLUID) continue;
-                        float numV = 0.0f, avgV = 0.0f;
+                        // validity of the 8 in-plane neighbour faces first (registers/LDS only) ...
+                        bool ok[8]; int ci[8]; int k8 = 0; bool any_ok = false;
 #pragma unroll
                         for (int b2 = -1; b2 <= 1; ++b2)
 #pragma unroll
@@ -552,10 +553,20 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, c
                                 else if (comp == 1) { ox = a; oy = 0; oz = b2; }
                                 else { ox = a; oy = b2; oz = 0; }
                                 const int cx = x + ox, cy = y + oy, cz = z + oz;
-                                const bool ok = M(cx, cy, cz) == CELL_FLUID || M(cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
-                                if (ok) { numV += 1.0f; avgV += fv(vel[comp], g, cx, cy, cz); }
+                                ok[k8] = M(cx, cy, cz) == CELL_FLUID || M(cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
+                                ci[k8] = inb(g, cx, cy, cz) ? cidx(g, cx, cy, cz) : -1;     // OOB faces read 0 (and are never valid)
+                                any_ok = any_ok || ok[k8];
+                                ++k8;
                             }
-                        if (numV > 0.0f) vel[comp][base + j] = avgV / numV;
+                        if (!any_ok) continue;
+                        // ... then all loads in one batch (independent, one memory round trip), summed in the reference's order
+                        float val[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) val[k] = (ok[k] && ci[k] >= 0) ? vel[comp][ci[k]] : 0.0f;
+                        float numV = 0.0f, avgV = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) if (ok[k]) { numV += 1.0f; avgV += val[k]; }
+                        vel[comp][base + j] = avgV / numV;
                     }
                 }
             }
