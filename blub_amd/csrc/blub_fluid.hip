@@ -119,8 +119,12 @@ struct blub_fluid {
     uint64_t total_iterations = 0;
     // profiling
     bool prof_enabled = false;
-    struct ProfPending { hipEvent_t a, b; int kc; };
+    struct ProfPending { hipEvent_t a, b; int kc; int stage; uint32_t step; };
     std::vector<ProfPending> prof_pending;
+    struct TraceEvent { int kc; int stage; uint32_t step; double start_us, dur_us; };
+    std::vector<TraceEvent> prof_trace;          // bounded per-launch timeline
+    hipEvent_t prof_origin = nullptr;            // first profiled launch since reset
+    int cur_stage = BLUB_STAGE_COUNT;
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[KC_COUNT] = {};
     uint64_t prof_launches[KC_COUNT] = {};
@@ -135,7 +139,14 @@ static int prof_flush(blub_fluid* h) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
         h->prof_ms[p.kc] += ms; h->prof_launches[p.kc] += 1;
-        h->prof_pool.push_back(p.a); h->prof_pool.push_back(p.b);
+        if (h->prof_trace.size() < 65536) {
+            if (!h->prof_origin) { h->prof_origin = p.a; }
+            float since = 0.f;
+            if (p.a != h->prof_origin) HIP_TRY(hipEventElapsedTime(&since, h->prof_origin, p.a));
+            h->prof_trace.push_back({p.kc, p.stage, p.step, since * 1e3, ms * 1e3});
+        }
+        if (p.a != h->prof_origin) h->prof_pool.push_back(p.a);
+        h->prof_pool.push_back(p.b);
     }
     h->prof_pending.clear();
     return BLUB_OK;
@@ -152,7 +163,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!a) return;
         (void)hipEventRecord(b, h->stream);
-        h->prof_pending.push_back({a, b, kc});
+        h->prof_pending.push_back({a, b, kc, h->cur_stage, h->step_counter});
     }
 };
 #define LAUNCH(h, kc, kernel, grid, block, ...)                                  \
@@ -419,8 +430,10 @@ static int stage_correct(blub_fluid* h) {   // :969-973
 // volume with every brick active, i.e. the stage has the reference's dense semantics on whatever state was written.
 static int run_stage(blub_fluid* h, int stage, float dt, bool standalone) {
     int rc;
+    h->cur_stage = BLUB_STAGE_COUNT;
     if (standalone && stage != BLUB_STAGE_TRANSFER && stage != BLUB_STAGE_BINNING)
         if ((rc = build_lists_from_marker(h)) != BLUB_OK) return rc;
+    h->cur_stage = stage;
     switch (stage) {
     case BLUB_STAGE_TRANSFER: return stage_transfer(h, dt);
     case BLUB_STAGE_DIVERGENCE: return stage_divergence(h);
@@ -457,6 +470,7 @@ static void destroy(blub_fluid* h) {
     for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
+    if (h->prof_origin) (void)hipEventDestroy(h->prof_origin);
     if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -808,7 +822,25 @@ int blub_fluid_profile_reset(blub_fluid* h) {
     REQUIRE_HANDLE(h);
     int rc = blub::prof_flush(h);
     for (int k = 0; k < blub::KC_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_launches[k] = 0; }
+    h->prof_trace.clear();
+    if (h->prof_origin) { h->prof_pool.push_back(h->prof_origin); h->prof_origin = nullptr; }
     return rc;
+}
+int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capacity, int* count_out) {
+    REQUIRE_HANDLE(h);
+    if (!count_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = blub::prof_flush(h);
+    if (rc != BLUB_OK) return rc;
+    const int n = (int)h->prof_trace.size();
+    *count_out = n;
+    if (!events) return BLUB_OK;   // size query
+    for (int i = 0; i < n && i < capacity; ++i) {
+        const auto& t = h->prof_trace[i];
+        memset(&events[i], 0, sizeof(blub_trace_event));
+        strncpy(events[i].name, blub::kKernelClassNames[t.kc], sizeof(events[i].name) - 1);
+        events[i].stage = (uint32_t)t.stage; events[i].step = t.step; events[i].start_us = t.start_us; events[i].duration_us = t.dur_us;
+    }
+    return BLUB_OK;
 }
 int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacity, int* count_out) {
     REQUIRE_HANDLE(h);

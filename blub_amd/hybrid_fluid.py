@@ -56,6 +56,10 @@ class _DeviceViews(C.Structure):
                                           "pressure_from_velocity", "pressure_from_density", "stream")]
 
 
+class _TraceEvent(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("stage", C.c_uint32), ("step", C.c_uint32), ("start_us", C.c_double), ("duration_us", C.c_double)]
+
+
 class _ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -143,6 +147,7 @@ def load_library():
         "blub_fluid_profile_reset": (C.c_int, [vp]),
         "blub_fluid_profile_read": (C.c_int, [vp, C.POINTER(_ProfEntry), C.c_int, C.POINTER(C.c_int)]),
         "blub_fluid_total_solver_iterations": (C.c_uint64, [vp]),
+        "blub_fluid_profile_trace": (C.c_int, [vp, C.POINTER(_TraceEvent), C.c_int, C.POINTER(C.c_int)]),
         "blub_fluid_set_pcg_work_mapping": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_brick_counts": (C.c_int, [vp, vp]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
@@ -382,11 +387,49 @@ class HybridFluid:
     def profile_reset(self):
         _check(self._L, self._L.blub_fluid_profile_reset(self._h))
 
+    def profile_trace(self):
+        n = C.c_int()
+        _check(self._L, self._L.blub_fluid_profile_trace(self._h, None, 0, C.byref(n)))
+        ev = (_TraceEvent * max(n.value, 1))()
+        _check(self._L, self._L.blub_fluid_profile_trace(self._h, ev, n.value, C.byref(n)))
+        return [{"name": ev[i].name.decode(), "stage": int(ev[i].stage), "step": int(ev[i].step), "start_us": float(ev[i].start_us),
+                 "duration_us": float(ev[i].duration_us)} for i in range(n.value)]
+
     def profile_read(self):
         ents = (_ProfEntry * PROF_MAX)()
         n = C.c_int()
         _check(self._L, self._L.blub_fluid_profile_read(self._h, ents, PROF_MAX, C.byref(n)))
         return {ents[i].name.decode(): {"launches": int(ents[i].launches), "total_ms": float(ents[i].total_ms)} for i in range(n.value)}
+
+
+# wgpu_profiler! scope labels of HybridFluid::step (hybrid_fluid.rs:798-973), indexed by blub_stage
+REFERENCE_SCOPES = ["transfer & divergence compute", "compute divergence", "primary pressure solver (divergence)", "Particle Binning",
+                    "make velocity grid divergence free + extrapolate velocity grid", "advect particles & write new linked list grid",
+                    "density projection: compute density error via gather", "secondary pressure solver (density)",
+                    "compute position change + extrapolate velocity grid", "correct particle density error", "brick work lists"]
+
+
+def write_chrome_trace(fluid, path):
+    """Dump the profiled launches as a chrome-trace JSON like the reference's `simulation-trace.json` (gui/mod.rs:487-491):
+    one track per simulation step, scopes named after the reference's wgpu_profiler! labels, kernels nested inside."""
+    import json
+    events = fluid.profile_trace()
+    out = []
+    for e in events:
+        stage = REFERENCE_SCOPES[min(e["stage"], len(REFERENCE_SCOPES) - 1)]
+        out.append({"name": e["name"], "cat": stage, "ph": "X", "ts": e["start_us"], "dur": e["duration_us"], "pid": 1, "tid": 1,
+                    "args": {"step": e["step"], "scope": stage}})
+    # enclosing scopes (one per stage and step)
+    groups = {}
+    for e in events:
+        k = (e["step"], e["stage"])
+        a = groups.setdefault(k, [e["start_us"], e["start_us"] + e["duration_us"]])
+        a[0] = min(a[0], e["start_us"]); a[1] = max(a[1], e["start_us"] + e["duration_us"])
+    for (step, stage), (t0, t1) in groups.items():
+        out.append({"name": REFERENCE_SCOPES[min(stage, len(REFERENCE_SCOPES) - 1)], "cat": "scope", "ph": "X", "ts": t0, "dur": t1 - t0, "pid": 1, "tid": 0, "args": {"step": step}})
+    with open(path, "w") as f:
+        json.dump({"traceEvents": sorted(out, key=lambda e: e["ts"]), "displayTimeUnit": "ns"}, f)
+    return len(events)
 
 
 class Scene:

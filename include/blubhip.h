@@ -194,6 +194,15 @@ typedef struct blub_prof_entry {
 int blub_fluid_profile_enable(blub_fluid* h, int enabled);
 int blub_fluid_profile_reset(blub_fluid* h);
 int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacity, int* count_out); /* blocks */
+/* Per-launch timeline of the profiled launches since the last reset (the data behind the reference's chrome-trace dump,
+ * gui/mod.rs:487-491 / wgpu-profiler): start relative to the first profiled launch, both in microseconds. */
+typedef struct blub_trace_event {
+    char name[48];        /* kernel class */
+    uint32_t stage;       /* blub_stage the launch belongs to (BLUB_STAGE_COUNT = list building / other) */
+    uint32_t step;        /* step counter at enqueue time */
+    double start_us, duration_us;
+} blub_trace_event;
+int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capacity, int* count_out); /* blocks */
 /* Work mapping of the PCG kernels: -1 = automatic (brick lists when < 30 % of the bricks hold fluid, dense rows otherwise),
  * 0 = dense rows, 1 = brick lists.  A performance knob only: both mappings run the same per-cell arithmetic (the
  * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise). */

@@ -82,3 +82,40 @@ def test_scene_json_to_fluid_matches_manual_construction():
         assert np.abs(a[:, [0, 2]] - b[:, [0, 2]]).max() < 1e-5
     finally:
         f.close()
+
+
+def test_profile_trace_and_chrome_trace(tmp_path):
+    """Observability parity: per-launch timeline with the reference's scope labels as chrome-trace JSON."""
+    import json
+    import os
+    import blub_amd
+    from blub_amd.hybrid_fluid import write_chrome_trace
+    from tests.conftest import ROOT
+    scene = blub_amd.Scene(path=os.path.join(ROOT, "scenes", "corner_dams_128.json"))
+    f = scene.fluid()
+    try:
+        scene.step(util.DT)
+        f.profile_enable(True)
+        f.profile_reset()
+        for _ in range(2):
+            scene.step(util.DT)
+        ev = f.profile_trace()
+        f.profile_enable(False)
+        names = {e["name"] for e in ev}
+        assert {"build_lists", "gather_velocity", "pcg_dir", "pcg_update", "advect", "correct", "extrapolate"} <= names
+        assert len(ev) > 250 and all(e["duration_us"] > 0 for e in ev)
+        starts = [e["start_us"] for e in ev]
+        assert starts == sorted(starts) and starts[0] == 0.0
+        assert {e["step"] for e in ev} == {1, 2}
+        per = f.profile_read()
+        assert abs(sum(e["duration_us"] for e in ev if e["name"] == "pcg_dir") - per["pcg_dir"]["total_ms"] * 1e3) < 1.0
+        path = tmp_path / "simulation-trace.json"
+        n = write_chrome_trace(f, str(path))
+        doc = json.load(open(path))
+        assert n == len(ev) and len(doc["traceEvents"]) > n
+        assert any(e["name"] == "primary pressure solver (divergence)" for e in doc["traceEvents"])
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            write_chrome_trace(f, os.path.join(out, "simulation-trace_corner_dams_128_2steps.json"))
+    finally:
+        f.close()
