@@ -91,8 +91,9 @@ def dense_pcg_benchmark(n=256, iterations=32):
             "iter_bytes_fused": fused, "iter_frac_fused": round(fused / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
 
 
-def cpu_baseline(scene_path, dt, budget_steps=2):
-    """The CPU oracle (a restatement of the reference, kind "port") on the same scene: bounded sample of whole steps."""
+def cpu_baseline(scene_path, dt, budget_steps=24):
+    """The CPU oracle (a restatement of the reference, kind "port") on the same scene: a bounded sample of whole steps
+    (~10 s of CPU work on the 16 usable cores of the GPU box)."""
     import blub_amd
     from oracle.oracle import Oracle
     sc = blub_amd.Scene.parse(path=scene_path).config
