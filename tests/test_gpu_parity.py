@@ -461,3 +461,45 @@ def test_z_slab_decomposition_matches_single_domain(slabs):
         single.close()
         rerun.close()
         group.close()
+
+
+def test_partial_bricks_odd_grid_full_step():
+    """Grid dimensions that are not multiples of the 16x8x4 brick (only x % 4 == 0 is required): partial bricks at the
+    upper domain faces, full step against the oracle with converged solves."""
+    dim = (36, 30, 22)
+    pos, vel, maxp = util.make_dam(*dim, fill=(0.7, 0.6, 1.0), seed=11)
+    o, h = util.new_pair(*dim, maxp, solver=dict(error_tolerance=0.0, max_num_iterations=150, error_check_frequency=8))
+    try:
+        o.set_particles(pos, *vel)
+        h.set_particles(pos, *vel)
+        for _ in range(2):
+            o.step(util.DT)
+            h.step(util.DT)
+        po, ph = o.get_particles()[0][:, :3], h.get_particles()[0][:, :3]
+        d = np.abs(ph - po).max(axis=1)
+        print("odd grid: median %.3g p99 %.3g max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
+        assert np.median(d) < 2e-4 and np.quantile(d, 0.99) < 3e-3 and d.max() < 0.1
+        assert (h.read_volume("marker") != o.read_volume("marker")).mean() < 2e-3
+        bc = h.brick_counts()
+        assert bc["total"] == 3 * 4 * 6
+    finally:
+        h.close()
+
+
+def test_empty_fluid_steps_are_harmless():
+    import blub_amd
+    h = blub_amd.HybridFluid((32, 32, 32), 128)
+    try:
+        h.set_gravity_grid((0, -981.0, 0))
+        for _ in range(3):
+            h.step(util.DT)
+        h.synchronize()
+        assert h.num_particles() == 0
+        for v in ("vel_x", "vel_y", "vel_z", "pressure_velocity", "pressure_density"):
+            a = h.read_volume(v)
+            assert np.all(a == 0) and np.all(np.isfinite(a))
+        m = h.read_volume("marker")
+        assert np.all(m[1:-1, 1:-1, 1:-1] == -1) and np.all(m[0] == 0) and np.all(m[:, 0] == 0) and np.all(m[:, :, -1] == 0)
+        assert h.solver_stats(0)[1] in range(0, 33)
+    finally:
+        h.close()
