@@ -121,7 +121,8 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
 // come out in brick (= memory) order, deterministically.
 __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uint8_t* __restrict__ brick_flags, const uint4* __restrict__ block_counts, int nblocks,
                                                          uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
-                                                         uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq) {
+                                                         uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq,
+                                                         uint8_t* __restrict__ brick_fluid_to_clear, BrickCounts* __restrict__ host_snapshot) {
     __shared__ uint32_t sm[17];
     __shared__ uint32_t base[4], total[4];
     if (threadIdx.x < 64) {   // one wave sums the block counts: lanes stride over the blocks in order
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uin
     __syncthreads();
     const int b = blockIdx.x * 1024 + threadIdx.x;
     const uint32_t fl = b < bg.nb ? brick_flags[b] : 0u;
+    if (b < bg.nb && brick_fluid_to_clear) brick_fluid_to_clear[b] = 0;   // consumed by k_bricks_classify: ready for the next build
     uint32_t t;
     const uint32_t of = block_exclusive_scan_1024((fl & BF_FLUID) != 0, sm, t);
     const uint32_t oa = block_exclusive_scan_1024((fl & BF_ACTIVE) != 0, sm, t);
@@ -147,7 +149,15 @@ __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uin
     if (fl & BF_FLUID) list_fluid[base[0] + of] = (uint32_t)b;
     if (fl & BF_ACTIVE) list_active[base[1] + oa] = (uint32_t)b;
     if (fl & BF_RESET) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { counts->n_fluid = total[0]; counts->n_active = total[1]; counts->n_reset = total[2]; counts->n_stale = total[3]; counts->seq = seq; counts->seq_check = seq; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        BrickCounts c; c.n_fluid = total[0]; c.n_active = total[1]; c.n_reset = total[2]; c.n_stale = total[3]; c.seq = seq; c.pad0 = 0; c.pad1 = 0; c.seq_check = seq;
+        *counts = c;
+        if (host_snapshot) {   // pinned host ring slot (path selection only): payload first, tags last
+            host_snapshot->n_fluid = c.n_fluid; host_snapshot->n_active = c.n_active; host_snapshot->n_reset = c.n_reset; host_snapshot->n_stale = c.n_stale;
+            __threadfence_system();
+            host_snapshot->seq = seq; host_snapshot->seq_check = seq;
+        }
+    }
 }
 
 // ---- static marker pattern: transfer_clear.comp:10-14 + transfer_set_boundary_marker.comp:11-19 --------------------

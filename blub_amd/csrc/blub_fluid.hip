@@ -91,6 +91,7 @@ struct blub_fluid {
     uint4* brick_block_counts = nullptr;
     BrickCounts* counts = nullptr;            // device
     BrickCounts* counts_host = nullptr;       // pinned ring of COUNTS_RING snapshots (path selection only), tagged by seq
+    BrickCounts* counts_host_dev = nullptr;   // the same ring as the device sees it (kernels write the snapshots directly)
     uint32_t counts_seq = 0;                  // number of list builds enqueued so far
     // run-ahead throttle: the device writes the number of the last finished step into pinned host memory
     volatile uint32_t* steps_done_host = nullptr;
@@ -112,6 +113,7 @@ struct blub_fluid {
     bool pressure_initialised[2] = {false, false};
     // statistics read-back ring (pressure_solver.rs:118-126, 148-209)
     PcgCtrl* stats_host[2] = {nullptr, nullptr};   // pinned ring of STATS_RING control-block snapshots, tagged by seq
+    PcgCtrl* stats_host_dev[2] = {nullptr, nullptr};
     uint32_t solve_seq[2] = {0, 0};                // number of solves enqueued so far
     std::deque<PendingStat> stats_pending[2];
     std::deque<float> stats_dt[2];
@@ -193,16 +195,12 @@ static int copy_sync(blub_fluid* h, void* dst, const void* src, size_t bytes, hi
 // Asynchronous read-backs never use hipEvents: querying a pending event makes the runtime push marker packets into the
 // stream, which costs milliseconds per step once the host runs ahead of the GPU.  Instead every snapshot carries the
 // sequence number of the enqueue that produced it and the host simply polls the pinned (coherent) ring.
-static int snapshot_counts(blub_fluid* h) {
-    const int slot = (int)(h->counts_seq % COUNTS_RING);
-    HIP_TRY(hipMemcpyAsync(&h->counts_host[slot], h->counts, sizeof(BrickCounts), hipMemcpyDeviceToHost, h->stream));
-    return BLUB_OK;
-}
+
 // phase: COMPACT_STEP_A (before P2G) / COMPACT_STEP_B (after advection) from the particle positions;
 // COMPACT_ALL_ACTIVE (stand-alone stage calls): FLUID bricks from the marker volume, every brick active
 static int build_lists(blub_fluid* h, int phase) {
     ProfScope ps(h, KC_BRICK_LISTS);
-    HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
+    // (brick_fluid is all zero here: allocated zeroed, and every build's scatter kernel clears it again)
     if (phase == COMPACT_ALL_ACTIVE)
         hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
     else if (h->num_particles + h->num_ghost)
@@ -213,9 +211,9 @@ static int build_lists(blub_fluid* h, int phase) {
     hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, (const uint8_t*)h->brick_fluid, h->brick_active,
                        h->brick_touched, h->brick_flags, h->brick_block_counts);
     hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
-                       h->list_fluid, h->list_active, h->list_reset, h->counts, h->counts_seq);
+                       h->list_fluid, h->list_active, h->list_reset, h->counts, h->counts_seq, h->brick_fluid, h->counts_host_dev + (h->counts_seq % COUNTS_RING));
     if (phase == COMPACT_STEP_A) h->all_touched = false;
-    return snapshot_counts(h);
+    return BLUB_OK;
 }
 static int build_lists_from_particles(blub_fluid* h, int phase) { return build_lists(h, phase); }
 static int build_lists_from_marker(blub_fluid* h) { return build_lists(h, COMPACT_ALL_ACTIVE); }
@@ -257,11 +255,12 @@ static int stage_divergence(blub_fluid* h) {   // :836-840
     return BLUB_OK;
 }
 
-static int enqueue_stats_readback(blub_fluid* h, int which, float dt) {   // enqueue_error_buffer_read, pressure_solver.rs:176-191
+// `written_by_kernel`: k_pcg_finalize already stored the sample into the pinned ring slot of this solve
+static int enqueue_stats_readback(blub_fluid* h, int which, float dt, bool written_by_kernel = false) {   // enqueue_error_buffer_read, pressure_solver.rs:176-191
     if ((int)h->stats_pending[which].size() < STATS_RING) {
         const uint32_t seq = h->solve_seq[which];
         const int slot = (int)(seq % STATS_RING);
-        HIP_TRY(hipMemcpyAsync(&h->stats_host[which][slot], h->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, h->stream));
+        if (!written_by_kernel) HIP_TRY(hipMemcpyAsync(&h->stats_host[which][slot], h->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, h->stream));
         h->stats_pending[which].push_back({seq, slot});
         h->stats_dt[which].push_back(dt);
     }   // else: "No more error buffer available" -- the reference warns and skips the sample (:188-190)
@@ -308,10 +307,10 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     }
     const float tol = c.error_tolerance / dt;   // :197
     PcgCtrl* ctrl = h->ctrl[which];
-    HIP_TRY(hipMemsetAsync(ctrl, 0, sizeof(PcgCtrl), h->stream));
     h->solve_seq[which] += 1;
     int rc;
     if (h->precond_mode != BLUB_PRECOND_ZERO) {
+        HIP_TRY(hipMemsetAsync(ctrl, 0, sizeof(PcgCtrl), h->stream));
         if ((rc = stage_solve_lod0(h, which, dt)) != BLUB_OK) return rc;
         return enqueue_stats_readback(h, which, dt);
     }
@@ -325,6 +324,9 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     const int freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };   // :672-673 (the i == max case is k_pcg_finalize)
     float* sbuf[2] = {h->search, h->aux};
+    // the statistics sample of this solve goes straight into its pinned ring slot (if the ring has room)
+    const bool ring_free = (int)h->stats_pending[which].size() < STATS_RING;
+    PcgCtrl* stat_slot = ring_free ? h->stats_host_dev[which] + (h->solve_seq[which] % STATS_RING) : (PcgCtrl*)nullptr;
     float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
     float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
     if (sparse) {
@@ -333,7 +335,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         int np = std::min((h->bg.nb + 1) / 2, PCG_GRID_BRICKS);
         if (have) np = std::max(64, std::min(np, (int)((bc.n_active * 3u / 2u + 1u) / 2u)));
         const dim3 grid(np), block(PCG_B_THREADS);
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd);
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl);
         for (int i = 0; i <= maxit; ++i) {
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
@@ -344,14 +346,14 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
                    (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
         }
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which]);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
     } else {
         const int np = h->pcg_grid_z;
         const dim3 grid(np);
 #define BLUB_LAUNCH_Z(TT)                                                                                                                                       \
         {                                                                                                                                                       \
             const dim3 block(TT);                                                                                                                               \
-            LAUNCH(h, KC_PCG_INIT, k_pcg_init_z<TT>, grid, block, h->gz, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags);   \
+            LAUNCH(h, KC_PCG_INIT, k_pcg_init_z<TT>, grid, block, h->gz, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags, ctrl);   \
             for (int i = 0; i <= maxit; ++i) {                                                                                                                  \
                 if (i == 0)                                                                                                                                     \
                     LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
@@ -365,11 +367,11 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         }
         if (h->gz.T == 256) BLUB_LAUNCH_Z(256) else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024) else BLUB_LAUNCH_Z(512)
 #undef BLUB_LAUNCH_Z
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which]);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
     }
     // the search direction of a full-length solve ends in sbuf[maxit & 1]; keep BLUB_VOLUME_SEARCH pointing at it
     if (maxit & 1) std::swap(h->search, h->aux);
-    return enqueue_stats_readback(h, which, dt);
+    return enqueue_stats_readback(h, which, dt, true);
 }
 
 static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
@@ -552,11 +554,13 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
         else { memset(hp, 0, 64); h->steps_done_host = (volatile uint32_t*)hp; }
     }
     if (rc == BLUB_OK) {
-        if (hipHostMalloc((void**)&h->counts_host, COUNTS_RING * sizeof(BrickCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+        if (hipHostMalloc((void**)&h->counts_host, COUNTS_RING * sizeof(BrickCounts), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&h->counts_host_dev, h->counts_host, 0) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
         else memset(h->counts_host, 0, COUNTS_RING * sizeof(BrickCounts));
     }
     for (int w = 0; w < 2 && rc == BLUB_OK; ++w) {
-        if (hipHostMalloc((void**)&h->stats_host[w], STATS_RING * sizeof(PcgCtrl)) != hipSuccess) { rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed"); break; }
+        if (hipHostMalloc((void**)&h->stats_host[w], STATS_RING * sizeof(PcgCtrl), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&h->stats_host_dev[w], h->stats_host[w], 0) != hipSuccess) { rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed"); break; }
         memset(h->stats_host[w], 0, STATS_RING * sizeof(PcgCtrl));
     }
     if (rc != BLUB_OK) { std::string keep = g_last_error; destroy(h); g_last_error = keep; return rc; }

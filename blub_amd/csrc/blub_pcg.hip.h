@@ -240,8 +240,9 @@ __device__ __forceinline__ bool pcg_upd_prologue(const PcgCtrl* __restrict__ ctr
 constexpr int PCG_B_THREADS = 2 * BRICK_THREADS;
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                               const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
-                                                              float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd) {
+                                                              float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, PcgCtrl* __restrict__ ctrl_to_clear) {
     __shared__ float sm[8];
+    if (ctrl_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { PcgCtrl z{}; *ctrl_to_clear = z; }   // nobody reads it before the next kernel
     float acc = 0.0f;
     const uint32_t n = *count;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
@@ -305,13 +306,19 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_b(BrickGeom bg, co
 
 // After the last update (i == max_num_iterations): statistics are written unconditionally if nothing converged before
 // (pressure_reduce.comp:84: MaxNumSolverIterations == iterationIdx).
-__global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, int iteration, uint32_t seq) {
+__global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, int iteration, uint32_t seq,
+                                                      PcgCtrl* __restrict__ host_snapshot) {
     __shared__ float2 sm2[4];
     const int done = ctrl->done;
     const float2 red = reduce_partials2<256>(part_upd, num_part, sm2);
     if (threadIdx.x == 0) {
         if (!done) { ctrl->max_err = red.y; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
         ctrl->seq = seq;
+        if (host_snapshot) {   // statistics read-back (pressure_solver.rs:176-191) written straight into the pinned ring: payload, fence, tag
+            host_snapshot->max_err = ctrl->max_err; host_snapshot->num_iter = ctrl->num_iter;
+            __threadfence_system();
+            host_snapshot->seq = seq;
+        }
     }
 }
 // end-of-step marker written straight into pinned host memory (run-ahead throttle, see blub_fluid_step)

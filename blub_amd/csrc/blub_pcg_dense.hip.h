@@ -228,8 +228,10 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
 // init for this mapping: same per-quad body as the row kernel, tile flags indexed by the z-march tiles
 template <int T>
 __global__ __launch_bounds__(T) void k_pcg_init_z(PcgGeomZ gz, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
-                                                  float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, uint8_t* __restrict__ tile_flags) {
+                                                  float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, uint8_t* __restrict__ tile_flags,
+                                                  PcgCtrl* __restrict__ ctrl_to_clear) {
     __shared__ float sm[T / 64 + 1];
+    if (ctrl_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { PcgCtrl z{}; *ctrl_to_clear = z; }
     float acc = 0.0f;
     const Grid g = gz.g;
     const int padded = ((gz.tiles + 7) >> 3) << 3;

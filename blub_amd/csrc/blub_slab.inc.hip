@@ -209,7 +209,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
         HIP_TRY(hipMemsetAsync(h->ctrl[which], 0, sizeof(PcgCtrl), G->stream));
         h->solve_seq[which] += 1;
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
-               reinterpret_cast<float2*>(h->part_sigma[0]));
+               reinterpret_cast<float2*>(h->part_sigma[0]), (PcgCtrl*)nullptr);
     }
     if ((rc = reduce_upd()) != BLUB_OK) return rc;
     if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1)) != BLUB_OK) return rc;
@@ -240,7 +240,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), h->ctrl[which], (const float2*)G->ex[i].packed, 1, maxit, h->solve_seq[which]);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), h->ctrl[which], (const float2*)G->ex[i].packed, 1, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
         if (maxit & 1) std::swap(h->search, h->aux);
         if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
     }
