@@ -109,6 +109,10 @@ struct blub_fluid {
     float *part_sas = nullptr, *part_sigma[2] = {nullptr, nullptr}, *part_max = nullptr;
     uint8_t* tile_flags = nullptr;
     PcgCtrl* ctrl[2] = {nullptr, nullptr};
+    PcgTailSync* tail_sync[2] = {nullptr, nullptr};
+    bool use_tail = true;            // persistent tail kernel for brick-mapped solves (BLUB_PCG_TAIL=0 disables)
+    int tail_margin_checks = 1;
+    int tail_first_forced = -1;      // test hook (BLUB_PCG_TAIL_FIRST): hand over to the tail after exactly this many launched iterations
     blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
     bool pressure_initialised[2] = {false, false};
     // statistics read-back ring (pressure_solver.rs:118-126, 148-209)
@@ -335,8 +339,17 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         int np = std::min((h->bg.nb + 1) / 2, PCG_GRID_BRICKS);
         if (have) np = std::max(64, std::min(np, (int)((bc.n_active * 3u / 2u + 1u) / 2u)));
         const dim3 grid(np), block(PCG_B_THREADS);
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl);
-        for (int i = 0; i <= maxit; ++i) {
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which]);
+        // Launch as many iterations as the last few solves needed (+ one check interval); a persistent tail kernel covers the
+        // rest: a single no-op launch when the solve has converged by then (the rule), a grid-barrier loop otherwise.
+        int launched = maxit + 1;
+        if (h->use_tail && freq > 0 && !h->stats_history[which].empty()) {
+            int recent = 0, k = 0;
+            for (auto it2 = h->stats_history[which].rbegin(); it2 != h->stats_history[which].rend() && k < 4; ++it2, ++k) recent = std::max(recent, (int)it2->iteration_count);
+            if (recent >= 0 && recent < maxit) launched = std::min(maxit + 1, (recent / freq + h->tail_margin_checks) * freq + 1);   // through `margin` checks past the recent maximum
+        }
+        if (h->use_tail && h->tail_first_forced >= 0) launched = std::min(maxit + 1, h->tail_first_forced);
+        for (int i = 0; i < launched; ++i) {
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
                        (const float2*)part_upd, part_dir, np, ctrl, tol, i, 0);
@@ -346,7 +359,11 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
                    (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
         }
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
+        if (launched <= maxit)
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_tail_b, dim3(std::min(np, 256)), block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, h->residual, sbuf[0], sbuf[1], p,
+                   part_upd, part_dir, np, ctrl, tol, launched, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
+        else
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
     } else {
         const int np = h->pcg_grid_z;
         const dim3 grid(np);
@@ -468,6 +485,7 @@ static void destroy(blub_fluid* h) {
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
     if (h->steps_done_host) (void)hipHostFree((void*)h->steps_done_host);
+    F(h->tail_sync[0]); F(h->tail_sync[1]);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
     for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -540,6 +558,10 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->part_sas, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[0], 2 * PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[1], PCG_GRID_MAX));
     A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, (size_t)std::max(gm.tiles, h->gz.tiles) + 8));
     A(dev_alloc_zero(h->stream, &h->ctrl[0], 1)); A(dev_alloc_zero(h->stream, &h->ctrl[1], 1));
+    A(dev_alloc_zero(h->stream, &h->tail_sync[0], 1)); A(dev_alloc_zero(h->stream, &h->tail_sync[1], 1));
+    if (const char* e = getenv("BLUB_PCG_TAIL")) h->use_tail = atoi(e) != 0;
+    if (const char* e = getenv("BLUB_PCG_TAIL_FIRST")) h->tail_first_forced = atoi(e);
+    if (const char* e = getenv("BLUB_PCG_TAIL_MARGIN")) h->tail_margin_checks = std::max(0, atoi(e));
     A(dev_alloc_zero(h->stream, &h->dvol, h->N));
     BrickGeom& bg = h->bg;
     bg.g = h->g; bg.nbx = (h->g.nx + BX - 1) / BX; bg.nby = (h->g.ny + BY - 1) / BY; bg.nbz = (h->g.nz + BZ - 1) / BZ; bg.nb = bg.nbx * bg.nby * bg.nbz;

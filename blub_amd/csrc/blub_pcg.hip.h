@@ -27,6 +27,7 @@ __device__ __forceinline__ int dbyte(uint32_t packed, int j) { return (int)((pac
 __device__ __forceinline__ bool any_fluid_d(uint32_t packed) { return (packed & 0x80808080u) != 0u; }
 
 struct QuadD { uint32_t c, ym, yp, zm, zp; int xm, xp; };
+struct PcgTailSync { uint32_t arrivals; int timed_out; uint32_t pad[2]; };   // grid-barrier state of k_pcg_tail_b, zeroed by the init kernel of every solve
 __device__ __forceinline__ void load_quad_d(const uint8_t* __restrict__ D, const Grid& g, int base, int x0, int y, int z, QuadD& q) {
     const int plane = g.nx * g.ny;
     q.xm = x0 > 0 ? (int)D[base - 1] : 0;
@@ -240,9 +241,11 @@ __device__ __forceinline__ bool pcg_upd_prologue(const PcgCtrl* __restrict__ ctr
 constexpr int PCG_B_THREADS = 2 * BRICK_THREADS;
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                               const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
-                                                              float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, PcgCtrl* __restrict__ ctrl_to_clear) {
+                                                              float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, PcgCtrl* __restrict__ ctrl_to_clear,
+                                                              PcgTailSync* __restrict__ sync_to_clear) {
     __shared__ float sm[8];
     if (ctrl_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { PcgCtrl z{}; *ctrl_to_clear = z; }   // nobody reads it before the next kernel
+    if (sync_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { PcgTailSync z{}; *sync_to_clear = z; }
     float acc = 0.0f;
     const uint32_t n = *count;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
@@ -302,6 +305,103 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_b(BrickGeom bg, co
     const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
     const float mx = block_reduce<PCG_B_THREADS, true>(emax, sm);
     if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, mx);
+}
+
+// ---- persistent tail of a brick-mapped solve -------------------------------------------------------------------------
+// The host launches iterations [0, first_iteration) as separate kernels (their count comes from the iteration counts of
+// the last few steps) and then this ONE kernel for iterations [first_iteration, max_iterations].  Normally the solve has
+// converged by then and the kernel is a single no-op launch instead of 2 x (max - first) of them.  Otherwise it runs the
+// remaining iterations itself: the same per-quad bodies, with an agent-scope grid barrier between the phases
+// (cdna_hip_programming.md G16: stores -> __syncthreads -> lane-0 release fence -> relaxed agent atomic; relaxed poll ->
+// acquire fence -> __syncthreads -> plain loads).  The grid is 256 blocks (one per CU, always co-resident) and every
+// spin is bounded: on a timeout the kernel reports num_iter = -1 instead of hanging.
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, int* timed_out_flag) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22) || __hip_atomic_load(timed_out_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+        }
+        if (!ok) __hip_atomic_store(timed_out_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                              const uint8_t* __restrict__ dvol, float* r, float* s_even, float* s_odd, float* p,
+                                                              float2* part_upd, float* part_dir, int num_part_in, PcgCtrl* ctrl, float tolerance,
+                                                              int first_iteration, int max_iterations, int check_frequency, PcgTailSync* sync,
+                                                              uint32_t seq, PcgCtrl* host_snapshot) {
+    __shared__ float sm[8];
+    __shared__ float2 sm2[4];
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    auto publish = [&]() {   // what k_pcg_finalize does
+        ctrl->seq = seq;
+        if (host_snapshot) { host_snapshot->max_err = ctrl->max_err; host_snapshot->num_iter = ctrl->num_iter; __threadfence_system(); host_snapshot->seq = seq; }
+    };
+    if (ctrl->done) { if (leader) publish(); return; }
+    const uint32_t n = *count;
+    const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    const uint32_t nblocks = gridDim.x;
+    uint32_t barrier_no = 0;
+    float sigma_prev = ctrl->sigma[(first_iteration + 1) & 1];
+    int num_part = num_part_in;      // the first reduction reads what the LAUNCHED update kernel wrote
+    for (int it = first_iteration; it <= max_iterations; ++it) {
+        // ---- KD(it)
+        const float2 red = reduce_partials2<PCG_B_THREADS>(part_upd, num_part, sm2);
+        const int prev = it - 1;
+        const bool check_prev = prev > 0 && check_frequency > 0 && prev % check_frequency == 0;
+        if (it > 0 && check_prev && red.y < tolerance) {
+            if (leader) { ctrl->max_err = red.y; ctrl->num_iter = (float)prev; ctrl->done = 1; publish(); }
+            return;
+        }
+        const float beta = it > 0 ? eps_div(red.x, sigma_prev) : 0.0f;
+        const float sigma = red.x;
+        const float* s_in = ((it - 1) & 1) ? s_odd : s_even;
+        float* s_out = (it & 1) ? s_odd : s_even;
+        float acc = 0.0f;
+        for (uint32_t i = blockIdx.x * 2 + half; i < n; i += nblocks * 2) {
+            int x0, y, z;
+            DirLoad L;
+            L.valid = brick_quad(bg, list[i], t, x0, y, z);
+            if (L.valid) { if (it == 0) dir_load<true>(bg.g, dvol, r, s_even, cidx(bg.g, x0, y, z), x0, y, z, L); else dir_load<false>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L); }
+            if (it == 0) dir_compute<true>(L, s_out, beta, acc); else dir_compute<false>(L, s_out, beta, acc);
+        }
+        const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
+        if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
+        if (!grid_barrier(&sync->arrivals, nblocks * ++barrier_no, &sync->timed_out)) { if (leader) { ctrl->num_iter = -1.0f; ctrl->done = 1; publish(); } return; }
+        // ---- KU(it)
+        const float sas = reduce_partials<PCG_B_THREADS, false>(part_dir, (int)nblocks, sm);
+        const float alpha = eps_div(sigma, sas);
+        float acc2 = 0.0f, emax = 0.0f;
+        const float* s_cur = (it & 1) ? s_odd : s_even;
+        for (uint32_t i = blockIdx.x * 2 + half; i < n; i += nblocks * 2) {
+            int x0, y, z;
+            UpdLoad L;
+            L.valid = brick_quad(bg, list[i], t, x0, y, z);
+            if (L.valid) upd_load(bg.g, dvol, s_cur, p, r, cidx(bg.g, x0, y, z), x0, y, z, L);
+            upd_compute(L, p, r, alpha, acc2, emax);
+        }
+        const float tot2 = block_reduce<PCG_B_THREADS, false>(acc2, sm);
+        const float mx2 = block_reduce<PCG_B_THREADS, true>(emax, sm);
+        __syncthreads();   // every thread has read the incoming partials (first pass: more entries than blocks) before they are overwritten
+        if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot2, mx2);
+        if (!grid_barrier(&sync->arrivals, nblocks * ++barrier_no, &sync->timed_out)) { if (leader) { ctrl->num_iter = -1.0f; ctrl->done = 1; publish(); } return; }
+        sigma_prev = sigma;
+        num_part = (int)nblocks;
+    }
+    // i == max_num_iterations reached without convergence (pressure_reduce.comp:84)
+    const float2 fin = reduce_partials2<PCG_B_THREADS>(part_upd, num_part, sm2);
+    if (leader) { ctrl->max_err = fin.y; ctrl->num_iter = (float)max_iterations; ctrl->done = 1; publish(); }
 }
 
 // After the last update (i == max_num_iterations): statistics are written unconditionally if nothing converged before

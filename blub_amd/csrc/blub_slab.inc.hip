@@ -209,7 +209,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
         HIP_TRY(hipMemsetAsync(h->ctrl[which], 0, sizeof(PcgCtrl), G->stream));
         h->solve_seq[which] += 1;
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
-               reinterpret_cast<float2*>(h->part_sigma[0]), (PcgCtrl*)nullptr);
+               reinterpret_cast<float2*>(h->part_sigma[0]), (PcgCtrl*)nullptr, (PcgTailSync*)nullptr);
     }
     if ((rc = reduce_upd()) != BLUB_OK) return rc;
     if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1)) != BLUB_OK) return rc;

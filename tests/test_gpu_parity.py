@@ -503,3 +503,40 @@ def test_empty_fluid_steps_are_harmless():
         assert h.solver_stats(0)[1] in range(0, 33)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("first", [0, 3, 9])
+def test_pcg_persistent_tail_kernel(first, monkeypatch):
+    """Brick-mapped solves hand the iterations the host did not launch to one persistent kernel (grid barriers between the
+    phases).  Forced hand-over after `first` launched iterations: the solve must equal the oracle exactly as the fully
+    launched one does (fixed 14 iterations, and a converging run that stops inside the tail)."""
+    import blub_amd
+    monkeypatch.setenv("BLUB_PCG_TAIL_FIRST", str(first))
+    pos, vel, maxp = util.make_dam(*GRID)
+    o, h = util.new_pair(*GRID, maxp)
+    try:
+        h.set_pcg_work_mapping("bricks")
+        o.set_particles(pos, *vel)
+        run_until(o, "solve_velocity")
+        util.copy_state(o, h)
+        state = {v: o.read_volume(v) for v in ("residual", "pressure_velocity", "search")}
+        fluid = o.read_volume("marker") == 1
+        for cfg in (dict(error_tolerance=0.0, max_num_iterations=14, error_check_frequency=4),
+                    dict(error_tolerance=0.26, max_num_iterations=64, error_check_frequency=4)):
+            for f in (o, h):
+                f.set_solver_config(0, **cfg)
+                for v, a in state.items():
+                    f.write_volume(v, a)
+            o.reset_pressure_cleared(0, False)
+            h.mark_pressure_initialised(0, False)
+            o.run_stage("solve_velocity", util.DT)
+            h.run_stage("solve_velocity", util.DT)
+            eo, io = o.solver_stats(0)
+            eh, ih = h.solver_stats(0)
+            assert ih == io and ih >= 0, (cfg, (eh, ih), (eo, io))
+            assert abs(eh - eo) <= 2e-3 * eo
+            for name in ("pressure_velocity", "residual"):
+                a, b = h.read_volume(name), o.read_volume(name)
+                util.assert_close(name, a[fluid], b[fluid], abs_=3e-4 * np.abs(b[fluid]).max())
+    finally:
+        h.close()
