@@ -117,6 +117,20 @@ def cpu_baseline(scene_path, dt, budget_steps=24):
             "pcg_iters_per_sec": round((it1 - it0) / max(s1 - s0, 1e-9), 2)}
 
 
+def fallback_to_replicas(reason):
+    """N > 1 only: re-execute this rank in replicas mode (same PID, so the launcher keeps tracking it).  Used when the z-slab
+    group fails or stalls on one rank: the multi-rank RCCL transport cannot be exercised on the 1-GPU development box, and a
+    rank that raised would otherwise leave its peers blocked inside a transport operation.  Every rank ends up here (the
+    failing one at once, its peers through the watchdog) and they meet again on MASTER_PORT + 17."""
+    sys.stderr.write("rank %s: leaving the z-slab path (%s); re-running as independent replicas\n" % (os.environ.get("RANK", "0"), reason))
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env["BLUB_BENCH_REPLICAS"] = "1"
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
+    env["TORCHELASTIC_USE_AGENT_STORE"] = "False"   # rank 0 hosts a fresh store there (the launcher's own store keeps the keys of the first rendezvous)
+    os.execve(sys.executable, [sys.executable] + sys.argv, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,8 +157,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank %= max(1, torch.cuda.device_count())   # (development: several ranks on the one GPU of the test box)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BLUB_BENCH_BACKEND", "nccl")   # control-plane collectives of this script only
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        ctl = "cuda" if backend == "nccl" else "cpu"
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
@@ -153,11 +173,16 @@ def main():
     dt = blub_amd.default_simulation_delta()
     parallelism = "single GPU"
     group = None
+    watchdog = None
     if world > 1 and not os.environ.get("BLUB_BENCH_REPLICAS"):
+        import threading
+        watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), fallback_to_replicas, args=("no progress within the deadline",))
+        watchdog.daemon = True
+        watchdog.start()
         # z-slab decomposition, weak scaling: rank k owns slab k of a (nx, ny, N*nz) domain made of N stacked
         # copies of the scene (the dams of neighbouring slabs meet at the interfaces, so ghosts / halos / migration carry data)
         from blub_amd import slab_scene
-        ok = torch.ones(1, device="cuda")
+        ok = torch.ones(1, device=ctl)
         try:
             cfg = blub_amd.Scene.parse(path=scene_path).config
             dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, world)
@@ -197,28 +222,39 @@ def main():
         torch.cuda.synchronize()
         sync()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    it0 = fluid.total_solver_iterations()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        it0 = fluid.total_solver_iterations()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    except Exception as e:
+        if group is None:
+            raise
+        fallback_to_replicas("z-slab step failed: %s" % e)
+    if watchdog is not None:
+        watchdog.cancel()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if group is not None:
-            cnt = torch.tensor([group.num_particles()], dtype=torch.float64, device="cuda")
+            cnt = torch.tensor([group.num_particles()], dtype=torch.float64, device=ctl)
             dist.all_reduce(cnt)
             P = int(cnt.item())
         dist.barrier()
     it1 = fluid.total_solver_iterations()
 
     if group is not None:
+        ops0 = group.transport_ops()
+        group.step(dt)
+        group.synchronize()
+        ops_per_step = group.transport_ops() - ops0
         # weak scaling: one global step advances `world` slabs of the single-GPU workload size
         if rank == 0:
             print(json.dumps({
@@ -228,7 +264,7 @@ def main():
                 "data": "synthetic", "config": {"workload": "%s stacked x%d along z" % (args.scene, world), "grid": [nx, ny, nz], "particles": P, "dt": dt,
                                                 "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60, "parallelism": parallelism},
                 "global_steps_per_sec": round(args.steps / elapsed, 3), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
-                "roofline": None, "cpu_baseline": None}))
+                "transport_ops_per_step": round(ops_per_step, 1), "roofline": None, "cpu_baseline": None}))
             sys.stdout.flush()
         dist.barrier()
         group.close()
@@ -290,7 +326,7 @@ def main():
                               "achieved": ku["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"],
                               "traffic": ku["traffic_bytes_pmc"], "algorithmic_bytes": ku["algorithmic_bytes"], "avg_us": ku["avg_us"],
                               "launches": ku["launches"]}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(scene_path, dt)
     print(json.dumps(result))
     sys.stdout.flush()

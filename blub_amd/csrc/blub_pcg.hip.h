@@ -127,18 +127,20 @@ __device__ __forceinline__ float4 snew4(uint32_t dq, const float4& r, const floa
 
 // ---- load / compute split of the KD and KU bodies (brick mapping): all global loads of a quad are issued up front,
 // unconditionally, so that they overlap the partial-reduction prologue; the sparse regime is latency- not byte-bound.
-struct DirLoad { QuadD m; QuadValues sv, rv; int base; bool valid; };
+struct DirLoad { QuadD m; QuadValues sv, rv; int base, z; bool valid; };
 template <bool FIRST>
 __device__ __forceinline__ void dir_load(const Grid& g, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
                                          int base, int x0, int y, int z, DirLoad& L) {
-    L.base = base;
+    L.base = base; L.z = z;
     L.m.c = *reinterpret_cast<const uint32_t*>(dvol + base);
     load_quad_d(dvol, g, base, x0, y, z, L.m);
     load_quad_values(s_in, g, base, x0, y, z, L.sv);
     if (!FIRST) load_quad_values(r, g, base, x0, y, z, L.rv);
 }
-template <bool FIRST>
-__device__ __forceinline__ void dir_compute(DirLoad& L, float* __restrict__ s_out, float beta, float& acc) {
+// HALO (z-slab groups): the quad also stores the s it computed for the ghost plane below `halo_lo` / above `halo_hi`
+// (own planes of the slab, -1 = none), so the search direction needs no halo exchange of its own.
+template <bool FIRST, bool HALO = false>
+__device__ __forceinline__ void dir_compute(DirLoad& L, float* __restrict__ s_out, float beta, float& acc, int halo_lo = -1, int halo_hi = -1, int plane = 0) {
     if (!L.valid || !any_fluid_d(L.m.c)) return;
     QuadValues& sv = L.sv;
     const QuadD& m = L.m;
@@ -155,6 +157,10 @@ __device__ __forceinline__ void dir_compute(DirLoad& L, float* __restrict__ s_ou
         if (!(dbyte(m.c, 2) & 0x80)) so.z = sold.z;
         if (!(dbyte(m.c, 3) & 0x80)) so.w = sold.w;
         *reinterpret_cast<float4*>(s_out + L.base) = so;
+        if (HALO) {
+            if (L.z == halo_lo) *reinterpret_cast<float4*>(s_out + L.base - plane) = sv.zm;
+            if (L.z == halo_hi) *reinterpret_cast<float4*>(s_out + L.base + plane) = sv.zp;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -257,11 +263,11 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, cons
     const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
     if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, 0.0f);
 }
-template <bool FIRST>
+template <bool FIRST, bool HALO = false>
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                              const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
                                                              const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
-                                                             PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
+                                                             PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev, int halo_lo = -1, int halo_hi = -1) {
     __shared__ float sm[8];
     __shared__ float2 sm2[4];
     const uint32_t n = *count;
@@ -272,12 +278,13 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const
     float beta;
     if (!pcg_dir_prologue<PCG_B_THREADS>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     float acc = 0.0f;
-    dir_compute<FIRST>(L, s_out, beta, acc);
+    const int plane = bg.g.nx * bg.g.ny;
+    dir_compute<FIRST, HALO>(L, s_out, beta, acc, halo_lo, halo_hi, plane);
     for (i += gridDim.x * 2; i < n; i += gridDim.x * 2) {
         int x0, y, z;
         L.valid = brick_quad(bg, list[i], t, x0, y, z);
         if (L.valid) dir_load<FIRST>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L);
-        dir_compute<FIRST>(L, s_out, beta, acc);
+        dir_compute<FIRST, HALO>(L, s_out, beta, acc, halo_lo, halo_hi, plane);
     }
     const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
     if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;

@@ -6,7 +6,7 @@
 //   * ghost particles  : copies of the neighbours' particles within GHOST_MARGIN cells of the interface (P2G, density
 //                        gather and the marker need them), appended behind the own particles,
 //   * halo planes      : one z-plane of a volume from each neighbour after every stage that produces it,
-//   * scalars          : the PCG dot products / max-norm, all-reduced across slabs,
+//   * partials         : the per-block partial sums / maxima of the PCG dot products, gathered from all slabs,
 //   * migrating particles after advection and after the density correction.
 #pragma once
 #include "blub_pcg.hip.h"
@@ -70,27 +70,19 @@ __global__ __launch_bounds__(256) void k_slab_insert_density_ghosts(Grid g, uint
     reinterpret_cast<uint32_t*>(pos)[4 * (size_t)i + 3] = old - 1u;
 }
 
-// Per-slab reduction of the block partials to the scalars that are all-reduced across slabs.
-__global__ __launch_bounds__(256) void k_slab_reduce_dir(const float* __restrict__ part_dir, int n, float* __restrict__ out) {
-    __shared__ float sm[8];
-    const float s = reduce_partials<256, false>(part_dir, n, sm);
-    if (threadIdx.x == 0) out[0] = s;
-}
-__global__ __launch_bounds__(256) void k_slab_reduce_upd(const float2* __restrict__ part_upd, int n, float* __restrict__ out_sum, float* __restrict__ out_max) {
-    __shared__ float2 sm2[4];
-    const float2 r = reduce_partials2<256>(part_upd, n, sm2);
-    if (threadIdx.x == 0) { out_sum[0] = r.x; out_max[0] = r.y; }
-}
-// loopback all-reduce over the slabs of one process (fixed order => deterministic)
+// Dot products across slabs: every slab's PCG kernels write their per-block partials into segment `rank` of a gather array
+// of nranks x SLAB_NP entries; after the segments have been exchanged (p2p, see slab_gather) the unchanged consumer kernels
+// re-reduce all nranks x SLAB_NP partials in the same fixed order on every slab => identical scalars and identical
+// convergence decisions everywhere, no all-reduce, no extra reduction kernels.
+constexpr int SLAB_NP = 256;   // PCG grid (= partials per slab) of a slab solve
 struct SlabPtrs { float* p[8]; };
-__global__ void k_slab_allreduce_local(SlabPtrs ptrs, int nslabs, int count, int op_max) {
-    const int j = threadIdx.x;
-    if (j >= count) return;
-    float v = ptrs.p[0][j];
-    for (int s = 1; s < nslabs; ++s) v = op_max ? fmaxf(v, ptrs.p[s][j]) : v + ptrs.p[s][j];
-    for (int s = 0; s < nslabs; ++s) ptrs.p[s][j] = v;
+// loopback transport: copy segment s of slab s's array into every other local slab's array
+__global__ __launch_bounds__(256) void k_slab_gather_local(SlabPtrs ptrs, int nslabs, int seg_floats) {
+    const int s = blockIdx.x;
+    for (int j = threadIdx.x; j < seg_floats; j += 256) {
+        const float v = ptrs.p[s][(size_t)s * seg_floats + j];
+        for (int d = 0; d < nslabs; ++d) if (d != s) ptrs.p[d][(size_t)s * seg_floats + j] = v;
+    }
 }
-// packs {sum, max} scalars into the float2 "partial" the direction kernel consumes (num_part = 1)
-__global__ void k_slab_pack_upd(const float* __restrict__ sum, const float* __restrict__ mx, float2* __restrict__ out) { out[0] = make_float2(sum[0], mx[0]); }
 
 }  // namespace blubk

@@ -4,9 +4,11 @@
 //   loopback : all slabs live in this process on one GPU and share one stream (validation of the protocol on a 1-GPU box);
 //              halo / particle transfers are device-to-device copies, the all-reduce is a tiny kernel
 //   RCCL     : one slab per process / GPU; halo planes and particles travel as grouped ncclSend/ncclRecv between
-//              z-neighbours (point-to-point over xGMI), the PCG scalars as ncclAllReduce on the slab's stream
-// Per step (defaults: 2 x 33 PCG iterations): 3 particle exchanges, 5 three-volume halo exchanges, 2 x (descriptor + r + s
-// + p) halos and per PCG iteration 2 one-plane halos + 2 (+1 on check iterations) scalar all-reduces.
+//              z-neighbours (point-to-point over xGMI), the PCG partials as ncclSend/ncclRecv to every other rank inside
+//              the same group (an all-gather spelled as p2p so that it fuses with the halo into one operation)
+// Per step: 3 particle exchanges, 5 three-volume halo exchanges, 2 x (descriptor + r + s + p) halos and per PCG iteration TWO
+// grouped point-to-point operations: the s.As partials after the direction kernel, and the r plane + {(M^-1 r).r, max|r|}
+// partials after the update kernel.  The iteration count follows the previous solve (+ re-checks), see slab_solve.
 #include <rccl/rccl.h>
 
 #include <functional>
@@ -24,12 +26,15 @@ struct blub_slab_group {
         float4 *up[4] = {nullptr, nullptr, nullptr, nullptr}, *dn[4] = {nullptr, nullptr, nullptr, nullptr};   // send buffers: pos, vx, vy, vz
         blubk::SlabCounts* counts = nullptr;     // device
         uint32_t* recv_counts = nullptr;         // device: {from below, from above}
-        float* red = nullptr;                    // device: [0] s.As  [1] sigma  [2] max|r|
-        float2* packed = nullptr;                // device: {sigma, max|r|} as a 1-element partial array
+        float* gat_dir = nullptr;                // device: nranks x SLAB_NP partials of s.As (own segment written by the direction kernel)
+        float2* gat_upd = nullptr;               // device: nranks x SLAB_NP partials {(M^-1 r).r, max|r|} (own segment written by init / update)
     };
     std::vector<Extra> ex;
     blubk::SlabCounts* counts_host = nullptr;    // pinned, one per local slab
     uint32_t* recv_host = nullptr;               // pinned, two per local slab
+    blubk::PcgCtrl* ctrl_host = nullptr;         // pinned: control block of slab 0's solves [velocity, density], read only after a stream sync
+    bool ctrl_host_valid[2] = {false, false};
+    uint64_t comm_ops = 0;                       // grouped transport operations issued so far (diagnostics)
 };
 
 namespace blub {
@@ -49,10 +54,11 @@ static bool down_local(const blub_slab_group* G, int i) { return i > 0; }
 
 // One z-plane of a volume from each z-neighbour: plane z1-1 goes up, plane z0 goes down; the receiver stores it at the
 // same global z (ghost planes z0-1 and z1).
-static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(blub_fluid*)>>& fields, size_t elem) {
+static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(blub_fluid*)>>& fields, size_t elem, bool own_group = true) {
     const blub_fluid* h0 = G->slabs[0];
     const size_t pb = (size_t)h0->g.nx * h0->g.ny * elem;
-    if (G->rccl) NCCL_TRY(ncclGroupStart());
+    if (own_group) G->comm_ops += 1;
+    if (G->rccl && own_group) NCCL_TRY(ncclGroupStart());
     for (int i = 0; i < (int)G->slabs.size(); ++i) {
         blub_fluid* h = G->slabs[i];
         for (auto& f : fields) {
@@ -73,24 +79,31 @@ static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(b
             }
         }
     }
-    if (G->rccl) NCCL_TRY(ncclGroupEnd());
+    if (G->rccl && own_group) NCCL_TRY(ncclGroupEnd());
     return BLUB_OK;
 }
 static int slab_halo_velocity(blub_slab_group* G) {
     return slab_halo(G, {[](blub_fluid* h) { return (void*)h->vel[0]; }, [](blub_fluid* h) { return (void*)h->vel[1]; }, [](blub_fluid* h) { return (void*)h->vel[2]; }}, 4);
 }
 
-// sum / max of `count` floats at red[offset] across all slabs
-static int slab_allreduce(blub_slab_group* G, int offset, int count, bool op_max) {
+// Segment `rank` of a gather array (seg_floats floats per slab) to every other slab.
+static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& array_of, int seg_floats, bool own_group = true) {
     if (G->nranks == 1) return BLUB_OK;
+    if (own_group) G->comm_ops += 1;
     if (!G->rccl) {
         blubk::SlabPtrs ptrs{};
-        for (size_t i = 0; i < G->slabs.size(); ++i) ptrs.p[i] = G->ex[i].red + offset;
-        hipLaunchKernelGGL(blubk::k_slab_allreduce_local, dim3(1), dim3(64), 0, G->stream, ptrs, (int)G->slabs.size(), count, (int)op_max);
+        for (size_t i = 0; i < G->slabs.size(); ++i) ptrs.p[i] = array_of((int)i);
+        hipLaunchKernelGGL(blubk::k_slab_gather_local, dim3((unsigned)G->slabs.size()), dim3(256), 0, G->stream, ptrs, (int)G->slabs.size(), seg_floats);
         return BLUB_OK;
     }
-    float* p = G->ex[0].red + offset;
-    NCCL_TRY(ncclAllReduce(p, p, (size_t)count, ncclFloat, op_max ? ncclMax : ncclSum, G->comm, G->stream));
+    float* arr = array_of(0);
+    if (own_group) NCCL_TRY(ncclGroupStart());
+    for (int q = 0; q < G->nranks; ++q) {
+        if (q == G->first) continue;
+        NCCL_TRY(ncclSend(arr + (size_t)G->first * seg_floats, (size_t)seg_floats, ncclFloat, q, G->comm, G->stream));
+        NCCL_TRY(ncclRecv(arr + (size_t)q * seg_floats, (size_t)seg_floats, ncclFloat, q, G->comm, G->stream));
+    }
+    if (own_group) NCCL_TRY(ncclGroupEnd());
     return BLUB_OK;
 }
 
@@ -121,6 +134,7 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
     }
     // counts to the host (the payload sizes of the transfers below are host-side arguments)
     for (int i = 0; i < S; ++i) HIP_TRY(hipMemcpyAsync(&G->counts_host[i], G->ex[i].counts, sizeof(blubk::SlabCounts), hipMemcpyDeviceToHost, G->stream));
+    G->comm_ops += 2;   // counts + payload
     if (G->rccl) {   // neighbours' counts
         NCCL_TRY(ncclGroupStart());
         for (int i = 0; i < S; ++i) {
@@ -183,7 +197,14 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
     return BLUB_OK;
 }
 
-// PressureSolver::solve on all slabs in lock step (brick mapping; blub_pcg.hip.h kernels with 1-element "partials")
+// PressureSolver::solve on all slabs in lock step (brick mapping; the blub_pcg.hip.h kernels fed with the gathered partials).
+//
+// Iteration count: a solve that converges at check iteration c sets `done` in the direction kernel of iteration c+1 and
+// everything launched after that is a no-op -- but the transport operations between the kernels would still be paid.  So the
+// host launches iterations through the check that ended the PREVIOUS solve of this kind, synchronises, looks at `done`, and
+// adds one check interval at a time until the solve is finished.  Every rank sees bit-identical control blocks (same
+// partials, same reduction order), and the previous iteration count is only taken from a read-back that a stream
+// synchronisation has completed on every rank, so all ranks issue the same sequence of transport operations.
 static int slab_solve(blub_slab_group* G, int which, float dt) {
     const int S = (int)G->slabs.size();
     blub_fluid* h0 = G->slabs[0];
@@ -192,58 +213,77 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     const float tol = c.error_tolerance / dt;
     const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };
-    const int np = std::min((h0->bg.nb + 1) / 2, PCG_GRID_BRICKS);
+    const int np = SLAB_NP, npall = SLAB_NP * G->nranks;
     const dim3 grid(np), block(PCG_B_THREADS);
     int rc;
-    auto reduce_upd = [&]() -> int {   // local partials -> {sigma, max} scalars -> all-reduce -> 1-element partial
-        for (int i = 0; i < S; ++i)
-            hipLaunchKernelGGL(k_slab_reduce_upd, dim3(1), dim3(256), 0, G->stream, (const float2*)reinterpret_cast<float2*>(G->slabs[i]->part_sigma[0]), np, G->ex[i].red + 1, G->ex[i].red + 2);
-        if ((rc = slab_allreduce(G, 1, 1, false)) != BLUB_OK) return rc;
-        if ((rc = slab_allreduce(G, 2, 1, true)) != BLUB_OK) return rc;
-        for (int i = 0; i < S; ++i) hipLaunchKernelGGL(k_slab_pack_upd, dim3(1), dim3(1), 0, G->stream, (const float*)(G->ex[i].red + 1), (const float*)(G->ex[i].red + 2), G->ex[i].packed);
-        return BLUB_OK;
-    };
+    auto seg_upd = [&](int i) { return G->ex[i].gat_upd + (size_t)(G->first + i) * np; };
+    auto seg_dir = [&](int i) { return G->ex[i].gat_dir + (size_t)(G->first + i) * np; };
+    auto gather_upd = [&](bool own_group) { return slab_gather(G, [G](int i) { return reinterpret_cast<float*>(G->ex[i].gat_upd); }, 2 * np, own_group); };
+    auto gather_dir = [&]() { return slab_gather(G, [G](int i) { return G->ex[i].gat_dir; }, np); };
+    // iterations to launch before the first look at `done`
+    int target = maxit + 1;
+    if (freq > 0 && G->ctrl_host_valid[which]) {
+        const int prev = (int)G->ctrl_host[which].num_iter;
+        if (prev >= 0 && prev < maxit) target = std::min(maxit + 1, (prev / freq) * freq + 2);
+    }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
         if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
-        HIP_TRY(hipMemsetAsync(h->ctrl[which], 0, sizeof(PcgCtrl), G->stream));
         h->solve_seq[which] += 1;
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
-               reinterpret_cast<float2*>(h->part_sigma[0]), (PcgCtrl*)nullptr, (PcgTailSync*)nullptr);
+               seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr);
     }
-    if ((rc = reduce_upd()) != BLUB_OK) return rc;
-    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1)) != BLUB_OK) return rc;
-    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }, [](blub_fluid* h) { return (void*)h->search; }}, 4)) != BLUB_OK) return rc;
-    for (int it = 0; it <= maxit; ++it) {
-        for (int i = 0; i < S; ++i) {
-            blub_fluid* h = G->slabs[i];
-            float* sbuf[2] = {h->search, h->aux};
-            if (it == 0)
-                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
-                       (const float2*)G->ex[i].packed, h->part_sas, 1, h->ctrl[which], tol, it, 0);
-            else
-                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<false>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(it - 1) & 1], sbuf[it & 1],
-                       (const float2*)G->ex[i].packed, h->part_sas, 1, h->ctrl[which], tol, it, (int)is_check(it - 1));
+    // descriptor, r, s planes and the initial partials: one grouped operation
+    G->comm_ops += 1;
+    if (G->rccl) NCCL_TRY(ncclGroupStart());
+    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1, false)) != BLUB_OK) return rc;
+    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }, [](blub_fluid* h) { return (void*)h->search; }}, 4, false)) != BLUB_OK) return rc;
+    if ((rc = gather_upd(false)) != BLUB_OK) return rc;
+    if (G->rccl) NCCL_TRY(ncclGroupEnd());
+    int it = 0;
+    bool done = false;
+    for (;;) {
+        for (; it < target; ++it) {
+            for (int i = 0; i < S; ++i) {
+                blub_fluid* h = G->slabs[i];
+                float* sbuf[2] = {h->search, h->aux};
+                const int halo_lo = has_down(G, i) ? h->slab_z0 : -1, halo_hi = has_up(G, i) ? h->slab_z1 - 1 : -1;
+                if (it == 0)
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_b<true, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
+                           (const float2*)G->ex[i].gat_upd, seg_dir(i), npall, h->ctrl[which], tol, it, 0, halo_lo, halo_hi);
+                else
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_b<false, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(it - 1) & 1], sbuf[it & 1],
+                           (const float2*)G->ex[i].gat_upd, seg_dir(i), npall, h->ctrl[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi);
+            }
+            if ((rc = gather_dir()) != BLUB_OK) return rc;
+            for (int i = 0; i < S; ++i) {
+                blub_fluid* h = G->slabs[i];
+                float* sbuf[2] = {h->search, h->aux};
+                LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[it & 1], h->pressure[which], h->residual,
+                       (const float*)G->ex[i].gat_dir, seg_upd(i), npall, (const PcgCtrl*)h->ctrl[which], it);
+            }
+            G->comm_ops += 1;
+            if (G->rccl) NCCL_TRY(ncclGroupStart());
+            if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }}, 4, false)) != BLUB_OK) return rc;
+            if ((rc = gather_upd(false)) != BLUB_OK) return rc;
+            if (G->rccl) NCCL_TRY(ncclGroupEnd());
         }
-        const int cur = it & 1;
-        if (it > 0 && (rc = slab_halo(G, {[cur](blub_fluid* h) { return (void*)(cur ? h->aux : h->search); }}, 4)) != BLUB_OK) return rc;
-        for (int i = 0; i < S; ++i) hipLaunchKernelGGL(k_slab_reduce_dir, dim3(1), dim3(256), 0, G->stream, (const float*)G->slabs[i]->part_sas, np, G->ex[i].red + 0);
-        if ((rc = slab_allreduce(G, 0, 1, false)) != BLUB_OK) return rc;
-        for (int i = 0; i < S; ++i) {
-            blub_fluid* h = G->slabs[i];
-            float* sbuf[2] = {h->search, h->aux};
-            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[it & 1], h->pressure[which], h->residual,
-                   (const float*)(G->ex[i].red + 0), reinterpret_cast<float2*>(h->part_sigma[0]), 1, (const PcgCtrl*)h->ctrl[which], it);
-        }
-        if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }}, 4)) != BLUB_OK) return rc;
-        if ((rc = reduce_upd()) != BLUB_OK) return rc;
+        if (target > maxit) break;
+        HIP_TRY(hipMemcpyAsync(&G->ctrl_host[which], h0->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, G->stream));
+        HIP_TRY(hipStreamSynchronize(G->stream));
+        done = G->ctrl_host[which].done != 0;
+        if (done) break;
+        target = std::min(maxit + 1, target + freq);
     }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), h->ctrl[which], (const float2*)G->ex[i].packed, 1, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), h->ctrl[which], (const float2*)G->ex[i].gat_upd, npall, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
         if (maxit & 1) std::swap(h->search, h->aux);
         if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
     }
+    // iteration count of this solve for the next one: lands before the next particle exchange synchronises the stream
+    HIP_TRY(hipMemcpyAsync(&G->ctrl_host[which], h0->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, G->stream));
+    G->ctrl_host_valid[which] = true;
     const int w = which;
     return slab_halo(G, {[w](blub_fluid* h) { return (void*)h->pressure[w]; }}, 4);
 }
@@ -303,11 +343,12 @@ static void slab_group_destroy(blub_slab_group* G) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     for (auto& e : G->ex) {
         F(e.pos_new); for (auto p : e.pvel_new) F(p); for (auto p : e.up) F(p); for (auto p : e.dn) F(p);
-        F(e.counts); F(e.recv_counts); F(e.red); F(e.packed);
+        F(e.counts); F(e.recv_counts); F(e.gat_dir); F(e.gat_upd);
     }
     for (auto h : G->slabs) destroy(h);
     if (G->counts_host) (void)hipHostFree(G->counts_host);
     if (G->recv_host) (void)hipHostFree(G->recv_host);
+    if (G->ctrl_host) (void)hipHostFree(G->ctrl_host);
     if (G->comm) (void)ncclCommDestroy(G->comm);
     if (G->stream) (void)hipStreamDestroy(G->stream);
     delete G;
@@ -350,12 +391,14 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         A(dev_alloc_zero(G->stream, &e.pos_new, P));
         for (int c = 0; c < 3; ++c) A(dev_alloc_zero(G->stream, &e.pvel_new[c], P));
         for (int k = 0; k < 4; ++k) { A(dev_alloc_zero(G->stream, &e.up[k], P)); A(dev_alloc_zero(G->stream, &e.dn[k], P)); }
-        A(dev_alloc_zero(G->stream, &e.counts, 1)); A(dev_alloc_zero(G->stream, &e.recv_counts, 2)); A(dev_alloc_zero(G->stream, &e.red, 4)); A(dev_alloc_zero(G->stream, &e.packed, 1));
+        A(dev_alloc_zero(G->stream, &e.counts, 1)); A(dev_alloc_zero(G->stream, &e.recv_counts, 2));
+        A(dev_alloc_zero(G->stream, &e.gat_dir, (size_t)nranks * blubk::SLAB_NP)); A(dev_alloc_zero(G->stream, &e.gat_upd, (size_t)nranks * blubk::SLAB_NP));
         G->ex.push_back(e);
     }
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->counts_host, nlocal * sizeof(blubk::SlabCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->recv_host, 2 * nlocal * sizeof(uint32_t)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
-    if (rc == BLUB_OK) { memset(G->counts_host, 0, nlocal * sizeof(blubk::SlabCounts)); memset(G->recv_host, 0, 2 * nlocal * sizeof(uint32_t)); }
+    if (rc == BLUB_OK && hipHostMalloc((void**)&G->ctrl_host, 2 * sizeof(blubk::PcgCtrl)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK) { memset(G->counts_host, 0, nlocal * sizeof(blubk::SlabCounts)); memset(G->recv_host, 0, 2 * nlocal * sizeof(uint32_t)); memset(G->ctrl_host, 0, 2 * sizeof(blubk::PcgCtrl)); }
     if (rc == BLUB_OK && G->rccl) {
         if (nlocal != 1) rc = set_error(BLUB_ERR_INVALID_ARGUMENT, "RCCL slab groups hold exactly one slab per process");
         else {
@@ -449,6 +492,7 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
     return blub::slab_step(g, dt);
 }
+uint64_t blub_slab_group_transport_ops(const blub_slab_group* g) { return g ? g->comm_ops : 0; }
 int blub_slab_group_synchronize(blub_slab_group* g) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");

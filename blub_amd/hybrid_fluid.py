@@ -505,7 +505,8 @@ class SlabGroup:
                 ("blub_slab_group_get_particles", C.c_int, [vp, vp, vp, vp, vp]), ("blub_slab_group_set_gravity_grid", C.c_int, [vp, vp]),
                 ("blub_slab_group_set_solver_config", C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
                 ("blub_slab_group_set_rebinning_frequency", C.c_int, [vp, C.c_uint32]),
-                ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp])]:
+                ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
+                ("blub_slab_group_transport_ops", C.c_uint64, [vp])]:
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         self.grid = tuple(int(v) for v in grid_dimension)
@@ -605,3 +606,7 @@ class SlabGroup:
 
     def synchronize(self):
         _check(self._L, self._L.blub_slab_group_synchronize(self._g))
+
+    def transport_ops(self):
+        """Grouped transport operations (halo / partial / particle exchanges) issued by this process so far."""
+        return int(self._L.blub_slab_group_transport_ops(self._g))

@@ -240,6 +240,8 @@ int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_
 int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t every_n_steps);
 int blub_slab_group_step(blub_slab_group* g, float simulation_delta_seconds);
 int blub_slab_group_synchronize(blub_slab_group* g);
+/* diagnostics: grouped transport operations (halo / partial / particle exchanges) issued by this process so far */
+uint64_t blub_slab_group_transport_ops(const blub_slab_group* g);
 
 #ifdef __cplusplus
 }

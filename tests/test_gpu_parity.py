@@ -463,6 +463,58 @@ def test_z_slab_decomposition_matches_single_domain(slabs):
         group.close()
 
 
+def test_z_slab_solve_follows_convergence():
+    """The slab solve launches iterations through the check that ended the previous solve, looks at `done` and extends by
+    one check interval at a time (blub_slab.inc.hip: slab_solve).  With the reference's solver defaults the group must report
+    the same iteration counts as the single-domain engine (within one check interval: the dot products are summed in a
+    different order), stay inside the run-to-run noise envelope, and issue far fewer transport operations than a
+    full-length solve once it has a previous iteration count to go by."""
+    import blub_amd
+    dim = (32, 32, 48)
+    rng = np.random.default_rng(5)
+    cells = np.stack(np.meshgrid(np.arange(4, 28), np.arange(2, 14), np.arange(4, 44), indexing="ij"), -1).reshape(-1, 3)
+    pos = (cells[:, None, :] + rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
+    single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
+    group = blub_amd.SlabGroup(dim, pos.shape[0], local=3, binning="off")
+    try:
+        for f in (single, group):
+            f.set_gravity_grid((0.0, -9.81 / 0.01, 0.0))
+            f.set_particles(pos)
+        ops = []
+        for step in range(6):
+            before = group.transport_ops()
+            single.step(util.DT)
+            group.step(util.DT)
+            group.synchronize()
+            ops.append(group.transport_ops() - before)
+        single.synchronize()
+        single.update_statistics()
+        slab_fluids = [group.local_fluid(i) for i in range(3)]
+        for f in slab_fluids:
+            f.update_statistics()
+        full = 4 * 2 + 5 + 2 * (1 + 2 * 33 + 1)      # particle exchanges, velocity halos, 2 solves of 33 iterations
+        assert ops[0] == full, (ops, full)           # first step: no previous iteration count
+        hist = lambda f, w: [x.iteration_count for x in (f.pressure_solver_stats_velocity() if w == 0 else f.pressure_solver_stats_density())]
+        its = []
+        for w in (0, 1):
+            it_s = hist(single, w)
+            it_all = [hist(f, w) for f in slab_fluids]
+            assert all(x == it_all[0] for x in it_all)           # every slab takes the same decisions
+            it_g = it_all[0]
+            its.append(it_g)
+            print("solve %d iterations: single %s  slabs %s  transport ops/step %s" % (w, it_s, it_g, ops))
+            assert len(it_g) == 6 and len(it_s) == 6 and all(abs(a - b) <= 4 for a, b in zip(it_s, it_g)), (it_s, it_g)
+            assert all(0 < x <= 32 for x in it_g)
+        for step in range(1, 6):   # launched per solve = iterations through the later of {previous, this} deciding check + its detection
+            need = 4 * 2 + 5 + sum(1 + 2 * min(33, max(its[w][step], its[w][step - 1]) + 2) + 1 for w in (0, 1))
+            assert ops[step] == need, (step, ops, need, its)
+        d = _match_particles(group.get_particles()[0][:, :3].astype(np.float64), single.get_particles()[0][:, :3].astype(np.float64))
+        assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 2e-2, (np.median(d), np.quantile(d, 0.99), d.max())
+    finally:
+        single.close()
+        group.close()
+
+
 def test_partial_bricks_odd_grid_full_step():
     """Grid dimensions that are not multiples of the 16x8x4 brick (only x % 4 == 0 is required): partial bricks at the
     upper domain faces, full step against the oracle with converged solves."""
