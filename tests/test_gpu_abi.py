@@ -103,7 +103,7 @@ def test_profile_trace_and_chrome_trace(tmp_path):
         f.profile_enable(False)
         names = {e["name"] for e in ev}
         assert {"build_lists", "gather_velocity", "pcg_dir", "pcg_update", "advect", "correct", "extrapolate"} <= names
-        assert len(ev) > 250 and all(e["duration_us"] > 0 for e in ev)
+        assert len(ev) > 100 and all(e["duration_us"] > 0 for e in ev)
         starts = [e["start_us"] for e in ev]
         assert starts == sorted(starts) and starts[0] == 0.0
         assert {e["step"] for e in ev} == {1, 2}
