@@ -5,4 +5,5 @@ only the Python mirror of the reference's host surface (src/simulation/hybrid_fl
 tests and the benchmark driver.  There is no CPU fallback: constructing a HybridFluid without a GPU raises.
 """
 from .hybrid_fluid import (BlubError, HybridFluid, Scene, SceneConfig, SlabGroup, SolverConfig, SolverStatisticSample, STAGES,  # noqa: F401
-                           VOLUMES, default_simulation_delta, lib_path, load_library, seed_fluid_cube)
+                           VOLUMES, MeshDesc, StaticObjectConfig, default_simulation_delta, duration_nanos, lib_path, load_library, load_obj,
+                           mesh_desc_at_time, seed_fluid_cube)

@@ -18,6 +18,7 @@
 #include "blub_internal.h"
 #include "blub_pcg_dense.hip.h"
 #include "blub_slab.hip.h"
+#include "blub_voxelize.hip.h"
 
 namespace blub {
 
@@ -38,12 +39,12 @@ using namespace blubk;
 enum KernelClass {
     KC_BRICK_LISTS, KC_RESET_BRICKS, KC_BUILD_LISTS, KC_GATHER_VELOCITY, KC_DIVERGENCE, KC_PCG_INIT, KC_PCG_DIR, KC_PCG_UPDATE, KC_PCG_FINALIZE,
     KC_PCG_LOD0, KC_DIVERGENCE_REMOVE, KC_EXTRAPOLATE, KC_ADVECT, KC_DENSITY_GATHER, KC_POSITION_CHANGE, KC_CORRECT,
-    KC_BIN_COUNT, KC_BIN_SCAN, KC_BIN_REWRITE, KC_COPY, KC_COUNT
+    KC_BIN_COUNT, KC_BIN_SCAN, KC_BIN_REWRITE, KC_COPY, KC_VOXELIZE, KC_COUNT
 };
 static const char* kKernelClassNames[KC_COUNT] = {
     "brick_lists", "reset_bricks", "build_lists", "gather_velocity", "divergence", "pcg_init", "pcg_dir", "pcg_update", "pcg_finalize",
     "pcg_lod0", "divergence_remove", "extrapolate", "advect", "density_gather", "position_change", "correct",
-    "bin_count", "bin_scan", "bin_rewrite", "copy"};
+    "bin_count", "bin_scan", "bin_rewrite", "copy", "voxelize"};
 
 constexpr int PCG_GRID_MAX = 4096;   // upper bound of persistent blocks of the PCG kernels (= number of dot-product partials)
 constexpr int PCG_GRID_DENSE = 2048; // dense rows: 8 blocks of 256 threads per CU
@@ -81,6 +82,10 @@ struct blub_fluid {
     uint32_t* ll[3] = {nullptr, nullptr, nullptr};
     float *vel[3] = {nullptr, nullptr, nullptr}, *pressure[2] = {nullptr, nullptr}, *residual = nullptr, *search = nullptr, *aux = nullptr, *aux_temp = nullptr;
     float4* solid = nullptr;
+    // static object meshes (scene/models.rs:354-375): positions (3 floats per vertex) + triangle indices
+    float* mesh_positions = nullptr;
+    uint32_t* mesh_indices = nullptr;
+    uint32_t mesh_num_vertices = 0, mesh_num_indices = 0;
     uint32_t* scan_totals = nullptr;
     // brick work lists (blub_bricks.hip.h)
     BrickGeom bg{};
@@ -485,7 +490,7 @@ static void destroy(blub_fluid* h) {
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
     if (h->steps_done_host) (void)hipHostFree((void*)h->steps_done_host);
-    F(h->tail_sync[0]); F(h->tail_sync[1]);
+    F(h->tail_sync[0]); F(h->tail_sync[1]); F(h->mesh_positions); F(h->mesh_indices);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
     for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -766,6 +771,40 @@ int blub_fluid_set_solid_voxels(blub_fluid* h, const float* vox) {
     h->all_touched = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return BLUB_OK;
+}
+int blub_fluid_set_meshes(blub_fluid* h, uint32_t nv, const float* positions, uint32_t ni, const uint32_t* indices) {
+    REQUIRE_HANDLE(h);
+    if ((nv && !positions) || (ni && !indices) || ni % 3 != 0) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad mesh arrays");
+    for (uint32_t k = 0; k < ni; ++k) if (indices[k] >= nv) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "mesh index out of range");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->mesh_positions) { (void)hipFree(h->mesh_positions); h->mesh_positions = nullptr; }
+    if (h->mesh_indices) { (void)hipFree(h->mesh_indices); h->mesh_indices = nullptr; }
+    h->mesh_num_vertices = nv; h->mesh_num_indices = ni;
+    if (nv) { HIP_TRY(hipMalloc((void**)&h->mesh_positions, (size_t)nv * 3 * sizeof(float))); int rc2 = blub::copy_sync(h, h->mesh_positions, positions, (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
+    if (ni) { HIP_TRY(hipMalloc((void**)&h->mesh_indices, (size_t)ni * sizeof(uint32_t))); int rc2 = blub::copy_sync(h, h->mesh_indices, indices, (size_t)ni * sizeof(uint32_t), hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
+    return BLUB_OK;
+}
+// SceneVoxelization::update, scene/voxelization.rs:116-157 (asynchronous, like the reference's render pass)
+int blub_fluid_voxelize(blub_fluid* h, uint32_t num_meshes, const blub_mesh_desc* meshes) {
+    REQUIRE_HANDLE(h);
+    if (num_meshes && !meshes) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t m = 0; m < num_meshes; ++m)
+        if (meshes[m].index_begin > meshes[m].index_end || meshes[m].index_end > h->mesh_num_indices) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "mesh index range outside the uploaded index buffer");
+    if (!h->solid) HIP_TRY(hipMalloc((void**)&h->solid, h->N * sizeof(float4)));
+    {
+        blub::ProfScope ps(h, blub::KC_VOXELIZE);
+        HIP_TRY(hipMemsetAsync(h->solid, 0, h->N * sizeof(float4), h->stream));   // encoder.clear_texture, :123
+        for (uint32_t m = 0; m < num_meshes; ++m) {
+            static_assert(sizeof(blubk::MeshDesc) == sizeof(blub_mesh_desc), "MeshDesc mirrors blub_mesh_desc");
+            blubk::MeshDesc d; memcpy(&d, &meshes[m], sizeof d);
+            const uint32_t ntri = (d.index_end - d.index_begin) / 3;
+            if (ntri) hipLaunchKernelGGL(blubk::k_voxelize_mesh, dim3((ntri + 3) / 4), dim3(256), 0, h->stream, h->g, d, (const float*)h->mesh_positions, (const uint32_t*)h->mesh_indices, h->solid);
+        }
+        // the static marker pattern changed: every brick may now differ from it (same as blub_fluid_set_solid_voxels)
+        hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker);
+    }
+    h->all_touched = true;
+    return blub::check_launch(h);
 }
 int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz) {
     REQUIRE_HANDLE(h);

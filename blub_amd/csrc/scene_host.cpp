@@ -139,7 +139,168 @@ int scene_parse(const char* text, size_t len, blub_scene_config* out) {
         if (!get_vec3(&cubes->arr[i], "min", out->cube_min[i]) || !get_vec3(&cubes->arr[i], "max", out->cube_max[i]))
             return set_error(BLUB_ERR_PARSE, "scene JSON: fluid cube needs `min` and `max`");
     const JValue* so = root.get("static_objects");   // #[serde(default)]
-    out->num_static_objects = (so && so->kind == JValue::Arr) ? (uint32_t)so->arr.size() : 0;
+    out->num_static_objects = 0;
+    if (so && so->kind == JValue::Arr) {
+        if (so->arr.size() > BLUB_SCENE_MAX_STATIC_OBJECTS) return set_error(BLUB_ERR_UNSUPPORTED, "scene JSON: too many static objects");
+        for (size_t i = 0; i < so->arr.size(); ++i) {   // StaticObjectConfig, scene/models.rs:11-19
+            const JValue& o = so->arr[i];
+            blub_static_object& d = out->static_objects[i];
+            const JValue* model = o.get("model");
+            if (!model || model->kind != JValue::Str || model->str.size() >= BLUB_SCENE_MAX_PATH) return set_error(BLUB_ERR_PARSE, "scene JSON: static object needs a `model` path");
+            memcpy(d.model, model->str.c_str(), model->str.size() + 1);
+            if (!get_vec3(&o, "world_position", d.world_position) || !get_f32(&o, "scale", &d.scale) || !get_vec3(&o, "rotation_angles", d.rotation_angles_deg))
+                return set_error(BLUB_ERR_PARSE, "scene JSON: static object needs `world_position`, `scale`, `rotation_angles`");
+            const JValue* anim = o.get("animation");
+            if (anim && anim->kind == JValue::Obj) {
+                const JValue* tr = anim->get("translation");
+                if (tr && tr->kind == JValue::Obj) {   // TranslationAnimation, models.rs:27-32
+                    const JValue* curve = tr->get("curve");
+                    if (!get_vec3(tr, "target", d.translation_target) || !get_f32(tr, "duration", &d.translation_duration) || !curve || curve->kind != JValue::Str)
+                        return set_error(BLUB_ERR_PARSE, "scene JSON: translation animation needs `target`, `curve`, `duration`");
+                    if (curve->str == "Linear") d.translation_curve = BLUB_CURVE_LINEAR;
+                    else if (curve->str == "SmoothStep") d.translation_curve = BLUB_CURVE_SMOOTHSTEP;
+                    else return set_error(BLUB_ERR_PARSE, "scene JSON: unknown animation curve");
+                    d.has_translation = 1;
+                }
+                const JValue* rot = anim->get("rotation");
+                if (rot && rot->kind == JValue::Obj) {   // RotationAnimation, models.rs:34-38
+                    if (!get_vec3(rot, "axis", d.rotation_axis) || !get_f32(rot, "deg_per_sec", &d.rotation_deg_per_sec))
+                        return set_error(BLUB_ERR_PARSE, "scene JSON: rotation animation needs `axis`, `deg_per_sec`");
+                    d.has_rotation = 1;
+                }
+            }
+        }
+        out->num_static_objects = (uint32_t)so->arr.size();
+    }
+    return BLUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// StaticMeshData::{world_position_at_time, rotation_at_time, to_gpu} (scene/models.rs:156-228) in f32, with the cgmath 0.18
+// operations it calls restated (crate source not vendored in /root/reference: Euler -> Quaternion uses the XYZ formula of
+// cgmath's quaternion.rs, matrix products sum their four terms left to right).
+// ------------------------------------------------------------------------------------------------------------------
+struct Quat { float s, x, y, z; };
+struct Mat4 { float c[4][4]; };   // column major: c[column][row]
+static float deg_to_rad(float d) { return d * (float)(3.14159265358979323846 / 180.0); }
+static Quat quat_mul(const Quat& a, const Quat& b) {
+    return {a.s * b.s - a.x * b.x - a.y * b.y - a.z * b.z, a.s * b.x + a.x * b.s + a.y * b.z - a.z * b.y,
+            a.s * b.y + a.y * b.s + a.z * b.x - a.x * b.z, a.s * b.z + a.z * b.s + a.x * b.y - a.y * b.x};
+}
+static Quat quat_from_euler_deg(const float e[3]) {
+    const float hx = deg_to_rad(e[0]) * 0.5f, hy = deg_to_rad(e[1]) * 0.5f, hz = deg_to_rad(e[2]) * 0.5f;
+    const float sx = sinf(hx), cx = cosf(hx), sy = sinf(hy), cy = cosf(hy), sz = sinf(hz), cz = cosf(hz);
+    return {-sx * sy * sz + cx * cy * cz, sx * cy * cz + sy * sz * cx, -sx * sz * cy + sy * cx * cz, sx * sy * cz + sz * cx * cy};
+}
+static void normalize3(const float v[3], float out[3]) {
+    const float inv = 1.0f / sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    for (int k = 0; k < 3; ++k) out[k] = v[k] * inv;
+}
+static Mat4 mat_identity() { Mat4 m{}; for (int k = 0; k < 4; ++k) m.c[k][k] = 1.0f; return m; }
+static Mat4 mat_mul(const Mat4& a, const Mat4& b) {
+    Mat4 r{};
+    for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row) r.c[col][row] = a.c[0][row] * b.c[col][0] + a.c[1][row] * b.c[col][1] + a.c[2][row] * b.c[col][2] + a.c[3][row] * b.c[col][3];
+    return r;
+}
+static Mat4 mat_from_quat(const Quat& q) {
+    const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    const float xx2 = x2 * q.x, xy2 = x2 * q.y, xz2 = x2 * q.z, yy2 = y2 * q.y, yz2 = y2 * q.z, zz2 = z2 * q.z, sy2 = y2 * q.s, sz2 = z2 * q.s, sx2 = x2 * q.s;
+    Mat4 m = mat_identity();
+    m.c[0][0] = 1.0f - yy2 - zz2; m.c[0][1] = xy2 + sz2; m.c[0][2] = xz2 - sy2;
+    m.c[1][0] = xy2 - sz2; m.c[1][1] = 1.0f - xx2 - zz2; m.c[1][2] = yz2 + sx2;
+    m.c[2][0] = xz2 + sy2; m.c[2][1] = yz2 - sx2; m.c[2][2] = 1.0f - xx2 - yy2;
+    return m;
+}
+static float duration_as_secs_f32(uint64_t ns) { return (float)(ns / 1000000000ull) + (float)(uint32_t)(ns % 1000000000ull) / 1000000000.0f; }
+
+static void world_position_at_time(const blub_static_object& o, uint64_t total_ns, float out[3]) {   // models.rs:157-175
+    if (!o.has_translation) { for (int k = 0; k < 3; ++k) out[k] = o.world_position[k]; return; }
+    float progress = fmodf(duration_as_secs_f32(total_ns), o.translation_duration * 2.0f);
+    if (progress > o.translation_duration) progress = o.translation_duration * 2.0f - progress;
+    progress /= o.translation_duration;
+    progress = progress < 0.0f ? 0.0f : (progress > 1.0f ? 1.0f : progress);   // f32::clamp (NaN stays NaN)
+    if (o.translation_curve == BLUB_CURVE_SMOOTHSTEP) progress = progress * progress * (3.0f - 2.0f * progress);
+    for (int k = 0; k < 3; ++k) out[k] = o.world_position[k] * (1.0f - progress) + o.translation_target[k] * progress;
+}
+static Quat rotation_at_time(const blub_static_object& o, uint64_t total_ns) {   // models.rs:177-188
+    const Quat st = quat_from_euler_deg(o.rotation_angles_deg);
+    if (!o.has_rotation) return st;
+    float axis[3]; normalize3(o.rotation_axis, axis);
+    const float half = deg_to_rad(o.rotation_deg_per_sec * duration_as_secs_f32(total_ns)) * 0.5f;
+    const float s = sinf(half), c = cosf(half);
+    return quat_mul(st, Quat{c, axis[0] * s, axis[1] * s, axis[2] * s});
+}
+
+int scene_mesh_desc_at_time(const blub_scene_config* scene, uint32_t index, uint64_t total_ns, uint64_t delta_ns, blub_mesh_desc* out) {   // to_gpu, models.rs:190-228
+    if (!scene || !out || index >= scene->num_static_objects) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad static object index");
+    const blub_static_object& o = scene->static_objects[index];
+    float wp[3]; world_position_at_time(o, total_ns, wp);
+    const Quat rot = rotation_at_time(o, total_ns);
+    float vel[3] = {0.0f, 0.0f, 0.0f};
+    if (total_ns > delta_ns) {   // "brute force" backward difference (:195-199)
+        float prev[3]; world_position_at_time(o, total_ns - delta_ns, prev);
+        const float dt = duration_as_secs_f32(delta_ns);
+        for (int k = 0; k < 3; ++k) vel[k] = (wp[k] - prev[k]) / dt;
+    }
+    Mat4 T = mat_identity(); for (int k = 0; k < 3; ++k) T.c[3][k] = wp[k];
+    Mat4 S = mat_identity(); for (int k = 0; k < 3; ++k) S.c[k][k] = o.scale;
+    const Mat4 world = mat_mul(mat_mul(T, S), mat_from_quat(rot));
+    const float inv = 1.0f / scene->grid_to_world_scale;
+    Mat4 Sv = mat_identity(); for (int k = 0; k < 3; ++k) Sv.c[k][k] = inv;
+    Mat4 Tv = mat_identity(); for (int k = 0; k < 3; ++k) Tv.c[3][k] = -scene->world_position[k];
+    const Mat4 voxel = mat_mul(mat_mul(Sv, Tv), world);
+    memset(out, 0, sizeof(*out));
+    for (int row = 0; row < 3; ++row) for (int col = 0; col < 4; ++col) out->voxel_transform[row][col] = voxel.c[col][row];
+    for (int k = 0; k < 3; ++k) out->fluid_space_velocity[k] = vel[k] / scene->grid_to_world_scale;
+    if (o.has_rotation) {
+        float axis[3]; normalize3(o.rotation_axis, axis);
+        const float w = deg_to_rad(o.rotation_deg_per_sec);
+        for (int k = 0; k < 3; ++k) out->fluid_space_rotation_axis_scaled[k] = axis[k] * w;
+    }
+    return BLUB_OK;
+}
+
+// tobj::load_obj stand-in (models.rs:267-276): positions and fan-triangulated faces; everything else is ignored.
+int load_obj(const char* path, float* pos, size_t vcap, uint32_t* nv_out, uint32_t* idx, size_t icap, uint32_t* ni_out) {
+    if (!path || !nv_out || !ni_out) return set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_error(BLUB_ERR_IO, (std::string("cannot open model file ") + path).c_str());
+    std::vector<float> P; std::vector<uint32_t> I;
+    char line[4096];
+    bool bad = false;
+    while (fgets(line, sizeof line, f)) {
+        const char* c = line;
+        while (*c == ' ' || *c == '\t') ++c;
+        if (c[0] == 'v' && (c[1] == ' ' || c[1] == '\t')) {
+            float x, y, z;
+            if (sscanf(c + 1, "%f %f %f", &x, &y, &z) != 3) { bad = true; break; }
+            P.push_back(x); P.push_back(y); P.push_back(z);
+        } else if (c[0] == 'f' && (c[1] == ' ' || c[1] == '\t')) {
+            std::vector<uint32_t> poly;
+            const char* q = c + 1;
+            for (;;) {
+                while (*q == ' ' || *q == '\t') ++q;
+                if (*q == 0 || *q == '\n' || *q == '\r') break;
+                char* endp = nullptr;
+                const long v = strtol(q, &endp, 10);
+                if (endp == q) { bad = true; break; }
+                const long nverts = (long)(P.size() / 3);
+                const long k = v > 0 ? v - 1 : nverts + v;   // negative = relative to the vertices read so far
+                if (k < 0 || k >= nverts) { bad = true; break; }
+                poly.push_back((uint32_t)k);
+                q = endp;
+                while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') ++q;   // skip /vt/vn
+            }
+            if (bad) break;
+            for (size_t k = 1; k + 1 < poly.size(); ++k) { I.push_back(poly[0]); I.push_back(poly[k]); I.push_back(poly[k + 1]); }
+        }
+    }
+    fclose(f);
+    if (bad) return set_error(BLUB_ERR_PARSE, (std::string("malformed OBJ record in ") + path).c_str());
+    *nv_out = (uint32_t)(P.size() / 3); *ni_out = (uint32_t)I.size();
+    if (pos) { if (vcap < P.size() / 3) return set_error(BLUB_ERR_INVALID_ARGUMENT, "vertex buffer too small"); memcpy(pos, P.data(), P.size() * sizeof(float)); }
+    if (idx) { if (icap < I.size()) return set_error(BLUB_ERR_INVALID_ARGUMENT, "index buffer too small"); memcpy(idx, I.data(), I.size() * sizeof(uint32_t)); }
     return BLUB_OK;
 }
 
@@ -219,6 +380,12 @@ int blub_scene_load_json(const char* path, blub_scene_config* out) {
     while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
     fclose(f);
     return blub::scene_parse(text.data(), text.size(), out);
+}
+int blub_scene_mesh_desc_at_time(const blub_scene_config* scene, uint32_t object_index, uint64_t total_simulated_time_ns, uint64_t simulation_delta_ns, blub_mesh_desc* out) {
+    return blub::scene_mesh_desc_at_time(scene, object_index, total_simulated_time_ns, simulation_delta_ns, out);
+}
+int blub_load_obj(const char* path, float* positions_xyz, size_t vertex_capacity, uint32_t* num_vertices, uint32_t* indices, size_t index_capacity, uint32_t* num_indices) {
+    return blub::load_obj(path, positions_xyz, vertex_capacity, num_vertices, indices, index_capacity, num_indices);
 }
 int blub_seed_fluid_cube(const uint32_t grid_dim[3], uint32_t max_num_particles, uint32_t num_particles_before,
                          const float min_grid[3], const float max_grid[3], float* pos_ll_out, size_t capacity, uint32_t* count_out) {

@@ -20,6 +20,8 @@ PRECOND = {"zero": 0, "lod0": 1}
 BINNING = {"fixed": 0, "off": 2}
 SOLVER_VELOCITY, SOLVER_DENSITY = 0, 1
 MAX_CUBES = 64
+MAX_STATIC_OBJECTS = 16
+MAX_PATH = 256
 PROF_MAX = 48
 
 
@@ -42,12 +44,25 @@ class _FluidDesc(C.Structure):
                 ("device", C.c_int32), ("precond_mode", C.c_uint32), ("binning_mode", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class StaticObjectConfig(C.Structure):
+    """scene/models.rs:11-46 (StaticObjectConfig + RigidAnimation)"""
+    _fields_ = [("model", C.c_char * MAX_PATH), ("world_position", C.c_float * 3), ("scale", C.c_float), ("rotation_angles_deg", C.c_float * 3),
+                ("has_translation", C.c_uint32), ("translation_target", C.c_float * 3), ("translation_curve", C.c_uint32), ("translation_duration", C.c_float),
+                ("has_rotation", C.c_uint32), ("rotation_axis", C.c_float * 3), ("rotation_deg_per_sec", C.c_float)]
+
+
 class SceneConfig(C.Structure):
     """src/scene/mod.rs:19-43"""
     _fields_ = [("gravity", C.c_float * 3), ("world_position", C.c_float * 3), ("grid_to_world_scale", C.c_float),
                 ("grid_dimension", C.c_uint32 * 3), ("max_num_particles", C.c_uint32), ("num_fluid_cubes", C.c_uint32),
                 ("cube_min", (C.c_float * 3) * MAX_CUBES), ("cube_max", (C.c_float * 3) * MAX_CUBES),
-                ("num_static_objects", C.c_uint32)]
+                ("num_static_objects", C.c_uint32), ("static_objects", StaticObjectConfig * MAX_STATIC_OBJECTS)]
+
+
+class MeshDesc(C.Structure):
+    """The fields of MeshDataGpu (scene/models.rs:55-70) the voxeliser reads; include/blubhip.h blub_mesh_desc."""
+    _fields_ = [("voxel_transform", (C.c_float * 4) * 3), ("fluid_space_velocity", C.c_float * 3), ("fluid_space_rotation_axis_scaled", C.c_float * 3),
+                ("index_begin", C.c_uint32), ("index_end", C.c_uint32)]
 
 
 class _DeviceViews(C.Structure):
@@ -151,6 +166,10 @@ def load_library():
         "blub_fluid_set_pcg_work_mapping": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_brick_counts": (C.c_int, [vp, vp]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
+        "blub_scene_mesh_desc_at_time": (C.c_int, [C.POINTER(SceneConfig), u32, C.c_uint64, C.c_uint64, C.POINTER(MeshDesc)]),
+        "blub_load_obj": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.POINTER(u32), vp, C.c_size_t, C.POINTER(u32)]),
+        "blub_fluid_set_meshes": (C.c_int, [vp, u32, vp, u32, vp]),
+        "blub_fluid_voxelize": (C.c_int, [vp, u32, C.POINTER(MeshDesc)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError = a symbol declared in include/blubhip.h is not exported
@@ -188,6 +207,29 @@ def seed_fluid_cube(grid_dim, max_num_particles, num_particles_before, min_grid,
     if cnt.value:
         _check(L, L.blub_seed_fluid_cube(_ptr(dim), max_num_particles, num_particles_before, _ptr(mn), _ptr(mx), _ptr(out), cnt.value, C.byref(cnt)))
     return out
+
+
+def load_obj(path):
+    """Host-only stand-in for tobj::load_obj(triangulate) (scene/models.rs:267-276): (positions (V,3) f32, indices (T*3,) u32)."""
+    L = load_library()
+    nv, ni = C.c_uint32(), C.c_uint32()
+    _check(L, L.blub_load_obj(os.fsencode(path), None, 0, C.byref(nv), None, 0, C.byref(ni)))
+    pos, idx = np.zeros((nv.value, 3), np.float32), np.zeros(ni.value, np.uint32)
+    _check(L, L.blub_load_obj(os.fsencode(path), _ptr(pos), nv.value, C.byref(nv), _ptr(idx), ni.value, C.byref(ni)))
+    return pos, idx
+
+
+def duration_nanos(seconds):
+    """A simulation delta given in (f32) seconds as the integer nanoseconds of the reference's `Duration`."""
+    return int(round(float(seconds) * 1e9))
+
+
+def mesh_desc_at_time(config, object_index, total_simulated_time_ns, simulation_delta_ns):
+    """Host-only: StaticMeshData::to_gpu (scene/models.rs:190-228)."""
+    L = load_library()
+    d = MeshDesc()
+    _check(L, L.blub_scene_mesh_desc_at_time(C.byref(config), int(object_index), int(total_simulated_time_ns), int(simulation_delta_ns), C.byref(d)))
+    return d
 
 
 class HybridFluid:
@@ -353,6 +395,17 @@ class HybridFluid:
     def set_solid_voxels(self, vox):
         self.write_volume("solid", vox)
 
+    def set_meshes(self, positions, indices):
+        """SceneModels vertex / index buffers (scene/models.rs:354-375)."""
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        indices = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        _check(self._L, self._L.blub_fluid_set_meshes(self._h, positions.shape[0], _ptr(positions), indices.shape[0], _ptr(indices)))
+
+    def voxelize(self, mesh_descs):
+        """SceneVoxelization::update (scene/voxelization.rs:116-157); enqueues on the engine's stream."""
+        arr = (MeshDesc * max(1, len(mesh_descs)))(*mesh_descs)
+        _check(self._L, self._L.blub_fluid_voxelize(self._h, len(mesh_descs), arr))
+
     def mark_pressure_initialised(self, which, initialised=True):
         _check(self._L, self._L.blub_fluid_mark_pressure_initialised(self._h, which, int(bool(initialised))))
 
@@ -445,6 +498,10 @@ class Scene:
             _check(self._L, self._L.blub_scene_parse_json(b, len(b), C.byref(self.config)))
         self._device = device
         self._fluid = None
+        self._path = path
+        self.models_dir = None if path is None else os.path.join(os.path.dirname(os.path.abspath(path)), "models")
+        self.total_simulated_time_ns = 0
+        self._meshes = None   # [(object index, index_begin, index_end)]
 
     @staticmethod
     def parse(path=None, text=None):
@@ -459,6 +516,10 @@ class Scene:
             _check(s._L, s._L.blub_scene_parse_json(b, len(b), C.byref(s.config)))
         s._device = -1
         s._fluid = None
+        s._path = path
+        s.models_dir = None if path is None else os.path.join(os.path.dirname(os.path.abspath(path)), "models")
+        s.total_simulated_time_ns = 0
+        s._meshes = None
         return s
 
     def fluid(self):
@@ -474,11 +535,49 @@ class Scene:
         if self._fluid is not None:
             self._fluid.close()
             self._fluid = None
+        self._meshes = None
         return self.fluid()
 
+    def static_objects(self):
+        return [self.config.static_objects[i] for i in range(self.config.num_static_objects)]
+
+    def _load_models(self, fluid):
+        """SceneModels::from_config (scene/models.rs:255-376): one shared vertex / index buffer, one mesh per object (the
+        reference splits an OBJ by material for texturing only; the voxeliser draws all of its index ranges alike)."""
+        positions, indices, meshes = [], [], []
+        nv = ni = 0
+        for i, o in enumerate(self.static_objects()):
+            if self.models_dir is None:
+                raise BlubError(-5, "scene has static objects but no models directory (Scene.models_dir)")
+            p, idx = load_obj(os.path.join(self.models_dir, o.model.decode()))
+            positions.append(p)
+            indices.append(idx + np.uint32(nv))
+            meshes.append((i, ni, ni + len(idx)))
+            nv += len(p)
+            ni += len(idx)
+        if meshes:
+            fluid.set_meshes(np.concatenate(positions), np.concatenate(indices))
+        self._meshes = meshes
+
+    def mesh_descs(self, simulation_delta_ns):
+        """SceneModels::step (scene/models.rs:379-387) at the current total simulated time."""
+        out = []
+        for i, begin, end in self._meshes or []:
+            d = mesh_desc_at_time(self.config, i, self.total_simulated_time_ns, simulation_delta_ns)
+            d.index_begin, d.index_end = begin, end
+            out.append(d)
+        return out
+
     def step(self, simulation_delta):
-        """scene/mod.rs:166-213: HybridFluid::step, submit, update_statistics."""
+        """scene/mod.rs:166-213: [animate models, voxelize scene,] HybridFluid::step, submit, update_statistics.  The timer has
+        already advanced by the step being taken when Scene::step runs (timer.rs:124, simulation_controller.rs:213-214)."""
         f = self.fluid()
+        delta_ns = duration_nanos(simulation_delta)
+        self.total_simulated_time_ns += delta_ns
+        if self.config.num_static_objects:
+            if self._meshes is None:
+                self._load_models(f)
+            f.voxelize(self.mesh_descs(delta_ns))
         f.step(simulation_delta)
         f.update_statistics()
 

@@ -75,7 +75,21 @@ typedef struct blub_fluid_desc {
 } blub_fluid_desc;
 
 /* ---- scene JSON: src/scene/mod.rs:19-43 (SceneConfig / FluidConfig / Box) -- host only, no device needed -------- */
-enum { BLUB_SCENE_MAX_CUBES = 64 };
+enum { BLUB_SCENE_MAX_CUBES = 64, BLUB_SCENE_MAX_STATIC_OBJECTS = 16, BLUB_SCENE_MAX_PATH = 256 };
+typedef enum blub_animation_curve { BLUB_CURVE_LINEAR = 0, BLUB_CURVE_SMOOTHSTEP = 1 } blub_animation_curve;   /* models.rs:21-25 */
+typedef struct blub_static_object {    /* StaticObjectConfig + RigidAnimation, scene/models.rs:11-46 */
+    char model[BLUB_SCENE_MAX_PATH];       /* relative to the `models` directory (models.rs:267) */
+    float world_position[3];
+    float scale;
+    float rotation_angles_deg[3];          /* cgmath::Euler<Deg<f32>> */
+    uint32_t has_translation;              /* animation.translation (models.rs:27-32) */
+    float translation_target[3];
+    uint32_t translation_curve;            /* blub_animation_curve */
+    float translation_duration;            /* seconds to reach the target */
+    uint32_t has_rotation;                 /* animation.rotation (models.rs:34-38) */
+    float rotation_axis[3];
+    float rotation_deg_per_sec;
+} blub_static_object;
 typedef struct blub_scene_config {
     float gravity[3];              /* world space */
     float world_position[3];
@@ -85,7 +99,8 @@ typedef struct blub_scene_config {
     uint32_t num_fluid_cubes;
     float cube_min[BLUB_SCENE_MAX_CUBES][3]; /* world space */
     float cube_max[BLUB_SCENE_MAX_CUBES][3];
-    uint32_t num_static_objects;   /* parsed for diagnostics only: static objects / voxelisation are out of scope */
+    uint32_t num_static_objects;
+    blub_static_object static_objects[BLUB_SCENE_MAX_STATIC_OBJECTS];
 } blub_scene_config;
 
 int blub_scene_load_json(const char* path, blub_scene_config* out);              /* Scene::new, scene/mod.rs:64-66 */
@@ -146,6 +161,32 @@ int blub_fluid_get_device_views(const blub_fluid* h, blub_device_views* out);
 /* Stand-in for the borrowed `SceneVoxelization` RGBA16F volume (scene/voxelization.rs:17, hybrid_fluid.rs:266):
  * N float4 {solid velocity xyz, solid flag w} or NULL for the all-zero volume every BASELINE scene has. */
 int blub_fluid_set_solid_voxels(blub_fluid* h, const float* voxels_xyzw_or_null);
+
+/* ---- static objects: scene/models.rs + scene/voxelization.rs + shader/voxelize/conservative_hull.{vert,frag} ----
+ * The reference rasterises every mesh with the hardware's conservative rasteriser into the RGBA16F volume once per step
+ * (scene/mod.rs:192-196).  Here the same per-fragment logic runs as a compute kernel over the pixels whose square
+ * overlaps the projected triangle ("overestimate" conservative rasterisation; depth = the triangle's plane at the pixel
+ * centre, clamped to the triangle's depth range).  Velocities are rounded to f16 like the RGBA16F store. */
+typedef struct blub_mesh_desc {              /* the fields of MeshDataGpu (models.rs:55-70) the voxeliser reads */
+    float voxel_transform[3][4];             /* rows of transform_voxel: voxel = (M * vec4(p, 1)).xyz (conservative_hull.vert:17-21) */
+    float fluid_space_velocity[3];
+    float fluid_space_rotation_axis_scaled[3];
+    uint32_t index_begin, index_end;         /* index_buffer_range */
+} blub_mesh_desc;
+/* StaticMeshData::to_gpu (models.rs:156-228) for object `object_index` of the scene: rigid animation evaluated at
+ * `total_simulated_time` (Timer::total_simulated_time, already advanced by the step being taken: timer.rs:124), velocity by
+ * the reference's backward difference over `simulation_delta`.  index_begin/index_end are left 0.  Host only. */
+int blub_scene_mesh_desc_at_time(const blub_scene_config* scene, uint32_t object_index, uint64_t total_simulated_time_ns,
+                                 uint64_t simulation_delta_ns, blub_mesh_desc* out);
+/* Stand-in for tobj::load_obj(triangulate) (models.rs:267-276): `v` and `f` records only, polygons fan-triangulated, indices
+ * into the position list.  Call with NULL outputs to query the sizes.  Host only. */
+int blub_load_obj(const char* path, float* positions_xyz, size_t vertex_capacity, uint32_t* num_vertices, uint32_t* indices,
+                  size_t index_capacity, uint32_t* num_indices);
+/* SceneModels::from_config's vertex / index buffers (models.rs:354-375); uploaded once. */
+int blub_fluid_set_meshes(blub_fluid* h, uint32_t num_vertices, const float* positions_xyz, uint32_t num_indices, const uint32_t* indices);
+/* SceneVoxelization::update (voxelization.rs:116-157): clear the solid volume, then one conservative-hull pass per mesh in
+ * order (a later mesh overwrites an earlier one).  Enqueues on the handle's stream; the next step sees the new solids. */
+int blub_fluid_voxelize(blub_fluid* h, uint32_t num_meshes, const blub_mesh_desc* meshes);
 
 /* ---- state exchange (parity tests, checkpoint/resume) ---------------------------------------------------------- */
 int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz);

@@ -663,6 +663,106 @@ struct Oracle {
         run_stage(ST_SOLVE_DENSITY, dt); run_stage(ST_POSITION_CHANGE, dt); run_stage(ST_CORRECT, dt);
         step_counter += 1;
     }
+
+    // ---- static objects: scene/voxelization.rs:116-157 + shader/voxelize/conservative_hull.{vert,frag} -----------------------
+    // Sequential restatement of the conservative-hull pass: vertex stage, an "overestimate" conservative rasteriser (a pixel
+    // yields a fragment iff its unit square overlaps the projected triangle), fragment stage.  What Vulkan leaves to the
+    // implementation is fixed as documented in include/blubhip.h (no sub-pixel snapping, depth = plane at the pixel centre
+    // clamped to the triangle's range, plane slopes for dFdx/dFdyCoarse, RGBA16F stores round to nearest even).  PARITY
+    // UNPINNED like the rest of the oracle: no reference test or fixture covers the voxelisation.
+    struct MeshDesc { float m[3][4]; float vel[3]; float axis[3]; uint32_t index_begin, index_end; };
+    static float f16_round(float v) {   // f32 -> f16 (round to nearest even) -> f32
+        uint32_t u; memcpy(&u, &v, 4);
+        const uint32_t sign = u & 0x80000000u; u &= 0x7FFFFFFFu;
+        if (u >= 0x7F800000u) return v;                                                   // inf / nan
+        if (u >= 0x477FF000u) { uint32_t inf = sign | 0x7F800000u; float r; memcpy(&r, &inf, 4); return r; }   // >= 65520 rounds to inf
+        if (u < 0x38800000u) {                                                            // f16 subnormal range: quantum 2^-24
+            float a; memcpy(&a, &u, 4);
+            const float q = std::nearbyint(a * 16777216.0f) / 16777216.0f;                // default rounding mode = nearest even
+            uint32_t r; memcpy(&r, &q, 4); r |= sign; float out; memcpy(&out, &r, 4); return out;
+        }
+        const uint32_t rem = u & 0x1FFFu;                                                 // 13 dropped mantissa bits
+        u &= ~0x1FFFu;
+        if (rem > 0x1000u || (rem == 0x1000u && (u & 0x2000u))) u += 0x2000u;
+        u |= sign; float out; memcpy(&out, &u, 4); return out;
+    }
+    void frag_store(const MeshDesc& d, const float vp[3]) {   // ComputeVoxelSpeed + imageStore (conservative_hull.frag:20-26)
+        const float px = vp[0] - d.m[0][3], py = vp[1] - d.m[1][3], pz = vp[2] - d.m[2][3];
+        const float dt = px * d.axis[0] + py * d.axis[1] + pz * d.axis[2];
+        const float tx = px - dt * d.axis[0], ty = py - dt * d.axis[1], tz = pz - dt * d.axis[2];
+        const float vx = (d.axis[1] * tz - d.axis[2] * ty) + d.vel[0];
+        const float vy = (d.axis[2] * tx - d.axis[0] * tz) + d.vel[1];
+        const float vz = (d.axis[0] * ty - d.axis[1] * tx) + d.vel[2];
+        const int ix = (int)vp[0], iy = (int)vp[1], iz = (int)vp[2];
+        if (inb(ix, iy, iz)) solid[idx(ix, iy, iz)] = F4{f16_round(vx), f16_round(vy), f16_round(vz), 1.0f};
+    }
+    void unswizzle_clamp(int side, float sx, float sy, float sz, float out[3]) const {   // :17-18
+        float x, y, z;
+        if (side == 0) { x = sz; y = sy; z = sx; } else if (side == 1) { x = sx; y = sz; z = sy; } else { x = sx; y = sy; z = sz; }
+        out[0] = std::fmin(std::fmax(x, 0.0f), (float)nx - 1.0f);
+        out[1] = std::fmin(std::fmax(y, 0.0f), (float)ny - 1.0f);
+        out[2] = std::fmin(std::fmax(z, 0.0f), (float)nz - 1.0f);
+    }
+    void voxelize(const float* positions, const uint32_t* indices, uint32_t num_meshes, const MeshDesc* meshes) {
+        solid.assign(N, F4{0, 0, 0, 0});   // clear_texture, voxelization.rs:123
+        const float viewport = (float)std::max(nx, std::max(ny, nz));   // :99
+        for (uint32_t mi = 0; mi < num_meshes; ++mi) {
+            const MeshDesc& d = meshes[mi];
+            for (uint32_t first = d.index_begin; first + 3 <= d.index_end; first += 3) {
+                // vertex stage (conservative_hull.vert:14-33)
+                float v[3][3];
+                for (int k = 0; k < 3; ++k) {
+                    const float* p = positions + 3 * (size_t)indices[first + k];
+                    for (int r = 0; r < 3; ++r) v[k][r] = p[0] * d.m[r][0] + p[1] * d.m[r][1] + p[2] * d.m[r][2] + d.m[r][3];
+                }
+                const float e1x = v[1][0] - v[0][0], e1y = v[1][1] - v[0][1], e1z = v[1][2] - v[0][2];
+                const float e2x = v[2][0] - v[0][0], e2y = v[2][1] - v[0][1], e2z = v[2][2] - v[0][2];
+                const float nax = std::fabs(e1y * e2z - e1z * e2y), nay = std::fabs(e1z * e2x - e1x * e2z), naz = std::fabs(e1x * e2y - e1y * e2x);
+                int side = nax > nay ? 0 : 1;
+                side = (side == 0 ? nax : nay) > naz ? side : 2;
+                float s[3][3];   // swizzled window-space vertices
+                for (int k = 0; k < 3; ++k) {
+                    if (side == 0) { s[k][0] = v[k][2]; s[k][1] = v[k][1]; s[k][2] = v[k][0]; }
+                    else if (side == 1) { s[k][0] = v[k][0]; s[k][1] = v[k][2]; s[k][2] = v[k][1]; }
+                    else { s[k][0] = v[k][0]; s[k][1] = v[k][1]; s[k][2] = v[k][2]; }
+                }
+                // rasteriser: cull_mode None => both windings; degenerate projections produce nothing
+                float area2 = (s[1][0] - s[0][0]) * (s[2][1] - s[0][1]) - (s[1][1] - s[0][1]) * (s[2][0] - s[0][0]);
+                if (!(area2 != 0.0f) || !(std::fabs(area2) < 3.0e38f)) continue;
+                if (area2 < 0.0f) { for (int c = 0; c < 3; ++c) std::swap(s[1][c], s[2][c]); area2 = -area2; }
+                const float ax = s[0][0], ay = s[0][1], az = s[0][2], bx = s[1][0], by = s[1][1], bz = s[1][2], cx = s[2][0], cy = s[2][1], cz = s[2][2];
+                const float dzdx = ((bz - az) * (cy - ay) - (cz - az) * (by - ay)) / area2;
+                const float dzdy = ((cz - az) * (bx - ax) - (bz - az) * (cx - ax)) / area2;
+                const float zmin = std::fmin(az, std::fmin(bz, cz)), zmax = std::fmax(az, std::fmax(bz, cz));
+                const float xlo = std::fmax(std::floor(std::fmin(ax, std::fmin(bx, cx))), 0.0f), xhi = std::fmin(std::floor(std::fmax(ax, std::fmax(bx, cx))), viewport - 1.0f);
+                const float ylo = std::fmax(std::floor(std::fmin(ay, std::fmin(by, cy))), 0.0f), yhi = std::fmin(std::floor(std::fmax(ay, std::fmax(by, cy))), viewport - 1.0f);
+                if (!(xhi >= xlo) || !(yhi >= ylo)) continue;
+                const float ex[3] = {bx - ax, cx - bx, ax - cx}, ey[3] = {by - ay, cy - by, ay - cy};
+                const float ox[3] = {ax, bx, cx}, oy[3] = {ay, by, cy};
+                for (int j = (int)ylo; j <= (int)yhi; ++j)
+                    for (int i = (int)xlo; i <= (int)xhi; ++i) {
+                        bool covered = true;
+                        for (int e = 0; e < 3 && covered; ++e) {   // the corner of the pixel square that maximises the edge function
+                            const float qx = ey[e] < 0.0f ? (float)i + 1.0f : (float)i, qy = ex[e] > 0.0f ? (float)j + 1.0f : (float)j;
+                            covered = (ex[e] * (qy - oy[e]) - ey[e] * (qx - ox[e])) >= 0.0f;
+                        }
+                        if (!covered) continue;
+                        // fragment stage (conservative_hull.frag:28-56); gl_FragCoord = (i + .5, j + .5, depth)
+                        const float fcx = (float)i + 0.5f, fcy = (float)j + 0.5f;
+                        float z = az + dzdx * (fcx - ax) + dzdy * (fcy - ay);
+                        z = std::fmin(std::fmax(z, zmin), zmax);
+                        if (!(z >= 0.0f && z <= viewport)) continue;   // depth clipping
+                        float vp[3];
+                        unswizzle_clamp(side, std::trunc(fcx), std::trunc(fcy), std::trunc(z), vp);   // ivec3(voxelPosSwizzled), :35-36
+                        frag_store(d, vp);
+                        const float max_change = std::fmax(std::fabs(dzdx), std::fabs(dzdy));            // :39-44
+                        if (std::floor(z) != std::floor(z - max_change)) { unswizzle_clamp(side, fcx, fcy, z - 1.0f, vp); frag_store(d, vp); }   // :46-49
+                        if (std::floor(z) != std::floor(z + max_change)) { unswizzle_clamp(side, fcx, fcy, z + 1.0f, vp); frag_store(d, vp); }   // :50-53
+                    }
+            }
+        }
+    }
+
     void* volume_ptr(int which, size_t* bytes) {
         switch (which) {
         case V_MARKER: *bytes = N; return marker.data();
@@ -712,6 +812,12 @@ int orc_write_volume(void* h, int which, const void* in) {
     if (which == V_SOLID) { if (!in) { o->solid.clear(); return 0; } o->solid.resize(o->N); }
     size_t b; void* p = o->volume_ptr(which, &b); if (!p) return -1; memcpy(p, in, b); return 0;
 }
+int orc_voxelize(void* h, const float* positions, const uint32_t* indices, uint32_t num_meshes, const void* mesh_descs) {
+    static_assert(sizeof(Oracle::MeshDesc) == 80, "layout of blub_mesh_desc");
+    ((Oracle*)h)->voxelize(positions, indices, num_meshes, (const Oracle::MeshDesc*)mesh_descs);
+    return 0;
+}
+float orc_f16_round(float v) { return Oracle::f16_round(v); }
 void orc_run_stage(void* h, int stage, float dt) { ((Oracle*)h)->run_stage(stage, dt); }
 void orc_step(void* h, float dt) { ((Oracle*)h)->step(dt); }
 void orc_get_solver_stats(void* h, int which, float* err, int* it) { *err = ((Oracle*)h)->last_stats[which].error; *it = ((Oracle*)h)->last_stats[which].iterations; }

@@ -65,6 +65,9 @@ def _load():
         L.orc_get_solver_totals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rng_from_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_rng_seed_from_u64.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_voxelize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_f16_round.restype = C.c_float
+        L.orc_f16_round.argtypes = [C.c_float]
         L.orc_set_num_threads.restype = None
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_get_max_threads.restype = C.c_int
@@ -193,6 +196,14 @@ class Oracle:
         if self._L.orc_write_volume(self._h, which, _ptr(a)) != 0:
             raise ValueError("volume %s unavailable" % name)
 
+    def voxelize(self, positions, indices, mesh_descs):
+        """scene/voxelization.rs:116-157 on the oracle's solid volume.  mesh_descs: (M, 20) float32-viewable array or a list of
+        20-word records laid out like include/blubhip.h blub_mesh_desc (12 transform floats, 3 velocity, 3 axis, 2 u32)."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        d = np.ascontiguousarray(mesh_descs).view(np.uint32).reshape(-1, 20)
+        self._L.orc_voxelize(self._h, _ptr(pos), _ptr(idx), d.shape[0], _ptr(d))
+
     def run_stage(self, name, dt):
         self._L.orc_run_stage(self._h, STAGES[name], float(dt))
 
@@ -210,6 +221,16 @@ class Oracle:
         s = C.c_double()
         self._L.orc_get_solver_totals(self._h, C.byref(it), C.byref(s))
         return it.value, s.value
+
+
+def f16_round(v):
+    return float(_load().orc_f16_round(float(v)))
+
+
+def pack_mesh_desc(voxel_transform, velocity=(0, 0, 0), rotation_axis_scaled=(0, 0, 0), index_begin=0, index_end=0):
+    """One blub_mesh_desc record (include/blubhip.h) as 20 uint32 words."""
+    f = np.concatenate([np.asarray(voxel_transform, np.float32).reshape(12), np.asarray(velocity, np.float32), np.asarray(rotation_axis_scaled, np.float32)])
+    return np.concatenate([f.view(np.uint32), np.asarray([index_begin, index_end], np.uint32)])
 
 
 def rng_from_seed(seed32: bytes, n: int):

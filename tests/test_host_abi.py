@@ -34,12 +34,16 @@ def test_scene_json_matches_reference_schema(tmp_path):
     assert list(s.grid_dimension) == [128, 64, 64] and s.max_num_particles == 2000000 and s.num_fluid_cubes == 2
     assert np.float32(s.grid_to_world_scale) == np.float32(0.01)
     assert np.allclose(list(s.gravity), [0, -9.81, 0]) and np.allclose(list(s.cube_min[1]), [0.96, 0, 0])
-    # static_objects is #[serde(default)]
-    txt = json.dumps({"gravity": {"x": 0, "y": -1, "z": 0}, "static_objects": [{"a": 1}, {"b": [1, 2, {"c": "d\\n"}]}],
+    # static_objects is #[serde(default)]; unknown fields are ignored like serde does (nested junk exercises the JSON reader)
+    obj = {"model": "m.obj", "world_position": {"x": 1, "y": 2, "z": 3}, "scale": 0.5, "rotation_angles": {"x": 0, "y": 90, "z": 0}}
+    txt = json.dumps({"gravity": {"x": 0, "y": -1, "z": 0}, "static_objects": [dict(obj, a=1), dict(obj, b=[1, 2, {"c": "d\\n"}])],
                       "fluid": {"world_position": {"x": 0, "y": 0, "z": 0}, "grid_to_world_scale": 1e-2, "max_num_particles": 10,
                                 "grid_dimension": {"x": 32, "y": 32, "z": 32}, "fluid_cubes": []}})
     c = blub_amd.Scene.parse(text=txt).config
-    assert c.num_static_objects == 2 and c.num_fluid_cubes == 0
+    assert c.num_static_objects == 2 and c.num_fluid_cubes == 0 and c.static_objects[1].model == b"m.obj"
+    assert blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", "double_dam.json")).config.num_static_objects == 0
+    w = blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", "wavegenerator_cube.json")).config
+    assert w.num_static_objects == 1 and w.static_objects[0].has_translation == 1 and w.static_objects[0].model == b"unit_cube.obj"
 
 
 @pytest.mark.parametrize("mutate,status", [
