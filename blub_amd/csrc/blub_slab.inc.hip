@@ -486,6 +486,16 @@ int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_
     return BLUB_OK;
 }
 int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t f) { if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); for (auto h : g->slabs) h->rebin_freq = f; return BLUB_OK; }
+int blub_slab_group_set_meshes(blub_slab_group* g, uint32_t nv, const float* positions, uint32_t ni, const uint32_t* indices) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    for (auto h : g->slabs) { int rc = blub_fluid_set_meshes(h, nv, positions, ni, indices); if (rc != BLUB_OK) return rc; }
+    return BLUB_OK;
+}
+int blub_slab_group_voxelize(blub_slab_group* g, uint32_t num_meshes, const blub_mesh_desc* meshes) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    for (auto h : g->slabs) { int rc = blub_fluid_voxelize(h, num_meshes, meshes); if (rc != BLUB_OK) return rc; }
+    return BLUB_OK;
+}
 int blub_slab_group_step(blub_slab_group* g, float dt) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");

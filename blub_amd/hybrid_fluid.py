@@ -605,7 +605,9 @@ class SlabGroup:
                 ("blub_slab_group_set_solver_config", C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
                 ("blub_slab_group_set_rebinning_frequency", C.c_int, [vp, C.c_uint32]),
                 ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
-                ("blub_slab_group_transport_ops", C.c_uint64, [vp])]:
+                ("blub_slab_group_transport_ops", C.c_uint64, [vp]),
+                ("blub_slab_group_set_meshes", C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
+                ("blub_slab_group_voxelize", C.c_int, [vp, C.c_uint32, C.POINTER(MeshDesc)])]:
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         self.grid = tuple(int(v) for v in grid_dimension)
@@ -705,6 +707,15 @@ class SlabGroup:
 
     def synchronize(self):
         _check(self._L, self._L.blub_slab_group_synchronize(self._g))
+
+    def set_meshes(self, positions, indices):
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        indices = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        _check(self._L, self._L.blub_slab_group_set_meshes(self._g, positions.shape[0], _ptr(positions), indices.shape[0], _ptr(indices)))
+
+    def voxelize(self, mesh_descs):
+        arr = (MeshDesc * max(1, len(mesh_descs)))(*mesh_descs)
+        _check(self._L, self._L.blub_slab_group_voxelize(self._g, len(mesh_descs), arr))
 
     def transport_ops(self):
         """Grouped transport operations (halo / partial / particle exchanges) issued by this process so far."""

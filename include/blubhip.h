@@ -279,6 +279,9 @@ int blub_slab_group_get_particles(blub_slab_group* g, float* pos_ll, float* vx, 
 int blub_slab_group_set_gravity_grid(blub_slab_group* g, const float gravity_grid[3]);
 int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_solver_config* cfg);
 int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t every_n_steps);
+/* static objects (see blub_fluid_set_meshes / blub_fluid_voxelize): every local slab voxelises the meshes in global grid coordinates */
+int blub_slab_group_set_meshes(blub_slab_group* g, uint32_t num_vertices, const float* positions_xyz, uint32_t num_indices, const uint32_t* indices);
+int blub_slab_group_voxelize(blub_slab_group* g, uint32_t num_meshes, const blub_mesh_desc* meshes);
 int blub_slab_group_step(blub_slab_group* g, float simulation_delta_seconds);
 int blub_slab_group_synchronize(blub_slab_group* g);
 /* diagnostics: grouped transport operations (halo / partial / particle exchanges) issued by this process so far */

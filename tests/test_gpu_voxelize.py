@@ -198,3 +198,48 @@ def test_scene_with_a_moving_solid_matches_oracle():
         assert inside.mean() < 0.01, inside.mean()
     finally:
         f.close()
+
+
+def test_moving_solid_in_a_z_slab_group_matches_single_domain():
+    """The voxelised solid straddles the interface of two z-slabs (every slab voxelises the meshes in global coordinates);
+    the group must stay inside the engine's run-to-run noise envelope of the single-domain run (see
+    test_gpu_parity.py::test_z_slab_decomposition_matches_single_domain for the envelope)."""
+    import blub_amd
+    from scipy.spatial import cKDTree
+    scene = blub_amd.Scene(text=json.dumps(SCENE))
+    scene.models_dir = os.path.join(ROOT, "scenes", "models")
+    single = scene.fluid()
+    dim = single.grid_dimension()
+    pos0 = single.get_particles()[0]
+    group = blub_amd.SlabGroup(dim, 40000, local=2)
+    try:
+        mesh_p, mesh_i = blub_amd.load_obj(os.path.join(scene.models_dir, "unit_cube.obj"))
+        group.set_meshes(mesh_p, mesh_i)
+        group.set_gravity_grid((0.0, -9.81 / 0.02, 0.0))
+        group.set_particles(pos0)
+        cfg = dict(error_tolerance=0.0, max_num_iterations=120, error_check_frequency=8)   # no convergence decision: see the slab test
+        for w in (0, 1):
+            single.set_solver_config(w, **cfg)
+            group.set_solver_config(w, **cfg)
+        single.particle_rebinning_step_frequency = 0
+        group.set_rebinning_frequency(0)
+        total = 0
+        for step in range(1, 5):
+            scene.step(util.DT)
+            total += DELTA_NS
+            d = blub_amd.mesh_desc_at_time(scene.config, 0, total, DELTA_NS)
+            d.index_begin, d.index_end = 0, len(mesh_i)
+            group.voxelize([d])
+            group.step(util.DT)
+            ps = single.get_particles()[0][:, :3].astype(np.float64)
+            pg = group.get_particles()[0][:, :3].astype(np.float64)
+            assert pg.shape == ps.shape
+            dd, idx = cKDTree(ps).query(pg, k=1)
+            assert len(np.unique(idx)) == len(pg)
+            print("step %d: slabs vs single: median %.3g p99 %.3g max %.3g" % (step, np.median(dd), np.quantile(dd, 0.99), dd.max()))
+            assert np.median(dd) < 2e-4 and np.quantile(dd, 0.99) < 3e-3 and dd.max() < 0.1
+        for i in range(2):
+            assert np.array_equal(group.local_fluid(i).read_volume("solid"), single.read_volume("solid"))
+    finally:
+        single.close()
+        group.close()
