@@ -74,7 +74,33 @@ def seeding_fixture():
                         checksum=np.array([p[:, :3].astype(np.float64).sum(), np.bitwise_xor.reduce(p[:, :3].view(np.uint32).reshape(-1))], np.float64))
 
 
+def voxelize_fixture():
+    """Solid voxels of two overlapping meshes (a rotated translating cube, a rotating octahedron) on a non-cubic grid."""
+    from oracle.oracle import pack_mesh_desc
+    dim = (40, 24, 32)
+    cube = np.array([[x, y, z] for z in (-.5, .5) for y in (-.5, .5) for x in (-.5, .5)], np.float32)
+    quads = [(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (1, 3, 7, 5), (3, 2, 6, 7), (2, 0, 4, 6)]
+    cube_i = np.array([[q[0], q[1], q[2], q[0], q[2], q[3]] for q in quads], np.uint32).reshape(-1)
+    octa = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    octa_i = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.uint32).reshape(-1) + 8
+    positions = np.concatenate([cube, octa])
+    indices = np.concatenate([cube_i, octa_i])
+    c, s_ = np.cos(0.6), np.sin(0.6)
+    rot = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]) @ np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    m0 = np.concatenate([rot * 11.5, np.array([[15.2], [11.7], [14.9]])], 1)
+    m1 = np.concatenate([np.eye(3) * 9.25, np.array([[26.4], [12.3], [17.6]])], 1)
+    descs = np.stack([pack_mesh_desc(m0, velocity=(7.5, -2.25, 1.0), index_begin=0, index_end=36),
+                      pack_mesh_desc(m1, velocity=(0.5, 0.25, -3.0), rotation_axis_scaled=(0.0, 2.5, 0.75), index_begin=36, index_end=60)])
+    o = Oracle(*dim, 8)
+    o.voxelize(positions, indices, descs)
+    vox = o.read_volume("solid")
+    zz, yy, xx = np.nonzero(vox[..., 3])
+    np.savez_compressed(os.path.join(HERE, "voxelize_40x24x32.npz"), dim=np.array(dim), positions=positions, indices=indices, descs=descs,
+                        solid_zyx=np.stack([zz, yy, xx], 1).astype(np.int16), solid_velocity=vox[zz, yy, xx, :3])
+
+
 if __name__ == "__main__":
+    voxelize_fixture()
     step_fixture()
     pcg_fixture()
     seeding_fixture()
