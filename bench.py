@@ -264,7 +264,7 @@ def main():
                 "data": "synthetic", "config": {"workload": "%s stacked x%d along z" % (args.scene, world), "grid": [nx, ny, nz], "particles": P, "dt": dt,
                                                 "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60, "parallelism": parallelism},
                 "global_steps_per_sec": round(args.steps / elapsed, 3), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
-                "transport_ops_per_step": round(ops_per_step, 1), "roofline": None, "cpu_baseline": None}))
+                "transport_ops_per_step": round(ops_per_step, 1), "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}))
             sys.stdout.flush()
         dist.barrier()
         group.close()

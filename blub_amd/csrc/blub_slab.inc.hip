@@ -35,6 +35,8 @@ struct blub_slab_group {
     blubk::PcgCtrl* ctrl_host = nullptr;         // pinned: control block of slab 0's solves [velocity, density], read only after a stream sync
     bool ctrl_host_valid[2] = {false, false};
     uint64_t comm_ops = 0;                       // grouped transport operations issued so far (diagnostics)
+    int gather_mode = 0;                         // RCCL only: 0 = partials as p2p inside the halo's group, 1 = ncclAllGather (calibrated at creation)
+    char transport[192] = "loopback";
 };
 
 namespace blub {
@@ -97,6 +99,10 @@ static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& arr
         return BLUB_OK;
     }
     float* arr = array_of(0);
+    if (G->gather_mode == 1) {   // (never inside a p2p group: see slab_fused)
+        NCCL_TRY(ncclAllGather(arr + (size_t)G->first * seg_floats, arr, (size_t)seg_floats, ncclFloat, G->comm, G->stream));
+        return BLUB_OK;
+    }
     if (own_group) NCCL_TRY(ncclGroupStart());
     for (int q = 0; q < G->nranks; ++q) {
         if (q == G->first) continue;
@@ -104,6 +110,18 @@ static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& arr
         NCCL_TRY(ncclRecv(arr + (size_t)q * seg_floats, (size_t)seg_floats, ncclFloat, q, G->comm, G->stream));
     }
     if (own_group) NCCL_TRY(ncclGroupEnd());
+    return BLUB_OK;
+}
+// Halo planes + a partial gather as ONE grouped operation (p2p mode) or as a p2p group followed by an all-gather.
+static int slab_fused(blub_slab_group* G, const std::function<int()>& halos, const std::function<int(bool)>& gather) {
+    int rc;
+    G->comm_ops += 1;
+    const bool split = G->rccl && G->gather_mode == 1;
+    if (G->rccl) NCCL_TRY(ncclGroupStart());
+    if ((rc = halos()) != BLUB_OK) return rc;
+    if (!split && (rc = gather(false)) != BLUB_OK) return rc;
+    if (G->rccl) NCCL_TRY(ncclGroupEnd());
+    if (split) { G->comm_ops += 1; if ((rc = gather(false)) != BLUB_OK) return rc; }
     return BLUB_OK;
 }
 
@@ -234,12 +252,10 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
                seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr);
     }
     // descriptor, r, s planes and the initial partials: one grouped operation
-    G->comm_ops += 1;
-    if (G->rccl) NCCL_TRY(ncclGroupStart());
-    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1, false)) != BLUB_OK) return rc;
-    if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }, [](blub_fluid* h) { return (void*)h->search; }}, 4, false)) != BLUB_OK) return rc;
-    if ((rc = gather_upd(false)) != BLUB_OK) return rc;
-    if (G->rccl) NCCL_TRY(ncclGroupEnd());
+    if ((rc = slab_fused(G, [&]() -> int {
+            int r2 = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1, false);
+            return r2 != BLUB_OK ? r2 : slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }, [](blub_fluid* h) { return (void*)h->search; }}, 4, false);
+        }, gather_upd)) != BLUB_OK) return rc;
     int it = 0;
     bool done = false;
     for (;;) {
@@ -262,11 +278,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
                 LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[it & 1], h->pressure[which], h->residual,
                        (const float*)G->ex[i].gat_dir, seg_upd(i), npall, (const PcgCtrl*)h->ctrl[which], it);
             }
-            G->comm_ops += 1;
-            if (G->rccl) NCCL_TRY(ncclGroupStart());
-            if ((rc = slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }}, 4, false)) != BLUB_OK) return rc;
-            if ((rc = gather_upd(false)) != BLUB_OK) return rc;
-            if (G->rccl) NCCL_TRY(ncclGroupEnd());
+            if ((rc = slab_fused(G, [&]() -> int { return slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }}, 4, false); }, gather_upd)) != BLUB_OK) return rc;
         }
         if (target > maxit) break;
         HIP_TRY(hipMemcpyAsync(&G->ctrl_host[which], h0->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, G->stream));
@@ -362,6 +374,62 @@ static void slab_range(int nz, int nranks, int index, int* z0, int* z1) {
     *z1 = std::min(hi * BZ, index + 1 == nranks ? nz + BZ : hi * BZ);
 }
 
+// RCCL transport of the PCG partials, chosen by measurement on the hardware at hand (the two candidates cannot be ranked
+// on the 1-GPU development box): per candidate, 30 rounds of what one PCG iteration issues; the slowest rank's time decides
+// (all-reduced, so every rank picks the same mode).  BLUB_SLAB_GATHER=0|1 overrides.
+static int slab_calibrate(blub_slab_group* G) {
+    snprintf(G->transport, sizeof G->transport, "rccl, %d ranks", G->nranks);
+    if (G->nranks == 1) return BLUB_OK;
+    if (const char* e = getenv("BLUB_SLAB_GATHER")) {
+        G->gather_mode = atoi(e) == 1 ? 1 : 0;
+        snprintf(G->transport, sizeof G->transport, "rccl, %d ranks, partials by %s (forced)", G->nranks, G->gather_mode ? "ncclAllGather" : "grouped send/recv");
+        return BLUB_OK;
+    }
+    blub_fluid* h = G->slabs[0];
+    auto& e = G->ex[0];
+    const int np = SLAB_NP;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    float* times = nullptr;
+    HIP_TRY(hipMalloc((void**)&times, 2 * sizeof(float)));
+    float ms[2] = {0.f, 0.f};
+    int rc = BLUB_OK;
+    auto round = [&]() -> int {
+        int r2 = slab_gather(G, [&](int) { return e.gat_dir; }, np);
+        if (r2 != BLUB_OK) return r2;
+        return slab_fused(G, [&]() -> int { return slab_halo(G, {[](blub_fluid* f) { return (void*)f->residual; }}, 4, false); },
+                          [&](bool own) { return slab_gather(G, [&](int) { return reinterpret_cast<float*>(e.gat_upd); }, 2 * np, own); });
+    };
+    for (int mode = 0; mode < 2 && rc == BLUB_OK; ++mode) {
+        G->gather_mode = mode;
+        for (int k = 0; k < 5 && rc == BLUB_OK; ++k) rc = round();
+        if (rc != BLUB_OK) break;
+        HIP_TRY(hipEventRecord(a, G->stream));
+        for (int k = 0; k < 30 && rc == BLUB_OK; ++k) rc = round();
+        HIP_TRY(hipEventRecord(b, G->stream));
+        HIP_TRY(hipEventSynchronize(b));
+        HIP_TRY(hipEventElapsedTime(&ms[mode], a, b));
+    }
+    if (rc == BLUB_OK) {
+        HIP_TRY(hipMemcpyAsync(times, ms, sizeof ms, hipMemcpyHostToDevice, G->stream));
+        NCCL_TRY(ncclAllReduce(times, times, 2, ncclFloat, ncclMax, G->comm, G->stream));
+        HIP_TRY(hipMemcpyAsync(ms, times, sizeof ms, hipMemcpyDeviceToHost, G->stream));
+        HIP_TRY(hipStreamSynchronize(G->stream));
+        G->gather_mode = ms[1] < ms[0] ? 1 : 0;
+        snprintf(G->transport, sizeof G->transport, "rccl, %d ranks, partials by %s (calibrated: grouped send/recv %.1f us, ncclAllGather %.1f us per PCG iteration)",
+                 G->nranks, G->gather_mode ? "ncclAllGather" : "grouped send/recv", ms[0] / 30.f * 1e3f, ms[1] / 30.f * 1e3f);
+    }
+    (void)hipFree(times); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)h;
+    G->comm_ops = 0;
+    // the calibration traffic went through the residual ghost planes and the gather arrays: put them back to zero
+    HIP_TRY(hipMemsetAsync(G->slabs[0]->residual, 0, G->slabs[0]->N * sizeof(float), G->stream));
+    HIP_TRY(hipMemsetAsync(e.gat_dir, 0, (size_t)G->nranks * np * sizeof(float), G->stream));
+    HIP_TRY(hipMemsetAsync(e.gat_upd, 0, (size_t)G->nranks * np * sizeof(float2), G->stream));
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    return rc;
+}
+
 static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, int nlocal, const void* nccl_id, blub_slab_group** out) {
     if (!d || !out || nranks < 1 || nlocal < 1 || first < 0 || first + nlocal > nranks || nlocal > 8) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad slab group arguments");
     *out = nullptr;
@@ -408,6 +476,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         }
     }
     if (rc == BLUB_OK && hipStreamSynchronize(G->stream) != hipSuccess) rc = set_error(BLUB_ERR_DEVICE, "slab group initialisation failed");
+    if (rc == BLUB_OK && G->rccl) rc = slab_calibrate(G);
     if (rc != BLUB_OK) { std::string keep = g_last_error; slab_group_destroy(G); g_last_error = keep; return rc; }
     *out = G;
     return BLUB_OK;
@@ -503,6 +572,7 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     return blub::slab_step(g, dt);
 }
 uint64_t blub_slab_group_transport_ops(const blub_slab_group* g) { return g ? g->comm_ops : 0; }
+const char* blub_slab_group_transport_description(const blub_slab_group* g) { return g ? g->transport : ""; }
 int blub_slab_group_synchronize(blub_slab_group* g) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");

@@ -605,7 +605,7 @@ class SlabGroup:
                 ("blub_slab_group_set_solver_config", C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
                 ("blub_slab_group_set_rebinning_frequency", C.c_int, [vp, C.c_uint32]),
                 ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
-                ("blub_slab_group_transport_ops", C.c_uint64, [vp]),
+                ("blub_slab_group_transport_ops", C.c_uint64, [vp]), ("blub_slab_group_transport_description", C.c_char_p, [vp]),
                 ("blub_slab_group_set_meshes", C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
                 ("blub_slab_group_voxelize", C.c_int, [vp, C.c_uint32, C.POINTER(MeshDesc)])]:
             fn = getattr(L, name)
@@ -716,6 +716,9 @@ class SlabGroup:
     def voxelize(self, mesh_descs):
         arr = (MeshDesc * max(1, len(mesh_descs)))(*mesh_descs)
         _check(self._L, self._L.blub_slab_group_voxelize(self._g, len(mesh_descs), arr))
+
+    def transport_description(self):
+        return self._L.blub_slab_group_transport_description(self._g).decode()
 
     def transport_ops(self):
         """Grouped transport operations (halo / partial / particle exchanges) issued by this process so far."""

@@ -286,6 +286,8 @@ int blub_slab_group_step(blub_slab_group* g, float simulation_delta_seconds);
 int blub_slab_group_synchronize(blub_slab_group* g);
 /* diagnostics: grouped transport operations (halo / partial / particle exchanges) issued by this process so far */
 uint64_t blub_slab_group_transport_ops(const blub_slab_group* g);
+/* "loopback" or the RCCL transport with the result of its start-up calibration (valid until the group is destroyed) */
+const char* blub_slab_group_transport_description(const blub_slab_group* g);
 
 #ifdef __cplusplus
 }
