@@ -91,6 +91,64 @@ def dense_pcg_benchmark(n=256, iterations=32):
             "iter_bytes_fused": fused, "iter_frac_fused": round(fused / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
 
 
+def transfer_microbenchmark(n=256, seed=1234):
+    """M4 of BASELINE.md / SURVEY 8(d): n^3 grid, 8 jittered particles in every interior cell of the lower half, smooth
+    velocity field; the transfer kernels (list building + P2G gathers), advection and the density gather are timed per
+    kernel class with HIP events, with the particles in random order and again after the engine's own binning pass."""
+    import blub_amd
+    rng = np.random.default_rng(seed)
+    xs, ys, zs = np.arange(1, n - 1), np.arange(1, n // 2), np.arange(1, n - 1)
+    cells = np.stack(np.meshgrid(xs, ys, zs, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    pos = np.repeat(cells, 8, axis=0)
+    pos += rng.random(pos.shape, dtype=np.float32)
+    P = pos.shape[0]
+    perm = rng.permutation(P)
+    pos = pos[perm]
+    vel = []
+    for c, fn in enumerate((np.sin, np.cos, None)):
+        rows = np.zeros((P, 4), np.float32)
+        if fn is not None:
+            rows[:, 3] = fn(pos[:, c] * 0.1) * 3.0
+        vel.append(rows)
+    dt = blub_amd.default_simulation_delta()
+    h = blub_amd.HybridFluid((n, n, n), P)
+    h.set_gravity_grid((0.0, -9.81 * n / 1.28, 0.0))
+    h.set_particles(pos, *vel)
+    del pos, vel, cells
+    N = n ** 3
+    out = {"grid": "%d^3" % n, "particles": P}
+
+    def timed(label):
+        res = {}
+        for rep in range(2):   # first repetition warms up
+            h.profile_enable(rep == 1)
+            h.profile_reset()
+            h.run_stage("transfer", dt)
+            h.run_stage("divergence", dt)
+            h.run_stage("advect", dt)
+            h.run_stage("density_gather", dt)
+            h.synchronize()
+        prof = h.profile_read()
+        h.profile_enable(False)
+        F = int((h.read_volume("marker") == 1).sum())
+        bc = h.brick_counts()
+        A, Fb = bc["active"] * bc["cells_per_brick"], bc["fluid"] * bc["cells_per_brick"]
+        for k in ("build_lists", "gather_velocity", "advect", "density_gather", "reset_bricks"):
+            if k not in prof:
+                continue
+            avg_ms = prof[k]["total_ms"] / prof[k]["launches"]
+            gbs = algorithmic_bytes(k, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
+            res[k] = {"avg_us": round(avg_ms * 1e3, 1), "launches": prof[k]["launches"], "algorithmic_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        res["fluid_cells"] = F
+        out[label] = res
+    timed("random_order")
+    h.step_counter = 0
+    h.run_stage("binning", dt)
+    timed("after_binning")
+    h.close()
+    return out
+
+
 def cpu_baseline(scene_path, dt, budget_steps=24):
     """The CPU oracle (a restatement of the reference, kind "port") on the same scene: a bounded sample of whole steps
     (~10 s of CPU work on the 16 usable cores of the GPU box)."""
@@ -141,6 +199,7 @@ def main():
     ap.add_argument("--no-dense-pcg", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--dense-only", action="store_true", help="only run the dense 256^3 PCG micro-benchmark (tuning)")
+    ap.add_argument("--transfer-only", action="store_true", help="only run the 256^3 transfer micro-benchmark M4 (65 M particles)")
     args = ap.parse_args()
 
     import torch
@@ -148,6 +207,9 @@ def main():
 
     if args.dense_only:
         print(json.dumps(dense_pcg_benchmark(256, 32)))
+        return
+    if args.transfer_only:
+        print(json.dumps(transfer_microbenchmark(256)))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
