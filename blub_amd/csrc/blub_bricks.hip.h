@@ -224,9 +224,9 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
                                                            const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
                                                            const float4* __restrict__ pos, const uint32_t* __restrict__ next,
                                                            const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
-    __shared__ float4 sPos[GT_N];
-    __shared__ float4 sVel[GT_N];
-    __shared__ int sAny[12];
+    __shared__ float4 sPosB[2][GT_N];   // double buffered by round parity: ONE barrier per round (round r+2 rewrites a buffer only
+    __shared__ float4 sVelB[2][GT_N];   // after the barrier of round r+1, which every wave reaches after its reads of round r)
+    __shared__ int sAnyB[2][12];
     const Grid g = bg.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool live = tid < GT_N;
@@ -254,6 +254,9 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
         if (has) { p = pos[cur]; r = rows[cur]; nxt = next ? next[cur] : __float_as_uint(p.w); }
         float v = 0.0f, wsum = 0.0f;
         for (int round = 0; round < 12; ++round) {                                               // :61
+            float4* sPos = sPosB[round & 1];
+            float4* sVel = sVelB[round & 1];
+            int* sAny = sAnyB[round & 1];
             if (has) {
                 if (computes) add_particle(v, wsum, p, r, sx, sy, sz);
                 sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
@@ -272,19 +275,28 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
 #pragma unroll
             for (int w = 0; w < 12; ++w) any |= sAny[w];
             if (any && computes) {
-                float4 q;
-                q = sPos[a1]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a1], sx, sy, sz);
-                q = sPos[a2]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a2], sx, sy, sz);
-                q = sPos[a3]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a3], sx, sy, sz);
-                q = sPos[a4]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a4], sx, sy, sz);
-                q = sPos[a5]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a5], sx, sy, sz);
-                q = sPos[a6]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a6], sx, sy, sz);
-                q = sPos[a7]; if (q.w != 0.0f) add_particle(v, wsum, q, sVel[a7], sx, sy, sz);
+                // The neighbours' particles are fetched in two batches of unconditional LDS reads (one wait each) instead of
+                // seven flag-then-data round trips: the exchange is LDS-latency bound, not LDS-bandwidth bound.
+                {
+                    const float4 q1 = sPos[a1], q2 = sPos[a2], q3 = sPos[a3], q4 = sPos[a4];
+                    const float4 r1 = sVel[a1], r2 = sVel[a2], r3 = sVel[a3], r4 = sVel[a4];
+                    if (q1.w != 0.0f) add_particle(v, wsum, q1, r1, sx, sy, sz);
+                    if (q2.w != 0.0f) add_particle(v, wsum, q2, r2, sx, sy, sz);
+                    if (q3.w != 0.0f) add_particle(v, wsum, q3, r3, sx, sy, sz);
+                    if (q4.w != 0.0f) add_particle(v, wsum, q4, r4, sx, sy, sz);
+                }
+                {
+                    const float4 q5 = sPos[a5], q6 = sPos[a6], q7 = sPos[a7];
+                    const float4 r5 = sVel[a5], r6 = sVel[a6], r7 = sVel[a7];
+                    if (q5.w != 0.0f) add_particle(v, wsum, q5, r5, sx, sy, sz);
+                    if (q6.w != 0.0f) add_particle(v, wsum, q6, r6, sx, sy, sz);
+                    if (q7.w != 0.0f) add_particle(v, wsum, q7, r7, sx, sy, sz);
+                }
             }
-            lds_barrier();   // reads (and the sAny poll) are done before the next round rewrites LDS
             if (!any) break;
             has = has_n; p = pn; r = rn; nxt = nn;
         }
+        lds_barrier();   // the last round's reads are done before the next brick's round 0 rewrites buffer 0
         if (writes) {
             if (computes) { if (wsum > 0.0f) v /= wsum; v += gravity_dt; }                       // :117-120
             else v = 0.0f;                                                                        // :121-124
@@ -297,8 +309,8 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
 __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                           const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
                                                           const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
-    __shared__ float4 sPos[GT_N];
-    __shared__ int sAny[12];
+    __shared__ float4 sPosB[2][GT_N];   // double buffered by round parity, see k_gather_velocity_b
+    __shared__ int sAnyB[2][12];
     const Grid g = bg.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool live = tid < GT_N;
@@ -323,6 +335,8 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
             density += ox * oy * oz;                                                              // :27-31
         };
         for (int round = 0; round < 32; ++round) {                                                // :69
+            float4* sPos = sPosB[round & 1];
+            int* sAny = sAnyB[round & 1];
             uint32_t nxt = INVALID_LL;
             if (has) {
                 nxt = __float_as_uint(p.w);
@@ -340,20 +354,20 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
             int any = 0;
 #pragma unroll
             for (int w = 0; w < 12; ++w) any |= sAny[w];
-            if (any && writes) {
-                float4 q;
-                q = sPos[a1]; if (q.w != 0.0f) add(q);
-                q = sPos[a2]; if (q.w != 0.0f) add(q);
-                q = sPos[a3]; if (q.w != 0.0f) add(q);
-                q = sPos[a4]; if (q.w != 0.0f) add(q);
-                q = sPos[a5]; if (q.w != 0.0f) add(q);
-                q = sPos[a6]; if (q.w != 0.0f) add(q);
-                q = sPos[a7]; if (q.w != 0.0f) add(q);
+            if (any && writes) {   // all seven neighbours in one batch of LDS reads (one wait), see k_gather_velocity_b
+                const float4 q1 = sPos[a1], q2 = sPos[a2], q3 = sPos[a3], q4 = sPos[a4], q5 = sPos[a5], q6 = sPos[a6], q7 = sPos[a7];
+                if (q1.w != 0.0f) add(q1);
+                if (q2.w != 0.0f) add(q2);
+                if (q3.w != 0.0f) add(q3);
+                if (q4.w != 0.0f) add(q4);
+                if (q5.w != 0.0f) add(q5);
+                if (q6.w != 0.0f) add(q6);
+                if (q7.w != 0.0f) add(q7);
             }
-            lds_barrier();
             if (!any) break;
             has = has_n; p = pn;
         }
+        lds_barrier();   // see k_gather_velocity_b
         if (writes) {
             const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
                               mk(marker, g, gx - 1, gy, gz), mk(marker, g, gx, gy - 1, gz), mk(marker, g, gx, gy, gz - 1)};   // :115-120
