@@ -547,8 +547,21 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, c
         int x0, y, z;
         const bool valid = brick_quad(bg, b, threadIdx.x, x0, y, z);
         if (valid) {
-            const int8_t* t8 = reinterpret_cast<const int8_t*>(tile);
-            auto M = [&](int x, int yy, int zz) -> int { return (int)t8[((zz - tz0) * (BY + 2) + (yy - ty0)) * ET_ROW + (x - tx0)]; };
+            // the quad's whole marker neighbourhood (x0-4 .. x0+7, y-1 .. y+1, z-1 .. z+1) in ONE batch of 27 independent LDS
+            // reads; every marker test below is then a byte extract from registers (the per-test LDS byte reads this replaces
+            // were ~260 serialised round trips per thread: the kernel was LDS-latency bound)
+            uint32_t win[3][3][3];
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int w = 0; w < 3; ++w)
+                        win[dz][dy][w] = tile[((z + dz - 1 - tz0) * (BY + 2) + (y + dy - 1 - ty0)) * (ET_ROW / 4) + ((x0 - tx0) >> 2) - 1 + w];
+            auto M = [&](int x, int yy, int zz) -> int {
+                const int k = x - x0 + 4;   // 3 .. 8 (compile-time after unrolling)
+                return (int)(int8_t)((win[zz - z + 1][yy - y + 1][k >> 2] >> (8 * (k & 3))) & 0xFFu);
+            };
             bool near_fluid = false;
 #pragma unroll
             for (int dz = -1; dz <= 1; ++dz)

@@ -210,11 +210,18 @@ __device__ __forceinline__ float quad_mulA(const QuadMarkers& m, const QuadValue
 // d in {0..6}.  Evaluated as (r * (1/d)) * (1/d) with a correctly rounded reciprocal: <= 1 ulp per factor away from a
 // correctly rounded division, i.e. inside the 2.5 ulp the GLSL/Vulkan precision contract grants the reference's own `/`,
 // and ~10x cheaper than two IEEE divisions (the fused direction kernel evaluates this 22 times per quad).
-__device__ __forceinline__ float precond_zero(float r, float d) {
-    const int di = (int)d;
-    const float inv = di <= 1 ? 1.0f : (di == 2 ? 0.5f : (di == 3 ? (1.0f / 3.0f) : (di == 4 ? 0.25f : (di == 5 ? 0.2f : (1.0f / 6.0f)))));
+// The reciprocal is picked by a flat chain of selects (v_cmp + v_cndmask): the nested form compiled to ~8 exec-mask branches
+// per cell, 280 branches per thread in the direction kernel, which made that kernel issue- instead of latency-bound.
+__device__ __forceinline__ float precond_zero_i(float r, int di) {
+    float inv = 1.0f;
+    inv = di == 2 ? 0.5f : inv;
+    inv = di == 3 ? (1.0f / 3.0f) : inv;
+    inv = di == 4 ? 0.25f : inv;
+    inv = di == 5 ? 0.2f : inv;
+    inv = di >= 6 ? (1.0f / 6.0f) : inv;
     return (r * inv) * inv;
 }
+__device__ __forceinline__ float precond_zero(float r, float d) { return precond_zero_i(r, (int)d); }
 __device__ __forceinline__ float eps_div(float num, float den) { return num / (den + (den < 0.0f ? -1e-10f : 1e-10f)); }   // pressure_reduce.comp:71-77
 
 #define PCG_TILE_LOOP_BEGIN(geom)                                                                            \

@@ -117,12 +117,34 @@ __device__ __forceinline__ float quad_mulA_d(const QuadD& m, const QuadValues& v
     if (dbyte(m.zp, j) & 0x80) r -= f4(v.zp, j);
     return r;
 }
-__device__ __forceinline__ float snew_of(int dv, float r, float sold, float beta) {   // pressure_update_search.comp:23 on top of M^-1 r
-    return (dv & 0x80) ? precond_zero(r, (float)(dv & 7)) + beta * sold : 0.0f;
+// 1/d for d = 0..7 in LDS (lut[0] = lut[1] = 1): the direction kernel needs 22 reciprocals per quad, and a table read is two
+// instructions where the select chain of precond_zero_i is fifteen -- in a kernel whose run time is the latency of ONE wave's
+// instruction stream.  The values are the same correctly rounded constants.
+__device__ __forceinline__ void pcg_fill_inv_lut(float* lut) {
+    if (threadIdx.x < 8) {
+        const int di = (int)threadIdx.x;
+        float inv = 1.0f;
+        inv = di == 2 ? 0.5f : inv; inv = di == 3 ? (1.0f / 3.0f) : inv; inv = di == 4 ? 0.25f : inv; inv = di == 5 ? 0.2f : inv; inv = di >= 6 ? (1.0f / 6.0f) : inv;
+        lut[di] = inv;
+    }
+}
+__device__ __forceinline__ float snew_of(int dv, float r, float sold, float beta, const float* lut) {   // pressure_update_search.comp:23 on top of M^-1 r
+    const float inv = lut[dv & 7];
+    const float sn = (r * inv) * inv + beta * sold;   // evaluated unconditionally: a select, not a branch
+    return (dv & 0x80) ? sn : 0.0f;
+}
+// (select-chain variants without a table: the dense 2.5-D kernels are bandwidth-, not issue-bound)
+__device__ __forceinline__ float snew_of(int dv, float r, float sold, float beta) {
+    const float sn = precond_zero_i(r, dv & 7) + beta * sold;
+    return (dv & 0x80) ? sn : 0.0f;
 }
 __device__ __forceinline__ float4 snew4(uint32_t dq, const float4& r, const float4& s, float beta) {
     return make_float4(snew_of(dbyte(dq, 0), r.x, s.x, beta), snew_of(dbyte(dq, 1), r.y, s.y, beta),
                        snew_of(dbyte(dq, 2), r.z, s.z, beta), snew_of(dbyte(dq, 3), r.w, s.w, beta));
+}
+__device__ __forceinline__ float4 snew4(uint32_t dq, const float4& r, const float4& s, float beta, const float* lut) {
+    return make_float4(snew_of(dbyte(dq, 0), r.x, s.x, beta, lut), snew_of(dbyte(dq, 1), r.y, s.y, beta, lut),
+                       snew_of(dbyte(dq, 2), r.z, s.z, beta, lut), snew_of(dbyte(dq, 3), r.w, s.w, beta, lut));
 }
 
 // ---- load / compute split of the KD and KU bodies (brick mapping): all global loads of a quad are issued up front,
@@ -140,17 +162,17 @@ __device__ __forceinline__ void dir_load(const Grid& g, const uint8_t* __restric
 // HALO (z-slab groups): the quad also stores the s it computed for the ghost plane below `halo_lo` / above `halo_hi`
 // (own planes of the slab, -1 = none), so the search direction needs no halo exchange of its own.
 template <bool FIRST, bool HALO = false>
-__device__ __forceinline__ void dir_compute(DirLoad& L, float* __restrict__ s_out, float beta, float& acc, int halo_lo = -1, int halo_hi = -1, int plane = 0) {
+__device__ __forceinline__ void dir_compute(DirLoad& L, float* __restrict__ s_out, float beta, float& acc, const float* lut, int halo_lo = -1, int halo_hi = -1, int plane = 0) {
     if (!L.valid || !any_fluid_d(L.m.c)) return;
     QuadValues& sv = L.sv;
     const QuadD& m = L.m;
     if (!FIRST) {
         const QuadValues& rv = L.rv;
         const float4 sold = sv.c;
-        sv.c = snew4(m.c, rv.c, sv.c, beta);
-        sv.ym = snew4(m.ym, rv.ym, sv.ym, beta); sv.yp = snew4(m.yp, rv.yp, sv.yp, beta);
-        sv.zm = snew4(m.zm, rv.zm, sv.zm, beta); sv.zp = snew4(m.zp, rv.zp, sv.zp, beta);
-        sv.xm = snew_of(m.xm, rv.xm, sv.xm, beta); sv.xp = snew_of(m.xp, rv.xp, sv.xp, beta);
+        sv.c = snew4(m.c, rv.c, sv.c, beta, lut);
+        sv.ym = snew4(m.ym, rv.ym, sv.ym, beta, lut); sv.yp = snew4(m.yp, rv.yp, sv.yp, beta, lut);
+        sv.zm = snew4(m.zm, rv.zm, sv.zm, beta, lut); sv.zp = snew4(m.zp, rv.zp, sv.zp, beta, lut);
+        sv.xm = snew_of(m.xm, rv.xm, sv.xm, beta, lut); sv.xp = snew_of(m.xp, rv.xp, sv.xp, beta, lut);
         float4 so = sv.c;
         if (!(dbyte(m.c, 0) & 0x80)) so.x = sold.x;
         if (!(dbyte(m.c, 1) & 0x80)) so.y = sold.y;
@@ -188,7 +210,7 @@ __device__ __forceinline__ void upd_compute(const UpdLoad& L, float* __restrict_
         res -= alpha * as;
         rr[j] = res;
         emax = fmaxf(emax, fabsf(res));
-        acc += precond_zero(res, (float)(dv & 7)) * res;
+        acc += precond_zero_i(res, dv & 7) * res;
     }
     *reinterpret_cast<float4*>(p + L.base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4*>(r + L.base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
@@ -270,6 +292,8 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const
                                                              PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev, int halo_lo = -1, int halo_hi = -1) {
     __shared__ float sm[8];
     __shared__ float2 sm2[4];
+    __shared__ float sInv[8];
+    pcg_fill_inv_lut(sInv);   // (published by the barriers of the prologue's reduction)
     const uint32_t n = *count;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     uint32_t i = blockIdx.x * 2 + half;
@@ -279,12 +303,12 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const
     if (!pcg_dir_prologue<PCG_B_THREADS>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     float acc = 0.0f;
     const int plane = bg.g.nx * bg.g.ny;
-    dir_compute<FIRST, HALO>(L, s_out, beta, acc, halo_lo, halo_hi, plane);
+    dir_compute<FIRST, HALO>(L, s_out, beta, acc, sInv, halo_lo, halo_hi, plane);
     for (i += gridDim.x * 2; i < n; i += gridDim.x * 2) {
         int x0, y, z;
         L.valid = brick_quad(bg, list[i], t, x0, y, z);
         if (L.valid) dir_load<FIRST>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L);
-        dir_compute<FIRST, HALO>(L, s_out, beta, acc, halo_lo, halo_hi, plane);
+        dir_compute<FIRST, HALO>(L, s_out, beta, acc, sInv, halo_lo, halo_hi, plane);
     }
     const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
     if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
@@ -350,6 +374,9 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_b(BrickGeom bg, cons
                                                               uint32_t seq, PcgCtrl* host_snapshot) {
     __shared__ float sm[8];
     __shared__ float2 sm2[4];
+    __shared__ float sInv[8];
+    pcg_fill_inv_lut(sInv);
+    __syncthreads();
     const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
     auto publish = [&]() {   // what k_pcg_finalize does
         ctrl->seq = seq;
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_b(BrickGeom bg, cons
             DirLoad L;
             L.valid = brick_quad(bg, list[i], t, x0, y, z);
             if (L.valid) { if (it == 0) dir_load<true>(bg.g, dvol, r, s_even, cidx(bg.g, x0, y, z), x0, y, z, L); else dir_load<false>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L); }
-            if (it == 0) dir_compute<true>(L, s_out, beta, acc); else dir_compute<false>(L, s_out, beta, acc);
+            if (it == 0) dir_compute<true>(L, s_out, beta, acc, sInv); else dir_compute<false>(L, s_out, beta, acc, sInv);
         }
         const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
         if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
