@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
         if (phase == COMPACT_ALL_ACTIVE) act = true;
         else {
             const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
-            act = false;
+            uint32_t any = 0;   // all 27 flags are loaded unconditionally (one batch of independent loads, no short-circuit chain)
 #pragma unroll
             for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
@@ -95,9 +95,10 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int qx = bx + dx, qy = by + dy, qz = bz + dz;
-                        if ((unsigned)qx < (unsigned)bg.nbx && (unsigned)qy < (unsigned)bg.nby && (unsigned)qz < (unsigned)bg.nbz)
-                            act = act || brick_fluid[(qz * bg.nby + qy) * bg.nbx + qx] != 0;
+                        const bool inside = (unsigned)qx < (unsigned)bg.nbx && (unsigned)qy < (unsigned)bg.nby && (unsigned)qz < (unsigned)bg.nbz;
+                        any |= (uint32_t)brick_fluid[inside ? (qz * bg.nby + qy) * bg.nbx + qx : b] & (inside ? 0xFFu : 0u);
                     }
+            act = any != 0;
             if (phase == COMPACT_STEP_B) act = act || brick_active[b] != 0;
         }
         const bool touched = all_touched || brick_touched[b] != 0;
@@ -110,12 +111,17 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
         if (phase == COMPACT_STEP_A) brick_touched[b] = act;
         else if (act) brick_touched[b] = 1;
     }
-    uint32_t tf, ta, tr, ts;
-    (void)block_exclusive_scan_1024((fl & BF_FLUID) != 0, sm, tf);
-    (void)block_exclusive_scan_1024((fl & BF_ACTIVE) != 0, sm, ta);
-    (void)block_exclusive_scan_1024((fl & BF_RESET) != 0, sm, tr);
-    (void)block_exclusive_scan_1024((fl & BF_STALE) != 0, sm, ts);
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = make_uint4(tf, ta, tr, ts);
+    // per-block totals of the four flags: wave ballots + one LDS exchange (no scans needed here)
+    const uint32_t packed = (uint32_t)__popcll(__ballot((fl & BF_FLUID) != 0)) | ((uint32_t)__popcll(__ballot((fl & BF_ACTIVE) != 0)) << 8) |
+                            ((uint32_t)__popcll(__ballot((fl & BF_RESET) != 0)) << 16) | ((uint32_t)__popcll(__ballot((fl & BF_STALE) != 0)) << 24);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = packed;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tf = 0, ta = 0, tr = 0, ts = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t q = sm[w]; tf += q & 0xFFu; ta += (q >> 8) & 0xFFu; tr += (q >> 16) & 0xFFu; ts += q >> 24; }
+        block_counts[blockIdx.x] = make_uint4(tf, ta, tr, ts);
+    }
 }
 // Pass 2: every block adds up the counts of the blocks before it (<= 256 of them) and scatters its bricks: the lists
 // come out in brick (= memory) order, deterministically.
@@ -142,10 +148,18 @@ __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uin
     const int b = blockIdx.x * 1024 + threadIdx.x;
     const uint32_t fl = b < bg.nb ? brick_flags[b] : 0u;
     if (b < bg.nb && brick_fluid_to_clear) brick_fluid_to_clear[b] = 0;   // consumed by k_bricks_classify: ready for the next build
-    uint32_t t;
-    const uint32_t of = block_exclusive_scan_1024((fl & BF_FLUID) != 0, sm, t);
-    const uint32_t oa = block_exclusive_scan_1024((fl & BF_ACTIVE) != 0, sm, t);
-    const uint32_t orr = block_exclusive_scan_1024((fl & BF_RESET) != 0, sm, t);
+    // exclusive prefix of the three flags: inside a wave = popcount of the ballot below the lane, across waves = one LDS
+    // exchange of the (packed) wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long bf = __ballot((fl & BF_FLUID) != 0), ba = __ballot((fl & BF_ACTIVE) != 0), br = __ballot((fl & BF_RESET) != 0);
+    __shared__ uint32_t wtot[16];
+    if (lane == 0) wtot[wave] = (uint32_t)__popcll(bf) | ((uint32_t)__popcll(ba) << 8) | ((uint32_t)__popcll(br) << 16);
+    __syncthreads();
+    uint32_t of = (uint32_t)__popcll(bf & below), oa = (uint32_t)__popcll(ba & below), orr = (uint32_t)__popcll(br & below);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t q = w < wave ? wtot[w] : 0u; of += q & 0xFFu; oa += (q >> 8) & 0xFFu; orr += (q >> 16) & 0xFFu; }
+    (void)sm;
     if (fl & BF_FLUID) list_fluid[base[0] + of] = (uint32_t)b;
     if (fl & BF_ACTIVE) list_active[base[1] + oa] = (uint32_t)b;
     if (fl & BF_RESET) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);

@@ -294,11 +294,14 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const
     __shared__ float2 sm2[4];
     __shared__ float sInv[8];
     pcg_fill_inv_lut(sInv);   // (published by the barriers of the prologue's reduction)
-    const uint32_t n = *count;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     uint32_t i = blockIdx.x * 2 + half;
+    // the block's first list entry is requested together with the list length (list[] has an entry per brick of the grid, so the
+    // read is always in bounds): one dependent round trip to memory less before the field loads can be issued
+    const uint32_t b0 = i < (uint32_t)bg.nb ? list[i] : 0u;
+    const uint32_t n = *count;
     DirLoad L; L.valid = false;
-    if (i < n) { int x0, y, z; L.valid = brick_quad(bg, list[i], t, x0, y, z); if (L.valid) dir_load<FIRST>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L); }
+    if (i < n) { int x0, y, z; L.valid = brick_quad(bg, b0, t, x0, y, z); if (L.valid) dir_load<FIRST>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L); }
     float beta;
     if (!pcg_dir_prologue<PCG_B_THREADS>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     float acc = 0.0f;
@@ -318,11 +321,12 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_b(BrickGeom bg, co
                                                                 float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
                                                                 const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[8];
-    const uint32_t n = *count;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     uint32_t i = blockIdx.x * 2 + half;
+    const uint32_t b0 = i < (uint32_t)bg.nb ? list[i] : 0u;   // requested together with the list length, see k_pcg_dir_b
+    const uint32_t n = *count;
     UpdLoad L; L.valid = false;
-    if (i < n) { int x0, y, z; L.valid = brick_quad(bg, list[i], t, x0, y, z); if (L.valid) upd_load(bg.g, dvol, s, p, r, cidx(bg.g, x0, y, z), x0, y, z, L); }
+    if (i < n) { int x0, y, z; L.valid = brick_quad(bg, b0, t, x0, y, z); if (L.valid) upd_load(bg.g, dvol, s, p, r, cidx(bg.g, x0, y, z), x0, y, z, L); }
     float alpha;
     if (!pcg_upd_prologue<PCG_B_THREADS>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
     float acc = 0.0f, emax = 0.0f;
