@@ -348,12 +348,15 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         // Launch as many iterations as the last few solves needed (+ one check interval); a persistent tail kernel covers the
         // rest: a single no-op launch when the solve has converged by then (the rule), a grid-barrier loop otherwise.
         int launched = maxit + 1;
-        if (h->use_tail && freq > 0 && !h->stats_history[which].empty()) {
+        // (only while the solve is launch-bound: with thousands of fluid bricks an iteration inside the tail -- 256 blocks, two grid
+        // barriers -- costs far more than the no-op launches it saves, so a misprediction would be expensive)
+        const bool tail_pays = !have || bc.n_fluid <= 2048u;
+        if (h->use_tail && tail_pays && freq > 0 && !h->stats_history[which].empty()) {
             int recent = 0, k = 0;
             for (auto it2 = h->stats_history[which].rbegin(); it2 != h->stats_history[which].rend() && k < 4; ++it2, ++k) recent = std::max(recent, (int)it2->iteration_count);
             if (recent >= 0 && recent < maxit) launched = std::min(maxit + 1, (recent / freq + h->tail_margin_checks) * freq + 1);   // through `margin` checks past the recent maximum
         }
-        if (h->use_tail && h->tail_first_forced >= 0) launched = std::min(maxit + 1, h->tail_first_forced);
+        if (h->use_tail && h->tail_first_forced >= 0) launched = std::min(maxit + 1, h->tail_first_forced);   // (test hook)
         for (int i = 0; i < launched; ++i) {
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
