@@ -12,7 +12,7 @@ def main(directory):
     for f in files:
         seen = set()
         for row in csv.DictReader(open(f)):
-            name = row["Kernel_Name"].split("(")[0][:48]
+            name = row["Kernel_Name"].split("(")[0][:48].replace(",", ";")
             acc[name][row["Counter_Name"]] += float(row["Counter_Value"])
             key = (row.get("Dispatch_Id"), name)
             if key not in seen:
