@@ -29,7 +29,7 @@ def algorithmic_bytes(kernel, F, P, A, Fb):
     table = {
         "reset_bricks": 13 * A,                  # marker + 3 list-head volumes (the advect variant writes 5 B/cell)
         "build_lists": 16 * P + 12 * P + 12 * P, # pos read, 3 atomic exchanges, 3 next pointers
-        "gather_velocity": 5 * A + 32 * P + 4 * F,
+        "gather_velocity": 3 * (5 * A + 32 * P + 4 * F),   # the three components are one launch
         "divergence": Fb + 28 * F,
         "pcg_init": 6 * A + 12 * F,              # marker + descriptor + p everywhere, r rw + s on FLUID
         "pcg_dir": Fb + 12 * F,                  # descriptor, r, s read, s write

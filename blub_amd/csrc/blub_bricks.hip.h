@@ -233,21 +233,26 @@ constexpr int GT_X = BX + 1, GT_Y = BY + 1, GT_Z = BZ + 1, GT_N = GT_X * GT_Y * 
 // list node stays in flight across the exchange (a __syncthreads() would drain vmcnt first).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+struct GatherShared {
+    float4 pos[2][GT_N];   // double buffered by round parity: ONE barrier per round (round r+2 rewrites a buffer only
+    float4 vel[2][GT_N];   // after the barrier of round r+1, which every wave reaches after its reads of round r)
+    int any[2][12];
+};
 template <int COMP>
-__global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                           const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
-                                                           const float4* __restrict__ pos, const uint32_t* __restrict__ next,
-                                                           const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
-    __shared__ float4 sPosB[2][GT_N];   // double buffered by round parity: ONE barrier per round (round r+2 rewrites a buffer only
-    __shared__ float4 sVelB[2][GT_N];   // after the barrier of round r+1, which every wave reaches after its reads of round r)
-    __shared__ int sAnyB[2][12];
+__device__ __forceinline__ void gather_velocity_body(GatherShared& sh, uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg, const uint32_t* __restrict__ list,
+                                                     const uint32_t* __restrict__ count, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                     const float4* __restrict__ pos, const uint32_t* __restrict__ next,
+                                                     const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
+    float4 (*sPosB)[GT_N] = sh.pos;
+    float4 (*sVelB)[GT_N] = sh.vel;
+    int (*sAnyB)[12] = sh.any;
     const Grid g = bg.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool live = tid < GT_N;
     const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
     const int a1 = tid - 1, a2 = tid - GT_X, a3 = tid - GT_X - 1, a4 = tid - GT_X * GT_Y, a5 = a4 - 1, a6 = a4 - GT_X, a7 = a4 - GT_X - 1;   // :87-93
     const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    for (uint32_t i = first_brick; i < n; i += brick_stride) {
         const uint32_t b = list[i];
         const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
         const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;      // :41
@@ -319,11 +324,22 @@ __global__ __launch_bounds__(768) void k_gather_velocity_b(BrickGeom bg, const u
     }
 }
 
+// The three components in ONE launch (blockIdx.y = component): three times the workgroups in flight, so bricks with long lists
+// of one component overlap with cheap bricks of another instead of three separately draining launches.
+struct GatherArgs3 { const uint32_t* heads[3]; const uint32_t* next[3]; const float4* rows[3]; float* out[3]; float gravity_dt[3]; };
+__global__ __launch_bounds__(768) void k_gather_velocity3_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                            const int8_t* __restrict__ marker, const float4* __restrict__ pos, GatherArgs3 a) {
+    __shared__ GatherShared sh;
+    if (blockIdx.y == 0) gather_velocity_body<0>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[0], pos, a.next[0], a.rows[0], a.out[0], a.gravity_dt[0]);
+    else if (blockIdx.y == 1) gather_velocity_body<1>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[1], pos, a.next[1], a.rows[1], a.out[1], a.gravity_dt[1]);
+    else gather_velocity_body<2>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[2], pos, a.next[2], a.rows[2], a.out[2], a.gravity_dt[2]);
+}
+
 // ---- R1 over fluid bricks: density_projection_gather_error.comp:41-198 -----------------------------------------------
 __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                           const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
                                                           const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
-    __shared__ float4 sPosB[2][GT_N];   // double buffered by round parity, see k_gather_velocity_b
+    __shared__ float4 sPosB[2][GT_N];   // double buffered by round parity, see gather_velocity_body
     __shared__ int sAnyB[2][12];
     const Grid g = bg.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
             int any = 0;
 #pragma unroll
             for (int w = 0; w < 12; ++w) any |= sAny[w];
-            if (any && writes) {   // all seven neighbours in one batch of LDS reads (one wait), see k_gather_velocity_b
+            if (any && writes) {   // all seven neighbours in one batch of LDS reads (one wait), see gather_velocity_body
                 const float4 q1 = sPos[a1], q2 = sPos[a2], q3 = sPos[a3], q4 = sPos[a4], q5 = sPos[a5], q6 = sPos[a6], q7 = sPos[a7];
                 if (q1.w != 0.0f) add(q1);
                 if (q2.w != 0.0f) add(q2);
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
             if (!any) break;
             has = has_n; p = pn;
         }
-        lds_barrier();   // see k_gather_velocity_b
+        lds_barrier();   // see gather_velocity_body
         if (writes) {
             const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
                               mk(marker, g, gx - 1, gy, gz), mk(marker, g, gx, gy - 1, gz), mk(marker, g, gx, gy, gz - 1)};   // :115-120

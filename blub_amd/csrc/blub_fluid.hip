@@ -253,9 +253,12 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     if (h->num_particles + h->num_ghost)
         LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), h->g, h->num_particles + h->num_ghost, h->pos, h->marker,
                h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2);
-    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<0>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[0], (const float4*)h->pos, (const uint32_t*)nullptr, (const float4*)h->pvel[0], h->vel[0], h->gravity[0] * dt);
-    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<1>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[1], (const float4*)h->pos, (const uint32_t*)h->next1, (const float4*)h->pvel[1], h->vel[1], h->gravity[1] * dt);
-    LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity_b<2>, bgrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const uint32_t*)h->ll[2], (const float4*)h->pos, (const uint32_t*)h->next2, (const float4*)h->pvel[2], h->vel[2], h->gravity[2] * dt);
+    {
+        GatherArgs3 a;
+        const uint32_t* nexts[3] = {nullptr, h->next1, h->next2};
+        for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.next[c] = nexts[c]; a.rows[c] = h->pvel[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
+        LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_b, dim3(h->brick_grid, 3), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
+    }
     return BLUB_OK;
 }
 static int stage_divergence(blub_fluid* h) {   // :836-840
