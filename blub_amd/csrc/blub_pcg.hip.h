@@ -266,7 +266,11 @@ __device__ __forceinline__ bool pcg_upd_prologue(const PcgCtrl* __restrict__ ctr
 // ---- brick-list wrappers ---------------------------------------------------------------------------------------------
 // 256-thread blocks work on two bricks at a time (one per 128-thread half).  init runs over the ACTIVE list (dvol / p
 // must be valid on every neighbour of a FLUID brick), KD / KU over the FLUID list.
-constexpr int PCG_B_THREADS = 2 * BRICK_THREADS;
+#ifndef BLUB_PCG_BPB
+#define BLUB_PCG_BPB 2
+#endif
+constexpr int PCG_BPB = BLUB_PCG_BPB;   // bricks per workgroup of the brick-mapped PCG kernels (one 128-thread slice per brick); measured on the 256^3 scene: 1 -> 645, 2 -> 773, 4 -> 762 steps/s
+constexpr int PCG_B_THREADS = PCG_BPB * BRICK_THREADS;
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                               const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
                                                               float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, PcgCtrl* __restrict__ ctrl_to_clear,
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, cons
     float acc = 0.0f;
     const uint32_t n = *count;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
-    for (uint32_t i = blockIdx.x * 2 + half; i < n; i += gridDim.x * 2) {
+    for (uint32_t i = blockIdx.x * PCG_BPB + half; i < n; i += gridDim.x * PCG_BPB) {
         int x0, y, z;
         if (!brick_quad(bg, list[i], t, x0, y, z)) continue;
         (void)pcg_init_quad(bg.g, marker, dvol, p, r, s, cidx(bg.g, x0, y, z), x0, y, z, acc);
@@ -291,11 +295,11 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const
                                                              const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
                                                              PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev, int halo_lo = -1, int halo_hi = -1) {
     __shared__ float sm[8];
-    __shared__ float2 sm2[4];
+    __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ float sInv[8];
     pcg_fill_inv_lut(sInv);   // (published by the barriers of the prologue's reduction)
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
-    uint32_t i = blockIdx.x * 2 + half;
+    uint32_t i = blockIdx.x * PCG_BPB + half;
     // the block's first list entry is requested together with the list length (list[] has an entry per brick of the grid, so the
     // read is always in bounds): one dependent round trip to memory less before the field loads can be issued
     const uint32_t b0 = i < (uint32_t)bg.nb ? list[i] : 0u;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_b(BrickGeom bg, const
     float acc = 0.0f;
     const int plane = bg.g.nx * bg.g.ny;
     dir_compute<FIRST, HALO>(L, s_out, beta, acc, sInv, halo_lo, halo_hi, plane);
-    for (i += gridDim.x * 2; i < n; i += gridDim.x * 2) {
+    for (i += gridDim.x * PCG_BPB; i < n; i += gridDim.x * PCG_BPB) {
         int x0, y, z;
         L.valid = brick_quad(bg, list[i], t, x0, y, z);
         if (L.valid) dir_load<FIRST>(bg.g, dvol, r, s_in, cidx(bg.g, x0, y, z), x0, y, z, L);
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_b(BrickGeom bg, co
                                                                 const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[8];
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
-    uint32_t i = blockIdx.x * 2 + half;
+    uint32_t i = blockIdx.x * PCG_BPB + half;
     const uint32_t b0 = i < (uint32_t)bg.nb ? list[i] : 0u;   // requested together with the list length, see k_pcg_dir_b
     const uint32_t n = *count;
     UpdLoad L; L.valid = false;
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_b(BrickGeom bg, co
     if (!pcg_upd_prologue<PCG_B_THREADS>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
     float acc = 0.0f, emax = 0.0f;
     upd_compute(L, p, r, alpha, acc, emax);
-    for (i += gridDim.x * 2; i < n; i += gridDim.x * 2) {
+    for (i += gridDim.x * PCG_BPB; i < n; i += gridDim.x * PCG_BPB) {
         int x0, y, z;
         L.valid = brick_quad(bg, list[i], t, x0, y, z);
         if (L.valid) upd_load(bg.g, dvol, s, p, r, cidx(bg.g, x0, y, z), x0, y, z, L);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_b(BrickGeom bg, cons
                                                               int first_iteration, int max_iterations, int check_frequency, PcgTailSync* sync,
                                                               uint32_t seq, PcgCtrl* host_snapshot) {
     __shared__ float sm[8];
-    __shared__ float2 sm2[4];
+    __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ float sInv[8];
     pcg_fill_inv_lut(sInv);
     __syncthreads();
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_b(BrickGeom bg, cons
         const float* s_in = ((it - 1) & 1) ? s_odd : s_even;
         float* s_out = (it & 1) ? s_odd : s_even;
         float acc = 0.0f;
-        for (uint32_t i = blockIdx.x * 2 + half; i < n; i += nblocks * 2) {
+        for (uint32_t i = blockIdx.x * PCG_BPB + half; i < n; i += nblocks * PCG_BPB) {
             int x0, y, z;
             DirLoad L;
             L.valid = brick_quad(bg, list[i], t, x0, y, z);
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_b(BrickGeom bg, cons
         const float alpha = eps_div(sigma, sas);
         float acc2 = 0.0f, emax = 0.0f;
         const float* s_cur = (it & 1) ? s_odd : s_even;
-        for (uint32_t i = blockIdx.x * 2 + half; i < n; i += nblocks * 2) {
+        for (uint32_t i = blockIdx.x * PCG_BPB + half; i < n; i += nblocks * PCG_BPB) {
             int x0, y, z;
             UpdLoad L;
             L.valid = brick_quad(bg, list[i], t, x0, y, z);
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_b(BrickGeom bg, cons
 // (pressure_reduce.comp:84: MaxNumSolverIterations == iterationIdx).
 __global__ __launch_bounds__(256) void k_pcg_finalize(PcgCtrl* __restrict__ ctrl, const float2* __restrict__ part_upd, int num_part, int iteration, uint32_t seq,
                                                       PcgCtrl* __restrict__ host_snapshot) {
-    __shared__ float2 sm2[4];
+    __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     const int done = ctrl->done;
     const float2 red = reduce_partials2<256>(part_upd, num_part, sm2);
     if (threadIdx.x == 0) {
