@@ -331,7 +331,12 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     BrickCounts bc{}; bool have = false;
     if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
     if (h->force_pcg_path >= 0) sparse = h->force_pcg_path == 1;
-    else sparse = (have && (float)bc.n_fluid < SPARSE_PCG_MAX_FILL * (float)h->bg.nb) || h->gz.tiles < 256;   // tiny grids: too few dense tiles to fill the chip
+    else {
+        // small grids stay launch/latency-bound even when fairly full: the brick mapping wins up to ~70 % fill there
+        // (dam_halfhalf, 128x64x64 at 40 %: 997 vs 925 steps/s); large ones are byte-bound and want the 2.5-D dense mapping early
+        const float max_fill = h->N <= (size_t)1 << 20 ? 0.70f : SPARSE_PCG_MAX_FILL;
+        sparse = (have && (float)bc.n_fluid < max_fill * (float)h->bg.nb) || h->gz.tiles < 256;   // tiny grids: too few dense tiles to fill the chip
+    }
     const int maxit = c.max_num_iterations;
     const int freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };   // :672-673 (the i == max case is k_pcg_finalize)
