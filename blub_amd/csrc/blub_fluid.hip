@@ -347,10 +347,11 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
     float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
     if (sparse) {
-        // grid (= number of dot-product partials) sized from the newest landed brick count with 50 % head room: the kernels
-        // stride over the device-side list, so a stale count only costs speed, never correctness
+        // grid (= number of dot-product partials) sized from the newest landed FLUID brick count with 12 % head room (the iteration
+        // kernels sweep the fluid list; the init kernel sweeps the larger active list with the same grid and simply strides): the
+        // kernels loop over the device-side list, so a stale count only costs speed, never correctness
         int np = std::min((h->bg.nb + PCG_BPB - 1) / PCG_BPB, PCG_GRID_BRICKS * 2 / PCG_BPB);
-        if (have) np = std::max(64, std::min(np, (int)((bc.n_active * 3u / 2u + (unsigned)PCG_BPB - 1u) / (unsigned)PCG_BPB)));
+        if (have) np = std::max(64, std::min(np, (int)((bc.n_fluid * 9u / 8u + 8u + (unsigned)PCG_BPB - 1u) / (unsigned)PCG_BPB)));
         const dim3 grid(np), block(PCG_B_THREADS);
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which]);
         // Launch as many iterations as the last few solves needed (+ one check interval); a persistent tail kernel covers the
