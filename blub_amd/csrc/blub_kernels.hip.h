@@ -476,6 +476,29 @@ __device__ __forceinline__ float trilinear_clamp(const Grid& g, Fetch fetch, flo
     const float c01 = mixf(fetch(xa, ya, zb), fetch(xb, ya, zb), fx), c11 = mixf(fetch(xa, yb, zb), fetch(xb, yb, zb), fx);
     return mixf(mixf(c00, c10, fy), mixf(c01, c11, fy), fz);
 }
+// The same filter for an f32 volume with the x-pairs fetched as ONE 8-byte load each (4-byte aligned): the two x-texels of a
+// pair are neighbours in memory, so the eight scattered 4-byte loads become four 8-byte ones (the particle kernels are
+// issue-bound on the memory pipe: profiles/r01_pmc_sq_sparse_bench.csv, k_correct).  Same values, same arithmetic.
+typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ float trilinear_clamp_f32(const Grid& g, const float* __restrict__ V, float tx, float ty, float tz) {
+    const float ux = tx * (float)g.nx - 0.5f, uy = ty * (float)g.ny - 0.5f, uz = tz * (float)g.nz - 0.5f;
+    const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
+    const float fx = ux - fx0, fy = uy - fy0, fz = uz - fz0;
+    const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+    const int xa = min(max(x0, 0), g.nx - 1), xb = min(max(x0 + 1, 0), g.nx - 1);
+    const int ya = min(max(y0, 0), g.ny - 1), yb = min(max(y0 + 1, 0), g.ny - 1);
+    const int za = min(max(z0, 0), g.nz - 1), zb = min(max(z0 + 1, 0), g.nz - 1);
+    const int xbase = min(xa, g.nx - 2);                     // the pair (xbase, xbase + 1) always lies inside the row
+    const bool lo_first = xa == xbase, hi_first = xb == xbase;
+    auto pair = [&](int y, int z, float& lo, float& hi) {
+        const float2_a4 q = *reinterpret_cast<const float2_a4*>(V + cidx(g, xbase, y, z));
+        lo = lo_first ? q.x : q.y; hi = hi_first ? q.x : q.y;
+    };
+    float a0, a1, b0, b1, c0, c1, d0, d1;
+    pair(ya, za, a0, a1); pair(yb, za, b0, b1); pair(ya, zb, c0, c1); pair(yb, zb, d0, d1);
+    const float c00 = mixf(a0, a1, fx), c10 = mixf(b0, b1, fx), c01 = mixf(c0, c1, fx), c11 = mixf(d0, d1, fx);
+    return mixf(mixf(c00, c10, fy), mixf(c01, c11, fy), fz);
+}
 // advect_particles.comp:139-148 / density_projection_correct_particles.comp:51-60 (Q12: literal)
 __device__ __forceinline__ void truncate_step(const float* orig, const float* move, float* dir, float& max_step) {
     const float len = sqrtf((move[0] * move[0] + move[1] * move[1]) + move[2] * move[2]) + 1e-10f;
@@ -520,10 +543,17 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
         for (int k = 0; k < 3; ++k) { o[k] = fmaxf(0.0f, op[k] - (k == i ? 1.0f : 0.5f)); lo[k] = (int)o[k]; hi[k] = min(lo[k] + 1, dimm1[k]); }
         ipx[i] = fractf(o[0]); ipy[i] = fractf(o[1]); ipz[i] = fractf(o[2]);
         const float* V = vel[i];
-        v[0][i] = fv(V, g, lo[0], lo[1], lo[2]); v[1][i] = fv(V, g, hi[0], lo[1], lo[2]);
-        v[2][i] = fv(V, g, lo[0], hi[1], lo[2]); v[3][i] = fv(V, g, hi[0], hi[1], lo[2]);
-        v[4][i] = fv(V, g, lo[0], lo[1], hi[2]); v[5][i] = fv(V, g, hi[0], lo[1], hi[2]);
-        v[6][i] = fv(V, g, lo[0], hi[1], hi[2]); v[7][i] = fv(V, g, hi[0], hi[1], hi[2]);
+        // the two x-texels of a pair are neighbours in memory: one 8-byte load per pair (see trilinear_clamp_f32).  Positions are
+        // inside [0.001, dim - 0.001] here (clamped every step, the solid escape moves by one cell), so lo / hi are valid texels;
+        // the clamps only keep wild caller-supplied positions from reading outside the volume.
+        const int xbase = min(max(min(lo[0], g.nx - 2), 0), g.nx - 2);
+        const bool lo_first = lo[0] <= xbase, hi_first = hi[0] <= xbase;
+        auto pair = [&](int y, int z, float& a, float& b) {
+            const float2_a4 q = *reinterpret_cast<const float2_a4*>(V + cidx(g, xbase, min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1)));
+            a = lo_first ? q.x : q.y; b = hi_first ? q.x : q.y;
+        };
+        pair(lo[1], lo[2], v[0][i], v[1][i]); pair(hi[1], lo[2], v[2][i], v[3][i]);
+        pair(lo[1], hi[2], v[4][i], v[5][i]); pair(hi[1], hi[2], v[6][i], v[7][i]);
     }
     float nv[3], cx[3], cy[3], cz[3];
 #pragma unroll
@@ -614,7 +644,7 @@ __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles,
 #pragma unroll
         for (int k = 0; k < 3; ++k) o[k] = fmaxf(0.0f, op[k] - (k == c ? 0.5f : 0.0f));
         const float* V = vel[c];
-        ch[c] = trilinear_clamp(g, [&](int ax, int ay, int az) -> float { return V[cidx(g, ax, ay, az)]; }, o[0] * inv[0], o[1] * inv[1], o[2] * inv[2]);
+        ch[c] = trilinear_clamp_f32(g, V, o[0] * inv[0], o[1] * inv[1], o[2] * inv[2]);
     }
     float np[3] = {op[0] + ch[0], op[1] + ch[1], op[2] + ch[2]};
     bool outside = false;
