@@ -252,7 +252,7 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
            h->vel[0], h->vel[1], h->vel[2], h->pressure[0], h->pressure[1]);
     if (h->num_particles + h->num_ghost)
         LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), h->g, h->num_particles + h->num_ghost, h->pos, h->marker,
-               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2);
+               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2, (int)(h->solid == nullptr));
     {
         GatherArgs3 a;
         const uint32_t* nexts[3] = {nullptr, h->next1, h->next2};

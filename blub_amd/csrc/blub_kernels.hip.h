@@ -91,14 +91,19 @@ __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ head
 
 __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_particles, float4* __restrict__ pos, int8_t* __restrict__ marker,
                                                      uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
-                                                     uint32_t* __restrict__ next1, uint32_t* __restrict__ next2) {
+                                                     uint32_t* __restrict__ next1, uint32_t* __restrict__ next2, int no_solid_voxels) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < num_particles;          // no early return: the wave-level insertion needs every lane
     float4 p = make_float4(-8.f, -8.f, -8.f, 0.f);
     if (live) {
         p = pos[i];
         const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
-        if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
+        if (inb(g, x, y, z)) {
+            const int c = cidx(g, x, y, z);
+            // without solid voxels only the domain shell is SOLID: an interior cell is marked without reading the marker first
+            const bool interior = no_solid_voxels && x > 0 && y > 0 && z > 0 && x < g.nx - 1 && y < g.ny - 1 && z < g.nz - 1;
+            if (interior || marker[c] != CELL_SOLID) marker[c] = CELL_FLUID;
+        }
     }
     uint32_t nxt[3];
     uint32_t* heads[3] = {ll0, ll1, ll2};
@@ -613,7 +618,11 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
     if (heads) {
         if (live) {
             const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
-            if (inb(g, x, y, z)) { const int c = cidx(g, x, y, z); if (marker[c] != CELL_SOLID) marker[c] = CELL_FLUID; }
+            if (inb(g, x, y, z)) {
+                const int c = cidx(g, x, y, z);
+                const bool interior = !solid && x > 0 && y > 0 && z > 0 && x < g.nx - 1 && y < g.ny - 1 && z < g.nz - 1;   // (see k_build_lists)
+                if (interior || marker[c] != CELL_SOLID) marker[c] = CELL_FLUID;
+            }
         }
         const int dx = (int)(np[0] - 0.5f), dy = (int)(np[1] - 0.5f), dz = (int)(np[2] - 0.5f);
         nxt = wave_list_insert(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, pi);
