@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--no-dense-pcg", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--dense-only", action="store_true", help="only run the dense 256^3 PCG micro-benchmark (tuning)")
-    ap.add_argument("--pcg-mapping", default="auto", choices=["auto", "rows", "bricks"], help="work mapping of the PCG kernels (tuning)")
+    ap.add_argument("--pcg-mapping", default="auto", choices=["auto", "rows", "bricks", "bricks_staged"], help="work mapping of the PCG kernels (tuning)")
     ap.add_argument("--transfer-only", action="store_true", help="only run the 256^3 transfer micro-benchmark M4 (65 M particles)")
     args = ap.parse_args()
 

@@ -53,6 +53,8 @@ constexpr int BRICK_GRID_MAX = 2048; // persistent blocks of the brick-list kern
 constexpr int STATS_RING = 32;       // pressure_solver.rs:49 NUM_PRESSURE_ERROR_BUFFER
 constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
 constexpr int COUNTS_RING = 8;
+constexpr uint32_t STAGED_PCG_MIN_BRICKS = 512;   // fluid bricks from which the LDS-staged iteration kernels are used: 256^3 / 1 M particles (~1300 bricks) 810 vs 779 steps/s,
+                                                  // dam_halfhalf (~400 bricks) 990 vs 1004, 512^3 (10 k bricks) 243 vs 246
 constexpr float SPARSE_PCG_MAX_FILL = 0.30f;   // fluid bricks / bricks below which the brick-list PCG kernels are used
 
 struct PendingStat { uint32_t seq; int slot; };
@@ -330,7 +332,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     bool sparse;
     BrickCounts bc{}; bool have = false;
     if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
-    if (h->force_pcg_path >= 0) sparse = h->force_pcg_path == 1;
+    if (h->force_pcg_path >= 0) sparse = h->force_pcg_path >= 1;
     else {
         // small grids stay launch/latency-bound even when fairly full: the brick mapping wins up to ~70 % fill there
         // (dam_halfhalf, 128x64x64 at 40 %: 997 vs 925 steps/s); large ones are byte-bound and want the 2.5-D dense mapping early
@@ -366,7 +368,20 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             if (recent >= 0 && recent < maxit) launched = std::min(maxit + 1, (recent / freq + h->tail_margin_checks) * freq + 1);   // through `margin` checks past the recent maximum
         }
         if (h->use_tail && h->tail_first_forced >= 0) launched = std::min(maxit + 1, h->tail_first_forced);   // (test hook)
+        // from a few hundred fluid bricks on: the LDS-staged variants of the two iteration kernels (same arithmetic, bit-identical results)
+        const bool staged = h->force_pcg_path == 2 || (h->force_pcg_path < 0 && have && bc.n_fluid >= STAGED_PCG_MIN_BRICKS);
         for (int i = 0; i < launched; ++i) {
+            if (staged) {
+                if (i == 0)
+                    LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
+                           (const float2*)part_upd, part_dir, np, ctrl, tol, i, 0);
+                else
+                    LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<false>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
+                           (const float2*)part_upd, part_dir, np, ctrl, tol, i, (int)is_check(i - 1));
+                LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
+                       (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
+                continue;
+            }
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
                        (const float2*)part_upd, part_dir, np, ctrl, tol, i, 0);
@@ -880,7 +895,7 @@ int blub_fluid_mark_pressure_initialised(blub_fluid* h, int which, int init) {
     return BLUB_OK;
 }
 int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode) {
-    if (!h || mode < -1 || mode > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!h || mode < -1 || mode > 2) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
     h->force_pcg_path = mode;
     return BLUB_OK;
 }

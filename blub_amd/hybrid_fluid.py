@@ -420,8 +420,8 @@ class HybridFluid:
         return s.error, s.iteration_count
 
     def set_pcg_work_mapping(self, mode):
-        """"auto" | "rows" | "bricks" -- performance knob, see include/blubhip.h"""
-        _check(self._L, self._L.blub_fluid_set_pcg_work_mapping(self._h, {"auto": -1, "rows": 0, "bricks": 1}[mode]))
+        """"auto" | "rows" | "bricks" | "bricks_staged" -- performance knob, see include/blubhip.h"""
+        _check(self._L, self._L.blub_fluid_set_pcg_work_mapping(self._h, {"auto": -1, "rows": 0, "bricks": 1, "bricks_staged": 2}[mode]))
 
     def set_max_steps_in_flight(self, n):
         _check(self._L, self._L.blub_fluid_set_max_steps_in_flight(self._h, int(n)))

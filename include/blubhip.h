@@ -245,7 +245,7 @@ typedef struct blub_trace_event {
 } blub_trace_event;
 int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capacity, int* count_out); /* blocks */
 /* Work mapping of the PCG kernels: -1 = automatic (brick lists when < 30 % of the bricks hold fluid, dense rows otherwise),
- * 0 = dense rows, 1 = brick lists.  A performance knob only: both mappings run the same per-cell arithmetic (the
+ * 0 = dense rows, 1 = brick lists, 2 = brick lists with LDS-staged tiles (many fluid bricks).  A performance knob only: both mappings run the same per-cell arithmetic (the
  * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise). */
 int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
 /* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks

@@ -87,7 +87,7 @@ def test_full_size_binning_is_a_permutation():
         f.close()
 
 
-@pytest.mark.parametrize("n,mapping", [(256, "rows"), (128, "bricks")])
+@pytest.mark.parametrize("n,mapping", [(256, "rows"), (128, "bricks"), (128, "bricks_staged")])
 def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
     """Dense n^3 Poisson problem (SOLID shell, FLUID inside, one AIR layer under the lid so that the system is not the
     singular pure-Neumann one; 16.3 M unknowns at 256^3): after the solve the engine's own residual volume must equal
@@ -179,3 +179,36 @@ def test_sixty_steps_of_the_reference_shaped_scene_track_the_oracle():
         assert com < 0.05 and l1 < 0.5 and abs(ker - 1.0) < 0.03
     finally:
         f.close()
+
+
+def test_staged_brick_kernels_are_bit_identical_to_the_plain_brick_kernels():
+    """k_pcg_dir_s / k_pcg_update_s (LDS-staged tiles, used from a few thousand fluid bricks on) map threads, quads and
+    partial sums exactly like k_pcg_dir_b / k_pcg_update_b and run the same per-cell arithmetic: same bits, on a grid with
+    partial bricks at its upper faces and a ragged fluid region."""
+    import blub_amd
+    dim = (72, 44, 30)
+    rng = np.random.default_rng(11)
+    marker = -np.ones(dim[::-1], np.int8)
+    marker[[0, -1], :, :] = 0; marker[:, [0, -1], :] = 0; marker[:, :, [0, -1]] = 0
+    blob = rng.random(dim[::-1]) < 0.55
+    blob[:, 30:, :] = False
+    marker[(marker == -1) & blob] = 1
+    marker[10:14, 5:9, 20:30] = 0
+    b = np.where(marker == 1, rng.standard_normal(dim[::-1]), 0).astype(np.float32)
+    out = {}
+    for mapping in ("bricks", "bricks_staged"):
+        h = blub_amd.HybridFluid(dim, 8, binning="off")
+        try:
+            h.set_pcg_work_mapping(mapping)
+            h.write_volume("marker", marker)
+            h.write_volume("residual", b)
+            h.set_solver_config(0, error_tolerance=0.0, max_num_iterations=9, error_check_frequency=4)
+            h.run_stage("solve_velocity", util.DT)
+            out[mapping] = (h.read_volume("pressure_velocity"), h.read_volume("residual"), h.read_volume("search"), h.solver_stats(0))
+        finally:
+            h.close()
+    a, c = out["bricks"], out["bricks_staged"]
+    assert np.abs(a[0]).max() > 0
+    for k in range(3):
+        assert np.array_equal(a[k].view(np.uint32), c[k].view(np.uint32)), k
+    assert a[3] == c[3]

@@ -62,7 +62,7 @@ def test_elementwise_grid_stage_bit_exact(pair, stage, outputs):
     assert any(np.abs(o.read_volume(v)).max() > 0 for v in outputs)
 
 
-@pytest.mark.parametrize("mapping", ["rows", "bricks"])
+@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged"])
 @pytest.mark.parametrize("iters", [0, 1, 4, 7, 8])
 def test_pcg_fixed_iterations(pair, iters, mapping):
     """Fixed iteration count (tolerance 0): p, r, s after k iterations. Only the dot-product summation order differs;
@@ -88,7 +88,7 @@ def test_pcg_fixed_iterations(pair, iters, mapping):
     assert abs(eh - eo) <= 1e-4 * abs(eo) + 1e-9
 
 
-@pytest.mark.parametrize("mapping", ["rows", "bricks"])
+@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged"])
 @pytest.mark.parametrize("which,stage", [(0, "solve_velocity"), (1, "solve_density")])
 def test_pcg_default_config(pair, which, stage, mapping):
     """The reference's operating point (32 iterations, check every 4) stops far from convergence (max|r| ~ 12), where
