@@ -299,8 +299,8 @@ int load_obj(const char* path, float* pos, size_t vcap, uint32_t* nv_out, uint32
     fclose(f);
     if (bad) return set_error(BLUB_ERR_PARSE, (std::string("malformed OBJ record in ") + path).c_str());
     *nv_out = (uint32_t)(P.size() / 3); *ni_out = (uint32_t)I.size();
-    if (pos) { if (vcap < P.size() / 3) return set_error(BLUB_ERR_INVALID_ARGUMENT, "vertex buffer too small"); memcpy(pos, P.data(), P.size() * sizeof(float)); }
-    if (idx) { if (icap < I.size()) return set_error(BLUB_ERR_INVALID_ARGUMENT, "index buffer too small"); memcpy(idx, I.data(), I.size() * sizeof(uint32_t)); }
+    if (pos) { if (vcap < P.size() / 3) return set_error(BLUB_ERR_INVALID_ARGUMENT, "vertex buffer too small"); if (!P.empty()) memcpy(pos, P.data(), P.size() * sizeof(float)); }
+    if (idx) { if (icap < I.size()) return set_error(BLUB_ERR_INVALID_ARGUMENT, "index buffer too small"); if (!I.empty()) memcpy(idx, I.data(), I.size() * sizeof(uint32_t)); }
     return BLUB_OK;
 }
 
