@@ -1,0 +1,189 @@
+"""Independent numpy restatements of four grid/particle stages, written from the shader semantics summarised in SURVEY.md 8(a)
+(NOT from oracle/blub_oracle.cpp), cross-checked against the C++ oracle on random inputs.  They use a different formulation
+where one exists (effective face velocities for the divergence, brute-force sums over ALL particles for the two gathers), so
+an error in the oracle's literal restatement of a shader would show up here.  Volumes are indexed [z, y, x]."""
+import numpy as np
+
+from oracle.oracle import Oracle
+from tests import util
+
+DT = util.DT
+FLUID, AIR, SOLID = 1, -1, 0
+DIM = (20, 16, 12)   # x, y, z
+
+
+def _random_marker(rng, solid_block=True):
+    nx, ny, nz = DIM
+    m = np.full((nz, ny, nx), AIR, np.int8)
+    blob = rng.random((nz, ny, nx)) < 0.6
+    blob[:, 11:, :] = False
+    m[blob] = FLUID
+    if solid_block:
+        m[3:7, 2:6, 8:12] = SOLID
+    m[[0, -1], :, :] = SOLID
+    m[:, [0, -1], :] = SOLID
+    m[:, :, [0, -1]] = SOLID
+    return m
+
+
+def _shift(a, axis, d, fill):
+    """b[g] = a[g + d * e_axis] with `fill` outside (axis: 0 = x, 1 = y, 2 = z for [z, y, x] arrays)."""
+    ax = 2 - axis
+    out = np.full_like(a, fill)
+    src = [slice(None)] * 3
+    dst = [slice(None)] * 3
+    if d > 0:
+        src[ax], dst[ax] = slice(d, None), slice(None, -d)
+    else:
+        src[ax], dst[ax] = slice(None, d), slice(-d, None)
+    out[tuple(dst)] = a[tuple(src)]
+    return out
+
+
+def test_divergence_equals_the_flux_of_effective_face_velocities():
+    """divergence_compute.comp:28-87: for FLUID cells, sum_c (v+_c - v-_c) where a face shared with a SOLID neighbour carries
+    the solid's own velocity component instead of the grid's (the shader adds +-(v_wall - v_solid) correction terms)."""
+    rng = np.random.default_rng(1)
+    nx, ny, nz = DIM
+    m = _random_marker(rng)
+    vel = [rng.standard_normal((nz, ny, nx)).astype(np.float32) for _ in range(3)]
+    solid = np.zeros((nz, ny, nx, 4), np.float32)
+    solid[..., 3] = (m == SOLID)
+    solid[3:7, 2:6, 8:12, :3] = rng.standard_normal(3).astype(np.float32)          # the block moves
+    o = Oracle(nx, ny, nz, 8)
+    o.write_volume("solid", solid)
+    o.write_volume("marker", m)
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        o.write_volume(n, vel[c])
+    o.write_volume("residual", np.full((nz, ny, nx), 7.0, np.float32))
+    o.run_stage("divergence", DT)
+    got = o.read_volume("residual")
+    want = np.zeros((nz, ny, nx), np.float64)
+    for c in range(3):
+        vplus = vel[c].astype(np.float64)                                             # face between g and g + e_c
+        vminus = _shift(vel[c], c, -1, 0.0).astype(np.float64)                        # face between g - e_c and g
+        m_plus, m_minus = _shift(m, c, +1, SOLID), _shift(m, c, -1, SOLID)
+        s_plus, s_minus = _shift(solid[..., c], c, +1, 0.0), _shift(solid[..., c], c, -1, 0.0)
+        want += np.where(m_plus == SOLID, s_plus, vplus) - np.where(m_minus == SOLID, s_minus, vminus)
+    fluid = m == FLUID
+    assert fluid.sum() > 500
+    assert np.abs(got[fluid] - want[fluid]).max() < 1e-5
+    assert np.all(got[~fluid] == 7.0)                                                 # only FLUID cells are written
+
+
+def test_pressure_gradient_subtraction_per_face():
+    """divergence_remove.comp:19-49 per face (g, c): either side FLUID -> (one side SOLID ? the solid's velocity component :
+    v - (p[g] - p[g + e_c]) with p = 0 outside FLUID); neither side FLUID -> 0."""
+    rng = np.random.default_rng(2)
+    nx, ny, nz = DIM
+    m = _random_marker(rng)
+    vel = [rng.standard_normal((nz, ny, nx)).astype(np.float32) for _ in range(3)]
+    p = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    solid = np.zeros((nz, ny, nx, 4), np.float32)
+    solid[..., 3] = (m == SOLID)
+    solid[3:7, 2:6, 8:12, :3] = np.float32([0.5, -1.25, 2.0])
+    o = Oracle(nx, ny, nz, 8)
+    o.write_volume("solid", solid)
+    o.write_volume("marker", m)
+    o.write_volume("pressure_velocity", p)
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        o.write_volume(n, vel[c])
+    o.run_stage("project", DT)                      # divergence_remove + extrapolate; compare on faces extrapolation never writes
+    pf = np.where(m == FLUID, p, 0).astype(np.float64)
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        got = o.read_volume(n)
+        m_n = _shift(m, c, +1, SOLID)
+        touched = (m == FLUID) | (m_n == FLUID)     # extrapolation only writes faces with NO fluid side
+        want = vel[c].astype(np.float64) - (pf - _shift(pf, c, +1, 0.0))   # blub's sign: A p = +divergence with A = -Laplacian, so v -= p_c - p_nbr
+        want = np.where(m_n == SOLID, _shift(solid[..., c], c, +1, 0.0), want)   # the +c side is the solid: its velocity
+        want = np.where(m == SOLID, solid[..., c], want)                          # this side is the solid
+        assert touched.sum() > 500
+        assert np.abs(got[touched] - want[touched]).max() < 1e-5, n
+
+
+def _jittered_particles(rng, per_cell=3):
+    nx, ny, nz = DIM
+    cells = np.stack(np.meshgrid(np.arange(2, nx - 3), np.arange(2, 9), np.arange(2, nz - 3), indexing="ij"), -1).reshape(-1, 3)
+    keep = rng.random(len(cells)) < 0.7
+    cells = cells[keep]
+    return (cells[:, None, :] + rng.random((len(cells), per_cell, 3))).reshape(-1, 3).astype(np.float32)
+
+
+def test_p2g_gather_equals_brute_force_shepard_sums():
+    """transfer_gather_velocity.comp:18-26, 39-127: v(face) = sum_p w (C_row . (s - p) + v_p) / sum_p w + g_c dt with
+    w = prod_k sat(1 - |s_k - p_k|), s = the face's sample point g + 0.5 + 0.5 e_c; 0 if exactly one side is SOLID; written only
+    where either side is FLUID.  With fewer than 12 particles per dual cell the 8-list walk visits exactly the particles with
+    w > 0, so a brute-force sum over ALL particles must agree."""
+    rng = np.random.default_rng(3)
+    nx, ny, nz = DIM
+    pos = _jittered_particles(rng)
+    rows = [np.concatenate([rng.standard_normal((len(pos), 3)) * 0.3, rng.standard_normal((len(pos), 1))], 1).astype(np.float32) for _ in range(3)]
+    grav = np.float32([0.3, -9.0, 1.5])
+    o = Oracle(nx, ny, nz, len(pos))
+    o.set_gravity_grid(grav)
+    o.set_particles(pos, *rows)
+    o.run_stage("transfer", DT)
+    m = o.read_volume("marker")
+    P = pos.astype(np.float64)
+    occupied = np.zeros((nz, ny, nx), bool)
+    occupied[P[:, 2].astype(int), P[:, 1].astype(int), P[:, 0].astype(int)] = True
+    assert np.array_equal(m == FLUID, occupied)                                   # FLUID = cells that hold a particle
+    gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    for c, name in enumerate(("vel_x", "vel_y", "vel_z")):
+        got = o.read_volume(name)
+        e = np.eye(3)[c]
+        s = np.stack([gx, gy, gz], -1).reshape(-1, 3) + 0.5 + 0.5 * e           # sample points, x-major list
+        num, den = np.zeros(len(s)), np.zeros(len(s))
+        R = rows[c].astype(np.float64)
+        for k in range(0, len(s), 2048):                                          # blocks of faces x all particles
+            d = s[k:k + 2048, None, :] - P[None, :, :]
+            w = np.clip(1.0 - np.abs(d), 0.0, 1.0).prod(-1)
+            val = (d * R[None, :, :3]).sum(-1) + R[None, :, 3]
+            num[k:k + 2048] = (w * val).sum(1)
+            den[k:k + 2048] = w.sum(1)
+        v = np.where(den > 0, num / np.maximum(den, 1e-300), 0.0) + float(grav[c]) * DT
+        v = v.reshape(nx, ny, nz).transpose(2, 1, 0)
+        m_n = _shift(m, c, +1, SOLID)
+        v = np.where((m == SOLID) | (m_n == SOLID), 0.0, v)
+        written = (m == FLUID) | (m_n == FLUID)
+        assert written.sum() > 300
+        assert np.abs(got[written] - v[written]).max() < 2e-5, name
+
+
+def test_density_error_equals_brute_force_kernel_sum():
+    """density_projection_gather_error.comp:27-31, 167-196 for FLUID cells: rho = sum_p prod_k sat(1 - |c_k - p_k|) at the cell
+    centre c = g + 0.5, + 0.5625 per SOLID face-neighbour, max(8, rho) if any face-neighbour is AIR, then
+    b = clamp(1 - rho / 8, -0.5, 0.5) / dt.  (The lists are built by the advection stage: run it with a zero velocity field.)"""
+    rng = np.random.default_rng(4)
+    nx, ny, nz = DIM
+    pos = _jittered_particles(rng, per_cell=9)                                    # dense enough for rho > 8 in the bulk
+    o = Oracle(nx, ny, nz, len(pos))
+    o.set_particles(pos)
+    o.run_stage("transfer", DT)                                                    # marker
+    for n in ("vel_x", "vel_y", "vel_z"):
+        o.write_volume(n, np.zeros((nz, ny, nx), np.float32))
+    o.run_stage("advect", DT)                                                      # zero velocity: positions stay, density lists are built
+    P = o.get_particles()[0][:, :3].astype(np.float64)
+    assert np.abs(P - pos).max() == 0.0
+    o.run_stage("density_gather", DT)
+    m = o.read_volume("marker")
+    got = o.read_volume("residual")
+    gx, gy, gz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    cen = np.stack([gx, gy, gz], -1).reshape(-1, 3) + 0.5
+    rho = np.zeros(len(cen))
+    for k in range(0, len(cen), 2048):
+        d = cen[k:k + 2048, None, :] - P[None, :, :]
+        rho[k:k + 2048] = np.clip(1.0 - np.abs(d), 0.0, 1.0).prod(-1).sum(1)
+    rho = rho.reshape(nx, ny, nz).transpose(2, 1, 0)
+    any_air = np.zeros((nz, ny, nx), bool)
+    for c in range(3):
+        for dd in (-1, +1):
+            mn = _shift(m, c, dd, SOLID)
+            rho = rho + 0.5625 * (mn == SOLID)
+            any_air |= mn == AIR
+    rho = np.where(any_air, np.maximum(8.0, rho), rho)
+    want = np.clip(1.0 - rho / 8.0, -0.5, 0.5) / DT
+    fluid = m == FLUID
+    assert fluid.sum() > 300 and (want[fluid] < -1.0).sum() > 20 and (np.abs(want[fluid]) < 1e-9).sum() > 20   # compressed bulk and clamped surface
+    # 1 - rho / 8 cancels: an f32 rounding of rho (~1e-6 relative) is worth ~1e-6 / dt on the result
+    assert np.abs(got[fluid] - want[fluid]).max() < 5e-6 / DT
