@@ -187,3 +187,37 @@ def test_density_error_equals_brute_force_kernel_sum():
     assert fluid.sum() > 300 and (want[fluid] < -1.0).sum() > 20 and (np.abs(want[fluid]) < 1e-9).sum() > 20   # compressed bulk and clamped surface
     # 1 - rho / 8 cancels: an f32 rounding of rho (~1e-6 relative) is worth ~1e-6 / dt on the result
     assert np.abs(got[fluid] - want[fluid]).max() < 5e-6 / DT
+
+
+def test_particle_correction_is_a_hardware_style_trilinear_fetch():
+    """density_projection_correct_particles.comp:32-40: x += (T_x, T_y, T_z) with T_c = the c-th position-change volume sampled
+    with a clamp-to-edge LINEAR filter at the normalised coordinate (x - 0.5 e_c) / dim, i.e. texel centres at integer + 0.5.
+    Particles far from walls / solids (no step truncation, :45-69)."""
+    rng = np.random.default_rng(5)
+    nx, ny, nz = DIM
+    o = Oracle(nx, ny, nz, 4000)
+    m = np.full((nz, ny, nx), AIR, np.int8)
+    m[[0, -1], :, :] = SOLID; m[:, [0, -1], :] = SOLID; m[:, :, [0, -1]] = SOLID
+    o.write_volume("marker", m)
+    vol = [(rng.standard_normal((nz, ny, nx)) * 0.2).astype(np.float32) for _ in range(3)]
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        o.write_volume(n, vol[c])
+    pos = (rng.random((3000, 3)) * (np.array(DIM) - 6.0) + 3.0).astype(np.float32)      # >= 3 cells from every wall, |delta| < 1
+    o.set_particles(pos)
+    o.run_stage("correct", DT)
+    got = o.get_particles()[0][:, :3].astype(np.float64)
+    P = pos.astype(np.float64)
+    want = P.copy()
+    for c in range(3):
+        u = P - 0.5 * np.eye(3)[c] - 0.5                                                  # continuous texel coordinates
+        i0 = np.floor(u).astype(int)
+        f = u - i0
+        acc = np.zeros(len(P))
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                    acc += w * vol[c][i0[:, 2] + dz, i0[:, 1] + dy, i0[:, 0] + dx]
+        want[:, c] += acc
+    assert np.abs(got - want).max() < 5e-6
+    assert np.abs(got - P).max() > 0.1
