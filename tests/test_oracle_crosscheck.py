@@ -221,3 +221,57 @@ def test_particle_correction_is_a_hardware_style_trilinear_fetch():
         want[:, c] += acc
     assert np.abs(got - want).max() < 5e-6
     assert np.abs(got - P).max() > 0.1
+
+
+def test_g2p_apic_rows_and_rk4_for_interior_particles():
+    """advect_particles.comp:74-127, 184-188 for particles that stay away from walls and solids: per component i the staggered
+    cell around o_i = x - (0.5 + 0.5 e_i) gives 8 corner values; velocity = trilinear; the stored rows are
+    (d/dx, d/dy, d/dz of the COMPONENT-INDEXED corner vector, v) -- i.e. transposed (Q2); RK4 adds the scalar dt * k_i to ALL
+    three interpolants of component i (Q11) with saturation; x += dt / 6 (k1 + 2 k2 + 2 k3 + k4).  Vectorised f64 numpy."""
+    rng = np.random.default_rng(6)
+    nx, ny, nz = DIM
+    o = Oracle(nx, ny, nz, 4000)
+    m = np.full((nz, ny, nx), AIR, np.int8)
+    m[[0, -1], :, :] = SOLID; m[:, [0, -1], :] = SOLID; m[:, :, [0, -1]] = SOLID
+    o.write_volume("marker", m)
+    vol = [(rng.standard_normal((nz, ny, nx)) * 8.0).astype(np.float32) for _ in range(3)]     # |v| dt ~ 0.07 cells
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        o.write_volume(n, vol[c])
+    pos = (rng.random((3000, 3)) * (np.array(DIM) - 6.0) + 3.0).astype(np.float32)
+    o.set_particles(pos)
+    o.run_stage("advect", DT)
+    got = o.get_particles()
+    X = pos.astype(np.float64)
+    corners, t = [], []
+    for i in range(3):
+        off = np.full(3, 0.5); off[i] = 1.0
+        oi = np.maximum(0.0, X - off)
+        lo = np.floor(oi).astype(int)
+        hi = np.minimum(lo + 1, np.array(DIM) - 1)
+        t.append(oi - lo)
+        V = vol[i].astype(np.float64)
+        corners.append({(dx, dy, dz): V[(hi if dz else lo)[:, 2], (hi if dy else lo)[:, 1], (hi if dx else lo)[:, 0]] for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)})
+    mix = lambda a, b, w: a * (1 - w) + b * w
+
+    def tri(i, tx, ty, tz):
+        c = corners[i]
+        return mix(mix(mix(c[0, 0, 0], c[1, 0, 0], tx), mix(c[0, 1, 0], c[1, 1, 0], tx), ty), mix(mix(c[0, 0, 1], c[1, 0, 1], tx), mix(c[0, 1, 1], c[1, 1, 1], tx), ty), tz)
+    nv = np.stack([tri(i, t[i][:, 0], t[i][:, 1], t[i][:, 2]) for i in range(3)], 1)
+    rows = np.zeros((3, len(X), 3))      # rows[axis][:, i] = d(corner vector component i) / d(axis)
+    for i in range(3):
+        c, (tx, ty, tz) = corners[i], (t[i][:, 0], t[i][:, 1], t[i][:, 2])
+        rows[0][:, i] = mix(mix(c[1, 0, 0], c[1, 1, 0], ty), mix(c[1, 0, 1], c[1, 1, 1], ty), tz) - mix(mix(c[0, 0, 0], c[0, 1, 0], ty), mix(c[0, 0, 1], c[0, 1, 1], ty), tz)
+        rows[1][:, i] = mix(mix(c[0, 1, 0], c[1, 1, 0], tx), mix(c[0, 1, 1], c[1, 1, 1], tx), tz) - mix(mix(c[0, 0, 0], c[1, 0, 0], tx), mix(c[0, 0, 1], c[1, 0, 1], tx), tz)
+        rows[2][:, i] = mix(mix(c[0, 0, 1], c[1, 0, 1], tx), mix(c[0, 1, 1], c[1, 1, 1], tx), ty) - mix(mix(c[0, 0, 0], c[1, 0, 0], tx), mix(c[0, 1, 0], c[1, 1, 0], tx), ty)
+    sat = lambda a: np.clip(a, 0.0, 1.0)
+    step = lambda k, f: np.stack([tri(i, sat(t[i][:, 0] + f * k[:, i]), sat(t[i][:, 1] + f * k[:, i]), sat(t[i][:, 2] + f * k[:, i])) for i in range(3)], 1)
+    k1 = nv
+    k2 = step(k1, DT * 0.5)
+    k3 = step(k2, DT * 0.5)
+    k4 = step(k3, DT)
+    newx = X + DT * (1.0 / 6.0) * (k1 + 2.0 * (k2 + k3) + k4)
+    assert np.abs(newx - X).max() > 0.05 and np.abs(newx - X).max() < 0.9
+    assert np.abs(got[0][:, :3] - newx).max() < 2e-5
+    for axis in range(3):                                   # ParticleBufferVelocity{X,Y,Z} = vec4(c{x,y,z}, v_{x,y,z})  (:186-188)
+        assert np.abs(got[1 + axis][:, :3] - rows[axis]).max() < 2e-4, axis
+        assert np.abs(got[1 + axis][:, 3] - nv[:, axis]).max() < 2e-5, axis
