@@ -275,3 +275,43 @@ def test_g2p_apic_rows_and_rk4_for_interior_particles():
     for axis in range(3):                                   # ParticleBufferVelocity{X,Y,Z} = vec4(c{x,y,z}, v_{x,y,z})  (:186-188)
         assert np.abs(got[1 + axis][:, :3] - rows[axis]).max() < 2e-4, axis
         assert np.abs(got[1 + axis][:, 3] - nv[:, axis]).max() < 2e-5, axis
+
+
+def test_particle_correction_wall_truncation_is_literal():
+    """density_projection_correct_particles.comp:47-68 for targets outside [1.001, dim - 1.001] or inside a SOLID cell: the step is
+    cut to min(L, (d_k > 0 ? fract(x_k) : 1 - fract(x_k)) / |d_k| - 0.001) along its direction (Q12: the shader's ternary measures
+    the distance to the face BEHIND the particle; followed literally), then clamped.  Uniform position-change volumes make the
+    sampled step known in closed form; a SOLID block in the interior exercises the marker branch."""
+    rng = np.random.default_rng(7)
+    nx, ny, nz = DIM
+    delta = np.float32([-0.8, 0.45, -0.3])
+    o = Oracle(nx, ny, nz, 4000)
+    m = np.full((nz, ny, nx), AIR, np.int8)
+    m[[0, -1], :, :] = SOLID; m[:, [0, -1], :] = SOLID; m[:, :, [0, -1]] = SOLID
+    m[4:8, 5:9, 6:10] = SOLID
+    o.write_volume("marker", m)
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        o.write_volume(n, np.full((nz, ny, nx), delta[c], np.float32))
+    near_wall = np.stack([rng.uniform(1.001, 1.9, 600), rng.uniform(1.001, ny - 1.001, 600), rng.uniform(1.001, 1.4, 600)], 1)
+    near_block = np.stack([rng.uniform(10.0, 10.9, 600), rng.uniform(4.2, 4.99, 600), rng.uniform(4.0, 8.0, 600)], 1)   # +x / below the block
+    free = np.stack([rng.uniform(12.0, 17.0, 600), rng.uniform(9.5, 13.0, 600), rng.uniform(3.0, 9.0, 600)], 1)
+    pos = np.concatenate([near_wall, near_block, free]).astype(np.float32)
+    o.set_particles(pos)
+    o.run_stage("correct", DT)
+    got = o.get_particles()[0][:, :3].astype(np.float64)
+    X = pos.astype(np.float64)
+    d64 = delta.astype(np.float64)
+    target = X + d64
+    lo, hi = 1.001, np.array(DIM) - 1.001
+    outside = np.any((target < lo) | (target > hi), axis=1)
+    cell = np.clip(np.floor(target).astype(int), 0, np.array(DIM) - 1)
+    in_solid = m[cell[:, 2], cell[:, 1], cell[:, 0]] == SOLID
+    L = np.linalg.norm(d64) + 1e-10
+    direction = d64 / L
+    pic = X - np.floor(X)
+    limit = np.where(direction > 0, pic, 1.0 - pic) / np.abs(direction) - 0.001
+    max_step = np.minimum(L, limit.min(axis=1))
+    cut = np.clip(X + direction[None, :] * max_step[:, None], lo, hi)
+    want = np.where((outside | in_solid)[:, None], cut, target)
+    assert outside.sum() > 300 and (in_solid & ~outside).sum() > 50 and (~outside & ~in_solid).sum() > 500
+    assert np.abs(got - want).max() < 5e-6
