@@ -320,18 +320,26 @@ def main():
         group.synchronize()
         ops_per_step = group.transport_ops() - ops0
         # weak scaling: one global step advances `world` slabs of the single-GPU workload size
-        if rank == 0:
-            print(json.dumps({
-                "metric": "simulation steps/sec, 1M particles @ 256^3 grid", "value": round(args.steps * world / elapsed, 3),
-                "unit": "steps/s (256^3-slab steps: one global step advances n_gpus slabs)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                "data": "synthetic", "config": {"workload": "%s stacked x%d along z" % (args.scene, world), "grid": [nx, ny, nz], "particles": P, "dt": dt,
-                                                "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60, "parallelism": parallelism},
-                "global_steps_per_sec": round(args.steps / elapsed, 3), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
-                "transport_ops_per_step": round(ops_per_step, 1), "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}))
-            sys.stdout.flush()
+        line = {
+            "metric": "simulation steps/sec, 1M particles @ 256^3 grid", "value": round(args.steps * world / elapsed, 3),
+            "unit": "steps/s (256^3-slab steps: one global step advances n_gpus slabs)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": "%s stacked x%d along z" % (args.scene, world), "grid": [nx, ny, nz], "particles": P, "dt": dt,
+                                            "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60, "parallelism": parallelism},
+            "global_steps_per_sec": round(args.steps / elapsed, 3), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
+            "transport_ops_per_step": round(ops_per_step, 1), "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}
         dist.barrier()
         group.close()
+        if rank == 0:
+            if not args.no_dense_pcg:   # the roofline kernel is a single-GPU micro-benchmark: rank 0 runs it while the others wait
+                dense = dense_pcg_benchmark(256, 32)
+                ku = dense["kernels"]["pcg_update"]
+                line["roofline"] = {"bound": "hbm", "kernel": "k_pcg_update_z (PCG stencil update, dense 256^3 micro-benchmark M3, rank 0)", "achieved": ku["achieved_GBs"],
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"], "traffic": ku["traffic_bytes_pmc"], "algorithmic_bytes": ku["algorithmic_bytes"],
+                                    "avg_us": ku["avg_us"], "launches": ku["launches"]}
+            print(json.dumps(line))
+            sys.stdout.flush()
+        dist.barrier()
         dist.destroy_process_group()
         return
 
