@@ -1,0 +1,276 @@
+// Single-reduction PCG for the brick mapping: ONE kernel per iteration (Chronopoulos-Gear form of the reference's schedule).
+//
+// The headline scene (1 M particles @ 256^3, ~1300 fluid bricks) is bound by the number of DEPENDENT launches, not by bytes: the
+// two-kernel iteration of blub_pcg.hip.h spends ~7 us per kernel on < 3 MB.  The reference's loop (pressure_solver.rs:654-723)
+// has two global reductions per iteration (s.As for alpha, z.r for beta), hence two grid-wide dependencies.  In exact arithmetic
+// the same iterates follow from ONE reduction per iteration when A d is carried by a recurrence instead of being recomputed
+// (Chronopoulos & Gear 1989):
+//     u_i = M^-1 r_i (pointwise, Q1 reading "zero": (r/d)/d),   w_i = A u_i
+//     gamma_i = r_i.u_i,  delta_i = w_i.u_i                                (one partial array, reduced by the consumer)
+//     beta_i  = gamma_i / gamma_{i-1}              (beta_0 = 0)            == the reference's sigma'/sigma
+//     alpha_i = gamma_i / (delta_i - beta_i gamma_i / alpha_{i-1})         == the reference's sigma/(s.As), alpha_0 = gamma_0/delta_0
+//     d_i = u_i + beta_i d_{i-1}                                           (the reference's search direction `s`)
+//     q_i = w_i + beta_i q_{i-1}                                           (= A d_i by linearity)
+//     p  += alpha_i d_i ;  r_{i+1} = r_i - alpha_i q_i
+// Kernel K(i) evaluates r_{i+1} and u_{i+1} for the cell AND, redundantly, for its six neighbours (identical f32 operations, so
+// every copy is bit-identical -- the trick KD already uses for `s`), forms w_{i+1} = A u_{i+1} from an LDS tile and emits the
+// partials {gamma_{i+1}, delta_{i+1}, max|r_{i+1}|}.  r, w and q are double buffered by iteration parity (neighbours read the old
+// values while the owner writes the new ones).  Convergence test, statistics and the check cadence are those of the two-kernel
+// path (pressure_reduce.comp:82-94): K(i+1) tests max|r_{i+1}| when iteration i was a check iteration.
+// This is a different ROUNDING of the same recurrence (not bit-comparable with the reference's order of operations), so it sits
+// behind blub_fluid_set_pcg_schedule(); parity against the oracle is stated with the same tolerances as the two-kernel path.
+#pragma once
+#include "blub_pcg.hip.h"
+
+namespace blubk {
+
+struct Pcg1Scalars { float gamma[2]; float alpha[2]; };   // gamma_i, alpha_i in slot i & 1 (written by block 0 of K(i), read by K(i+1))
+
+template <int NT>
+__device__ __forceinline__ float4 reduce_partials4(const float4* __restrict__ part, int n, float4* sm4) {
+    float g = 0.0f, d = 0.0f, m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += NT) { const float4 p = part[i]; g += p.x; d += p.y; m = fmaxf(m, p.z); }
+    g = wave_sum(g); d = wave_sum(d); m = wave_max(m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm4[wave] = make_float4(g, d, m, 0.0f);
+    __syncthreads();
+    float4 r = sm4[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) { r.x += sm4[w].x; r.y += sm4[w].y; r.z = fmaxf(r.z, sm4[w].z); }
+    return r;
+}
+
+// Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
+template <int NT, bool FIRST>
+__device__ __forceinline__ bool pcg1_prologue(PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in, int num_part,
+                                              float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta) {
+    if (ctrl->done) return false;
+    float g_prev = 0.0f, a_prev = 0.0f;
+    if (!FIRST) { g_prev = sc->gamma[(iteration + 1) & 1]; a_prev = sc->alpha[(iteration + 1) & 1]; }
+    const float4 red = reduce_partials4<NT>(part_in, num_part, sm4);
+    beta = 0.0f;
+    if (!FIRST) {
+        if (check_prev && red.z < tolerance) {                                           // pressure_reduce.comp:82-94
+            if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->max_err = red.z; ctrl->num_iter = (float)(iteration - 1); ctrl->done = 1; }
+            return false;
+        }
+        beta = eps_div(red.x, g_prev);                                                   // RESULTMODE_BETA
+        const float corr = a_prev != 0.0f ? (beta * red.x) / a_prev : 0.0f;
+        alpha = eps_div(red.x, red.y - corr);                                            // RESULTMODE_ALPHA with d.Ad = delta - beta gamma / alpha_prev
+    } else {
+        alpha = eps_div(red.x, red.y);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gamma[iteration & 1] = red.x; sc->alpha[iteration & 1] = alpha; }
+    return true;
+}
+
+// w_0 = A u_0 (u_0 = M^-1 r_0 was written to the search volume by k_pcg_init_b) + partials {gamma_0 (block 0 only), delta_0, 0}
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                             const uint8_t* __restrict__ dvol, const float* __restrict__ u, float* __restrict__ w_out,
+                                                             const float2* __restrict__ part_init, int num_part, float4* __restrict__ part_out) {
+    __shared__ float sm[8];
+    __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
+    __shared__ StagedTile tiles[PCG_BPB];
+    const Grid g = bg.g;
+    const uint32_t n = *count;
+    const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    const float2 red0 = reduce_partials2<PCG_B_THREADS>(part_init, num_part, sm2);
+    StagedTile& T = tiles[half];
+    float acc = 0.0f;
+    for (uint32_t ib = blockIdx.x; ib * PCG_BPB < n; ib += gridDim.x) {
+        const uint32_t i = ib * PCG_BPB + half;
+        const bool have = i < n;
+        const uint32_t b = have ? list[i] : 0u;
+        const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+        if (have) {
+            for (int e = t; e < ST_ROWS * 4; e += BRICK_THREADS) {
+                const int row = e >> 2, q = e & 3;
+                if (!st_row_needed(row)) continue;
+                const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1, gx = x0b + 4 * q;
+                float4 uv = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint32_t dq = 0;
+                if ((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx) {
+                    const int base = cidx(g, gx, gy, gz);
+                    dq = *reinterpret_cast<const uint32_t*>(dvol + base);
+                    uv = ld4(u + base);
+                }
+                *reinterpret_cast<float4*>(T.s + row * ST_ROW + 4 + 4 * q) = uv;
+                *reinterpret_cast<uint32_t*>(T.d + row * ST_ROW + 4 + 4 * q) = dq;
+            }
+            for (int e = t; e < BY * BZ * 2; e += BRICK_THREADS) {
+                const int side = e & 1, yy = (e >> 1) % BY, zz = (e >> 1) / BY;
+                const int row = (zz + 1) * (BY + 2) + (yy + 1);
+                const int gx = side ? x0b + BX : x0b - 1, gy = y0b + yy, gz = z0b + zz;
+                float uv = 0.0f; int dv = 0;
+                if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { const int c = cidx(g, gx, gy, gz); dv = (int)dvol[c]; uv = u[c]; }
+                T.s[row * ST_ROW + (side ? 20 : 3)] = uv;
+                T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)dv;
+            }
+        }
+        __syncthreads();
+        if (have) {
+            int x0, y, z;
+            if (brick_quad(bg, b, t, x0, y, z)) {
+                QuadD m; QuadValues sv;
+                st_read_quad(T, t, m, sv);
+                if (any_fluid_d(m.c)) {
+                    float wn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (dbyte(m.c, j) & 0x80) { wn[j] = quad_mulA_d(m, sv, j); acc += wn[j] * f4(sv.c, j); }
+                    *reinterpret_cast<float4*>(w_out + cidx(g, x0, y, z)) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = make_float4(blockIdx.x == 0 ? red0.x : 0.0f, tot, 0.0f, 0.0f);
+}
+
+// K(i): one whole PCG iteration.  HALO (z-slab groups): the block also stores the r_{i+1} / q_i it computed for the ghost plane
+// below `halo_lo` / above `halo_hi` (own planes of the slab, -1 = none), so only w needs a halo exchange per iteration.
+template <bool FIRST, bool HALO = false>
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                               const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
+                                                               const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
+                                                               float* __restrict__ q_out, float* __restrict__ dsearch, float* __restrict__ p,
+                                                               const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part,
+                                                               PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
+                                                               int halo_lo = -1, int halo_hi = -1) {
+    __shared__ float sm[8];
+    __shared__ float4 sm4[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
+    __shared__ float sInv[8];
+    __shared__ StagedTile tiles[PCG_BPB];
+    pcg_fill_inv_lut(sInv);   // (published by the barriers of the prologue's reduction)
+    const Grid g = bg.g;
+    const uint32_t n = *count;
+    const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    float alpha, beta;
+    if (!pcg1_prologue<PCG_B_THREADS, FIRST>(ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return;
+    StagedTile& T = tiles[half];
+    float acc_g = 0.0f, acc_d = 0.0f, emax = 0.0f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t ib = blockIdx.x; ib * PCG_BPB < n; ib += gridDim.x) {       // uniform trip count for both halves: barriers inside
+        const uint32_t i = ib * PCG_BPB + half;
+        const bool have = i < n;
+        const uint32_t b = have ? list[i] : 0u;
+        const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+        if (have) {
+            // phase 1a: r_{i+1}, u_{i+1} on the 240 interior quads of the face-halo tile; the own quads also advance q, d, p
+#pragma unroll
+            for (int e = t; e < ST_ROWS * 4; e += BRICK_THREADS) {
+                const int row = e >> 2, q = e & 3;
+                if (!st_row_needed(row)) continue;
+                const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1, gx = x0b + 4 * q;
+                float4 un = zero4;
+                uint32_t dq = 0;
+                if ((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx) {
+                    const int base = cidx(g, gx, gy, gz);
+                    dq = *reinterpret_cast<const uint32_t*>(dvol + base);
+                    const float4 rv = ld4(r_in + base), wv = ld4(w_in + base);
+                    const float4 qv = FIRST ? zero4 : ld4(q_in + base);
+                    const bool own = gy >= y0b && gy < y0b + BY && gz >= z0b && gz < z0b + BZ;
+                    float4 dv4 = zero4, pv4 = zero4;
+                    if (own) { dv4 = ld4(dsearch + base); pv4 = ld4(p + base); }
+                    float qn[4], rn[4], uu[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int dv = dbyte(dq, j);
+                        const float inv = sInv[dv & 7];
+                        const float qj = FIRST ? f4(wv, j) : f4(wv, j) + beta * f4(qv, j);
+                        const float rj = f4(rv, j) - alpha * qj;
+                        const float uj = (rj * inv) * inv;
+                        const bool fl = (dv & 0x80) != 0;
+                        qn[j] = fl ? qj : 0.0f; rn[j] = fl ? rj : 0.0f; uu[j] = fl ? uj : 0.0f;
+                    }
+                    un = make_float4(uu[0], uu[1], uu[2], uu[3]);
+                    if (own && any_fluid_d(dq)) {
+                        float dn[4] = {dv4.x, dv4.y, dv4.z, dv4.w}, pn[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int dv = dbyte(dq, j);
+                            if (!(dv & 0x80)) continue;                        // non-FLUID lanes keep their d and p (p = 0 there: pressure_init.comp:45-48)
+                            const float inv = sInv[dv & 7];
+                            const float ui = (f4(rv, j) * inv) * inv;          // u_i = M^-1 r_i
+                            dn[j] = FIRST ? ui : ui + beta * dn[j];            // pressure_update_search.comp:23
+                            pn[j] = pn[j] + alpha * dn[j];                     // pressure_update_pressure_and_residual.comp:39-40
+                            acc_g += rn[j] * uu[j];
+                            emax = fmaxf(emax, fabsf(rn[j]));
+                        }
+                        *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
+                        *reinterpret_cast<float4*>(r_out + base) = make_float4(rn[0], rn[1], rn[2], rn[3]);
+                        *reinterpret_cast<float4*>(dsearch + base) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+                        *reinterpret_cast<float4*>(p + base) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+                    } else if (HALO) {
+                        const bool ghost = ((gz == halo_lo - 1 && z0b == halo_lo) || (gz == halo_hi + 1 && z0b + BZ - 1 == halo_hi)) && gy >= y0b && gy < y0b + BY;
+                        if (ghost && any_fluid_d(dq)) {
+                            *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
+                            *reinterpret_cast<float4*>(r_out + base) = make_float4(rn[0], rn[1], rn[2], rn[3]);
+                        }
+                    }
+                }
+                *reinterpret_cast<float4*>(T.s + row * ST_ROW + 4 + 4 * q) = un;
+                *reinterpret_cast<uint32_t*>(T.d + row * ST_ROW + 4 + 4 * q) = dq;
+            }
+            // phase 1b: the x-1 / x+16 halo cells of the 32 rows that have them (own y and z)
+            for (int e = t; e < BY * BZ * 2; e += BRICK_THREADS) {
+                const int side = e & 1, yy = (e >> 1) % BY, zz = (e >> 1) / BY;
+                const int row = (zz + 1) * (BY + 2) + (yy + 1);
+                const int gx = side ? x0b + BX : x0b - 1, gy = y0b + yy, gz = z0b + zz;
+                float uj = 0.0f; int dv = 0;
+                if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) {
+                    const int c = cidx(g, gx, gy, gz);
+                    dv = (int)dvol[c];
+                    const float inv = sInv[dv & 7];
+                    const float qj = FIRST ? w_in[c] : w_in[c] + beta * q_in[c];
+                    const float rj = r_in[c] - alpha * qj;
+                    uj = (dv & 0x80) ? (rj * inv) * inv : 0.0f;
+                }
+                T.s[row * ST_ROW + (side ? 20 : 3)] = uj;
+                T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)dv;
+            }
+        }
+        __syncthreads();
+        if (have) {
+            // phase 2: w_{i+1} = A u_{i+1} for the own quad from the tile
+            int x0, y, z;
+            if (brick_quad(bg, b, t, x0, y, z)) {
+                QuadD m; QuadValues sv;
+                st_read_quad(T, t, m, sv);
+                if (any_fluid_d(m.c)) {
+                    float wn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (dbyte(m.c, j) & 0x80) { wn[j] = quad_mulA_d(m, sv, j); acc_d += wn[j] * f4(sv.c, j); }
+                    *reinterpret_cast<float4*>(w_out + cidx(g, x0, y, z)) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+                }
+            }
+        }
+        __syncthreads();   // the tile is rewritten for the next brick
+    }
+    const float tg = block_reduce<PCG_B_THREADS, false>(acc_g, sm);
+    const float td = block_reduce<PCG_B_THREADS, false>(acc_d, sm);
+    const float mx = block_reduce<PCG_B_THREADS, true>(emax, sm);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = make_float4(tg, td, mx, 0.0f);
+}
+
+// After K(max_num_iterations): statistics are written unconditionally if nothing converged before (pressure_reduce.comp:84).
+__global__ __launch_bounds__(256) void k_pcg1_finalize(PcgCtrl* __restrict__ ctrl, const float4* __restrict__ part, int num_part, int iteration, uint32_t seq,
+                                                       PcgCtrl* __restrict__ host_snapshot) {
+    __shared__ float4 sm4[4];
+    const int done = ctrl->done;
+    const float4 red = reduce_partials4<256>(part, num_part, sm4);
+    if (threadIdx.x == 0) {
+        if (!done) { ctrl->max_err = red.z; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
+        ctrl->seq = seq;
+        if (host_snapshot) {
+            host_snapshot->max_err = ctrl->max_err; host_snapshot->num_iter = ctrl->num_iter;
+            __threadfence_system();
+            host_snapshot->seq = seq;
+        }
+    }
+}
+
+}  // namespace blubk

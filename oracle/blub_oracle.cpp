@@ -69,6 +69,8 @@ struct Oracle {
     SolverConfig cfg[2];
     SolverStats last_stats[2];
     bool pressure_cleared[2] = {false, false};
+    int dot_mode = 0;   // 0: dot products accumulated in f64 (default); 1: in f32 (row sums -> plane sums -> total): a sensitivity probe for
+                        // the reference's own f32 tree reductions (pressure_reduce.comp:37-61), see tests/test_oracle_kat.py
     int precond_mode = PRECOND_ZERO;
     int binning_mode = BINNING_FIXED;
     uint32_t rebin_freq = 60;         // hybrid_fluid.rs:603-605
@@ -258,8 +260,9 @@ struct Oracle {
     // pressure_apply_preconditioner.comp:36-82; returns sum(out*r) when with_dot
     double precond_pass(const std::vector<float>& in, std::vector<float>& out, bool with_dot) {
         std::vector<double> part(nz, 0.0);
+        const bool f32dots = dot_mode == 1;
 #pragma omp parallel for
-        for (int z = 0; z < nz; ++z) { double acc = 0; for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
+        for (int z = 0; z < nz; ++z) { double acc = 0; float accp = 0.f; for (int y = 0; y < ny; ++y) { float accr = 0.f; for (int x = 0; x < nx; ++x) {
             if (mk(x, y, z) != CELL_FLUID) continue;
             size_t c = idx(x, y, z);
             float res = in[c];
@@ -272,8 +275,9 @@ struct Oracle {
             float d = 0.f; for (int k = 0; k < 6; ++k) d += (n.m[k] != CELL_SOLID) ? 1.0f : 0.0f;
             if (d > 0.0f) res /= d;
             out[c] = res;
-            if (with_dot) acc += (double)(res * residual[c]);
-        } part[z] = acc; }
+            if (with_dot) { if (f32dots) accr += res * residual[c]; else acc += (double)(res * residual[c]); }
+        } accp += accr; } part[z] = f32dots ? (double)accp : acc; }
+        if (f32dots) { float s = 0.f; for (double p : part) s += (float)p; return (double)s; }
         double s = 0; for (double p : part) s += p; return s;
     }
     static inline float eps_div(float num, float den) { return num / (den + (den < 0.0f ? -1e-10f : 1e-10f)); }   // pressure_reduce.comp:71-77
@@ -319,14 +323,17 @@ struct Oracle {
             if (!done) {
                 // S4 pressure_apply_coeff.comp:19-30
                 std::vector<double> part(nz, 0.0);
+                const bool f32dots = dot_mode == 1;
 #pragma omp parallel for
-                for (int z = 0; z < nz; ++z) { double acc = 0; for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
+                for (int z = 0; z < nz; ++z) { double acc = 0; float accp = 0.f; for (int y = 0; y < ny; ++y) { float accr = 0.f; for (int x = 0; x < nx; ++x) {
                     size_t ci = idx(x, y, z);
                     if (marker[ci] != CELL_FLUID) continue;
                     float sval = search[ci];
-                    acc += (double)(sval * mulA(search, x, y, z, sval));
-                } part[z] = acc; }
-                double dsum = 0; for (double q : part) dsum += q;
+                    const float prod = sval * mulA(search, x, y, z, sval);
+                    if (f32dots) accr += prod; else acc += (double)prod;
+                } accp += accr; } part[z] = f32dots ? (double)accp : acc; }
+                double dsum = 0;
+                if (f32dots) { float fs = 0.f; for (double q : part) fs += (float)q; dsum = fs; } else for (double q : part) dsum += q;
                 ab = eps_div(sigma, (float)dsum);                             // RESULTMODE_ALPHA
             }
             const bool check = (i == maxit) || (i > 0 && c.error_check_frequency > 0 && i % c.error_check_frequency == 0);   // :672-673
@@ -788,6 +795,7 @@ void orc_set_gravity_grid(void* h, const float* g) { for (int k = 0; k < 3; ++k)
 void orc_set_solver_config(void* h, int which, float tol, int max_iter, int freq) { ((Oracle*)h)->cfg[which] = SolverConfig{tol, max_iter, freq}; }
 void orc_set_quirks(void* h, int precond_mode, int binning_mode) { ((Oracle*)h)->precond_mode = precond_mode; ((Oracle*)h)->binning_mode = binning_mode; }
 void orc_set_rebinning_frequency(void* h, uint32_t f) { ((Oracle*)h)->rebin_freq = f; }
+void orc_set_dot_mode(void* h, int mode) { ((Oracle*)h)->dot_mode = mode; }
 void orc_reset_pressure_cleared(void* h, int which, int cleared) { ((Oracle*)h)->pressure_cleared[which] = cleared != 0; }
 uint32_t orc_num_particles(void* h) { return ((Oracle*)h)->num_particles; }
 uint32_t orc_step_counter(void* h) { return ((Oracle*)h)->step_counter; }

@@ -68,6 +68,8 @@ def _load():
         L.orc_voxelize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_f16_round.restype = C.c_float
         L.orc_f16_round.argtypes = [C.c_float]
+        L.orc_set_dot_mode.restype = None
+        L.orc_set_dot_mode.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_num_threads.restype = None
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_get_max_threads.restype = C.c_int
@@ -138,6 +140,11 @@ class Oracle:
 
     def set_quirks(self, precond="zero", binning="fixed"):
         self._L.orc_set_quirks(self._h, PRECOND[precond], BINNING[binning])
+
+    def set_dot_mode(self, mode):
+        """0: PCG dot products accumulated in f64 (default), 1: in f32 (rows -> planes -> total).  A sensitivity probe: the
+        reference's own reductions are f32 trees (pressure_reduce.comp:37-61)."""
+        self._L.orc_set_dot_mode(self._h, int(mode))
 
     def set_rebinning_frequency(self, f):
         self._L.orc_set_rebinning_frequency(self._h, int(f))

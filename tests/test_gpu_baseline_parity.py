@@ -1,0 +1,282 @@
+"""HIP path vs CPU oracle on the BASELINE.json configurations THEMSELVES, at full size.
+
+  * corner_dams_256 (968 688 particles @ 256^3, the headline), dam_halfhalf and double_dam (1.2 M particles @ 128x64x64):
+    every stage of step 0 compared field by field on identical inputs (the oracle drives, the engine gets the oracle's state
+    before each stage), then three free-running steps with the reference's defaults: iteration counts and max|r|*dt.
+  * single_cell_debug (8 particles, 64x64x128): 120 steps, positions per step.
+  * the dense 2.5-D `_z` PCG mapping vs the oracle at 128^3 for k in {1, 4, 8} iterations.
+
+Tolerances (same contract as tests/test_gpu_parity.py): marker / D1 / D2+D3 / A1 / R2+D3 / R3 bit-exact; the two gathers
+|d| <= 1e-5 max(1, |ref|); PCG with k <= 8 fixed iterations |d| <= 3e-4 max|field| at these sizes; default solver: iteration counts
+within one check interval, pressure within 3 % relative L2, max|r| as stated in _compare_solve.  The oracle is the checker here, never the thing measured.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.conftest import ROOT, has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def _pair_from_scene(name, binning="fixed"):
+    """The engine seeded from the scene JSON exactly like Scene::create_fluid_from_config, and an oracle holding the same
+    particle arrays (parity tests never depend on the RNG restatement)."""
+    import blub_amd
+    from oracle.oracle import Oracle
+    scene = blub_amd.Scene(path=os.path.join(ROOT, "scenes", name + ".json"))
+    f = scene.fluid()
+    nx, ny, nz = f.grid_dimension()
+    o = Oracle(nx, ny, nz, f.num_particles() + 64)
+    o.set_quirks(binning=binning)
+    gravity = np.float32(list(scene.config.gravity)) / np.float32(scene.config.grid_to_world_scale)
+    o.set_gravity_grid(gravity)
+    o.set_particles(f.get_particles()[0])
+    return scene, f, o
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def _stage_on_both(o, h, stage):
+    util.copy_state(o, h)
+    o.run_stage(stage, util.DT)
+    h.run_stage(stage, util.DT)
+
+
+def _compare_solve(name, o, h, which, stage, fluid):
+    """One PressureSolver::solve on identical inputs (the oracle's current state): k = 4 and 8 fixed iterations -> p, r, s within
+    1e-4 of their scale and identical statistics; then the reference's defaults (tolerance 0.1, 32 iterations, check every 4):
+    iteration counts within one check interval; if the solve converged both errors are below the tolerance, otherwise (the
+    reference's usual operating point: max|r| of an UNCONVERGED CG iterate, which is not monotone and amplifies dot-product
+    rounding -- the oracle against itself with f32 instead of f64 dots moves by tens of percent) the errors agree within 2x and
+    the pressure fields within 3 % in relative L2."""
+    pname = "pressure_velocity" if which == 0 else "pressure_density"
+    state = {v: o.read_volume(v) for v in ("residual", pname, "search")}
+
+    def restore():
+        for v, a in state.items():
+            o.write_volume(v, a)
+            h.write_volume(v, a)
+        o.reset_pressure_cleared(which, False)
+        h.mark_pressure_initialised(which, False)
+    for k in (4, 8):
+        restore()
+        for fl in (o, h):
+            fl.set_solver_config(which, error_tolerance=0.0, max_num_iterations=k, error_check_frequency=4)
+        o.run_stage(stage, util.DT)
+        h.run_stage(stage, util.DT)
+        for vol in (pname, "residual", "search"):
+            a, b = h.read_volume(vol), o.read_volume(vol)
+            scale = np.abs(b[fluid]).max()
+            assert scale > 0
+            util.assert_close("%s after %d iterations" % (vol, k), a[fluid], b[fluid], abs_=3e-4 * scale)   # measured worst: 1.3e-4 in one cell of 150 k (double_dam)
+        assert np.all(h.read_volume(pname)[~fluid] == 0)
+        (eo, io), (eh, ih) = o.solver_stats(which), h.solver_stats(which)
+        assert ih == io == k and abs(eh - eo) <= 1e-4 * abs(eo) + 1e-9, ((eh, ih), (eo, io))
+    restore()
+    for fl in (o, h):
+        fl.set_solver_config(which, error_tolerance=0.1, max_num_iterations=32, error_check_frequency=4)
+    o.run_stage(stage, util.DT)
+    h.run_stage(stage, util.DT)
+    (eo, io), (eh, ih) = o.solver_stats(which), h.solver_stats(which)
+    po, ph = o.read_volume(pname).astype(np.float64), h.read_volume(pname).astype(np.float64)
+    rel_l2 = np.linalg.norm(ph - po) / max(np.linalg.norm(po), 1e-30)
+    print("%s step 0 %s: oracle %d iterations / %.4g, engine %d / %.4g, pressure rel. L2 %.3g" % (name, stage, io, eo, ih, eh, rel_l2))
+    assert abs(ih - io) <= 4, ((eh, ih), (eo, io))
+    if io < 32 and ih < 32:
+        assert eo < 0.1 and eh < 0.1
+    else:
+        # The oracle against ITSELF, dam_halfhalf step 0 / step 1, only the particle order inside the arrays changed (i.e. the rounding
+        # of the gathers, 1e-7): velocity solve 0.3794 / 0.3794 / 0.3794 and 0.5539 / 0.5537 / 0.5524, density solve 0.953 / 0.616 /
+        # 0.446 and 0.132 / 0.154 / 0.363.  The max-norm of the unconverged DENSITY residual is carried by single cells and is
+        # erratic at a factor ~3; the pressure field itself is not (rel. L2 below).
+        lo, hi = (0.5, 2.0) if which == 0 else (0.25, 4.0)
+        assert lo < eh / eo < hi, ((eh, ih), (eo, io))
+    assert rel_l2 < 3e-2, rel_l2
+
+
+@pytest.mark.parametrize("name,particles", [("corner_dams_256", 968688), ("dam_halfhalf", 1218672), ("double_dam", 1199328)])
+def test_every_stage_of_step_zero_matches_the_oracle_at_full_size(name, particles):
+    t_start = time.time()
+    scene, h, o = _pair_from_scene(name)
+    try:
+        assert h.num_particles() == o.num_particles == particles
+        # ---- T1-T4
+        _stage_on_both(o, h, "transfer")
+        marker = o.read_volume("marker")
+        assert np.array_equal(h.read_volume("marker"), marker)
+        fluid = marker == 1
+        assert fluid.sum() > 100000
+        for v in ("vel_x", "vel_y", "vel_z"):
+            util.assert_close(v, h.read_volume(v), o.read_volume(v), rel=1e-5)
+        # ---- D1 (bit-exact on identical inputs)
+        _stage_on_both(o, h, "divergence")
+        assert _bits_equal(h.read_volume("residual")[fluid], o.read_volume("residual")[fluid])
+        assert np.abs(o.read_volume("residual")[fluid]).max() > 0
+        # ---- solve #1: fixed small iteration counts (fields), then the reference's defaults (statistics + pressure field)
+        _compare_solve(name, o, h, 0, "solve_velocity", fluid)
+        # ---- D2 + D3
+        _stage_on_both(o, h, "project")
+        for v in ("vel_x", "vel_y", "vel_z"):
+            assert _bits_equal(h.read_volume(v), o.read_volume(v)), v
+        # ---- A1: positions, the three APIC rows, the new marker; the density list has the same cells occupied
+        _stage_on_both(o, h, "advect")
+        po, ph = o.get_particles(), h.get_particles()
+        assert _bits_equal(ph[0][:, :3], po[0][:, :3])
+        for c in (1, 2, 3):
+            assert _bits_equal(ph[c], po[c]), c
+        assert np.array_equal(h.read_volume("marker"), o.read_volume("marker"))
+        assert np.array_equal(h.read_volume("linked_list") != 0, o.read_volume("linked_list") != 0)
+        assert np.abs(po[2][:, 3]).max() > 0
+        # ---- R1
+        _stage_on_both(o, h, "density_gather")
+        fluid2 = o.read_volume("marker") == 1
+        util.assert_close("density residual", h.read_volume("residual")[fluid2], o.read_volume("residual")[fluid2], rel=1e-5)
+        # ---- solve #2: the same three comparisons
+        util.copy_state(o, h)
+        _compare_solve(name, o, h, 1, "solve_density", fluid2)
+        # ---- R2 + D3, R3
+        _stage_on_both(o, h, "position_change")
+        for v in ("vel_x", "vel_y", "vel_z"):
+            assert _bits_equal(h.read_volume(v), o.read_volume(v)), v
+        _stage_on_both(o, h, "correct")
+        assert _bits_equal(h.get_particles()[0][:, :3], o.get_particles()[0][:, :3])
+        print("%s: all stages compared in %.1f s" % (name, time.time() - t_start))
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("name", ["corner_dams_256", "dam_halfhalf"])
+def test_three_free_running_steps_stay_inside_the_oracles_own_rounding_envelope(name):
+    """Reference defaults (tolerance 0.1, 32 iterations, check every 4, rebinning at step 0, Q13) on both sides, nothing
+    copied between them after seeding.  What can be asserted is bounded by how the ORACLE ITSELF reacts to the rounding of
+    its dot products (tests/test_oracle_kat.py::test_unconverged_cg_is_sensitive_to_dot_product_rounding; dam_halfhalf, f64 vs
+    f32 accumulation, nothing else changed): step 0 identical to 4 digits, then max|r|*dt 0.554 vs 1.361 (velocity, step 1) and
+    0.386 vs 1.387 (density, step 2), pressure fields 0.5 % / 4.5 % apart in relative L2, particles median 3e-4 / p99 1.6e-3 /
+    max 0.24 cells.  The reference's own f32 tree reductions are a third rounding of the same kind.  Hence: step 0's velocity
+    solve within 1 %; afterwards errors within 4x, iteration counts may only differ while both sides hover at the tolerance,
+    velocity pressure within 5 % (density 15 %) relative L2, centre of mass and occupancy histogram close."""
+    scene, h, o = _pair_from_scene(name)
+    try:
+        for step in range(3):
+            scene.step(util.DT)
+            o.step(util.DT)
+            h.synchronize()
+            for w, hist in ((0, h.pressure_solver_stats_velocity()), (1, h.pressure_solver_stats_density())):
+                eo, io = o.solver_stats(w)
+                s = hist[-1]
+                pname = "pressure_velocity" if w == 0 else "pressure_density"
+                po, ph = o.read_volume(pname).astype(np.float64), h.read_volume(pname).astype(np.float64)
+                rel_l2 = np.linalg.norm(ph - po) / max(np.linalg.norm(po), 1e-30)
+                print("%s step %d solver %d: oracle %d / %.4g, engine %d / %.4g, pressure rel. L2 %.3g" % (name, step, w, io, eo, s.iteration_count, s.error, rel_l2))
+                assert len(hist) == step + 1
+                if step == 0 and w == 0:
+                    assert s.iteration_count == io and abs(s.error - eo) <= 0.01 * eo, (s, io, eo)
+                assert 0.25 < s.error / eo < 4.0, (step, w, s, io, eo)
+                if s.iteration_count != io:
+                    assert max(s.error, eo) < 0.4, (step, w, s, io, eo)       # both hover around the tolerance of 0.1
+                assert rel_l2 < (0.05 if w == 0 else 0.15), (step, w, rel_l2)
+        # permutation-invariant particle metrics after three steps (binning orders differ inside a cell)
+        a, b = h.get_particles()[0][:, :3].astype(np.float64), o.get_particles()[0][:, :3].astype(np.float64)
+        assert a.shape == b.shape
+        assert np.abs(a.mean(0) - b.mean(0)).max() < 2e-3
+        nx, ny, nz = h.grid_dimension()
+        occ = lambda p: np.bincount(((p[:, 2].astype(int) * ny + p[:, 1].astype(int)) * nx + p[:, 0].astype(int)), minlength=nx * ny * nz)
+        l1 = np.abs(occ(a) - occ(b)).sum() / len(a)
+        print("%s after 3 steps: occupancy L1 %.4g, centre of mass %.3g" % (name, l1, np.abs(a.mean(0) - b.mean(0)).max()))
+        assert l1 < 0.05
+    finally:
+        h.close()
+
+
+def test_single_cell_debug_tracks_the_oracle_for_120_steps():
+    """BASELINE configs[0]: 8 particles in cell (31, 31, 63) fall, hit the floor and spread.
+    (a) per step from the SAME state (the engine restarts every step from the oracle's particles and pressure fields):
+        positions within 1e-5 cells, every one of the 120 steps;
+    (b) free running, nothing copied: within 1e-5 cells while the particles fall freely (measured: bit-identical); the deviation
+        after the impact is reported only (8 particles bouncing off a wall are a chaotic system)."""
+    scene, h, o = _pair_from_scene("single_cell_debug", binning="off")
+    import blub_amd
+    h2 = blub_amd.HybridFluid(h.grid_dimension(), 64, binning="off")
+    try:
+        assert h.num_particles() == 8
+        h.particle_rebinning_step_frequency = 0
+        h2.set_gravity_grid(np.float32(list(scene.config.gravity)) / np.float32(scene.config.grid_to_world_scale))
+        worst_sync, worst_free, worst_free_fall = 0.0, 0.0, 0.0
+        y0 = o.get_particles()[0][:, 1].copy()
+        for step in range(120):
+            # (a) h2 := oracle state, one step on both
+            pos, vx, vy, vz = o.get_particles()
+            h2.set_particles(pos, vx, vy, vz)
+            for v in ("pressure_velocity", "pressure_density"):
+                h2.write_volume(v, o.read_volume(v))
+            h2.mark_pressure_initialised(0, True); h2.mark_pressure_initialised(1, True)
+            h2.step_counter = o.step_counter
+            o.step(util.DT)
+            h2.step(util.DT)
+            h.step(util.DT)
+            po = o.get_particles()[0][:, :3]
+            d_sync = np.abs(h2.get_particles()[0][:, :3] - po).max()
+            d_free = np.abs(h.get_particles()[0][:, :3] - po).max()
+            worst_sync = max(worst_sync, float(d_sync))
+            worst_free = max(worst_free, float(d_free))
+            falling = po[:, 1].min() > 2.5
+            if falling:
+                worst_free_fall = max(worst_free_fall, float(d_free))
+            assert d_sync <= 1e-5, "step %d: %g cells from the same state" % (step, d_sync)
+        print("single_cell_debug: worst per-step deviation %.3g, free running %.3g while falling / %.3g overall" % (worst_sync, worst_free_fall, worst_free))
+        assert o.get_particles()[0][:, 1].max() < y0.min() - 20       # they did fall to the floor
+        assert worst_free_fall <= 1e-5
+        # after the impact the 8-particle system is chaotic (measured: per-step deviations of <= 8e-6 grow to tens of cells within
+        # 90 steps on both sides alike); the free-running engine only has to stay inside the domain
+        pf = h.get_particles()[0][:, :3]
+        assert np.all(np.isfinite(pf)) and np.all(pf >= 1.001) and np.all(pf <= np.float32(h.grid_dimension()) - np.float32(1.001))
+    finally:
+        h.close()
+        h2.close()
+
+
+@pytest.mark.parametrize("iters", [1, 4, 8])
+def test_dense_z_mapping_matches_the_oracle_at_128_cubed(iters):
+    """The 2.5-D dense mapping (k_pcg_*_z, the roofline path) against the oracle itself -- not only self-consistency: SOLID shell,
+    FLUID interior with an AIR layer under the lid and a SOLID block inside, b = sin sin sin, warm start p != 0."""
+    import blub_amd
+    from oracle.oracle import Oracle
+    n = 128
+    h = blub_amd.HybridFluid((n, n, n), 16, binning="off")
+    try:
+        h.set_pcg_work_mapping("rows")
+        o = Oracle(n, n, n, 16)
+        marker = np.zeros((n, n, n), np.int8)
+        marker[1:-1, 1:-1, 1:-1] = 1
+        marker[1:-1, -2, 1:-1] = -1
+        marker[40:50, 20:30, 60:90] = 0
+        fluid = marker == 1
+        ax = np.sin(2 * np.pi * (np.arange(n) + 0.5) / n).astype(np.float32)
+        b = (ax[:, None, None] * ax[None, :, None] * ax[None, None, :]).astype(np.float32)
+        b[~fluid] = 0
+        rng = np.random.default_rng(3)
+        p0 = np.where(fluid, rng.standard_normal((n, n, n)) * 0.05, 0).astype(np.float32)
+        for fl in (o, h):
+            fl.write_volume("marker", marker)
+            fl.write_volume("residual", b)
+            fl.write_volume("pressure_velocity", p0)
+            fl.set_solver_config(0, error_tolerance=0.0, max_num_iterations=iters, error_check_frequency=4)
+        o.reset_pressure_cleared(0, True)      # warm start: neither side clears the pressure field (pressure_solver.rs:601-603)
+        h.mark_pressure_initialised(0, True)
+        o.run_stage("solve_velocity", util.DT)
+        h.run_stage("solve_velocity", util.DT)
+        for vol in ("pressure_velocity", "residual", "search"):
+            a, c = h.read_volume(vol), o.read_volume(vol)
+            scale = np.abs(c[fluid]).max()
+            util.assert_close("%s after %d iterations" % (vol, iters), a[fluid], c[fluid], abs_=1e-4 * scale)
+        assert np.all(h.read_volume("pressure_velocity")[~fluid] == 0)
+        (eo, io), (eh, ih) = o.solver_stats(0), h.solver_stats(0)
+        assert ih == io == iters and abs(eh - eo) <= 1e-4 * abs(eo), ((eh, ih), (eo, io))
+    finally:
+        h.close()
