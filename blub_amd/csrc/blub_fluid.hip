@@ -17,6 +17,7 @@
 
 #include "blub_internal.h"
 #include "blub_pcg_dense.hip.h"
+#include "blub_pcg1.hip.h"
 #include "blub_slab.hip.h"
 #include "blub_voxelize.hip.h"
 
@@ -38,12 +39,12 @@ using namespace blubk;
 
 enum KernelClass {
     KC_BRICK_LISTS, KC_RESET_BRICKS, KC_BUILD_LISTS, KC_GATHER_VELOCITY, KC_DIVERGENCE, KC_PCG_INIT, KC_PCG_DIR, KC_PCG_UPDATE, KC_PCG_FINALIZE,
-    KC_PCG_LOD0, KC_DIVERGENCE_REMOVE, KC_EXTRAPOLATE, KC_ADVECT, KC_DENSITY_GATHER, KC_POSITION_CHANGE, KC_CORRECT,
+    KC_PCG_ITER, KC_PCG_LOD0, KC_DIVERGENCE_REMOVE, KC_EXTRAPOLATE, KC_ADVECT, KC_DENSITY_GATHER, KC_POSITION_CHANGE, KC_CORRECT,
     KC_BIN_COUNT, KC_BIN_SCAN, KC_BIN_REWRITE, KC_COPY, KC_VOXELIZE, KC_COUNT
 };
 static const char* kKernelClassNames[KC_COUNT] = {
     "brick_lists", "reset_bricks", "build_lists", "gather_velocity", "divergence", "pcg_init", "pcg_dir", "pcg_update", "pcg_finalize",
-    "pcg_lod0", "divergence_remove", "extrapolate", "advect", "density_gather", "position_change", "correct",
+    "pcg_iter", "pcg_lod0", "divergence_remove", "extrapolate", "advect", "density_gather", "position_change", "correct",
     "bin_count", "bin_scan", "bin_rewrite", "copy", "voxelize"};
 
 constexpr int PCG_GRID_MAX = 4096;   // upper bound of persistent blocks of the PCG kernels (= number of dot-product partials)
@@ -116,6 +117,11 @@ struct blub_fluid {
     float *part_sas = nullptr, *part_sigma[2] = {nullptr, nullptr}, *part_max = nullptr;
     uint8_t* tile_flags = nullptr;
     PcgCtrl* ctrl[2] = {nullptr, nullptr};
+    // single-reduction schedule (blub_pcg1.hip.h): second buffers of r / w / q (allocated on first use), float4 partials, scalars
+    int pcg_schedule = 0;            // 0: the reference's two-reduction schedule, 1: one kernel per iteration on the brick mapping
+    float* cgbuf[3] = {nullptr, nullptr, nullptr};
+    float4* part4 = nullptr;
+    Pcg1Scalars* pcg1_scalars[2] = {nullptr, nullptr};
     PcgTailSync* tail_sync[2] = {nullptr, nullptr};
     bool use_tail = true;            // persistent tail kernel for brick-mapped solves (BLUB_PCG_TAIL=0 disables)
     int tail_margin_checks = 1;
@@ -311,6 +317,14 @@ static int stage_solve_lod0(blub_fluid* h, int which, float dt) {
     return BLUB_OK;
 }
 
+static int ensure_pcg1_buffers(blub_fluid* h) {
+    int rc = BLUB_OK;
+    for (int k = 0; k < 3 && rc == BLUB_OK; ++k) if (!h->cgbuf[k]) rc = dev_alloc_zero(h->stream, &h->cgbuf[k], h->N);
+    if (rc == BLUB_OK && !h->part4) rc = dev_alloc_zero(h->stream, &h->part4, 2 * (size_t)PCG_GRID_MAX);
+    for (int w = 0; w < 2 && rc == BLUB_OK; ++w) if (!h->pcg1_scalars[w]) rc = dev_alloc_zero(h->stream, &h->pcg1_scalars[w], 1);
+    return rc;
+}
+
 // PressureSolver::solve, pressure_solver.rs:591-729 (schedule: SURVEY Appendix D), fused two-kernel iteration (blub_pcg.hip.h)
 static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float* p = h->pressure[which];
@@ -356,6 +370,34 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         if (have) np = std::max(64, std::min(np, (int)((bc.n_fluid * 9u / 8u + 8u + (unsigned)PCG_BPB - 1u) / (unsigned)PCG_BPB)));
         const dim3 grid(np), block(PCG_B_THREADS);
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which]);
+        if (h->pcg_schedule == 1) {
+            // ONE kernel per iteration (blub_pcg1.hip.h): r, w = A M^-1 r and q = A d are double buffered by iteration parity,
+            // the search direction d (BLUB_VOLUME_SEARCH) and p are updated in place
+            if ((rc = ensure_pcg1_buffers(h)) != BLUB_OK) return rc;
+            float* R[2] = {h->residual, h->cgbuf[0]};
+            float* W[2] = {h->aux, h->cgbuf[1]};
+            float* Q[2] = {h->aux_temp, h->cgbuf[2]};
+            float4* part[2] = {h->part4, h->part4 + PCG_GRID_MAX};
+            Pcg1Scalars* sc = h->pcg1_scalars[which];
+            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, np, part[0]);
+            static const int early = getenv("BLUB_PCG1_EARLY") ? atoi(getenv("BLUB_PCG1_EARLY")) : 1;   // (tuning switch, see k_pcg1_iter_s)
+#define BLUB_LAUNCH_K(FIRSTV, ...)                                                                                    \
+    do {                                                                                                              \
+        if (early <= 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 0>), grid, block, __VA_ARGS__);          \
+        else if (early == 1) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 1>), grid, block, __VA_ARGS__);     \
+        else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 2>), grid, block, __VA_ARGS__);                     \
+    } while (0)
+            for (int i = 0; i <= maxit; ++i) {
+                const float4* pin = part[i & 1]; float4* pout = part[(i + 1) & 1];
+                if (i == 0) BLUB_LAUNCH_K(true, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, np, ctrl, sc, tol, 0, 0, -1, -1);
+                else BLUB_LAUNCH_K(false, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, np, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1);
+            }
+#undef BLUB_LAUNCH_K
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], np, maxit, h->solve_seq[which], stat_slot);
+            // the residual of a full-length solve ends in R[(maxit + 1) & 1]; keep BLUB_VOLUME_RESIDUAL pointing at it
+            if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
+            return enqueue_stats_readback(h, which, dt, true);
+        }
         // Launch as many iterations as the last few solves needed (+ one check interval); a persistent tail kernel covers the
         // rest: a single no-op launch when the solve has converged by then (the rule), a grid-barrier loop otherwise.
         int launched = maxit + 1;
@@ -517,7 +559,7 @@ static void destroy(blub_fluid* h) {
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
     if (h->steps_done_host) (void)hipHostFree((void*)h->steps_done_host);
-    F(h->tail_sync[0]); F(h->tail_sync[1]); F(h->mesh_positions); F(h->mesh_indices);
+    F(h->tail_sync[0]); F(h->tail_sync[1]); for (auto q : h->cgbuf) F(q); F(h->part4); F(h->pcg1_scalars[0]); F(h->pcg1_scalars[1]); F(h->mesh_positions); F(h->mesh_indices);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
     for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -591,6 +633,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, (size_t)std::max(gm.tiles, h->gz.tiles) + 8));
     A(dev_alloc_zero(h->stream, &h->ctrl[0], 1)); A(dev_alloc_zero(h->stream, &h->ctrl[1], 1));
     A(dev_alloc_zero(h->stream, &h->tail_sync[0], 1)); A(dev_alloc_zero(h->stream, &h->tail_sync[1], 1));
+    if (const char* e = getenv("BLUB_PCG_SCHEDULE")) h->pcg_schedule = atoi(e) == 1 ? 1 : 0;
     if (const char* e = getenv("BLUB_PCG_TAIL")) h->use_tail = atoi(e) != 0;
     if (const char* e = getenv("BLUB_PCG_TAIL_FIRST")) h->tail_first_forced = atoi(e);
     if (const char* e = getenv("BLUB_PCG_TAIL_MARGIN")) h->tail_margin_checks = std::max(0, atoi(e));
@@ -899,6 +942,12 @@ int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode) {
     h->force_pcg_path = mode;
     return BLUB_OK;
 }
+int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    h->pcg_schedule = mode;
+    return BLUB_OK;
+}
+int blub_fluid_get_pcg_schedule(const blub_fluid* h) { return h ? h->pcg_schedule : BLUB_ERR_INVALID_ARGUMENT; }
 int blub_fluid_set_max_steps_in_flight(blub_fluid* h, uint32_t m) { if (!h) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); h->max_steps_in_flight = m; return BLUB_OK; }
 int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]) {
     REQUIRE_HANDLE(h);

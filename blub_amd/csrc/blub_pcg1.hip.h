@@ -41,22 +41,50 @@ __device__ __forceinline__ float4 reduce_partials4(const float4* __restrict__ pa
     return r;
 }
 
+// The prologue is split in two so that everything the kernel needs from memory is requested in TWO dependent round trips:
+//   (1) `done`, the previous scalars, this thread's share of the partial array -- together with the list length and the block's
+//       list entry (the caller issues those in the same batch);
+//   (2) the field loads of the block's first brick, issued by the caller between the two halves: they are in flight while the
+//       partials are reduced.
+// The kernels are latency-bound: each saved round trip is ~1.5 us of a ~9 us kernel.
+constexpr int PCG1_PART_PER_THREAD = 4;   // 4 x 256 threads >= the 1024 partials a brick-mapped solve can have
+struct Pcg1PrologueLoads { int done; float g_prev, a_prev; float4 pl[PCG1_PART_PER_THREAD]; };
+template <int NT, bool FIRST>
+__device__ __forceinline__ void pcg1_prologue_load(const PcgCtrl* __restrict__ ctrl, const Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in, int num_part,
+                                                   int iteration, Pcg1PrologueLoads& L) {
+    L.done = ctrl->done;
+    L.g_prev = 0.0f; L.a_prev = 0.0f;
+    if (!FIRST) { L.g_prev = sc->gamma[(iteration + 1) & 1]; L.a_prev = sc->alpha[(iteration + 1) & 1]; }
+#pragma unroll
+    for (int k = 0; k < PCG1_PART_PER_THREAD; ++k) {
+        const int i = (int)threadIdx.x + k * NT;
+        L.pl[k] = i < num_part ? part_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 // Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
 template <int NT, bool FIRST>
-__device__ __forceinline__ bool pcg1_prologue(PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in, int num_part,
-                                              float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta) {
-    if (ctrl->done) return false;
-    float g_prev = 0.0f, a_prev = 0.0f;
-    if (!FIRST) { g_prev = sc->gamma[(iteration + 1) & 1]; a_prev = sc->alpha[(iteration + 1) & 1]; }
-    const float4 red = reduce_partials4<NT>(part_in, num_part, sm4);
+__device__ __forceinline__ bool pcg1_prologue_finish(const Pcg1PrologueLoads& L, PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in,
+                                                     int num_part, float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta) {
+    float g = 0.0f, d = 0.0f, m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PCG1_PART_PER_THREAD; ++k) { g += L.pl[k].x; d += L.pl[k].y; m = fmaxf(m, L.pl[k].z); }
+    for (int i = (int)threadIdx.x + PCG1_PART_PER_THREAD * NT; i < num_part; i += NT) { const float4 p = part_in[i]; g += p.x; d += p.y; m = fmaxf(m, p.z); }
+    g = wave_sum(g); d = wave_sum(d); m = wave_max(m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm4[wave] = make_float4(g, d, m, 0.0f);
+    __syncthreads();
+    float4 red = sm4[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) { red.x += sm4[w].x; red.y += sm4[w].y; red.z = fmaxf(red.z, sm4[w].z); }
     beta = 0.0f;
     if (!FIRST) {
         if (check_prev && red.z < tolerance) {                                           // pressure_reduce.comp:82-94
             if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->max_err = red.z; ctrl->num_iter = (float)(iteration - 1); ctrl->done = 1; }
             return false;
         }
-        beta = eps_div(red.x, g_prev);                                                   // RESULTMODE_BETA
-        const float corr = a_prev != 0.0f ? (beta * red.x) / a_prev : 0.0f;
+        beta = eps_div(red.x, L.g_prev);                                                 // RESULTMODE_BETA
+        const float corr = L.a_prev != 0.0f ? (beta * red.x) / L.a_prev : 0.0f;
         alpha = eps_div(red.x, red.y - corr);                                            // RESULTMODE_ALPHA with d.Ad = delta - beta gamma / alpha_prev
     } else {
         alpha = eps_div(red.x, red.y);
@@ -129,9 +157,62 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const
     if (threadIdx.x == 0) part_out[blockIdx.x] = make_float4(blockIdx.x == 0 ? red0.x : 0.0f, tot, 0.0f, 0.0f);
 }
 
+// Raw loads of one brick's face-halo tile for K(i), held in registers: two passes over the 240 interior quads (thread t takes
+// elements t and t + 128) and one x-halo scalar (threads 0..63).
+struct Pcg1TileLoads {
+    uint32_t dq[2]; float4 rv[2], wv[2], qv[2], dv4[2], pv4[2]; int base[2];   // base < 0: element not loaded (outside the grid / corner row)
+    int hdv; float hr, hw, hq; bool hin;
+    bool own[2]; int hc;
+};
+// Only ~1/4 of the cells of a fluid brick are FLUID in the headline scene (1 M particles @ 256^3: 150 k FLUID cells in 1300 bricks
+// of 512), and the kernel is bound by the bytes it pulls through the fabric (every kernel boundary invalidates the L2s), not by
+// the number of dependent loads: the stencil descriptors are fetched first and the five f32 fields only for quads that hold a
+// FLUID cell (measured: see DESIGN.md 6).
+__device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const BrickGeom& bg, uint32_t b, int t, const uint8_t* __restrict__ dvol) {
+    const Grid g = bg.g;
+    const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = t + k * BRICK_THREADS;
+        const int row = e >> 2, q = e & 3;
+        L.base[k] = -1; L.dq[k] = 0; L.own[k] = false;
+        if (e >= ST_ROWS * 4 || !st_row_needed(row)) continue;
+        const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1, gx = x0b + 4 * q;
+        if (!((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx)) continue;
+        const int base = cidx(g, gx, gy, gz);
+        L.base[k] = base;
+        L.dq[k] = *reinterpret_cast<const uint32_t*>(dvol + base);
+        L.own[k] = gy >= y0b && gy < y0b + BY && gz >= z0b && gz < z0b + BZ;
+    }
+    L.hin = false; L.hdv = 0; L.hc = -1;
+    if (t < BY * BZ * 2) {
+        const int side = t & 1, yy = (t >> 1) % BY, zz = (t >> 1) / BY;
+        const int gx = side ? x0b + BX : x0b - 1, gy = y0b + yy, gz = z0b + zz;
+        if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { L.hc = cidx(g, gx, gy, gz); L.hin = true; L.hdv = (int)dvol[L.hc]; }
+    }
+}
+template <bool FIRST>
+__device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const float* __restrict__ r_in, const float* __restrict__ w_in, const float* __restrict__ q_in,
+                                                      const float* __restrict__ dsearch, const float* __restrict__ p) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        L.rv[k] = zero4; L.wv[k] = zero4; L.qv[k] = zero4; L.dv4[k] = zero4; L.pv4[k] = zero4;
+        if (L.base[k] < 0 || !any_fluid_d(L.dq[k])) continue;
+        const int base = L.base[k];
+        L.rv[k] = ld4(r_in + base); L.wv[k] = ld4(w_in + base);
+        if (!FIRST) L.qv[k] = ld4(q_in + base);
+        if (L.own[k]) { L.dv4[k] = ld4(dsearch + base); L.pv4[k] = ld4(p + base); }
+    }
+    L.hr = 0.f; L.hw = 0.f; L.hq = 0.f;
+    if (L.hc >= 0 && (L.hdv & 0x80)) { L.hr = r_in[L.hc]; L.hw = w_in[L.hc]; if (!FIRST) L.hq = q_in[L.hc]; }
+}
+
 // K(i): one whole PCG iteration.  HALO (z-slab groups): the block also stores the r_{i+1} / q_i it computed for the ghost plane
 // below `halo_lo` / above `halo_hi` (own planes of the slab, -1 = none), so only w needs a halo exchange per iteration.
-template <bool FIRST, bool HALO = false>
+// EARLY (tuning): 0 = the first brick's loads are issued after the reduction, 1 = its descriptors before / its fields after,
+// 2 = everything before the reduction
+template <bool FIRST, bool HALO = false, int EARLY = 1>
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
                                                                const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
@@ -139,97 +220,101 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                                                                const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part,
                                                                PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
                                                                int halo_lo = -1, int halo_hi = -1) {
-    __shared__ float sm[8];
     __shared__ float4 sm4[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ float sInv[8];
     __shared__ StagedTile tiles[PCG_BPB];
     pcg_fill_inv_lut(sInv);   // (published by the barriers of the prologue's reduction)
     const Grid g = bg.g;
-    const uint32_t n = *count;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
+    // the previous scalars and the partials
+    const uint32_t i0 = blockIdx.x * PCG_BPB + half;
+    const uint32_t b0 = i0 < (uint32_t)bg.nb ? list[i0] : 0u;
+    const uint32_t n = *count;
+    Pcg1PrologueLoads PL;
+    pcg1_prologue_load<PCG_B_THREADS, FIRST>(ctrl, sc, part_in, num_part, iteration, PL);
+    if (PL.done) return;      // uniform
+    // round trip 2: the first brick's fields, in flight during the reduction
+    Pcg1TileLoads TL;
+    if (EARLY >= 1 && i0 < n) pcg1_tile_load_desc(TL, bg, b0, t, dvol);
+    if (EARLY >= 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
     float alpha, beta;
-    if (!pcg1_prologue<PCG_B_THREADS, FIRST>(ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return;
+    if (!pcg1_prologue_finish<PCG_B_THREADS, FIRST>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return;
+    if (EARLY < 1 && i0 < n) pcg1_tile_load_desc(TL, bg, b0, t, dvol);
+    if (EARLY < 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
     StagedTile& T = tiles[half];
     float acc_g = 0.0f, acc_d = 0.0f, emax = 0.0f;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool first = true;
     for (uint32_t ib = blockIdx.x; ib * PCG_BPB < n; ib += gridDim.x) {       // uniform trip count for both halves: barriers inside
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
-        const uint32_t b = have ? list[i] : 0u;
-        const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+        const uint32_t b = first ? b0 : (have ? list[i] : 0u);
+        if (!first && have) { pcg1_tile_load_desc(TL, bg, b, t, dvol); pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p); }
+        first = false;
+        const int y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
         if (have) {
-            // phase 1a: r_{i+1}, u_{i+1} on the 240 interior quads of the face-halo tile; the own quads also advance q, d, p
+            // phase 1a: r_{i+1}, u_{i+1} on the interior quads of the face-halo tile; the own quads also advance q, d, p
 #pragma unroll
-            for (int e = t; e < ST_ROWS * 4; e += BRICK_THREADS) {
+            for (int k = 0; k < 2; ++k) {
+                const int e = t + k * BRICK_THREADS;
                 const int row = e >> 2, q = e & 3;
-                if (!st_row_needed(row)) continue;
-                const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1, gx = x0b + 4 * q;
-                float4 un = zero4;
-                uint32_t dq = 0;
-                if ((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx) {
-                    const int base = cidx(g, gx, gy, gz);
-                    dq = *reinterpret_cast<const uint32_t*>(dvol + base);
-                    const float4 rv = ld4(r_in + base), wv = ld4(w_in + base);
-                    const float4 qv = FIRST ? zero4 : ld4(q_in + base);
-                    const bool own = gy >= y0b && gy < y0b + BY && gz >= z0b && gz < z0b + BZ;
-                    float4 dv4 = zero4, pv4 = zero4;
-                    if (own) { dv4 = ld4(dsearch + base); pv4 = ld4(p + base); }
-                    float qn[4], rn[4], uu[4];
+                if (e >= ST_ROWS * 4 || !st_row_needed(row)) continue;
+                const uint32_t dq = TL.dq[k];
+                float qn[4], rn[4], uu[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int dv = dbyte(dq, j);
+                    const float inv = sInv[dv & 7];
+                    const float qj = FIRST ? f4(TL.wv[k], j) : f4(TL.wv[k], j) + beta * f4(TL.qv[k], j);
+                    const float rj = f4(TL.rv[k], j) - alpha * qj;
+                    const float uj = (rj * inv) * inv;
+                    const bool fl = (dv & 0x80) != 0;
+                    qn[j] = fl ? qj : 0.0f; rn[j] = fl ? rj : 0.0f; uu[j] = fl ? uj : 0.0f;
+                }
+                *reinterpret_cast<float4*>(T.s + row * ST_ROW + 4 + 4 * q) = make_float4(uu[0], uu[1], uu[2], uu[3]);
+                *reinterpret_cast<uint32_t*>(T.d + row * ST_ROW + 4 + 4 * q) = dq;
+                const int base = TL.base[k];
+                if (base < 0 || !any_fluid_d(dq)) continue;
+                const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1;
+                const bool own = gy >= y0b && gy < y0b + BY && gz >= z0b && gz < z0b + BZ;
+                if (own) {
+                    float dn[4] = {TL.dv4[k].x, TL.dv4[k].y, TL.dv4[k].z, TL.dv4[k].w}, pn[4] = {TL.pv4[k].x, TL.pv4[k].y, TL.pv4[k].z, TL.pv4[k].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int dv = dbyte(dq, j);
+                        if (!(dv & 0x80)) continue;                            // non-FLUID lanes keep their d and p (p = 0 there: pressure_init.comp:45-48)
                         const float inv = sInv[dv & 7];
-                        const float qj = FIRST ? f4(wv, j) : f4(wv, j) + beta * f4(qv, j);
-                        const float rj = f4(rv, j) - alpha * qj;
-                        const float uj = (rj * inv) * inv;
-                        const bool fl = (dv & 0x80) != 0;
-                        qn[j] = fl ? qj : 0.0f; rn[j] = fl ? rj : 0.0f; uu[j] = fl ? uj : 0.0f;
+                        const float ui = (f4(TL.rv[k], j) * inv) * inv;        // u_i = M^-1 r_i
+                        dn[j] = FIRST ? ui : ui + beta * dn[j];                // pressure_update_search.comp:23
+                        pn[j] = pn[j] + alpha * dn[j];                         // pressure_update_pressure_and_residual.comp:39-40
+                        acc_g += rn[j] * uu[j];
+                        emax = fmaxf(emax, fabsf(rn[j]));
                     }
-                    un = make_float4(uu[0], uu[1], uu[2], uu[3]);
-                    if (own && any_fluid_d(dq)) {
-                        float dn[4] = {dv4.x, dv4.y, dv4.z, dv4.w}, pn[4] = {pv4.x, pv4.y, pv4.z, pv4.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int dv = dbyte(dq, j);
-                            if (!(dv & 0x80)) continue;                        // non-FLUID lanes keep their d and p (p = 0 there: pressure_init.comp:45-48)
-                            const float inv = sInv[dv & 7];
-                            const float ui = (f4(rv, j) * inv) * inv;          // u_i = M^-1 r_i
-                            dn[j] = FIRST ? ui : ui + beta * dn[j];            // pressure_update_search.comp:23
-                            pn[j] = pn[j] + alpha * dn[j];                     // pressure_update_pressure_and_residual.comp:39-40
-                            acc_g += rn[j] * uu[j];
-                            emax = fmaxf(emax, fabsf(rn[j]));
-                        }
+                    *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
+                    *reinterpret_cast<float4*>(r_out + base) = make_float4(rn[0], rn[1], rn[2], rn[3]);
+                    *reinterpret_cast<float4*>(dsearch + base) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+                    *reinterpret_cast<float4*>(p + base) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+                } else if (HALO) {
+                    const bool ghost = ((gz == halo_lo - 1 && z0b == halo_lo) || (gz == halo_hi + 1 && z0b + BZ - 1 == halo_hi)) && gy >= y0b && gy < y0b + BY;
+                    if (ghost) {
                         *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
                         *reinterpret_cast<float4*>(r_out + base) = make_float4(rn[0], rn[1], rn[2], rn[3]);
-                        *reinterpret_cast<float4*>(dsearch + base) = make_float4(dn[0], dn[1], dn[2], dn[3]);
-                        *reinterpret_cast<float4*>(p + base) = make_float4(pn[0], pn[1], pn[2], pn[3]);
-                    } else if (HALO) {
-                        const bool ghost = ((gz == halo_lo - 1 && z0b == halo_lo) || (gz == halo_hi + 1 && z0b + BZ - 1 == halo_hi)) && gy >= y0b && gy < y0b + BY;
-                        if (ghost && any_fluid_d(dq)) {
-                            *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
-                            *reinterpret_cast<float4*>(r_out + base) = make_float4(rn[0], rn[1], rn[2], rn[3]);
-                        }
                     }
                 }
-                *reinterpret_cast<float4*>(T.s + row * ST_ROW + 4 + 4 * q) = un;
-                *reinterpret_cast<uint32_t*>(T.d + row * ST_ROW + 4 + 4 * q) = dq;
             }
             // phase 1b: the x-1 / x+16 halo cells of the 32 rows that have them (own y and z)
-            for (int e = t; e < BY * BZ * 2; e += BRICK_THREADS) {
-                const int side = e & 1, yy = (e >> 1) % BY, zz = (e >> 1) / BY;
+            if (t < BY * BZ * 2) {
+                const int side = t & 1, yy = (t >> 1) % BY, zz = (t >> 1) / BY;
                 const int row = (zz + 1) * (BY + 2) + (yy + 1);
-                const int gx = side ? x0b + BX : x0b - 1, gy = y0b + yy, gz = z0b + zz;
-                float uj = 0.0f; int dv = 0;
-                if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) {
-                    const int c = cidx(g, gx, gy, gz);
-                    dv = (int)dvol[c];
-                    const float inv = sInv[dv & 7];
-                    const float qj = FIRST ? w_in[c] : w_in[c] + beta * q_in[c];
-                    const float rj = r_in[c] - alpha * qj;
-                    uj = (dv & 0x80) ? (rj * inv) * inv : 0.0f;
+                float uj = 0.0f;
+                if (TL.hin) {
+                    const float inv = sInv[TL.hdv & 7];
+                    const float qj = FIRST ? TL.hw : TL.hw + beta * TL.hq;
+                    const float rj = TL.hr - alpha * qj;
+                    uj = (TL.hdv & 0x80) ? (rj * inv) * inv : 0.0f;
                 }
                 T.s[row * ST_ROW + (side ? 20 : 3)] = uj;
-                T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)dv;
+                T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)TL.hdv;
             }
         }
         __syncthreads();
@@ -250,10 +335,17 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
         }
         __syncthreads();   // the tile is rewritten for the next brick
     }
-    const float tg = block_reduce<PCG_B_THREADS, false>(acc_g, sm);
-    const float td = block_reduce<PCG_B_THREADS, false>(acc_d, sm);
-    const float mx = block_reduce<PCG_B_THREADS, true>(emax, sm);
-    if (threadIdx.x == 0) part_out[blockIdx.x] = make_float4(tg, td, mx, 0.0f);
+    // one combined block reduction of the three partials
+    acc_g = wave_sum(acc_g); acc_d = wave_sum(acc_d); emax = wave_max(emax);
+    __syncthreads();          // (a block without bricks reaches this point straight from the prologue's reads of sm4)
+    if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = make_float4(acc_g, acc_d, emax, 0.0f);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 tot = sm4[0];
+#pragma unroll
+        for (int w = 1; w < PCG_B_THREADS / 64; ++w) { tot.x += sm4[w].x; tot.y += sm4[w].y; tot.z = fmaxf(tot.z, sm4[w].z); }
+        part_out[blockIdx.x] = tot;
+    }
 }
 
 // After K(max_num_iterations): statistics are written unconditionally if nothing converged before (pressure_reduce.comp:84).

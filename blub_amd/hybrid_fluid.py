@@ -165,6 +165,8 @@ def load_library():
         "blub_fluid_profile_trace": (C.c_int, [vp, C.POINTER(_TraceEvent), C.c_int, C.POINTER(C.c_int)]),
         "blub_fluid_set_pcg_work_mapping": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_brick_counts": (C.c_int, [vp, vp]),
+        "blub_fluid_set_pcg_schedule": (C.c_int, [vp, C.c_int]),
+        "blub_fluid_get_pcg_schedule": (C.c_int, [vp]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
         "blub_scene_mesh_desc_at_time": (C.c_int, [C.POINTER(SceneConfig), u32, C.c_uint64, C.c_uint64, C.POINTER(MeshDesc)]),
         "blub_load_obj": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.POINTER(u32), vp, C.c_size_t, C.POINTER(u32)]),
@@ -422,6 +424,14 @@ class HybridFluid:
     def set_pcg_work_mapping(self, mode):
         """"auto" | "rows" | "bricks" | "bricks_staged" -- performance knob, see include/blubhip.h"""
         _check(self._L, self._L.blub_fluid_set_pcg_work_mapping(self._h, {"auto": -1, "rows": 0, "bricks": 1, "bricks_staged": 2}[mode]))
+
+    def set_pcg_schedule(self, mode):
+        """"reference" (two reductions / two kernels per iteration) | "single_reduction" (one kernel per iteration on the brick
+        mappings), see include/blubhip.h"""
+        _check(self._L, self._L.blub_fluid_set_pcg_schedule(self._h, {"reference": 0, "single_reduction": 1}[mode]))
+
+    def pcg_schedule(self):
+        return ("reference", "single_reduction")[int(self._L.blub_fluid_get_pcg_schedule(self._h))]
 
     def set_max_steps_in_flight(self, n):
         _check(self._L, self._L.blub_fluid_set_max_steps_in_flight(self._h, int(n)))

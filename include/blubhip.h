@@ -248,6 +248,13 @@ int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capaci
  * 0 = dense rows, 1 = brick lists, 2 = brick lists with LDS-staged tiles (many fluid bricks).  A performance knob only: both mappings run the same per-cell arithmetic (the
  * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise). */
 int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
+/* Schedule of the PCG iteration on the brick mappings: 0 = the reference's (pressure_solver.rs:654-723: two global reductions, here
+ * two kernels per iteration), 1 = single-reduction (Chronopoulos-Gear) form of the same recurrence: ONE kernel per iteration, A d
+ * carried by a recurrence.  Identical in exact arithmetic, a different rounding in f32 (not bit-comparable); convergence test,
+ * check cadence and statistics are the same.  The dense-row mapping always runs schedule 0 (it is byte-, not launch-bound).
+ * Environment default: BLUB_PCG_SCHEDULE. */
+int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode);
+int blub_fluid_get_pcg_schedule(const blub_fluid* h);
 /* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks
  * (polling pinned memory) until step n - max has finished. */
 int blub_fluid_set_max_steps_in_flight(blub_fluid* h, uint32_t max_steps);

@@ -1,0 +1,172 @@
+"""The single-reduction PCG schedule (blub_pcg1.hip.h: ONE kernel per iteration on the brick mapping) against the oracle, with
+the SAME tolerances the reference-order schedule is held to in tests/test_gpu_parity.py: it is the same recurrence in exact
+arithmetic (Chronopoulos-Gear), only rounded differently.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.conftest import ROOT, has_gpu
+from tests.test_gpu_parity import GRID, run_until
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+@pytest.fixture()
+def pair():
+    pos, vel, maxp = util.make_dam(*GRID)
+    o, h = util.new_pair(*GRID, maxp)
+    h.set_pcg_work_mapping("bricks_staged")
+    h.set_pcg_schedule("single_reduction")
+    assert h.pcg_schedule() == "single_reduction"
+    o.set_particles(pos, *vel)
+    h.set_particles(pos, *vel)
+    yield o, h
+    h.close()
+
+
+@pytest.mark.parametrize("iters", [0, 1, 2, 4, 7, 8])
+def test_fixed_iterations_match_the_oracle(pair, iters):
+    o, h = pair
+    for f in (o, h):
+        f.set_solver_config(0, error_tolerance=0.0, max_num_iterations=iters, error_check_frequency=4)
+    run_until(o, "solve_velocity")
+    util.copy_state(o, h)
+    o.run_stage("solve_velocity", util.DT)
+    h.run_stage("solve_velocity", util.DT)
+    fluid = o.read_volume("marker") == 1
+    for name in ("pressure_velocity", "residual", "search"):
+        a, b = h.read_volume(name), o.read_volume(name)
+        scale = np.abs(b[fluid]).max()
+        assert scale > 0
+        util.assert_close(name, a[fluid], b[fluid], abs_=1e-4 * scale)
+    assert np.all(h.read_volume("pressure_velocity")[~fluid] == 0)
+    (eo, io), (eh, ih) = o.solver_stats(0), h.solver_stats(0)
+    assert ih == io == iters
+    assert abs(eh - eo) <= 1e-4 * abs(eo) + 1e-9
+
+
+@pytest.mark.parametrize("which,stage", [(0, "solve_velocity"), (1, "solve_density")])
+def test_default_operating_point(pair, which, stage):
+    """32 iterations, far from convergence: same statement as test_gpu_parity.py::test_pcg_default_config, plus self-consistency of
+    the carried quantities: r == b - A p and the recurrence-carried residual agree (the single-reduction form never recomputes A d)."""
+    o, h = pair
+    for f in (o, h):
+        f.set_solver_config(which, error_tolerance=0.0, max_num_iterations=32, error_check_frequency=4)
+    run_until(o, stage)
+    util.copy_state(o, h)
+    b = o.read_volume("residual").astype(np.float64)
+    o.run_stage(stage, util.DT)
+    h.run_stage(stage, util.DT)
+    name = "pressure_velocity" if which == 0 else "pressure_density"
+    marker = o.read_volume("marker")
+    fluid = marker == 1
+    po, ph = o.read_volume(name).astype(np.float64), h.read_volume(name).astype(np.float64)
+    assert np.all(ph[~fluid] == 0)
+    rel_l2 = np.linalg.norm(ph - po) / np.linalg.norm(po)
+    (eo, io), (eh, ih) = o.solver_stats(which), h.solver_stats(which)
+    print("single-reduction, solver %d: rel L2 %.3g, errors %.4g (engine) / %.4g (oracle)" % (which, rel_l2, eh, eo))
+    assert rel_l2 < 3e-2, rel_l2
+    assert ih == io == 32 and 0.5 < eh / eo < 2.0, ((eh, ih), (eo, io))
+    mpad = np.pad(marker, 1, constant_values=0)
+    ppad = np.pad(ph * fluid, 1)
+    diag = np.zeros_like(ph)
+    nb = np.zeros_like(ph)
+    for ax in range(3):
+        for sft in (-1, 1):
+            diag += np.roll(mpad, sft, ax)[1:-1, 1:-1, 1:-1] != 0
+            nb += np.roll(ppad, sft, ax)[1:-1, 1:-1, 1:-1] * (np.roll(mpad, sft, ax)[1:-1, 1:-1, 1:-1] == 1)
+    r_expected = (b - (diag * ph - nb)) * fluid
+    r_hip = h.read_volume("residual").astype(np.float64) * fluid
+    assert np.abs(r_hip - r_expected).max() <= 5e-4 * max(1.0, np.abs(b).max())
+    assert abs(np.abs(r_hip).max() * util.DT - eh) <= 1e-5 * eh + 1e-9
+
+
+def test_convergence_decision_and_cadence(pair):
+    """Tolerance placed in a gap of the oracle's error history: both report the same check iteration (pressure_reduce.comp:82-94)."""
+    o, h = pair
+    run_until(o, "solve_velocity")
+    util.copy_state(o, h)
+    state = {v: o.read_volume(v) for v in ("residual", "pressure_velocity", "search")}
+    errs = {}
+    for it in range(4, 68, 4):
+        for v, a in state.items():
+            o.write_volume(v, a)
+        o.reset_pressure_cleared(0, False)
+        o.set_solver_config(0, error_tolerance=0.0, max_num_iterations=it, error_check_frequency=4)
+        o.run_stage("solve_velocity", util.DT)
+        errs[it] = o.solver_stats(0)[0]
+    hi = next(it for it in range(8, 68, 4) if errs[it] < 0.7 * min(errs[j] for j in range(4, it, 4)))
+    tol = float(np.sqrt(errs[hi] * min(errs[j] for j in range(4, hi, 4))))
+    for f in (o, h):
+        f.set_solver_config(0, error_tolerance=tol, max_num_iterations=64, error_check_frequency=4)
+    for v, a in state.items():
+        o.write_volume(v, a)
+        h.write_volume(v, a)
+    o.reset_pressure_cleared(0, False)
+    h.mark_pressure_initialised(0, False)
+    o.run_stage("solve_velocity", util.DT)
+    h.run_stage("solve_velocity", util.DT)
+    (eo, io), (eh, ih) = o.solver_stats(0), h.solver_stats(0)
+    assert ih == io == hi and abs(eh - eo) <= 0.05 * eo, ((eh, ih), (eo, io))
+
+
+def test_full_step_converged_solver(pair):
+    """Converged solves: the solution no longer depends on the rounding of the iteration -- positions within 1e-4 cells."""
+    o, h = pair
+    cfg = dict(error_tolerance=2e-6, max_num_iterations=400, error_check_frequency=8)
+    for f in (o, h):
+        f.set_solver_config(0, **cfg)
+        f.set_solver_config(1, **cfg)
+    o.step(util.DT)
+    h.step(util.DT)
+    po, ph = o.get_particles(), h.get_particles()
+    d = np.abs(ph[0][:, :3] - po[0][:, :3]).max(axis=1)
+    (eo, io), (eh, ih) = o.solver_stats(0), h.solver_stats(0)
+    print("converged step: max deviation %.3g cells; iterations engine %d oracle %d" % (d.max(), ih, io))
+    assert (d > 1e-4).mean() < 1e-4, "fraction of particles off by > 1e-4 cells: %g (max %g)" % ((d > 1e-4).mean(), d.max())
+    assert ih < 400 and io < 400 and abs(ih - io) <= 8
+
+
+def test_full_step_loose_solver(pair):
+    o, h = pair
+    for f in (o, h):
+        for w in (0, 1):
+            f.set_solver_config(w, error_tolerance=0.0, max_num_iterations=32, error_check_frequency=4)
+    o.step(util.DT)
+    h.step(util.DT)
+    po, ph = o.get_particles(), h.get_particles()
+    d = np.abs(ph[0][:, :3] - po[0][:, :3]).max(axis=1)
+    print("single-reduction deviation quantiles (cells): median %.3g  p99 %.3g  max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
+    assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 5e-3 and d.max() < 0.15
+
+
+def test_headline_scene_statistics_track_the_reference_schedule():
+    """corner_dams_256, reference defaults, 12 steps with each schedule: step 0 reports the same statistics (within 1 %), later
+    steps stay inside the rounding envelope (tests/test_gpu_baseline_parity.py), iteration counts stay comparable in total."""
+    import blub_amd
+    out = {}
+    for sched in ("reference", "single_reduction"):
+        scene = blub_amd.Scene(path=os.path.join(ROOT, "scenes", "corner_dams_256.json"))
+        f = scene.fluid()
+        try:
+            f.set_pcg_schedule(sched)
+            for _ in range(12):
+                scene.step(util.DT)
+            f.synchronize()
+            out[sched] = ([(s.error, s.iteration_count) for s in f.pressure_solver_stats_velocity()],
+                          [(s.error, s.iteration_count) for s in f.pressure_solver_stats_density()], f.get_particles()[0][:, :3].astype(np.float64))
+        finally:
+            f.close()
+    a, b = out["reference"], out["single_reduction"]
+    print("velocity solver:", a[0], "\n           vs   :", b[0])
+    assert a[0][0][1] == b[0][0][1] and abs(a[0][0][0] - b[0][0][0]) <= 0.01 * a[0][0][0]
+    for w in (0, 1):
+        assert len(a[w]) == len(b[w]) == 12
+        ia, ib = sum(s[1] for s in a[w]), sum(s[1] for s in b[w])
+        assert abs(ia - ib) <= 0.25 * ia, (w, ia, ib)
+        for (ea, na), (eb, nb) in list(zip(a[w], b[w]))[:2]:      # later steps: two chaotic trajectories, see test_gpu_baseline_parity.py
+            assert 0.25 < ea / eb < 4.0
+    assert np.abs(a[2].mean(0) - b[2].mean(0)).max() < 5e-3
