@@ -118,7 +118,7 @@ struct blub_fluid {
     uint8_t* tile_flags = nullptr;
     PcgCtrl* ctrl[2] = {nullptr, nullptr};
     // single-reduction schedule (blub_pcg1.hip.h): second buffers of r / w / q (allocated on first use), float4 partials, scalars
-    int pcg_schedule = 0;            // 0: the reference's two-reduction schedule, 1: one kernel per iteration on the brick mapping
+    int pcg_schedule = 1;            // 0: the reference's two-reduction schedule, 1 (default): one kernel per iteration on the brick mapping
     float* cgbuf[3] = {nullptr, nullptr, nullptr};
     float4* part4 = nullptr;
     Pcg1Scalars* pcg1_scalars[2] = {nullptr, nullptr};

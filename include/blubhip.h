@@ -252,7 +252,8 @@ int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
  * two kernels per iteration), 1 = single-reduction (Chronopoulos-Gear) form of the same recurrence: ONE kernel per iteration, A d
  * carried by a recurrence.  Identical in exact arithmetic, a different rounding in f32 (not bit-comparable); convergence test,
  * check cadence and statistics are the same.  The dense-row mapping always runs schedule 0 (it is byte-, not launch-bound).
- * Environment default: BLUB_PCG_SCHEDULE. */
+ * Default 1 (parity against the oracle holds with the tolerances of schedule 0: tests/test_gpu_pcg_schedule.py); the environment
+ * variable BLUB_PCG_SCHEDULE overrides the default at creation. */
 int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode);
 int blub_fluid_get_pcg_schedule(const blub_fluid* h);
 /* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks

@@ -87,7 +87,7 @@ def test_full_size_binning_is_a_permutation():
         f.close()
 
 
-@pytest.mark.parametrize("n,mapping", [(256, "rows"), (128, "bricks"), (128, "bricks_staged")])
+@pytest.mark.parametrize("n,mapping", [(256, "rows"), (128, "bricks"), (128, "bricks_staged"), (128, "bricks_single")])
 def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
     """Dense n^3 Poisson problem (SOLID shell, FLUID inside, one AIR layer under the lid so that the system is not the
     singular pure-Neumann one; 16.3 M unknowns at 256^3): after the solve the engine's own residual volume must equal
@@ -95,7 +95,7 @@ def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
     import blub_amd
     h = blub_amd.HybridFluid((n, n, n), 16, binning="off")
     try:
-        h.set_pcg_work_mapping(mapping)
+        util.set_mapping(h, mapping)
         marker = np.zeros((n, n, n), np.int8)
         marker[1:-1, 1:-1, 1:-1] = 1
         marker[1:-1, -2, 1:-1] = -1          # AIR: Dirichlet p = 0
@@ -199,7 +199,7 @@ def test_staged_brick_kernels_are_bit_identical_to_the_plain_brick_kernels():
     for mapping in ("bricks", "bricks_staged"):
         h = blub_amd.HybridFluid(dim, 8, binning="off")
         try:
-            h.set_pcg_work_mapping(mapping)
+            util.set_mapping(h, mapping)
             h.write_volume("marker", marker)
             h.write_volume("residual", b)
             h.set_solver_config(0, error_tolerance=0.0, max_num_iterations=9, error_check_frequency=4)

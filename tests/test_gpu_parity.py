@@ -62,13 +62,13 @@ def test_elementwise_grid_stage_bit_exact(pair, stage, outputs):
     assert any(np.abs(o.read_volume(v)).max() > 0 for v in outputs)
 
 
-@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged"])
+@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged", "bricks_single"])
 @pytest.mark.parametrize("iters", [0, 1, 4, 7, 8])
 def test_pcg_fixed_iterations(pair, iters, mapping):
     """Fixed iteration count (tolerance 0): p, r, s after k iterations. Only the dot-product summation order differs;
     before the rounding noise is amplified by many unconverged CG iterations the fields agree to 1e-4 of their scale."""
     o, h = pair
-    h.set_pcg_work_mapping(mapping)
+    util.set_mapping(h, mapping)
     for f in (o, h):
         f.set_solver_config(0, error_tolerance=0.0, max_num_iterations=iters, error_check_frequency=4)
     run_until(o, "solve_velocity")
@@ -88,7 +88,7 @@ def test_pcg_fixed_iterations(pair, iters, mapping):
     assert abs(eh - eo) <= 1e-4 * abs(eo) + 1e-9
 
 
-@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged"])
+@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged", "bricks_single"])
 @pytest.mark.parametrize("which,stage", [(0, "solve_velocity"), (1, "solve_density")])
 def test_pcg_default_config(pair, which, stage, mapping):
     """The reference's operating point (32 iterations, check every 4) stops far from convergence (max|r| ~ 12), where
@@ -97,7 +97,7 @@ def test_pcg_default_config(pair, which, stage, mapping):
     reported state must be self-consistent: r == b - A p recomputed in f64.  (Tolerance 0 pins the iteration count: with
     0.1 this scene sits at 0.0995 after 28 iterations, a coin flip between 28 and 32.)"""
     o, h = pair
-    h.set_pcg_work_mapping(mapping)
+    util.set_mapping(h, mapping)
     for f in (o, h):
         f.set_solver_config(which, error_tolerance=0.0, max_num_iterations=32, error_check_frequency=4)
     run_until(o, stage)
@@ -198,7 +198,7 @@ def test_full_step_converged_solver(pair, mapping):
     """With both pressure solves run to convergence the solution no longer depends on CG rounding: one whole step
     (binning off, identical particle order) reproduces the oracle's particle positions to 1e-4 cells."""
     o, h = pair
-    h.set_pcg_work_mapping(mapping)
+    util.set_mapping(h, mapping)
     cfg = dict(error_tolerance=2e-6, max_num_iterations=400, error_check_frequency=8)
     for f in (o, h):
         f.set_solver_config(0, **cfg)
@@ -568,6 +568,7 @@ def test_pcg_persistent_tail_kernel(first, monkeypatch):
     o, h = util.new_pair(*GRID, maxp)
     try:
         h.set_pcg_work_mapping("bricks")
+        h.set_pcg_schedule("reference")
         o.set_particles(pos, *vel)
         run_until(o, "solve_velocity")
         util.copy_state(o, h)

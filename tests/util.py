@@ -79,3 +79,17 @@ def lists_as_sets(ll, pos_ll, n):
         assert guard <= n, "cycle in linked list"
         out[int(cell)] = frozenset(members)
     return out
+
+
+def set_mapping(h, mapping):
+    """Work mapping AND schedule of the PCG kernels for a parametrised test: "rows" / "bricks" / "bricks_staged" run the reference's
+    two-reduction schedule (two kernels per iteration), "bricks_single" the single-reduction schedule (one kernel per iteration,
+    staged brick tiles), "auto" leaves the engine's defaults."""
+    if mapping == "auto":
+        return
+    if mapping == "bricks_single":
+        h.set_pcg_work_mapping("bricks_staged")
+        h.set_pcg_schedule("single_reduction")
+    else:
+        h.set_pcg_work_mapping(mapping)
+        h.set_pcg_schedule("reference")
