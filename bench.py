@@ -20,6 +20,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_FILE = os.path.join("profiles", "r01_pmc_dense_pcg_256.json")   # FETCH_SIZE / WRITE_SIZE capture of the dense PCG benchmark
 
 
 def algorithmic_bytes(kernel, F, P, A, Fb):
@@ -34,6 +35,7 @@ def algorithmic_bytes(kernel, F, P, A, Fb):
         "pcg_init": 6 * A + 12 * F,              # marker + descriptor + p everywhere, r rw + s on FLUID
         "pcg_dir": Fb + 12 * F,                  # descriptor, r, s read, s write
         "pcg_update": Fb + 20 * F,               # descriptor, s, p rw, r rw
+        "pcg_iter": Fb + 40 * F,                 # single-reduction iteration: descriptor; r, w, q, d, p read and written
         "divergence_remove": 13 * A + 16 * F,
         "extrapolate": A + 8 * F,
         "advect": 176 * P,
@@ -76,11 +78,12 @@ def dense_pcg_benchmark(n=256, iterations=32):
     h.close()
     pmc = {}
     try:   # HBM bytes per launch from the committed PMC capture of this same benchmark (rocprofv3 cannot run inside bench.py)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_pcg_256.json")))
+        pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except (OSError, ValueError):
         pass
     for k in out:
         out[k]["traffic_bytes_pmc"] = pmc.get(k, {}).get("traffic") if n == 256 else None
+        out[k]["traffic_source"] = ("committed rocprofv3 --pmc capture of this benchmark: %s (counters cannot be read from inside bench.py)" % PMC_FILE) if out[k]["traffic_bytes_pmc"] else None
         out[k]["algorithmic_bytes"] = algorithmic_bytes(k, F, 0, N, N)
     # one iteration = pcg_dir + pcg_update.  "iter_bytes" is SURVEY 8(d)'s figure for the UNFUSED three-phase iteration
     # (3N + 36F); the fused pair itself only has to move 2N + 32F ("iter_bytes_fused"), both fractions are reported.
@@ -177,16 +180,136 @@ def cpu_baseline(scene_path, dt, budget_steps=24):
 
 def fallback_to_replicas(reason):
     """N > 1 only: re-execute this rank in replicas mode (same PID, so the launcher keeps tracking it).  Used when the z-slab
-    group fails or stalls on one rank: the multi-rank RCCL transport cannot be exercised on the 1-GPU development box, and a
-    rank that raised would otherwise leave its peers blocked inside a transport operation.  Every rank ends up here (the
-    failing one at once, its peers through the watchdog) and they meet again on MASTER_PORT + 17."""
+    group fails or stalls on one rank: a rank that raised would otherwise leave its peers blocked inside a transport operation.
+    Every rank ends up here (the failing one at once, its peers through the watchdog) and they meet again on MASTER_PORT + 17.
+    The line printed in that mode is NOT a scaling result: "value" is null, "scaling" is "fallback-replicas", the reason is kept."""
     sys.stderr.write("rank %s: leaving the z-slab path (%s); re-running as independent replicas\n" % (os.environ.get("RANK", "0"), reason))
     sys.stderr.flush()
     env = dict(os.environ)
     env["BLUB_BENCH_REPLICAS"] = "1"
+    env["BLUB_BENCH_FALLBACK_REASON"] = str(reason)[:400]
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
     env["TORCHELASTIC_USE_AGENT_STORE"] = "False"   # rank 0 hosts a fresh store there (the launcher's own store keeps the keys of the first rendezvous)
     os.execve(sys.executable, [sys.executable] + sys.argv, env)
+
+
+METRIC = "simulation steps/sec, 1M particles @ 256^3 grid"
+
+
+def roofline_object(dense, where):
+    ku = dense["kernels"]["pcg_update"]
+    return {"bound": "hbm", "kernel": "k_pcg_update_z (PCG stencil update, dense 256^3 micro-benchmark M3, %s)" % where, "achieved": ku["achieved_GBs"],
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"], "traffic": ku["traffic_bytes_pmc"],
+            "traffic_source": ku.get("traffic_source"), "algorithmic_bytes": ku["algorithmic_bytes"], "avg_us": ku["avg_us"], "launches": ku["launches"]}
+
+
+def multi_gpu(args, torch, dist, rank, world, dev, ctl):
+    """N > 1: ONE domain cut into z-slabs.  --scaling strong (default): the scene itself (the 256^3 / 1 M particle
+    domain of the metric, BASELINE configs 4-5) split over N slabs, value = steps/s of that one domain.  --scaling weak: N copies
+    stacked along z, value = steps/s of the N-times larger domain.  Transport: RCCL (one slab per rank / GPU); BLUB_BENCH_TRANSPORT=
+    loopback keeps all N slabs on rank 0's GPU (development on a 1-GPU box: the other ranks only take part in the control plane)."""
+    import threading
+    import blub_amd
+    from blub_amd import slab_scene
+    dt = blub_amd.default_simulation_delta()
+    transport = os.environ.get("BLUB_BENCH_TRANSPORT", "rccl")
+    scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
+    watchdog = None
+    if transport == "rccl":
+        watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), fallback_to_replicas, args=("no progress within the deadline",))
+        watchdog.daemon = True
+        watchdog.start()
+    ok = torch.ones(1, device=ctl)
+    group, err = None, ""
+    try:
+        cfg = blub_amd.Scene.parse(path=scene_path).config
+        if args.scaling == "weak":
+            dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, world)
+            workload = "%s stacked x%d along z (weak scaling: every slab is one copy)" % (args.scene, world)
+        else:
+            dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, 1)
+            workload = "%s, ONE domain cut into %d z-slabs (strong scaling)" % (args.scene, world)
+        pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
+        P = len(pos)
+        if transport == "loopback":
+            if rank == 0:
+                group = blub_amd.SlabGroup(dim, P + 64, local=world, device=dev)
+        else:
+            group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev)
+        if group is not None:
+            group.set_gravity_grid(gravity)
+            group.set_particles(pos)
+        del pos
+    except Exception as e:   # all ranks must take the same path
+        err = "%s: %s" % (type(e).__name__, e)
+        sys.stderr.write("rank %d: z-slab group unavailable (%s)\n" % (rank, err))
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 0.0:
+        if group is not None:
+            group.close()
+        if watchdog is not None:
+            watchdog.cancel()
+        fallback_to_replicas("z-slab group could not be created on every rank" + (" (%s)" % err if err else ""))
+    active = group is not None
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+        if active:
+            group.synchronize()
+    try:
+        for _ in range(args.warmup):
+            if active:
+                group.step(dt)
+        barrier()
+        fluid0 = group.local_fluid(0) if active else None
+        it0 = fluid0.total_solver_iterations() if active else 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if active:
+                group.step(dt)
+        if active:
+            group.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    except Exception as e:
+        fallback_to_replicas("z-slab step failed: %s" % e)
+    if watchdog is not None:
+        watchdog.cancel()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    dist.barrier()
+    line = None
+    if active:
+        it1 = fluid0.total_solver_iterations()
+        ops0 = group.transport_ops()
+        group.step(dt)
+        group.synchronize()
+        ops_per_step = group.transport_ops() - ops0
+        if transport == "loopback":
+            parallelism = "%d z-slabs EMULATED on one GPU (loopback transport, rank 0 only): protocol cost without a wire, not a scaling result" % world
+        else:
+            parallelism = "z-slab decomposition over RCCL: %d slabs, 1 rank per GPU" % world
+        line = {
+            "metric": METRIC, "value": round(args.steps / elapsed, 3), "unit": "steps/s (global steps of the whole domain)", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": args.scaling if transport != "loopback" else args.scaling + "-emulated-on-one-gpu", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "grid": list(dim), "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
+                       "parallelism": parallelism},
+            "pcg_iters_per_step": round((it1 - it0) / args.steps, 2), "transport_ops_per_step": round(ops_per_step, 1),
+            "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}
+    dist.barrier()
+    if active:
+        group.close()
+    if rank == 0 and line is not None:
+        if not args.no_dense_pcg:   # the roofline kernel is a single-GPU micro-benchmark: rank 0 runs it while the others wait
+            line["roofline"] = roofline_object(dense_pcg_benchmark(256, 32), "rank 0")
+        print(json.dumps(line))
+        sys.stdout.flush()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -195,10 +318,13 @@ def main():
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="corner_dams_256")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: split ONE domain (default) or stack N copies along z")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-pcg", action="store_true")
+    ap.add_argument("--no-fast-forward", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
-    ap.add_argument("--dense-only", action="store_true", help="only run the dense 256^3 PCG micro-benchmark (tuning)")
+    ap.add_argument("--dense-only", action="store_true", help="only run the dense PCG micro-benchmark (tuning)")
+    ap.add_argument("--dense-size", type=int, default=256)
     ap.add_argument("--pcg-mapping", default="auto", choices=["auto", "rows", "bricks", "bricks_staged"], help="work mapping of the PCG kernels (tuning)")
     ap.add_argument("--transfer-only", action="store_true", help="only run the 256^3 transfer micro-benchmark M4 (65 M particles)")
     args = ap.parse_args()
@@ -207,7 +333,7 @@ def main():
     import blub_amd
 
     if args.dense_only:
-        print(json.dumps(dense_pcg_benchmark(256, 32)))
+        print(json.dumps(dense_pcg_benchmark(args.dense_size, 32)))
         return
     if args.transfer_only:
         print(json.dumps(transfer_microbenchmark(256)))
@@ -217,6 +343,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ctl = "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -231,54 +358,19 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
+    replicas = world > 1 and bool(os.environ.get("BLUB_BENCH_REPLICAS"))
+    if world > 1 and not replicas:
+        return multi_gpu(args, torch, dist, rank, world, dev, ctl)
 
     scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
     dt = blub_amd.default_simulation_delta()
-    parallelism = "single GPU"
-    group = None
-    watchdog = None
-    if world > 1 and not os.environ.get("BLUB_BENCH_REPLICAS"):
-        import threading
-        watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), fallback_to_replicas, args=("no progress within the deadline",))
-        watchdog.daemon = True
-        watchdog.start()
-        # z-slab decomposition, weak scaling: rank k owns slab k of a (nx, ny, N*nz) domain made of N stacked
-        # copies of the scene (the dams of neighbouring slabs meet at the interfaces, so ghosts / halos / migration carry data)
-        from blub_amd import slab_scene
-        ok = torch.ones(1, device=ctl)
-        try:
-            cfg = blub_amd.Scene.parse(path=scene_path).config
-            dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, world)
-            pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
-            group = blub_amd.SlabGroup.from_torch_distributed(dim, len(pos) + 64, device=dev)
-            group.set_gravity_grid(gravity)
-            group.set_particles(pos)
-            del pos
-        except Exception as e:   # all ranks must take the same path
-            sys.stderr.write("rank %d: z-slab group unavailable (%s)\n" % (rank, e))
-            ok.zero_()
-            group = None
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok.item()) == 0.0:
-            if group is not None:
-                group.close()
-            group = None
-    if group is not None:
-        parallelism = "z-slab decomposition over RCCL: %d slabs of %dx%dx%d (weak scaling), 1 rank per GPU" % (world, dim[0], dim[1], dim[2] // world)
-        fluid = group.local_fluid(0)
-        step, sync = (lambda: group.step(dt)), group.synchronize
-        nx, ny, nz = dim
-        P = int(maxp)   # global particle count is reported below from the seeded set
-    else:
-        if world > 1:
-            parallelism = "replicas x%d (one independent domain per GPU; z-slab group unavailable or disabled)" % world
-        scene = blub_amd.Scene(path=scene_path, device=dev)
-        fluid = scene.fluid()
-        fluid.set_pcg_work_mapping(args.pcg_mapping)
-        step, sync = (lambda: scene.step(dt)), fluid.synchronize
-        nx, ny, nz = fluid.grid_dimension()
+    scene = blub_amd.Scene(path=scene_path, device=dev)
+    fluid = scene.fluid()
+    fluid.set_pcg_work_mapping(args.pcg_mapping)
+    step, sync = (lambda: scene.step(dt)), fluid.synchronize
+    nx, ny, nz = fluid.grid_dimension()
     N = nx * ny * nz
-    P = fluid.num_particles() if group is None else None
+    P = fluid.num_particles()
 
     def barrier():
         if dist is not None:
@@ -286,102 +378,83 @@ def main():
         torch.cuda.synchronize()
         sync()
 
-    try:
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        it0 = fluid.total_solver_iterations()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    except Exception as e:
-        if group is None:
-            raise
-        fallback_to_replicas("z-slab step failed: %s" % e)
-    if watchdog is not None:
-        watchdog.cancel()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    it0 = fluid.total_solver_iterations()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        if group is not None:
-            cnt = torch.tensor([group.num_particles()], dtype=torch.float64, device=ctl)
-            dist.all_reduce(cnt)
-            P = int(cnt.item())
         dist.barrier()
     it1 = fluid.total_solver_iterations()
 
-    if group is not None:
-        ops0 = group.transport_ops()
-        group.step(dt)
-        group.synchronize()
-        ops_per_step = group.transport_ops() - ops0
-        # weak scaling: one global step advances `world` slabs of the single-GPU workload size
-        line = {
-            "metric": "simulation steps/sec, 1M particles @ 256^3 grid", "value": round(args.steps * world / elapsed, 3),
-            "unit": "steps/s (256^3-slab steps: one global step advances n_gpus slabs)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": "%s stacked x%d along z" % (args.scene, world), "grid": [nx, ny, nz], "particles": P, "dt": dt,
-                                            "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60, "parallelism": parallelism},
-            "global_steps_per_sec": round(args.steps / elapsed, 3), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
-            "transport_ops_per_step": round(ops_per_step, 1), "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}
-        dist.barrier()
-        group.close()
+    if replicas:
+        # NOT a scaling result: every rank stepped its own independent copy because the z-slab path was unavailable.
         if rank == 0:
-            if not args.no_dense_pcg:   # the roofline kernel is a single-GPU micro-benchmark: rank 0 runs it while the others wait
-                dense = dense_pcg_benchmark(256, 32)
-                ku = dense["kernels"]["pcg_update"]
-                line["roofline"] = {"bound": "hbm", "kernel": "k_pcg_update_z (PCG stencil update, dense 256^3 micro-benchmark M3, rank 0)", "achieved": ku["achieved_GBs"],
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"], "traffic": ku["traffic_bytes_pmc"], "algorithmic_bytes": ku["algorithmic_bytes"],
-                                    "avg_us": ku["avg_us"], "launches": ku["launches"]}
-            print(json.dumps(line))
+            print(json.dumps({
+                "metric": METRIC, "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "fallback-replicas", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": args.scene, "grid": [nx, ny, nz], "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
+                           "parallelism": "FALLBACK: %d independent replicas, one per GPU -- the z-slab decomposition did not run" % world},
+                "fallback_reason": os.environ.get("BLUB_BENCH_FALLBACK_REASON", "BLUB_BENCH_REPLICAS set by the caller"),
+                "replica_steps_per_sec_each": round(args.steps / elapsed, 3), "roofline": None, "cpu_baseline": None}))
             sys.stdout.flush()
         dist.barrier()
         dist.destroy_process_group()
         return
 
-    if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+    # ---- fast-forward through the native scheduler (simulation_controller.rs:96-157): the reference's own way of timing steps
+    fast_forward = None
+    if not args.no_fast_forward:
+        from blub_amd.simulation_controller import SimulationController
+        sc = SimulationController()
+        n_ff = sc.fast_forward_steps_fluid(fluid, args.steps * sc.simulation_delta_ns)
+        fast_forward = {"steps": n_ff, "steps_per_s": round(n_ff / max(sc.computation_time_last_fast_forward, 1e-9), 3),
+                        "computation_time_last_fast_forward_s": round(sc.computation_time_last_fast_forward, 5), "batch": 16}
+        sc.close()
 
     # ---- instrumented pass: per-kernel-class HIP-event timing on the engine's own stream -----------------------------
-    fluid.profile_enable(True)
-    fluid.profile_reset()
-    for _ in range(args.profile_steps):
-        step()
-    fluid.synchronize()
-    prof = fluid.profile_read()
-    fluid.profile_enable(False)
-    F = int((fluid.read_volume("marker") == 1).sum())
-    bc = fluid.brick_counts()
-    A, Fb = bc["active"] * bc["cells_per_brick"], bc["fluid"] * bc["cells_per_brick"]
-    total_ms = sum(v["total_ms"] for v in prof.values())
-    dominant = max(prof, key=lambda k: prof[k]["total_ms"])
-    avg_ms = prof[dominant]["total_ms"] / prof[dominant]["launches"]
-    ach = algorithmic_bytes(dominant, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
-    roofline_workload = {"bound": "launch latency (see DESIGN.md 6): < 1 MB per launch", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
-                "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F,
-                "active_brick_cells": A, "fluid_brick_cells": Fb, "launches_per_step": round(prof[dominant]["launches"] / args.profile_steps, 1)}
-    pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
-    solver_iters_prof = None
-    breakdown = {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+    roofline_workload, breakdown, pcg_ms = None, None, 0.0
+    if args.profile_steps > 0:
+        fluid.profile_enable(True)
+        fluid.profile_reset()
+        for _ in range(args.profile_steps):
+            step()
+        fluid.synchronize()
+        prof = fluid.profile_read()
+        fluid.profile_enable(False)
+        F = int((fluid.read_volume("marker") == 1).sum())
+        bc = fluid.brick_counts()
+        A, Fb = bc["active"] * bc["cells_per_brick"], bc["fluid"] * bc["cells_per_brick"]
+        total_ms = sum(v["total_ms"] for v in prof.values())
+        dominant = max(prof, key=lambda k: prof[k]["total_ms"])
+        avg_ms = prof[dominant]["total_ms"] / prof[dominant]["launches"]
+        ach = algorithmic_bytes(dominant, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
+        roofline_workload = {"bound": "fabric latency / launch count (see DESIGN.md 6): a few MB per launch", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
+                             "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F, "active_brick_cells": A, "fluid_brick_cells": Fb,
+                             "launches_per_step": round(prof[dominant]["launches"] / args.profile_steps, 1)}
+        pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
+        breakdown = {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
 
-    steps_per_s = args.steps * world / elapsed   # weak scaling: every rank steps its own domain
     result = {
-        "metric": "simulation steps/sec, 1M particles @ 256^3 grid", "value": round(steps_per_s, 3), "unit": "steps/s",
+        "metric": METRIC, "value": round(args.steps / elapsed, 3), "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.scene, "grid": [nx, ny, nz], "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4",
-                   "rebinning": 60, "parallelism": parallelism},
-        "pcg_iters_per_sec": round((it1 - it0) * world / elapsed, 1),
+                   "rebinning": 60, "parallelism": "single GPU", "pcg_schedule": fluid.pcg_schedule()},
+        "pcg_iters_per_sec": round((it1 - it0) / elapsed, 1),
         "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
         "pcg_iters_per_sec_in_solver": round((it1 - it0) / args.steps * args.profile_steps / (pcg_ms * 1e-3), 1) if pcg_ms > 0 else None,
+        "fast_forward": fast_forward,
         "roofline": None,
         "roofline_workload": roofline_workload,
         "kernel_us_per_step": breakdown,
@@ -393,18 +466,11 @@ def main():
         scene._fluid = None
         dense = dense_pcg_benchmark(256, 32)
         result["roofline_pcg_dense"] = dense
-        ku = dense["kernels"]["pcg_update"]
-        result["roofline"] = {"bound": "hbm", "kernel": "k_pcg_update_z (PCG stencil update, dense 256^3 micro-benchmark M3, same process)",
-                              "achieved": ku["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"],
-                              "traffic": ku["traffic_bytes_pmc"], "algorithmic_bytes": ku["algorithmic_bytes"], "avg_us": ku["avg_us"],
-                              "launches": ku["launches"]}
-    if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
+        result["roofline"] = roofline_object(dense, "same process")
+    if not args.no_cpu_baseline:   # rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(scene_path, dt)
     print(json.dumps(result))
     sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

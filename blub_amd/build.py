@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libblubhip.so")
-SOURCES = [os.path.join(CSRC, "blub_fluid.hip"), os.path.join(CSRC, "scene_host.cpp")]
+SOURCES = [os.path.join(CSRC, "blub_fluid.hip"), os.path.join(CSRC, "scene_host.cpp"), os.path.join(CSRC, "scheduler_host.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, n) for n in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "blubhip.h")]
 # -ffp-contract=off: element-wise kernels must round exactly like the (unfused) reference arithmetic / the oracle.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-gpu-rdc",

@@ -264,6 +264,48 @@ int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]);
 /* Total PCG iterations executed (sum of reported iteration counts) since creation, both solvers. */
 uint64_t blub_fluid_total_solver_iterations(const blub_fluid* h);
 
+/* ---- step scheduler: `SimulationController` + `Timer` (src/simulation_controller.rs, src/timer.rs) ---------------
+ * Host only, integer-nanosecond `Duration` arithmetic like the reference.  Stepping goes through callbacks so that a host can run
+ * its whole `Scene::step` (animate models, voxelise, fluid step: scene/mod.rs:166-213); the *_fluid variants step a bare fluid. */
+typedef struct blub_controller blub_controller;
+typedef enum blub_controller_status {            /* SimulationControllerStatus, simulation_controller.rs:12-17 */
+    BLUB_CONTROLLER_REALTIME = 0, BLUB_CONTROLLER_RECORDING = 1, BLUB_CONTROLLER_FAST_FORWARD = 2, BLUB_CONTROLLER_PAUSED = 3
+} blub_controller_status;
+typedef struct blub_step_callbacks {
+    /* Scene::step for one simulation step: dt = Timer::simulation_delta().as_secs_f32(); total_simulated_time_ns already includes this
+     * step (timer.rs:124).  Return BLUB_OK or an error (which ends the frame / fast-forward and is passed on). */
+    int (*step)(void* user, float simulation_delta_seconds, uint64_t total_simulated_time_ns);
+    int (*wait)(void* user);                     /* device.poll(Maintain::Wait), simulation_controller.rs:140; may be NULL */
+    void* user;
+} blub_step_callbacks;
+int blub_controller_create(uint64_t simulation_steps_per_second /* 0 = the default 120 */, blub_controller** out);   /* ::new, :38-50 */
+void blub_controller_destroy(blub_controller* c);
+int blub_controller_set_simulation_steps_per_second(blub_controller* c, uint64_t steps_per_second);                  /* :88-92 */
+uint64_t blub_controller_simulation_steps_per_second(const blub_controller* c);                                      /* :64 */
+uint64_t blub_controller_simulation_delta_ns(const blub_controller* c);              /* Timer::simulation_delta: 1e9 / steps per second, :33-35 */
+uint64_t blub_controller_total_simulated_time_ns(const blub_controller* c);          /* Timer::total_simulated_time */
+uint64_t blub_controller_total_render_time_ns(const blub_controller* c);             /* Timer::total_render_time */
+uint32_t blub_controller_num_simulation_steps_performed(const blub_controller* c);
+uint32_t blub_controller_num_simulation_steps_performed_for_current_frame(const blub_controller* c);
+uint64_t blub_controller_computation_time_last_fast_forward_ns(const blub_controller* c);                            /* :60, 147 */
+int blub_controller_get_status(const blub_controller* c);                                                                /* :68 */
+int blub_controller_set_simulation_stop_time_ns(blub_controller* c, uint64_t t);     /* pub simulation_stop_time (default one hour) */
+uint64_t blub_controller_simulation_stop_time_ns(const blub_controller* c);
+int blub_controller_set_time_scale(blub_controller* c, float time_scale);            /* pub time_scale */
+int blub_controller_pause_or_resume(blub_controller* c);                                                             /* :72-78 */
+int blub_controller_start_recording_with_fixed_frame_length(blub_controller* c, double frames_per_second);           /* :80-82 */
+int blub_controller_restart(blub_controller* c);                                                                     /* :94-96 */
+/* Timer::on_frame_submitted (timer.rs:76-88).  measured_frame_duration_ns < 0: measure the real time since the last call. */
+int blub_controller_on_frame_submitted(blub_controller* c, int64_t measured_frame_duration_ns);                      /* :56-58 */
+/* One rendered frame: step while the simulation lags the render clock; in real-time mode give up (accept lag) once the steps of
+ * this frame cover more than 1/50 s of simulated time (:31, 159-217; timer.rs:94-130). */
+int blub_controller_frame_steps(blub_controller* c, const blub_step_callbacks* cb, uint32_t* steps_out);
+/* Batches of 16 steps + wait until max(jump, one step) of simulated time has passed (:96-157).  Like in the reference the status is
+ * PAUSED afterwards (the stop-time mechanism ends the jump) and the wall clock of the whole jump is kept. */
+int blub_controller_fast_forward_steps(blub_controller* c, uint64_t simulation_jump_length_ns, const blub_step_callbacks* cb, uint32_t* steps_out);
+int blub_controller_frame_steps_fluid(blub_controller* c, blub_fluid* h, uint32_t* steps_out);
+int blub_controller_fast_forward_steps_fluid(blub_controller* c, uint64_t simulation_jump_length_ns, blub_fluid* h, uint32_t* steps_out);
+
 /* ---- z-slab domain decomposition over up to 8 GPUs (not part of the reference, which is single-GPU) ---- */
 /* The global grid is cut into `num_slabs` z-ranges of whole 16x8x4-cell bricks.  Every slab keeps its volumes in GLOBAL
  * grid coordinates but only works on its own planes; neighbours exchange ghost particles, halo planes (RCCL

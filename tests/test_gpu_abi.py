@@ -1,9 +1,11 @@
 """Error behaviour and bookkeeping of the C-ABI on a real device (the reference's unwrap()/assert!/error! paths)."""
+import os
+
 import numpy as np
 import pytest
 
 from tests import util
-from tests.conftest import has_gpu
+from tests.conftest import ROOT, has_gpu
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
 
@@ -167,3 +169,29 @@ def test_checkpoint_and_resume_through_the_state_exchange_calls():
         a.close()
         if b is not None:
             b.close()
+
+
+def test_native_scheduler_fast_forwards_the_fluid_through_the_c_abi():
+    """SURVEY 8f-3: `SimulationController::fast_forward_steps` (simulation_controller.rs:96-157) as blub_controller_* -- batches of 16
+    blub_fluid_step + a wait, at least one step, wall clock kept; no Python in the stepping loop."""
+    import blub_amd
+    from blub_amd.simulation_controller import NS, SimulationController
+    scene = blub_amd.Scene(path=os.path.join(ROOT, "scenes", "corner_dams_128.json"))
+    f = scene.fluid()
+    c = SimulationController()
+    try:
+        n = c.fast_forward_steps_fluid(f, 40 * c.simulation_delta_ns)
+        assert n == 40 and f.step_counter == 40 and c.total_simulated_time_ns == 40 * c.simulation_delta_ns
+        assert c.status == SimulationController.PAUSED and c.computation_time_last_fast_forward > 0
+        assert len(f.pressure_solver_stats_velocity()) == 40            # update_statistics after every step + the waits: every sample landed
+        print("fast-forward of 40 steps of corner_dams_128: %.1f steps/s" % (n / c.computation_time_last_fast_forward))
+        assert c.fast_forward_steps_fluid(f, 1) == 1 and f.step_counter == 41    # "jump at least one simulation step" (:119-121)
+        # the same controller drives a whole Scene (Python callbacks): one 60 Hz frame = two steps
+        c.pause_or_resume()
+        c.on_frame_submitted(NS // 60 + 1000)
+        assert c.frame_steps(scene) == 2 and f.step_counter == 43
+        pos = f.get_particles()[0]
+        assert np.all(np.isfinite(pos[:, :3]))
+    finally:
+        c.close()
+        f.close()
