@@ -20,7 +20,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = os.path.join("profiles", "r01_pmc_dense_pcg_256.json")   # FETCH_SIZE / WRITE_SIZE capture of the dense PCG benchmark
+PMC_FILE = os.path.join("profiles", "r02_pmc_dense_pcg_256.json")   # FETCH_SIZE / WRITE_SIZE capture of the dense PCG benchmark
 
 
 def algorithmic_bytes(kernel, F, P, A, Fb):

@@ -125,6 +125,7 @@ struct blub_fluid {
     PcgTailSync* tail_sync[2] = {nullptr, nullptr};
     bool use_tail = true;            // persistent tail kernel for brick-mapped solves (BLUB_PCG_TAIL=0 disables)
     int tail_margin_checks = 1;
+    int tail_grid = 256;             // co-resident blocks of the tail kernel: occupancy x CUs, at most one per CU (set at creation)
     int tail_first_forced = -1;      // test hook (BLUB_PCG_TAIL_FIRST): hand over to the tail after exactly this many launched iterations
     blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
     bool pressure_initialised[2] = {false, false};
@@ -136,6 +137,7 @@ struct blub_fluid {
     std::deque<float> stats_dt[2];
     std::deque<blub_solver_stats> stats_history[2];
     uint64_t total_iterations = 0;
+    uint32_t failed_solves = 0, failed_solves_reported = 0;   // solves whose tail kernel reported a grid-barrier timeout (num_iter < 0)
     // profiling
     bool prof_enabled = false;
     struct ProfPending { hipEvent_t a, b; int kc; int stage; uint32_t step; };
@@ -434,29 +436,32 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
                    (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
         }
         if (launched <= maxit)
-            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_tail_b, dim3(std::min(np, 256)), block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, h->residual, sbuf[0], sbuf[1], p,
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_tail_b, dim3(std::min(np, h->tail_grid)), block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, h->residual, sbuf[0], sbuf[1], p,
                    part_upd, part_dir, np, ctrl, tol, launched, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
         else
             LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
     } else {
         const int np = h->pcg_grid_z;
         const dim3 grid(np);
-#define BLUB_LAUNCH_Z(TT)                                                                                                                                       \
+#define BLUB_LAUNCH_Z(TT, NTU, NTD)                                                                                                                             \
         {                                                                                                                                                       \
             const dim3 block(TT);                                                                                                                               \
             LAUNCH(h, KC_PCG_INIT, k_pcg_init_z<TT>, grid, block, h->gz, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags, ctrl);   \
             for (int i = 0; i <= maxit; ++i) {                                                                                                                  \
                 if (i == 0)                                                                                                                                     \
-                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true, NTD>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);                                              \
                 else                                                                                                                                            \
-                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));                           \
-                LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_z<TT>, grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,             \
+                LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,     \
                        (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
             }                                                                                                                                                   \
         }
-        if (h->gz.T == 256) BLUB_LAUNCH_Z(256) else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024) else BLUB_LAUNCH_Z(512)
+        static const int nt_mode = getenv("BLUB_PCGZ_NT") ? atoi(getenv("BLUB_PCGZ_NT")) : 1;   // bit 0: p / r of KU non-temporal (default: 66.8 -> 62.5 us at 256^3), bit 1: s_out of KD (no gain)
+        if (h->gz.T == 256) { if (nt_mode == 0) BLUB_LAUNCH_Z(256, false, false) else if (nt_mode == 1) BLUB_LAUNCH_Z(256, true, false) else if (nt_mode == 2) BLUB_LAUNCH_Z(256, false, true) else BLUB_LAUNCH_Z(256, true, true) }
+        else if (h->gz.T == 1024) { if (nt_mode & 1) BLUB_LAUNCH_Z(1024, true, false) else BLUB_LAUNCH_Z(1024, false, false) }
+        else { if (nt_mode & 1) BLUB_LAUNCH_Z(512, true, false) else BLUB_LAUNCH_Z(512, false, false) }
 #undef BLUB_LAUNCH_Z
         LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
     }
@@ -467,14 +472,19 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
 
 static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
     if (h->binning_mode == BLUB_BINNING_OFF || h->num_particles == 0) return BLUB_OK;
-    HIP_TRY(hipMemsetAsync(h->ll[0], 0, h->N * sizeof(uint32_t), h->stream));   // clear_texture :858
-    LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->ll[0]);
+    // The reference counts and scans in its linked-list volume (:858-876) because the dense transfer_clear pass re-zeroes it
+    // anyway.  Here list heads are only re-zeroed inside the reset-list bricks, so the per-cell counters / prefix sums live in a
+    // volume that is scratch at this point of the step instead (aux_temp: only ever read inside a solve, after being rewritten) and
+    // ll[0] keeps the invariant "zero outside the touched bricks".
+    uint32_t* counters = reinterpret_cast<uint32_t*>(h->aux_temp);
+    HIP_TRY(hipMemsetAsync(counters, 0, h->N * sizeof(uint32_t), h->stream));   // clear_texture :858
+    LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, counters);
     const int n = (int)h->N, nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    LAUNCH(h, KC_BIN_SCAN, k_scan_block_totals, dim3(nblocks), dim3(1024), (const uint32_t*)h->ll[0], n, h->scan_totals);
+    LAUNCH(h, KC_BIN_SCAN, k_scan_block_totals, dim3(nblocks), dim3(1024), (const uint32_t*)counters, n, h->scan_totals);
     LAUNCH(h, KC_BIN_SCAN, k_scan_totals, dim3(1), dim3(1024), h->scan_totals, nblocks);
-    LAUNCH(h, KC_BIN_SCAN, k_scan_apply, dim3(nblocks), dim3(1024), h->ll[0], n, (const uint32_t*)h->scan_totals);
+    LAUNCH(h, KC_BIN_SCAN, k_scan_apply, dim3(nblocks), dim3(1024), counters, n, (const uint32_t*)h->scan_totals);
     LAUNCH(h, KC_BIN_REWRITE, k_bin_rewrite, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->max_particles,
-           (const float4*)h->pos, h->pos_tmp, (const uint32_t*)h->ll[0]);
+           (const float4*)h->pos, h->pos_tmp, (const uint32_t*)counters);
     {
         ProfScope ps(h, KC_COPY);   // :885-891 (only the live range; the rest of the buffer is never read)
         HIP_TRY(hipMemcpyAsync(h->pos, h->pos_tmp, (size_t)h->num_particles * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
@@ -633,6 +643,13 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, (size_t)std::max(gm.tiles, h->gz.tiles) + 8));
     A(dev_alloc_zero(h->stream, &h->ctrl[0], 1)); A(dev_alloc_zero(h->stream, &h->ctrl[1], 1));
     A(dev_alloc_zero(h->stream, &h->tail_sync[0], 1)); A(dev_alloc_zero(h->stream, &h->tail_sync[1], 1));
+    {   // the tail kernel's grid barrier needs every block resident at once: bound the grid by what the device can hold
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_tail_b, PCG_B_THREADS, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+            h->tail_grid = std::max(1, std::min(256, cus));          // one block per CU: always fits when per_cu >= 1
+        else h->use_tail = false;
+    }
     if (const char* e = getenv("BLUB_PCG_SCHEDULE")) h->pcg_schedule = atoi(e) == 1 ? 1 : 0;
     if (const char* e = getenv("BLUB_PCG_TAIL")) h->use_tail = atoi(e) != 0;
     if (const char* e = getenv("BLUB_PCG_TAIL_FIRST")) h->tail_first_forced = atoi(e);
@@ -682,11 +699,23 @@ static int poll_stats(blub_fluid* h, bool wait) {   // retrieve_new_error_sample
             const float max_err = c->max_err, iters = c->num_iter;
             if (c->seq != ps.seq) continue;
             blub_solver_stats s; s.error = max_err * h->stats_dt[w].front(); s.iteration_count = (int32_t)iters;   // :162-163
+            h->stats_pending[w].pop_front(); h->stats_dt[w].pop_front();
+            if (s.iteration_count < 0) {
+                // the persistent tail kernel gave up on a grid barrier (its 256 blocks were not co-resident: shared or partitioned
+                // device): the pressure field of that solve is unfinished.  Not a statistics sample; reported as a device error by
+                // the next blub_fluid_synchronize / update_statistics, and the tail is not used again on this handle.
+                h->failed_solves += 1;
+                h->use_tail = false;
+                continue;
+            }
             h->stats_history[w].push_back(s);
             while (h->stats_history[w].size() > STATS_HISTORY) h->stats_history[w].pop_front();
             h->total_iterations += (uint64_t)s.iteration_count;
-            h->stats_pending[w].pop_front(); h->stats_dt[w].pop_front();
         }
+    }
+    if (h->failed_solves != h->failed_solves_reported) {
+        h->failed_solves_reported = h->failed_solves;
+        return set_error(BLUB_ERR_DEVICE, "a pressure solve did not finish: the persistent tail kernel timed out on a grid barrier (device shared or partitioned?); the tail is now disabled for this handle");
     }
     return BLUB_OK;
 }

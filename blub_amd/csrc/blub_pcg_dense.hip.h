@@ -32,13 +32,25 @@ __device__ __forceinline__ int xcd_tile(int i, int tiles) {
     return t;   // may be >= tiles for the padded tail: callers skip those
 }
 
+// Streaming accesses that must not displace the halo rows other tiles are about to re-read from the L2 (p and r in KU have no
+// halo: each value is touched exactly once per kernel): non-temporal loads / stores.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 ld4s(const float* p) {
+    if (NT) { const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return ld4(p);
+}
+template <bool NT> __device__ __forceinline__ void st4s(float* p, const float4& a) {
+    if (NT) { v4f_t v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(p)); }
+    else *reinterpret_cast<float4*>(p) = a;
+}
+
 __device__ __forceinline__ float4 sel4(uint32_t dq, const float4& a, const float4& fallback) {   // FLUID lanes take a, others fallback
     return make_float4((dbyte(dq, 0) & 0x80) ? a.x : fallback.x, (dbyte(dq, 1) & 0x80) ? a.y : fallback.y,
                        (dbyte(dq, 2) & 0x80) ? a.z : fallback.z, (dbyte(dq, 3) & 0x80) ? a.w : fallback.w);
 }
 
 // ---- KU: p += alpha s; r -= alpha A s; partial (M^-1 r).r and max|r|  (pressure_update_pressure_and_residual.comp:23-59)
-template <int T>
+template <int T, bool NT = false>
 __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
                                                     float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
                                                     const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
@@ -67,12 +79,27 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
         // planes z_begin-1 (m), z_begin (c), z_begin+1 (p) in registers; plane z+2 and the next plane's p, r are in flight
         float4 s_m = zero4, s_c = zero4, s_p = zero4, s_n = zero4, pc = zero4, rc = zero4, pn = zero4, rn = zero4;
         uint32_t d_m = 0, d_c = 0, d_p = 0, d_n = 0;
+        // tile-edge values of plane z that other tiles own (two rows + the row-continuation cells): fetched ONE PLANE AHEAD like
+        // everything else -- loaded and consumed inside the same iteration they put a full memory latency on every plane's critical path
+        struct Halo { float4 lo, hi; uint32_t dlo, dhi; float xm, xp; int dxm, dxp; };
+        auto load_halo = [&](int base, bool cond) -> Halo {
+            Halo h; h.lo = zero4; h.hi = zero4; h.dlo = 0; h.dhi = 0; h.xm = 0.f; h.xp = 0.f; h.dxm = 0; h.dxp = 0;
+            if (cond) {
+                if (edge_lo && !in_lo) { h.lo = ld4(s + base - g.nx); h.dlo = *reinterpret_cast<const uint32_t*>(dvol + base - g.nx); }
+                if (edge_hi && !in_hi) { h.hi = ld4(s + base + g.nx); h.dhi = *reinterpret_cast<const uint32_t*>(dvol + base + g.nx); }
+                if (xm_glob) { h.xm = s[base - 1]; h.dxm = dvol[base - 1]; }
+                if (xp_glob) { h.xp = s[base + 4]; h.dxp = dvol[base + 4]; }
+            }
+            return h;
+        };
+        Halo hc; hc.lo = zero4; hc.hi = zero4; hc.dlo = 0; hc.dhi = 0; hc.xm = 0.f; hc.xp = 0.f; hc.dxm = 0; hc.dxp = 0;
         if (valid) {
             const int b0 = z_begin * plane + row_base;
             s_c = ld4(s + b0); d_c = *reinterpret_cast<const uint32_t*>(dvol + b0);
             if (z_begin > 0) { s_m = ld4(s + b0 - plane); d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); }
             if (z_begin + 1 < g.nz) { s_p = ld4(s + b0 + plane); d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane); }
-            if (any_fluid_d(d_c)) { pc = ld4(p + b0); rc = ld4(r + b0); }
+            if (any_fluid_d(d_c)) { pc = ld4s<NT>(p + b0); rc = ld4s<NT>(r + b0); }
+            hc = load_halo(b0, any_fluid_d(d_c));
         }
         for (int z = z_begin; z < z_end; ++z) {
             const int base = z * plane + row_base;
@@ -81,26 +108,20 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
             if (valid && z + 2 < g.nz && z + 1 < z_end) { s_n = ld4(s + base + 2 * plane); d_n = *reinterpret_cast<const uint32_t*>(dvol + base + 2 * plane); }
             else { s_n = zero4; d_n = 0; }
             const bool work_next = valid && z + 1 < z_end && any_fluid_d(d_p);
-            if (work_next) { pn = ld4(p + base + plane); rn = ld4(r + base + plane); }
-            float4 h_lo = zero4, h_hi = zero4;
-            uint32_t hd_lo = 0, hd_hi = 0;
-            float gxm = 0.f, gxp = 0.f; int gdxm = 0, gdxp = 0;
+            if (work_next) { pn = ld4s<NT>(p + base + plane); rn = ld4s<NT>(r + base + plane); }
+            const Halo hn = load_halo(base + plane, work_next);
             const bool work = valid && any_fluid_d(d_c);
-            if (work) {
-                if (edge_lo && !in_lo) { h_lo = ld4(s + base - g.nx); hd_lo = *reinterpret_cast<const uint32_t*>(dvol + base - g.nx); }
-                if (edge_hi && !in_hi) { h_hi = ld4(s + base + g.nx); hd_hi = *reinterpret_cast<const uint32_t*>(dvol + base + g.nx); }
-                if (xm_glob) { gxm = s[base - 1]; gdxm = dvol[base - 1]; }
-                if (xp_glob) { gxp = s[base + 4]; gdxp = dvol[base + 4]; }
-            }
             ls[buf][t] = s_c; ld[buf][t] = d_c;
-            __syncthreads();
+            // LDS-only barrier: a __syncthreads() would first drain vmcnt, i.e. wait for the planes just requested (the whole point of
+            // requesting them ahead); the exchange is double buffered by plane parity, so one barrier per plane suffices
+            lds_barrier();
             if (work) {
                 QuadD m; QuadValues sv;
                 m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
-                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hd_lo; sv.ym = h_lo; } } else { m.ym = 0; sv.ym = zero4; }
-                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hd_hi; sv.yp = h_hi; } } else { m.yp = 0; sv.yp = zero4; }
-                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = gdxm; sv.xm = gxm; } } else { m.xm = 0; sv.xm = 0.f; }
-                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = gdxp; sv.xp = gxp; } } else { m.xp = 0; sv.xp = 0.f; }
+                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = hc.lo; } } else { m.ym = 0; sv.ym = zero4; }
+                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = hc.hi; } } else { m.yp = 0; sv.yp = zero4; }
+                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = hc.xm; } } else { m.xm = 0; sv.xm = 0.f; }
+                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = hc.xp; } } else { m.xp = 0; sv.xp = 0.f; }
                 float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -114,10 +135,10 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
                     emax = fmaxf(emax, fabsf(res));
                     acc += precond_zero(res, (float)(dv & 7)) * res;
                 }
-                *reinterpret_cast<float4*>(p + base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-                *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                st4s<NT>(p + base, make_float4(pp[0], pp[1], pp[2], pp[3]));
+                st4s<NT>(r + base, make_float4(rr[0], rr[1], rr[2], rr[3]));
             }
-            s_m = s_c; s_c = s_p; s_p = s_n; d_m = d_c; d_c = d_p; d_p = d_n; pc = pn; rc = rn;
+            s_m = s_c; s_c = s_p; s_p = s_n; d_m = d_c; d_c = d_p; d_p = d_n; pc = pn; rc = rn; hc = hn;
         }
         __syncthreads();   // the LDS buffers are reused by the next tile
     }
@@ -128,7 +149,7 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
 
 // ---- KD: [convergence test] beta; s = M^-1 r + beta s; partial s.As  (pressure_update_search.comp + pressure_apply_coeff.comp)
 // Registers hold s_new of planes z-1, z, z+1; s_new of a plane is computed (and written to s_out) when the plane enters.
-template <int T, bool FIRST>
+template <int T, bool FIRST, bool NT = false>
 __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
                                                  float* __restrict__ s_out, const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
                                                  const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
@@ -167,9 +188,22 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
             if (FIRST) return so;
             if (!any_fluid_d(dq)) return zero4;
             const float4 n = snew4(dq, rr, so, beta);
-            if (own) *reinterpret_cast<float4*>(s_out + b) = sel4(dq, n, so);
+            if (own) st4s<NT>(s_out + b, sel4(dq, n, so));
             return n;
         };
+        // raw tile-edge values (converted to s_new when they are used), fetched one plane ahead: see k_pcg_update_z
+        struct Halo { float4 s_lo, s_hi, r_lo, r_hi; uint32_t dlo, dhi; float sxm, sxp, rxm, rxp; int dxm, dxp; };
+        auto load_halo = [&](int base, bool cond) -> Halo {
+            Halo h; h.s_lo = zero4; h.s_hi = zero4; h.r_lo = zero4; h.r_hi = zero4; h.dlo = 0; h.dhi = 0; h.sxm = 0.f; h.sxp = 0.f; h.rxm = 0.f; h.rxp = 0.f; h.dxm = 0; h.dxp = 0;
+            if (cond) {
+                if (edge_lo && !in_lo) { h.dlo = *reinterpret_cast<const uint32_t*>(dvol + base - g.nx); h.s_lo = ld4(s_in + base - g.nx); if (!FIRST) h.r_lo = ld4(r + base - g.nx); }
+                if (edge_hi && !in_hi) { h.dhi = *reinterpret_cast<const uint32_t*>(dvol + base + g.nx); h.s_hi = ld4(s_in + base + g.nx); if (!FIRST) h.r_hi = ld4(r + base + g.nx); }
+                if (xm_glob) { h.dxm = dvol[base - 1]; h.sxm = s_in[base - 1]; if (!FIRST) h.rxm = r[base - 1]; }
+                if (xp_glob) { h.dxp = dvol[base + 4]; h.sxp = s_in[base + 4]; if (!FIRST) h.rxp = r[base + 4]; }
+            }
+            return h;
+        };
+        Halo hc = load_halo(0, false);
         if (valid) {
             const int b0 = z_begin * plane + row_base;
             d_c = *reinterpret_cast<const uint32_t*>(dvol + b0);
@@ -179,11 +213,13 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
                 d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane);
                 n_p = enter_plane(b0 + plane, d_p, FIRST ? zero4 : ld4(r + b0 + plane), ld4(s_in + b0 + plane), z_begin + 1 < z_end);
             }
+            hc = load_halo(b0, any_fluid_d(d_c));
         }
         for (int z = z_begin; z < z_end; ++z) {
             const int base = z * plane + row_base;
             const int buf = z & 1;
-            // raw loads of plane z+2 are issued now and consumed after this plane's compute
+            // raw loads of plane z+2 are issued now and consumed after this plane's compute (requesting them a whole iteration earlier
+            // was measured slower: 55.4 vs 52.7 us at 256^3 -- the kernel is not waiting on these loads)
             const bool fetch = valid && z + 1 < z_end && z + 2 < g.nz;
             uint32_t d_n = 0; float4 r_n = zero4, so_n = zero4;
             if (fetch) {
@@ -191,25 +227,17 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
                 so_n = ld4(s_in + base + 2 * plane);
                 if (!FIRST) r_n = ld4(r + base + 2 * plane);
             }
+            const Halo hn = load_halo(base + plane, valid && z + 1 < z_end && any_fluid_d(d_p));
             const bool work = valid && any_fluid_d(d_c);
-            float4 h_lo = zero4, h_hi = zero4, hr_lo = zero4, hr_hi = zero4;
-            uint32_t hd_lo = 0, hd_hi = 0;
-            float gxm = 0.f, gxp = 0.f, grxm = 0.f, grxp = 0.f; int gdxm = 0, gdxp = 0;
-            if (work) {   // raw halo values (converted to s_new after the barrier)
-                if (edge_lo && !in_lo) { hd_lo = *reinterpret_cast<const uint32_t*>(dvol + base - g.nx); h_lo = ld4(s_in + base - g.nx); if (!FIRST) hr_lo = ld4(r + base - g.nx); }
-                if (edge_hi && !in_hi) { hd_hi = *reinterpret_cast<const uint32_t*>(dvol + base + g.nx); h_hi = ld4(s_in + base + g.nx); if (!FIRST) hr_hi = ld4(r + base + g.nx); }
-                if (xm_glob) { gdxm = dvol[base - 1]; gxm = s_in[base - 1]; if (!FIRST) grxm = r[base - 1]; }
-                if (xp_glob) { gdxp = dvol[base + 4]; gxp = s_in[base + 4]; if (!FIRST) grxp = r[base + 4]; }
-            }
             ls[buf][t] = n_c; ld[buf][t] = d_c;
-            __syncthreads();
+            lds_barrier();   // (see k_pcg_update_z)
             if (work) {
                 QuadD m; QuadValues sv;
                 m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
-                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hd_lo; sv.ym = FIRST ? h_lo : snew4(hd_lo, hr_lo, h_lo, beta); } } else { m.ym = 0; sv.ym = zero4; }
-                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hd_hi; sv.yp = FIRST ? h_hi : snew4(hd_hi, hr_hi, h_hi, beta); } } else { m.yp = 0; sv.yp = zero4; }
-                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = gdxm; sv.xm = FIRST ? gxm : snew_of(gdxm, grxm, gxm, beta); } } else { m.xm = 0; sv.xm = 0.f; }
-                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = gdxp; sv.xp = FIRST ? gxp : snew_of(gdxp, grxp, gxp, beta); } } else { m.xp = 0; sv.xp = 0.f; }
+                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = FIRST ? hc.s_lo : snew4(hc.dlo, hc.r_lo, hc.s_lo, beta); } } else { m.ym = 0; sv.ym = zero4; }
+                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = FIRST ? hc.s_hi : snew4(hc.dhi, hc.r_hi, hc.s_hi, beta); } } else { m.yp = 0; sv.yp = zero4; }
+                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = FIRST ? hc.sxm : snew_of(hc.dxm, hc.rxm, hc.sxm, beta); } } else { m.xm = 0; sv.xm = 0.f; }
+                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = FIRST ? hc.sxp : snew_of(hc.dxp, hc.rxp, hc.sxp, beta); } } else { m.xp = 0; sv.xp = 0.f; }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (dbyte(d_c, j) & 0x80) acc += f4(n_c, j) * quad_mulA_d(m, sv, j);
@@ -217,7 +245,7 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
             // plane z+2 enters (its loads have been in flight during the compute above)
             float4 n_n = zero4;
             if (fetch) n_n = enter_plane(base + 2 * plane, d_n, r_n, so_n, z + 2 < z_end);
-            n_m = n_c; n_c = n_p; n_p = n_n; d_m = d_c; d_c = d_p; d_p = d_n;
+            n_m = n_c; n_c = n_p; n_p = n_n; d_m = d_c; d_c = d_p; d_p = d_n; hc = hn;
         }
         __syncthreads();
     }
