@@ -41,7 +41,8 @@ def main(size, d, stats_csv, out):
         wr = write.get(k, (0.0, 0))[0]
         tr = 2 * fr + wr
         us = dur.get(k, (float("nan"), 0))[0]
-        a = alg.get(base) if ("false" in k or base == "k_pcg_update_z") else None
+        args = [v.strip() for v in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+        a = alg.get(base) if (base == "k_pcg_update_z" or (base == "k_pcg_dir_z" and len(args) > 1 and args[1] == "false")) else None   # (dir<.., true, ..> = iteration 0: no r, no store)
         lines.append("%-30s %6d  %7.2f  %10.1f  %9.1f  %9.1f  %10.1f  %14s  %10s  %8s  %s" % (
             k[:30], nl, us, fr / 1e6, 2 * fr / 1e6, wr / 1e6, tr / 1e6, "%.1f" % (a / 1e6) if a else "--", "%.3f" % (tr / a) if a else "--",
             "%.0f" % (a / us / 1e3) if a else "--", "%.3f" % (a / us / 1e3 / 8000.0) if a else "--"))
