@@ -384,7 +384,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             float* Q[2] = {h->aux_temp, h->cgbuf[2]};
             float4* part[2] = {h->part4, h->part4 + PCG_GRID_MAX};
             Pcg1Scalars* sc = h->pcg1_scalars[which];
-            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, np, part[0]);
+            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, np, part[0], 1);
             static const int early = getenv("BLUB_PCG1_EARLY") ? atoi(getenv("BLUB_PCG1_EARLY")) : 1;   // (tuning switch, see k_pcg1_iter_s)
 #define BLUB_LAUNCH_K(FIRSTV, ...)                                                                                    \
     do {                                                                                                              \

@@ -96,7 +96,7 @@ __device__ __forceinline__ bool pcg1_prologue_finish(const Pcg1PrologueLoads& L,
 // w_0 = A u_0 (u_0 = M^-1 r_0 was written to the search volume by k_pcg_init_b) + partials {gamma_0 (block 0 only), delta_0, 0}
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                              const uint8_t* __restrict__ dvol, const float* __restrict__ u, float* __restrict__ w_out,
-                                                             const float2* __restrict__ part_init, int num_part, float4* __restrict__ part_out) {
+                                                             const float2* __restrict__ part_init, int num_part, float4* __restrict__ part_out, int gamma_owner) {
     __shared__ float sm[8];
     __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const
         __syncthreads();
     }
     const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
-    if (threadIdx.x == 0) part_out[blockIdx.x] = make_float4(blockIdx.x == 0 ? red0.x : 0.0f, tot, 0.0f, 0.0f);
+    // gamma_0 (already reduced over ALL partials of the init kernels) enters the partial array exactly once: block 0 of the one
+    // domain, or of the first slab of a z-slab group
+    if (threadIdx.x == 0) part_out[blockIdx.x] = make_float4((blockIdx.x == 0 && gamma_owner) ? red0.x : 0.0f, tot, 0.0f, 0.0f);
 }
 
 // Raw loads of one brick's face-halo tile for K(i), held in registers: two passes over the 240 interior quads (thread t takes

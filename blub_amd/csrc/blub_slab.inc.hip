@@ -22,12 +22,13 @@ struct blub_slab_group {
     int device = 0;
     uint32_t capacity = 0;            // particle capacity of every slab and of the transfer buffers
     struct Extra {
-        float4 *pos_new = nullptr, *pvel_new[3] = {nullptr, nullptr, nullptr};
+        uint32_t *leave_idx = nullptr, *hole_idx = nullptr, *fill_idx = nullptr;   // in-place migration (blub_slab.hip.h: k_slab_migrate_*)
         float4 *up[4] = {nullptr, nullptr, nullptr, nullptr}, *dn[4] = {nullptr, nullptr, nullptr, nullptr};   // send buffers: pos, vx, vy, vz
         blubk::SlabCounts* counts = nullptr;     // device
         uint32_t* recv_counts = nullptr;         // device: {from below, from above}
         float* gat_dir = nullptr;                // device: nranks x SLAB_NP partials of s.As (own segment written by the direction kernel)
         float2* gat_upd = nullptr;               // device: nranks x SLAB_NP partials {(M^-1 r).r, max|r|} (own segment written by init / update)
+        float4* gat4[2] = {nullptr, nullptr};    // device: nranks x SLAB_NP partials {gamma, delta, max|r|} of the single-reduction schedule, by iteration parity
     };
     std::vector<Extra> ex;
     blubk::SlabCounts* counts_host = nullptr;    // pinned, one per local slab
@@ -35,6 +36,7 @@ struct blub_slab_group {
     blubk::PcgCtrl* ctrl_host = nullptr;         // pinned: control block of slab 0's solves [velocity, density], read only after a stream sync
     bool ctrl_host_valid[2] = {false, false};
     uint64_t comm_ops = 0;                       // grouped transport operations issued so far (diagnostics)
+    blubk::SlabCopyList copies{};                // loopback transport: plane copies collected for one batched launch
     int gather_mode = 0;                         // RCCL only: 0 = partials as p2p inside the halo's group, 1 = ncclAllGather (calibrated at creation)
     char transport[192] = "loopback";
 };
@@ -48,6 +50,31 @@ namespace blub {
     } while (0)
 
 enum { XFER_GHOST_FULL = 0, XFER_GHOST_POS = 1, XFER_MIGRATE = 2 };
+
+// loopback transport: device-to-device plane copies are collected and issued as ONE kernel per exchange
+static int slab_copy_flush(blub_slab_group* G) {
+    if (G->copies.n == 0) return BLUB_OK;
+    uint32_t mx = 0;
+    for (int k = 0; k < G->copies.n; ++k) mx = std::max(mx, G->copies.c[k].bytes);
+    const unsigned bx = std::max(1u, std::min(64u, (mx / 16u + 255u) / 256u));
+    hipLaunchKernelGGL(blubk::k_slab_copy_planes, dim3(bx, (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies);
+    G->copies.n = 0;
+    return BLUB_OK;
+}
+static int slab_copy(blub_slab_group* G, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return BLUB_OK;
+    if (bytes % 16 != 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15) || bytes > 0xFFFFFFF0u) {
+        int rc = slab_copy_flush(G);
+        if (rc != BLUB_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, G->stream));
+        return BLUB_OK;
+    }
+    if (G->copies.n == blubk::SLAB_COPY_MAX) { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
+    blubk::SlabCopy& c = G->copies.c[G->copies.n];
+    c.src = src; c.dst = dst; c.bytes = (uint32_t)bytes; c.pad = 0;
+    G->copies.n += 1;
+    return BLUB_OK;
+}
 
 static bool has_up(const blub_slab_group* G, int i) { return G->first + i + 1 < G->nranks; }
 static bool has_down(const blub_slab_group* G, int i) { return G->first + i > 0; }
@@ -68,8 +95,8 @@ static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(b
             if (has_up(G, i)) {
                 if (up_local(G, i)) {
                     char* nb = (char*)f(G->slabs[i + 1]);
-                    HIP_TRY(hipMemcpyAsync(nb + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb, hipMemcpyDeviceToDevice, G->stream));
-                    HIP_TRY(hipMemcpyAsync(base + (size_t)h->slab_z1 * pb, nb + (size_t)h->slab_z1 * pb, pb, hipMemcpyDeviceToDevice, G->stream));
+                    { int rc = slab_copy(G, nb + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (rc != BLUB_OK) return rc; }
+                    { int rc = slab_copy(G, base + (size_t)h->slab_z1 * pb, nb + (size_t)h->slab_z1 * pb, pb); if (rc != BLUB_OK) return rc; }
                 } else {
                     NCCL_TRY(ncclSend(base + (size_t)(h->slab_z1 - 1) * pb, pb, ncclChar, G->first + i + 1, G->comm, G->stream));
                     NCCL_TRY(ncclRecv(base + (size_t)h->slab_z1 * pb, pb, ncclChar, G->first + i + 1, G->comm, G->stream));
@@ -82,7 +109,7 @@ static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(b
         }
     }
     if (G->rccl && own_group) NCCL_TRY(ncclGroupEnd());
-    return BLUB_OK;
+    return own_group ? slab_copy_flush(G) : BLUB_OK;   // (inside slab_fused the caller flushes)
 }
 static int slab_halo_velocity(blub_slab_group* G) {
     return slab_halo(G, {[](blub_fluid* h) { return (void*)h->vel[0]; }, [](blub_fluid* h) { return (void*)h->vel[1]; }, [](blub_fluid* h) { return (void*)h->vel[2]; }}, 4);
@@ -92,11 +119,15 @@ static int slab_halo_velocity(blub_slab_group* G) {
 static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& array_of, int seg_floats, bool own_group = true) {
     if (G->nranks == 1) return BLUB_OK;
     if (own_group) G->comm_ops += 1;
-    if (!G->rccl) {
-        blubk::SlabPtrs ptrs{};
-        for (size_t i = 0; i < G->slabs.size(); ++i) ptrs.p[i] = array_of((int)i);
-        hipLaunchKernelGGL(blubk::k_slab_gather_local, dim3((unsigned)G->slabs.size()), dim3(256), 0, G->stream, ptrs, (int)G->slabs.size(), seg_floats);
-        return BLUB_OK;
+    if (!G->rccl) {   // loopback: segment s of slab s's array into every other slab's array, batched with the plane copies of the same exchange
+        const int S = (int)G->slabs.size();
+        for (int sidx = 0; sidx < S; ++sidx)
+            for (int d = 0; d < S; ++d) {
+                if (d == sidx) continue;
+                int rc = slab_copy(G, array_of(d) + (size_t)sidx * seg_floats, array_of(sidx) + (size_t)sidx * seg_floats, (size_t)seg_floats * sizeof(float));
+                if (rc != BLUB_OK) return rc;
+            }
+        return own_group ? slab_copy_flush(G) : BLUB_OK;
     }
     float* arr = array_of(0);
     if (G->gather_mode == 1) {   // (never inside a p2p group: see slab_fused)
@@ -120,6 +151,7 @@ static int slab_fused(blub_slab_group* G, const std::function<int()>& halos, con
     if (G->rccl) NCCL_TRY(ncclGroupStart());
     if ((rc = halos()) != BLUB_OK) return rc;
     if (!split && (rc = gather(false)) != BLUB_OK) return rc;
+    if ((rc = slab_copy_flush(G)) != BLUB_OK) return rc;      // loopback: planes + partial segments in one launch
     if (G->rccl) NCCL_TRY(ncclGroupEnd());
     if (split) { G->comm_ops += 1; if ((rc = gather(false)) != BLUB_OK) return rc; }
     return BLUB_OK;
@@ -136,9 +168,13 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
         const uint32_t n = h->num_particles;
         if (!n) continue;
         if (mode == XFER_MIGRATE) {
-            hipLaunchKernelGGL(blubk::k_slab_partition, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
-                               (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.pos_new, e.pvel_new[0], e.pvel_new[1], e.pvel_new[2],
-                               e.up[0], e.up[1], e.up[2], e.up[3], e.dn[0], e.dn[1], e.dn[2], e.dn[3]);
+            hipLaunchKernelGGL(blubk::k_slab_migrate_mark, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                               (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.up[0], e.up[1], e.up[2], e.up[3], e.dn[0], e.dn[1], e.dn[2], e.dn[3], e.leave_idx);
+            // (grids cover the worst case -- every particle leaves --; blocks beyond the device-side counts exit at once)
+            hipLaunchKernelGGL(blubk::k_slab_migrate_match, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (float)h->slab_z0, (float)h->slab_z1, e.counts,
+                               (const uint32_t*)e.leave_idx, e.hole_idx, e.fill_idx);
+            hipLaunchKernelGGL(blubk::k_slab_migrate_fill, dim3(particle_blocks(n)), dim3(256), 0, G->stream, (const blubk::SlabCounts*)e.counts, (const uint32_t*)e.hole_idx,
+                               (const uint32_t*)e.fill_idx, h->pos, h->pvel[0], h->pvel[1], h->pvel[2]);
         } else {
             if (has_up(G, i))
                 hipLaunchKernelGGL(blubk::k_slab_select, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
@@ -171,8 +207,6 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
             blub_fluid* h = G->slabs[i];
             auto& e = G->ex[i];
             if (!h->num_particles) continue;
-            std::swap(h->pos, e.pos_new);
-            for (int c = 0; c < 3; ++c) std::swap(h->pvel[c], e.pvel_new[c]);
             h->num_particles = G->counts_host[i].n_stay;
         }
     // payload
@@ -223,10 +257,12 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
 // adds one check interval at a time until the solve is finished.  Every rank sees bit-identical control blocks (same
 // partials, same reduction order), and the previous iteration count is only taken from a read-back that a stream
 // synchronisation has completed on every rank, so all ranks issue the same sequence of transport operations.
+static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt);
 static int slab_solve(blub_slab_group* G, int which, float dt) {
     const int S = (int)G->slabs.size();
     blub_fluid* h0 = G->slabs[0];
     if (h0->precond_mode != BLUB_PRECOND_ZERO) return set_error(BLUB_ERR_UNSUPPORTED, "z-slab groups support the default preconditioner reading only");
+    if (h0->pcg_schedule == 1) return slab_solve_single_reduction(G, which, dt);
     const blub_solver_config c = h0->cfg[which];
     const float tol = c.error_tolerance / dt;
     const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
@@ -300,6 +336,112 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     return slab_halo(G, {[w](blub_fluid* h) { return (void*)h->pressure[w]; }}, 4);
 }
 
+// The same solve with the single-reduction schedule (blub_pcg1.hip.h): ONE kernel and ONE grouped transport operation per iteration
+// -- the w = A M^-1 r plane to the z-neighbours together with the {gamma, delta, max|r|} partials to every slab.  r and q of the
+// ghost planes are recomputed locally (HALO variant of k_pcg1_iter_s), exactly like s in the two-kernel schedule.
+static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) {
+    const int S = (int)G->slabs.size();
+    blub_fluid* h0 = G->slabs[0];
+    const blub_solver_config c = h0->cfg[which];
+    const float tol = c.error_tolerance / dt;
+    const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
+    auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };
+    const int np = SLAB_NP, npall = SLAB_NP * G->nranks;
+    const dim3 grid(np), block(PCG_B_THREADS);
+    int rc;
+    auto seg_upd = [&](int i) { return G->ex[i].gat_upd + (size_t)(G->first + i) * np; };
+    auto seg4 = [&](int i, int par) { return G->ex[i].gat4[par] + (size_t)(G->first + i) * np; };
+    auto gather_upd = [&](bool own_group) { return slab_gather(G, [G](int i) { return reinterpret_cast<float*>(G->ex[i].gat_upd); }, 2 * np, own_group); };
+    int target = maxit + 1;
+    if (freq > 0 && G->ctrl_host_valid[which]) {
+        const int prev = (int)G->ctrl_host[which].num_iter;
+        if (prev >= 0 && prev < maxit) target = std::min(maxit + 1, (prev / freq) * freq + 2);
+    }
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        if ((rc = ensure_pcg1_buffers(h)) != BLUB_OK) return rc;
+        if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
+        h->solve_seq[which] += 1;
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
+               seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr);
+    }
+    // descriptor, r_0 and u_0 = M^-1 r_0 planes and the gamma_0 partials: one grouped operation
+    if ((rc = slab_fused(G, [&]() -> int {
+            int r2 = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1, false);
+            return r2 != BLUB_OK ? r2 : slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }, [](blub_fluid* h) { return (void*)h->search; }}, 4, false);
+        }, gather_upd)) != BLUB_OK) return rc;
+    // per-slab buffer roles of this solve (see stage_solve)
+    struct Bufs { float* R[2]; float* W[2]; float* Q[2]; };
+    std::vector<Bufs> B(S);
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        B[i] = Bufs{{h->residual, h->cgbuf[0]}, {h->aux, h->cgbuf[1]}, {h->aux_temp, h->cgbuf[2]}};
+        LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
+               seg4(i, 0), (int)(G->first + i == 0));
+    }
+    auto exchange = [&](int wpar, int ppar) -> int {   // plane of W[wpar] to the z-neighbours + partials of parity ppar to every slab
+        return slab_fused(G, [&]() -> int {
+            // (the volumes differ per slab: pass the slab index through a per-call table)
+            const blub_fluid* h0l = G->slabs[0];
+            const size_t pb = (size_t)h0l->g.nx * h0l->g.ny * sizeof(float);
+            for (int i = 0; i < S; ++i) {
+                blub_fluid* h = G->slabs[i];
+                char* base = (char*)B[i].W[wpar];
+                if (has_up(G, i)) {
+                    if (up_local(G, i)) {
+                        char* nb = (char*)B[i + 1].W[wpar];
+                        { int r3 = slab_copy(G, nb + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (r3 != BLUB_OK) return r3; }
+                        { int r3 = slab_copy(G, base + (size_t)h->slab_z1 * pb, nb + (size_t)h->slab_z1 * pb, pb); if (r3 != BLUB_OK) return r3; }
+                    } else {
+                        NCCL_TRY(ncclSend(base + (size_t)(h->slab_z1 - 1) * pb, pb, ncclChar, G->first + i + 1, G->comm, G->stream));
+                        NCCL_TRY(ncclRecv(base + (size_t)h->slab_z1 * pb, pb, ncclChar, G->first + i + 1, G->comm, G->stream));
+                    }
+                }
+                if (has_down(G, i) && !down_local(G, i)) {
+                    NCCL_TRY(ncclSend(base + (size_t)h->slab_z0 * pb, pb, ncclChar, G->first + i - 1, G->comm, G->stream));
+                    NCCL_TRY(ncclRecv(base + (size_t)(h->slab_z0 - 1) * pb, pb, ncclChar, G->first + i - 1, G->comm, G->stream));
+                }
+            }
+            return BLUB_OK;
+        }, [&](bool own_group) { return slab_gather(G, [G, ppar](int i) { return reinterpret_cast<float*>(G->ex[i].gat4[ppar]); }, 4 * np, own_group); });
+    };
+    if ((rc = exchange(0, 0)) != BLUB_OK) return rc;
+    int it = 0;
+    for (;;) {
+        for (; it < target; ++it) {
+            for (int i = 0; i < S; ++i) {
+                blub_fluid* h = G->slabs[i];
+                const int halo_lo = has_down(G, i) ? h->slab_z0 : -1, halo_hi = has_up(G, i) ? h->slab_z1 - 1 : -1;
+                const float4* pin = G->ex[i].gat4[it & 1];
+                float4* pout = seg4(i, (it + 1) & 1);
+                if (it == 0)
+                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true, true, 1, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)B[i].R[0], B[i].R[1], (const float*)B[i].W[0],
+                           B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi);
+                else
+                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false, true, 1, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)B[i].R[it & 1], B[i].R[(it + 1) & 1],
+                           (const float*)B[i].W[it & 1], B[i].W[(it + 1) & 1], (const float*)B[i].Q[(it + 1) & 1], B[i].Q[it & 1], h->search, h->pressure[which], pin, pout, npall,
+                           h->ctrl[which], h->pcg1_scalars[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi);
+            }
+            if ((rc = exchange((it + 1) & 1, (it + 1) & 1)) != BLUB_OK) return rc;
+        }
+        if (target > maxit) break;
+        HIP_TRY(hipMemcpyAsync(&G->ctrl_host[which], h0->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, G->stream));
+        HIP_TRY(hipStreamSynchronize(G->stream));
+        if (G->ctrl_host[which].done != 0) break;
+        target = std::min(maxit + 1, target + freq);
+    }
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
+        if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
+        if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(&G->ctrl_host[which], h0->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, G->stream));
+    G->ctrl_host_valid[which] = true;
+    const int w = which;
+    return slab_halo(G, {[w](blub_fluid* h) { return (void*)h->pressure[w]; }}, 4);
+}
+
 // HybridFluid::step (hybrid_fluid.rs:770-977) over all slabs in lock step
 static int slab_step(blub_slab_group* G, float dt) {
     int rc;
@@ -354,8 +496,8 @@ static void slab_group_destroy(blub_slab_group* G) {
     if (G->stream) (void)hipStreamSynchronize(G->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     for (auto& e : G->ex) {
-        F(e.pos_new); for (auto p : e.pvel_new) F(p); for (auto p : e.up) F(p); for (auto p : e.dn) F(p);
-        F(e.counts); F(e.recv_counts); F(e.gat_dir); F(e.gat_upd);
+        F(e.leave_idx); F(e.hole_idx); F(e.fill_idx); for (auto p : e.up) F(p); for (auto p : e.dn) F(p);
+        F(e.counts); F(e.recv_counts); F(e.gat_dir); F(e.gat_upd); F(e.gat4[0]); F(e.gat4[1]);
     }
     for (auto h : G->slabs) destroy(h);
     if (G->counts_host) (void)hipHostFree(G->counts_host);
@@ -456,11 +598,11 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         blub_slab_group::Extra e;
         auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
         const size_t P = G->capacity;
-        A(dev_alloc_zero(G->stream, &e.pos_new, P));
-        for (int c = 0; c < 3; ++c) A(dev_alloc_zero(G->stream, &e.pvel_new[c], P));
+        A(dev_alloc_zero(G->stream, &e.leave_idx, P)); A(dev_alloc_zero(G->stream, &e.hole_idx, P)); A(dev_alloc_zero(G->stream, &e.fill_idx, P));
         for (int k = 0; k < 4; ++k) { A(dev_alloc_zero(G->stream, &e.up[k], P)); A(dev_alloc_zero(G->stream, &e.dn[k], P)); }
         A(dev_alloc_zero(G->stream, &e.counts, 1)); A(dev_alloc_zero(G->stream, &e.recv_counts, 2));
         A(dev_alloc_zero(G->stream, &e.gat_dir, (size_t)nranks * blubk::SLAB_NP)); A(dev_alloc_zero(G->stream, &e.gat_upd, (size_t)nranks * blubk::SLAB_NP));
+        A(dev_alloc_zero(G->stream, &e.gat4[0], (size_t)nranks * blubk::SLAB_NP)); A(dev_alloc_zero(G->stream, &e.gat4[1], (size_t)nranks * blubk::SLAB_NP));
         G->ex.push_back(e);
     }
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->counts_host, nlocal * sizeof(blubk::SlabCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
@@ -552,6 +694,11 @@ int blub_slab_group_set_gravity_grid(blub_slab_group* g, const float gr[3]) { if
 int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_solver_config* cfg) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     for (auto h : g->slabs) { int rc = blub_fluid_set_solver_config(h, which, cfg); if (rc != BLUB_OK) return rc; }
+    return BLUB_OK;
+}
+int blub_slab_group_set_pcg_schedule(blub_slab_group* g, int mode) {   // every rank must pass the same mode
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    for (auto h : g->slabs) { int rc = blub_fluid_set_pcg_schedule(h, mode); if (rc != BLUB_OK) return rc; }
     return BLUB_OK;
 }
 int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t f) { if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); for (auto h : g->slabs) h->rebin_freq = f; return BLUB_OK; }

@@ -614,6 +614,7 @@ class SlabGroup:
                 ("blub_slab_group_get_particles", C.c_int, [vp, vp, vp, vp, vp]), ("blub_slab_group_set_gravity_grid", C.c_int, [vp, vp]),
                 ("blub_slab_group_set_solver_config", C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
                 ("blub_slab_group_set_rebinning_frequency", C.c_int, [vp, C.c_uint32]),
+                ("blub_slab_group_set_pcg_schedule", C.c_int, [vp, C.c_int]),
                 ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
                 ("blub_slab_group_transport_ops", C.c_uint64, [vp]), ("blub_slab_group_transport_description", C.c_char_p, [vp]),
                 ("blub_slab_group_set_meshes", C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
@@ -711,6 +712,10 @@ class SlabGroup:
 
     def set_rebinning_frequency(self, f):
         _check(self._L, self._L.blub_slab_group_set_rebinning_frequency(self._g, int(f)))
+
+    def set_pcg_schedule(self, mode):
+        """"reference" | "single_reduction" on every local slab (all ranks must pass the same mode)"""
+        _check(self._L, self._L.blub_slab_group_set_pcg_schedule(self._g, {"reference": 0, "single_reduction": 1}[mode]))
 
     def step(self, simulation_delta):
         _check(self._L, self._L.blub_slab_group_step(self._g, float(simulation_delta)))

@@ -329,6 +329,7 @@ int blub_slab_group_get_particles(blub_slab_group* g, float* pos_ll, float* vx, 
 int blub_slab_group_set_gravity_grid(blub_slab_group* g, const float gravity_grid[3]);
 int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_solver_config* cfg);
 int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t every_n_steps);
+int blub_slab_group_set_pcg_schedule(blub_slab_group* g, int mode);   /* blub_fluid_set_pcg_schedule on every local slab; all ranks must agree */
 /* static objects (see blub_fluid_set_meshes / blub_fluid_voxelize): every local slab voxelises the meshes in global grid coordinates */
 int blub_slab_group_set_meshes(blub_slab_group* g, uint32_t num_vertices, const float* positions_xyz, uint32_t num_indices, const uint32_t* indices);
 int blub_slab_group_voxelize(blub_slab_group* g, uint32_t num_meshes, const blub_mesh_desc* meshes);

@@ -467,7 +467,8 @@ def test_z_slab_decomposition_matches_single_domain(slabs):
         group.close()
 
 
-def test_z_slab_solve_follows_convergence():
+@pytest.mark.parametrize("schedule", ["single_reduction", "reference"])
+def test_z_slab_solve_follows_convergence(schedule):
     """The slab solve launches iterations through the check that ended the previous solve, looks at `done` and extends by
     one check interval at a time (blub_slab.inc.hip: slab_solve).  With the reference's solver defaults the group must report
     the same iteration counts as the single-domain engine (within one check interval: the dot products are summed in a
@@ -480,8 +481,12 @@ def test_z_slab_solve_follows_convergence():
     pos = (cells[:, None, :] + rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
     single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     group = blub_amd.SlabGroup(dim, pos.shape[0], local=3, binning="off")
+    # transport operations of one solve with k launched iterations: init exchange (+ the w_0 exchange of the single-reduction
+    # schedule), per iteration ONE grouped operation (single reduction) or TWO (reference schedule), the pressure halo
+    solve_ops = (lambda k: 2 + k + 1) if schedule == "single_reduction" else (lambda k: 1 + 2 * k + 1)
     try:
         for f in (single, group):
+            f.set_pcg_schedule(schedule)
             f.set_gravity_grid((0.0, -9.81 / 0.01, 0.0))
             f.set_particles(pos)
         ops = []
@@ -496,7 +501,7 @@ def test_z_slab_solve_follows_convergence():
         slab_fluids = [group.local_fluid(i) for i in range(3)]
         for f in slab_fluids:
             f.update_statistics()
-        full = 4 * 2 + 5 + 2 * (1 + 2 * 33 + 1)      # particle exchanges, velocity halos, 2 solves of 33 iterations
+        full = 4 * 2 + 5 + 2 * solve_ops(33)      # particle exchanges, velocity halos, 2 solves of 33 iterations
         assert ops[0] == full, (ops, full)           # first step: no previous iteration count
         hist = lambda f, w: [x.iteration_count for x in (f.pressure_solver_stats_velocity() if w == 0 else f.pressure_solver_stats_density())]
         its = []
@@ -510,7 +515,7 @@ def test_z_slab_solve_follows_convergence():
             assert len(it_g) == 6 and len(it_s) == 6 and all(abs(a - b) <= 4 for a, b in zip(it_s, it_g)), (it_s, it_g)
             assert all(0 < x <= 32 for x in it_g)
         for step in range(1, 6):   # launched per solve = iterations through the later of {previous, this} deciding check + its detection
-            need = 4 * 2 + 5 + sum(1 + 2 * min(33, max(its[w][step], its[w][step - 1]) + 2) + 1 for w in (0, 1))
+            need = 4 * 2 + 5 + sum(solve_ops(min(33, max(its[w][step], its[w][step - 1]) + 2)) for w in (0, 1))
             assert ops[step] == need, (step, ops, need, its)
         d = _match_particles(group.get_particles()[0][:, :3].astype(np.float64), single.get_particles()[0][:, :3].astype(np.float64))
         assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 2e-2, (np.median(d), np.quantile(d, 0.99), d.max())
