@@ -205,7 +205,6 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
     if (mode == XFER_MIGRATE)
         for (int i = 0; i < S; ++i) {
             blub_fluid* h = G->slabs[i];
-            auto& e = G->ex[i];
             if (!h->num_particles) continue;
             h->num_particles = G->counts_host[i].n_stay;
         }
@@ -503,7 +502,7 @@ static void slab_group_destroy(blub_slab_group* G) {
     if (G->counts_host) (void)hipHostFree(G->counts_host);
     if (G->recv_host) (void)hipHostFree(G->recv_host);
     if (G->ctrl_host) (void)hipHostFree(G->ctrl_host);
-    if (G->comm) (void)ncclCommDestroy(G->comm);
+    if (G->comm) (void)ncclCommDestroy(G->comm);   // (nullptr after an abort)
     if (G->stream) (void)hipStreamDestroy(G->stream);
     delete G;
 }
@@ -716,7 +715,17 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
-    return blub::slab_step(g, dt);
+    if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
+    const int rc = blub::slab_step(g, dt);
+    if (rc != BLUB_OK && g->rccl && g->comm) {
+        // A rank that leaves the lock-step sequence (buffer overflow, a failed HIP / RCCL call) must not leave its peers blocked inside
+        // their next grouped send / receive: aborting the communicator makes their pending operations fail, so every rank returns an error.
+        const std::string keep = blub::g_last_error;
+        (void)ncclCommAbort(g->comm);
+        g->comm = nullptr;
+        blub::g_last_error = keep + " (communicator aborted: the peers' pending transport operations fail instead of hanging)";
+    }
+    return rc;
 }
 uint64_t blub_slab_group_transport_ops(const blub_slab_group* g) { return g ? g->comm_ops : 0; }
 const char* blub_slab_group_transport_description(const blub_slab_group* g) { return g ? g->transport : ""; }
