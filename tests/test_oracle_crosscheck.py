@@ -315,3 +315,211 @@ def test_particle_correction_wall_truncation_is_literal():
     want = np.where((outside | in_solid)[:, None], cut, target)
     assert outside.sum() > 300 and (in_solid & ~outside).sum() > 50 and (~outside & ~in_solid).sum() > 500
     assert np.abs(got - want).max() < 5e-6
+
+
+# ---- second formulations for the kernels that had none ("weak" #1) ------------------------------------------------
+
+def _extrapolate_numpy(m, vel):
+    """extrapolate_velocity.comp:26-90, vectorised: for every non-FLUID cell g and component c whose +c neighbour is non-FLUID
+    too, the face value becomes the mean of the VALID faces (one side FLUID) among the 8 neighbours in the plane normal to c,
+    accumulated in f32 in the shader's order (offsets listed z-row by z-row / y-row by y-row); written only if any is valid."""
+    fluid = m == FLUID
+    out = [v.copy() for v in vel]
+    for c in range(3):
+        valid = fluid | _shift(fluid, c, +1, False)                       # isValidVelocity (:9-14); OOB marker reads SOLID
+        target = (~fluid) & (~_shift(fluid, c, +1, False))
+        others = [a for a in range(3) if a != c]                           # in-plane axes, the first one varies fastest in the shader's list
+        num = np.zeros(m.shape, np.float32)
+        acc = np.zeros(m.shape, np.float32)
+        for d1 in (-1, 0, 1):                                              # slower in-plane axis (z for c = x, y; y for c = z)
+            for d0 in (-1, 0, 1):
+                if d0 == 0 and d1 == 0:
+                    continue
+                vs, vv = valid, vel[c]
+                for axis, d in ((others[0], d0), (others[1], d1)):
+                    if d:
+                        vs, vv = _shift(vs, axis, d, False), _shift(vv, axis, d, np.float32(0))
+                num = num + vs.astype(np.float32)
+                acc = np.where(vs, acc + vv, acc).astype(np.float32)
+        write = target & (num > 0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out[c] = np.where(write, (acc / num).astype(np.float32), out[c])
+    return out
+
+
+def test_position_change_and_extrapolation_equal_vectorised_restatements():
+    """R2 (density_projection_position_change.comp:18-51): face (g, c) = (p[g + e_c] - p[g]) * dt with p = 0 outside FLUID and 0
+    if either side is SOLID -- every face of the grid is written; followed by D3 (extrapolate_velocity.comp) on the result.
+    Both in f32 with the shader's operation order: bit-exact against the oracle's `position_change` stage."""
+    rng = np.random.default_rng(21)
+    nx, ny, nz = DIM
+    m = _random_marker(rng)
+    p = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    o = Oracle(nx, ny, nz, 8)
+    o.write_volume("marker", m)
+    o.write_volume("pressure_density", p)
+    for n in ("vel_x", "vel_y", "vel_z"):
+        o.write_volume(n, rng.standard_normal((nz, ny, nx)).astype(np.float32))      # must be overwritten everywhere
+    o.run_stage("position_change", DT)
+    dt = np.float32(DT)
+    pf = np.where(m == FLUID, p, np.float32(0)).astype(np.float32)
+    r2 = []
+    for c in range(3):
+        m_n = _shift(m, c, +1, SOLID)
+        d = ((_shift(pf, c, +1, np.float32(0)) - pf) * dt).astype(np.float32)
+        r2.append(np.where((m == SOLID) | (m_n == SOLID), np.float32(0), d).astype(np.float32))
+    want = _extrapolate_numpy(m, r2)
+    changed = 0
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        got = o.read_volume(n)
+        assert np.array_equal(got.view(np.uint32), want[c].view(np.uint32)), n
+        changed += int((want[c] != r2[c]).sum())
+    assert changed > 300                                                           # the extrapolation did write faces
+
+
+def test_extrapolation_after_the_pressure_projection_equals_the_vectorised_restatement():
+    """D3 on the output of D2 with p = 0 (D2 then keeps v on valid faces, puts the solid's velocity on solid-sided ones and 0 on
+    faces without a FLUID side): the faces D3 may write are exactly those D2 zeroed."""
+    rng = np.random.default_rng(22)
+    nx, ny, nz = DIM
+    m = _random_marker(rng)
+    vel = [rng.standard_normal((nz, ny, nx)).astype(np.float32) for _ in range(3)]
+    o = Oracle(nx, ny, nz, 8)
+    o.write_volume("marker", m)
+    o.write_volume("pressure_velocity", np.zeros((nz, ny, nx), np.float32))
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        o.write_volume(n, vel[c])
+    o.run_stage("project", DT)
+    d2 = []
+    for c in range(3):
+        m_n = _shift(m, c, +1, SOLID)
+        touched = (m == FLUID) | (m_n == FLUID)
+        v = np.where(touched, vel[c], np.float32(0))
+        v = np.where(touched & ((m == SOLID) | (m_n == SOLID)), np.float32(0), v)      # no solid voxel volume: the solid's velocity is 0
+        d2.append(v.astype(np.float32))
+    want = _extrapolate_numpy(m, d2)
+    for c, n in enumerate(("vel_x", "vel_y", "vel_z")):
+        assert np.array_equal(o.read_volume(n).view(np.uint32), want[c].view(np.uint32)), n
+
+
+def _apply_A(m, x):
+    """pressure.glsl:34-75 in f64: (number of non-SOLID neighbours) * x - sum over FLUID neighbours, on FLUID cells."""
+    fluid = m == FLUID
+    xf = np.where(fluid, x, 0.0).astype(np.float64)
+    diag = np.zeros(m.shape)
+    nb = np.zeros(m.shape)
+    for c in range(3):
+        for d in (-1, 1):
+            diag += _shift(m, c, d, SOLID) != SOLID
+            nb += _shift(xf, c, d, 0.0) * _shift(fluid, c, d, False)
+    return np.where(fluid, diag * xf - nb, 0.0)
+
+
+def test_warm_start_initialisation_is_b_minus_A_p0():
+    """S0 (pressure_init.comp:45-83): p := 0 outside FLUID, r := b - A p0 with last step's pressure as warm start.  With
+    b = A p0 (f64, rounded to f32) the initial residual is rounding noise, so the solve must leave p0 (masked to FLUID) where it is
+    and report a vanishing error -- a wrong sign / diagonal / neighbour rule in S0 would send it off by O(|b|)."""
+    rng = np.random.default_rng(23)
+    nx, ny, nz = DIM
+    m = _random_marker(rng)
+    p0 = rng.standard_normal((nz, ny, nx)).astype(np.float32)                      # also garbage outside the fluid: must be zeroed
+    b = _apply_A(m, np.where(m == FLUID, p0, 0)).astype(np.float32)
+    o = Oracle(nx, ny, nz, 8)
+    o.write_volume("marker", m)
+    o.write_volume("pressure_velocity", p0)
+    o.write_volume("residual", b)
+    o.reset_pressure_cleared(0, True)                                              # not the first solve: keep the warm start (pressure_solver.rs:601-603)
+    o.set_solver_config(0, error_tolerance=0.0, max_num_iterations=6, error_check_frequency=2)
+    o.run_stage("solve_velocity", DT)
+    p = o.read_volume("pressure_velocity")
+    fluid = m == FLUID
+    assert np.all(p[~fluid] == 0)
+    assert np.abs(p[fluid] - p0[fluid]).max() < 2e-5
+    err, it = o.solver_stats(0)
+    assert it == 6 and err < 1e-5 * np.abs(b).max() * DT + 1e-7
+    # and the carried residual stays the true residual: r == b - A p (f64)
+    r = o.read_volume("residual").astype(np.float64)
+    assert np.abs(r[fluid] - (b.astype(np.float64) - _apply_A(m, p))[fluid]).max() < 1e-5
+
+
+def test_literal_binning_equals_a_numpy_emulation_of_the_three_shaders():
+    """Q4, from the shaders alone (particle_binning_count.comp:9-13, _prefixsum.comp:31-61, _rewrite_particles.comp:8-16,
+    hybrid_fluid.rs:871-891): ceil(P / 64) * 64 threads without a bounds check bin the zero records behind the live range too,
+    the destination `inclusive - slot` is 1-based (slot 0 is never written), and the WHOLE buffer is copied back.  Atomic orders
+    fixed like the oracle's (ascending thread / block index).  Compared record by record."""
+    dim = (24, 20, 16)
+    rng = np.random.default_rng(24)
+    cells = np.stack(np.meshgrid(np.arange(2, 12), np.arange(2, 10), np.arange(2, 9), indexing="ij"), -1).reshape(-1, 3)
+    pos = (cells[:, None, :] + rng.random((len(cells), 6, 3))).reshape(-1, 3).astype(np.float32)
+    pos = pos[rng.permutation(len(pos))][:3003]                                    # not a multiple of 64
+    n, cap = len(pos), len(pos) + 200
+    o = Oracle(*dim, cap)
+    o.set_quirks(binning="literal")
+    o.set_particles(pos)
+    o.run_stage("binning", DT)
+    got = o.get_particles()[0][:, :3]
+    T = (n + 63) // 64 * 64
+    old = np.zeros((cap, 3), np.float32)
+    old[:n] = pos
+    N = dim[0] * dim[1] * dim[2]
+    counts = np.zeros(N, np.int64)
+    slot = np.zeros(T, np.int64)
+    lin = np.zeros(T, np.int64)
+    for i in range(T):
+        c = old[i].astype(np.int64)                                               # ivec3(Position): truncation
+        lin[i] = (c[2] * dim[1] + c[1]) * dim[0] + c[0]                            # x fastest (particle_binning_prefixsum.comp:17-22)
+        slot[i] = counts[lin[i]]
+        counts[lin[i]] += 1
+    inclusive = np.cumsum(counts)
+    new = np.zeros((cap, 3), np.float32)                                           # the tmp buffer starts zero-initialised
+    for i in range(T):
+        d = inclusive[lin[i]] - slot[i]
+        if d < cap:                                                               # out-of-bounds stores are dropped
+            new[d] = old[i]
+    assert np.array_equal(got.view(np.uint32), new[:n].view(np.uint32))
+    rec = lambda a: np.sort(np.ascontiguousarray(a).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).reshape(-1), order=("x", "y", "z"))
+    lost = n - np.isin(rec(pos), rec(got)).sum()
+    assert lost == (T - n) + 1                                                     # pad + 1 live particles are replaced by zero records
+
+
+def test_reduced_precision_filter_weights_bound_the_particle_correction():
+    """R3 reads the position-change volumes through the hardware's LINEAR filter (density_projection_correct_particles.comp:32-40).
+    Real GPUs evaluate that filter with fixed-point weights -- 8 fractional bits is the common minimum (Vulkan: subTexelPrecisionBits
+    >= 4; D3D requires 8) -- while the oracle (and the HIP path, bit-identically) use exact f32 weights.  This bounds what that
+    could move: the oracle's own position-change field of a collapsing dam, sampled at its particles with exact and with
+    1/256-quantised weights.  Measured: 3.0e-4 cells at most, for corrections of up to 0.23 cells (a violently collapsing block);
+    bound asserted: 5e-4 cells, i.e. inside the 1e-4 .. 1e-3 cells the whole-step parity statements are made at and below the effect of
+    the unconverged solver's sensitivity to dot-product rounding."""
+    pos, vel, maxp = util.make_dam(32, 24, 24, seed=3)
+    o = Oracle(32, 24, 24, maxp)
+    o.set_quirks(binning="off")
+    o.set_gravity_grid((0.0, -981.0, 0.0))
+    o.set_particles(pos, *vel)
+    for st in util.STEP_ORDER[:-1]:
+        if st != "binning":
+            o.run_stage(st, DT)
+    vols = [o.read_volume(n).astype(np.float64) for n in ("vel_x", "vel_y", "vel_z")]
+    P = o.get_particles()[0][:, :3].astype(np.float64)
+    dim = np.array([32, 24, 24])
+    worst, scale = 0.0, 0.0
+    for c in range(3):
+        u = P - 0.5 * np.eye(3)[c] - 0.5
+        i0 = np.floor(u).astype(int)
+        f = u - i0
+        fq = np.round(f * 256.0) / 256.0                                          # 8 fractional bits
+        lo = np.clip(i0, 0, dim - 1)
+        hi = np.clip(i0 + 1, 0, dim - 1)                                          # clamp-to-edge
+        res = []
+        for w in (f, fq):
+            acc = np.zeros(len(P))
+            for dz in (0, 1):
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        wt = (w[:, 0] if dx else 1 - w[:, 0]) * (w[:, 1] if dy else 1 - w[:, 1]) * (w[:, 2] if dz else 1 - w[:, 2])
+                        ix, iy, iz = (hi if dx else lo)[:, 0], (hi if dy else lo)[:, 1], (hi if dz else lo)[:, 2]
+                        acc += wt * vols[c][iz, iy, ix]
+            res.append(acc)
+        worst = max(worst, float(np.abs(res[0] - res[1]).max()))
+        scale = max(scale, float(np.abs(res[0]).max()))
+    print("8-bit filter weights move the density correction by at most %.3g cells (largest correction %.3g cells)" % (worst, scale))
+    assert scale > 1e-3 and worst < 5e-4
