@@ -67,6 +67,7 @@ struct blub_fluid {
     Grid g{};
     size_t N = 0;
     uint32_t max_particles = 0, num_particles = 0;
+    uint32_t last_add_dropped = 0;   // particles the last add_fluid_cube could not add (capacity)
     // z-slab decomposition (blub_slab.hip): own planes [slab_z0, slab_z1), ghost particles live at [num_particles, +num_ghost)
     int slab_z0 = 0, slab_z1 = 0;
     uint32_t num_ghost = 0;
@@ -767,9 +768,12 @@ int blub_fluid_add_fluid_cube(blub_fluid* h, const float mn[3], const float mx[3
     REQUIRE_HANDLE(h);
     if (!mn || !mx) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     const uint32_t dim[3] = {(uint32_t)h->g.nx, (uint32_t)h->g.ny, (uint32_t)h->g.nz};
-    uint32_t count = 0;
+    uint32_t count = 0, demand = 0;
     int rc = blub::seed_fluid_cube(dim, h->max_particles, h->num_particles, mn, mx, nullptr, 0, &count);
     if (rc != BLUB_OK) return rc;
+    // what the cube asked for without the capacity limit: the reference logs error! for the difference (hybrid_fluid.rs:627-633)
+    if (blub::seed_fluid_cube(dim, 0xFFFFFFFFu, h->num_particles, mn, mx, nullptr, 0, &demand) != BLUB_OK) demand = count;
+    h->last_add_dropped = demand > count ? demand - count : 0u;
     if (count == 0) return BLUB_OK;
     std::vector<float> buf((size_t)count * 4);
     rc = blub::seed_fluid_cube(dim, h->max_particles, h->num_particles, mn, mx, buf.data(), count, &count);
@@ -850,6 +854,7 @@ int blub_fluid_solver_stats_latest(const blub_fluid* h, int which, blub_solver_s
 int blub_fluid_set_rebinning_frequency(blub_fluid* h, uint32_t f) { if (!h) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); h->rebin_freq = f; return BLUB_OK; }
 uint32_t blub_fluid_get_rebinning_frequency(const blub_fluid* h) { return h ? h->rebin_freq : 0; }
 uint32_t blub_fluid_num_particles(const blub_fluid* h) { return h ? h->num_particles : 0; }
+uint32_t blub_fluid_last_add_dropped(const blub_fluid* h) { return h ? h->last_add_dropped : 0; }
 uint32_t blub_fluid_max_num_particles(const blub_fluid* h) { return h ? h->max_particles : 0; }
 int blub_fluid_grid_dimension(const blub_fluid* h, uint32_t d[3]) {
     if (!h || !d) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");

@@ -146,6 +146,7 @@ def load_library():
         "blub_fluid_get_rebinning_frequency": (u32, [vp]),
         "blub_fluid_num_particles": (u32, [vp]),
         "blub_fluid_max_num_particles": (u32, [vp]),
+        "blub_fluid_last_add_dropped": (u32, [vp]),
         "blub_fluid_grid_dimension": (C.c_int, [vp, vp]),
         "blub_fluid_step_counter": (u32, [vp]),
         "blub_fluid_set_step_counter": (C.c_int, [vp, u32]),
@@ -336,6 +337,10 @@ class HybridFluid:
     def num_particles(self):
         """hybrid_fluid.rs:696"""
         return int(self._L.blub_fluid_num_particles(self._h))
+
+    def last_add_dropped(self):
+        """Particles the last add_fluid_cube could not add (the reference's `error!` case, hybrid_fluid.rs:627-633)."""
+        return int(self._L.blub_fluid_last_add_dropped(self._h))
 
     def grid_dimension(self):
         """hybrid_fluid.rs:727"""

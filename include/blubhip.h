@@ -137,6 +137,9 @@ int blub_fluid_set_rebinning_frequency(blub_fluid* h, uint32_t every_n_steps);  
 uint32_t blub_fluid_get_rebinning_frequency(const blub_fluid* h);
 uint32_t blub_fluid_num_particles(const blub_fluid* h);                                              /* :696 */
 uint32_t blub_fluid_max_num_particles(const blub_fluid* h);
+/* Particles the LAST blub_fluid_add_fluid_cube call could not add because max_num_particles was reached (the call itself returns
+ * BLUB_OK and truncates, like the reference, which logs `error!`: hybrid_fluid.rs:627-633). */
+uint32_t blub_fluid_last_add_dropped(const blub_fluid* h);
 int blub_fluid_grid_dimension(const blub_fluid* h, uint32_t dim_out[3]);                             /* :727 */
 uint32_t blub_fluid_step_counter(const blub_fluid* h);
 int blub_fluid_set_step_counter(blub_fluid* h, uint32_t c);
@@ -194,7 +197,7 @@ int blub_fluid_get_particles(blub_fluid* h, float* pos_ll, float* vx, float* vy,
 
 typedef enum blub_volume {
     BLUB_VOLUME_MARKER = 0,            /* int8   */
-    BLUB_VOLUME_LINKED_LIST = 1,       /* uint32 (list heads of component x / density, or binning counters) */
+    BLUB_VOLUME_LINKED_LIST = 1,       /* uint32 (list heads of component x / density; the binning counters live in AUX_TEMP) */
     BLUB_VOLUME_VELOCITY_X = 2, BLUB_VOLUME_VELOCITY_Y = 3, BLUB_VOLUME_VELOCITY_Z = 4,
     BLUB_VOLUME_PRESSURE_VELOCITY = 5, BLUB_VOLUME_PRESSURE_DENSITY = 6,
     BLUB_VOLUME_RESIDUAL = 7, BLUB_VOLUME_SEARCH = 8, BLUB_VOLUME_AUX = 9, BLUB_VOLUME_AUX_TEMP = 10,

@@ -26,9 +26,9 @@ def test_add_fluid_cube_truncates_and_counts_like_the_reference():
     f = blub_amd.HybridFluid((32, 32, 32), 1000)
     try:
         f.add_fluid_cube((1, 1, 1), (5, 5, 5))            # 4*4*4*8 = 512
-        assert f.num_particles() == 512
+        assert f.num_particles() == 512 and f.last_add_dropped() == 0
         f.add_fluid_cube((8, 8, 8), (16, 16, 16))         # would be 4096: truncated to the 488 left (hybrid_fluid.rs:627-633)
-        assert f.num_particles() == 1000
+        assert f.num_particles() == 1000 and f.last_add_dropped() == 4096 - 488     # what the reference's error! reports
         p = f.get_particles()[0]
         assert np.all(p[:512, :3] >= 1) and np.all(p[:512, :3] <= 5) and np.all(p[512:, :3] >= 8)
         assert np.all(p.view(np.uint32)[:, 3] == 0xFFFFFFFF)

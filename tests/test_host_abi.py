@@ -29,6 +29,20 @@ def test_library_exports_every_declared_symbol():
     blub_amd.load_library()
 
 
+def test_integration_md_ffi_block_is_generated_from_the_header():
+    """INTEGRATION.md section 2 is the output of tools/gen_rust_ffi.py for today's include/blubhip.h: every declared function has
+    a Rust binding line, nothing is stale."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    block, names = gen.generate()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a, b = doc.index(gen.BEGIN) + len(gen.BEGIN), doc.index(gen.END)
+    assert doc[a:b].strip() == block.strip(), "run `python tools/gen_rust_ffi.py --write`"
+    assert sorted(names) == declared_functions()
+
+
 def test_scene_json_matches_reference_schema(tmp_path):
     s = blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", "double_dam.json")).config
     assert list(s.grid_dimension) == [128, 64, 64] and s.max_num_particles == 2000000 and s.num_fluid_cubes == 2
