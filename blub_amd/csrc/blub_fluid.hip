@@ -395,13 +395,17 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 2>), grid, block, __VA_ARGS__);                     \
     } while (0)
             static const bool xmap = getenv("BLUB_PCG1_XMAP") ? atoi(getenv("BLUB_PCG1_XMAP")) != 0 : true;   // XCD-contiguous list order (+2 % steps/s; needs np % 8 == 0, guaranteed above)
+            static const bool done_first_env = getenv("BLUB_PCG1_DONEFIRST") ? atoi(getenv("BLUB_PCG1_DONEFIRST")) != 0 : false;   // (tuning switch)
             for (int i = 0; i <= maxit; ++i) {
                 const float4* pin = part[i & 1]; float4* pout = part[(i + 1) & 1];
-                if (i == 0) BLUB_LAUNCH_K(true, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, np, ctrl, sc, tol, 0, 0, -1, -1);
-                else BLUB_LAUNCH_K(false, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, np, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1);
+                // the first check is iteration `freq`, its verdict is formed by K(freq + 1): K(freq + 2) is the first launch that can find `done` set
+                const int done_first = (done_first_env && freq > 0 && i >= freq + 2) ? 1 : 0;
+                if (i == 0) BLUB_LAUNCH_K(true, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, np, ctrl, sc, tol, 0, 0, -1, -1, 0);
+                else BLUB_LAUNCH_K(false, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, np, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1, done_first);
             }
+            const int np_final = np;
 #undef BLUB_LAUNCH_K
-            LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], np, maxit, h->solve_seq[which], stat_slot);
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], np_final, maxit, h->solve_seq[which], stat_slot);
             // the residual of a full-length solve ends in R[(maxit + 1) & 1]; keep BLUB_VOLUME_RESIDUAL pointing at it
             if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
             return enqueue_stats_readback(h, which, dt, true);
