@@ -411,15 +411,23 @@ def main():
         dist.destroy_process_group()
         return
 
-    # ---- fast-forward through the native scheduler (simulation_controller.rs:96-157): the reference's own way of timing steps
+    # ---- fast-forward through the native scheduler (simulation_controller.rs:96-157): the reference's own way of timing steps.
+    # Same window as the timed region above (a fresh scene, the same warm-up), no Python in the stepping loop, a wait every 16 steps.
     fast_forward = None
     if not args.no_fast_forward:
         from blub_amd.simulation_controller import SimulationController
+        scene_ff = blub_amd.Scene(path=scene_path, device=dev)
+        fluid_ff = scene_ff.fluid()
+        fluid_ff.set_pcg_work_mapping(args.pcg_mapping)
         sc = SimulationController()
-        n_ff = sc.fast_forward_steps_fluid(fluid, args.steps * sc.simulation_delta_ns)
-        fast_forward = {"steps": n_ff, "steps_per_s": round(n_ff / max(sc.computation_time_last_fast_forward, 1e-9), 3),
-                        "computation_time_last_fast_forward_s": round(sc.computation_time_last_fast_forward, 5), "batch": 16}
+        if args.warmup:
+            sc.fast_forward_steps_fluid(fluid_ff, args.warmup * sc.simulation_delta_ns)
+        n_ff = sc.fast_forward_steps_fluid(fluid_ff, args.steps * sc.simulation_delta_ns)
+        fast_forward = {"steps": n_ff, "warmup": args.warmup, "steps_per_s": round(n_ff / max(sc.computation_time_last_fast_forward, 1e-9), 3),
+                        "computation_time_last_fast_forward_s": round(sc.computation_time_last_fast_forward, 5), "batch": 16,
+                        "driver": "blub_controller_fast_forward_steps_fluid (C-ABI; batches of 16 blub_fluid_step + blub_fluid_synchronize)"}
         sc.close()
+        fluid_ff.close()
 
     # ---- instrumented pass: per-kernel-class HIP-event timing on the engine's own stream -----------------------------
     roofline_workload, breakdown, pcg_ms = None, None, 0.0
