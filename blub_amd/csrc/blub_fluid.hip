@@ -371,7 +371,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         // grid (= number of dot-product partials) sized from the newest landed FLUID brick count with 12 % head room (the iteration
         // kernels sweep the fluid list; the init kernel sweeps the larger active list with the same grid and simply strides): the
         // kernels loop over the device-side list, so a stale count only costs speed, never correctness
-        int np = std::min((h->bg.nb + PCG_BPB - 1) / PCG_BPB, PCG_GRID_BRICKS * 2 / PCG_BPB);
+        static const int np_cap = getenv("BLUB_PCG_NP_MAX") ? std::max(64, std::min(PCG_GRID_MAX, atoi(getenv("BLUB_PCG_NP_MAX")))) : PCG_GRID_BRICKS * 2 / PCG_BPB;   // (tuning switch)
+        int np = std::min((h->bg.nb + PCG_BPB - 1) / PCG_BPB, np_cap);
         if (have) np = std::max(64, std::min(np, (int)((bc.n_fluid * 9u / 8u + 8u + (unsigned)PCG_BPB - 1u) / (unsigned)PCG_BPB)));
         np = (np + 7) & ~7;   // (a multiple of 8: the single-reduction kernels can hand the list out XCD-contiguously)
         const dim3 grid(np), block(PCG_B_THREADS);

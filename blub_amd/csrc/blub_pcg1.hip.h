@@ -24,6 +24,14 @@
 
 namespace blubk {
 
+// M^-1 x exactly as the reference's two preconditioner passes write it with the Q1 reading "zero" (pressure_apply_preconditioner.comp:36-82):
+// (x / d) / d with two correctly rounded divisions, d = number of non-SOLID neighbours, skipped for d = 0.  (The two-kernel schedule of
+// blub_pcg.hip.h multiplies by correctly rounded reciprocals instead -- within 1 ulp per factor; its dense mapping is the byte-bound one.)
+__device__ __forceinline__ float precond_exact(float x, int dv) {
+    const float d = (float)(dv & 7);
+    return (dv & 7) > 0 ? (x / d) / d : x;
+}
+
 struct Pcg1Scalars { float gamma[2]; float alpha[2]; };   // gamma_i, alpha_i in slot i & 1 (written by block 0 of K(i), read by K(i+1))
 
 template <int NT>
@@ -223,9 +231,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                                                                PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
                                                                int halo_lo = -1, int halo_hi = -1, int done_first = 0) {
     __shared__ float4 sm4[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
-    __shared__ float sInv[8];
     __shared__ StagedTile tiles[PCG_BPB];
-    pcg_fill_inv_lut(sInv);   // (published by the barriers of the prologue's reduction)
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
@@ -272,10 +278,9 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int dv = dbyte(dq, j);
-                    const float inv = sInv[dv & 7];
                     const float qj = FIRST ? f4(TL.wv[k], j) : f4(TL.wv[k], j) + beta * f4(TL.qv[k], j);
                     const float rj = f4(TL.rv[k], j) - alpha * qj;
-                    const float uj = (rj * inv) * inv;
+                    const float uj = precond_exact(rj, dv);
                     const bool fl = (dv & 0x80) != 0;
                     qn[j] = fl ? qj : 0.0f; rn[j] = fl ? rj : 0.0f; uu[j] = fl ? uj : 0.0f;
                 }
@@ -291,8 +296,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                     for (int j = 0; j < 4; ++j) {
                         const int dv = dbyte(dq, j);
                         if (!(dv & 0x80)) continue;                            // non-FLUID lanes keep their d and p (p = 0 there: pressure_init.comp:45-48)
-                        const float inv = sInv[dv & 7];
-                        const float ui = (f4(TL.rv[k], j) * inv) * inv;        // u_i = M^-1 r_i
+                        const float ui = precond_exact(f4(TL.rv[k], j), dv);   // u_i = M^-1 r_i
                         dn[j] = FIRST ? ui : ui + beta * dn[j];                // pressure_update_search.comp:23
                         pn[j] = pn[j] + alpha * dn[j];                         // pressure_update_pressure_and_residual.comp:39-40
                         acc_g += rn[j] * uu[j];
@@ -316,10 +320,9 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                 const int row = (zz + 1) * (BY + 2) + (yy + 1);
                 float uj = 0.0f;
                 if (TL.hin) {
-                    const float inv = sInv[TL.hdv & 7];
                     const float qj = FIRST ? TL.hw : TL.hw + beta * TL.hq;
                     const float rj = TL.hr - alpha * qj;
-                    uj = (TL.hdv & 0x80) ? (rj * inv) * inv : 0.0f;
+                    uj = (TL.hdv & 0x80) ? precond_exact(rj, TL.hdv) : 0.0f;
                 }
                 T.s[row * ST_ROW + (side ? 20 : 3)] = uj;
                 T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)TL.hdv;
