@@ -344,7 +344,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     ctl = "cpu"
-    if world > 1:
+    force_slab = bool(os.environ.get("BLUB_BENCH_FORCE_SLAB"))   # development: run the z-slab path (RCCL transport) with a single rank
+    if world > 1 or force_slab:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank %= max(1, torch.cuda.device_count())   # (development: several ranks on the one GPU of the test box)
@@ -359,7 +360,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
     replicas = world > 1 and bool(os.environ.get("BLUB_BENCH_REPLICAS"))
-    if world > 1 and not replicas:
+    if (world > 1 or force_slab) and not replicas:
         return multi_gpu(args, torch, dist, rank, world, dev, ctl)
 
     scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
