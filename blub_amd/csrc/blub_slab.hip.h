@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256) void k_slab_copy_planes(SlabCopyList L) {
 // of nranks x SLAB_NP entries; after the segments have been exchanged (p2p, see slab_gather) the unchanged consumer kernels
 // re-reduce all nranks x SLAB_NP partials in the same fixed order on every slab => identical scalars and identical
 // convergence decisions everywhere, no all-reduce, no extra reduction kernels.
-constexpr int SLAB_NP = 256;   // PCG grid (= partials per slab) of a slab solve
+// PCG grid (= partials per slab) of a slab solve: the same on every slab (the gathered segments have one size), chosen per step from the
+// largest fluid-brick count of any slab (gathered at the start of the step, blub_slab.inc.hip: slab_step)
+constexpr int SLAB_NP_MAX = 1024, SLAB_NP_DEFAULT = 512;
 
 }  // namespace blubk

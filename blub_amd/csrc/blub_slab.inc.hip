@@ -29,6 +29,7 @@ struct blub_slab_group {
         float* gat_dir = nullptr;                // device: nranks x SLAB_NP partials of s.As (own segment written by the direction kernel)
         float2* gat_upd = nullptr;               // device: nranks x SLAB_NP partials {(M^-1 r).r, max|r|} (own segment written by init / update)
         float4* gat4[2] = {nullptr, nullptr};    // device: nranks x SLAB_NP partials {gamma, delta, max|r|} of the single-reduction schedule, by iteration parity
+        float* gat_cnt = nullptr;                // device: nranks fluid-brick counts (own entry written at the start of a step)
     };
     std::vector<Extra> ex;
     blubk::SlabCounts* counts_host = nullptr;    // pinned, one per local slab
@@ -36,6 +37,8 @@ struct blub_slab_group {
     blubk::PcgCtrl* ctrl_host = nullptr;         // pinned: control block of slab 0's solves [velocity, density], read only after a stream sync
     bool ctrl_host_valid[2] = {false, false};
     uint64_t comm_ops = 0;                       // grouped transport operations issued so far (diagnostics)
+    float* cnt_host = nullptr;                   // pinned: [0, nranks) gathered fluid-brick counts, [nranks, nranks + nlocal) staging of the own ones
+    int np_cur = blubk::SLAB_NP_DEFAULT;         // PCG grid of this step's slab solves
     blubk::SlabCopyList copies{};                // loopback transport: plane copies collected for one batched launch
     int gather_mode = 0;                         // RCCL only: 0 = partials as p2p inside the halo's group, 1 = ncclAllGather (calibrated at creation)
     char transport[192] = "loopback";
@@ -266,7 +269,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     const float tol = c.error_tolerance / dt;
     const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };
-    const int np = SLAB_NP, npall = SLAB_NP * G->nranks;
+    const int np = G->np_cur, npall = np * G->nranks;
     const dim3 grid(np), block(PCG_B_THREADS);
     int rc;
     auto seg_upd = [&](int i) { return G->ex[i].gat_upd + (size_t)(G->first + i) * np; };
@@ -345,7 +348,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     const float tol = c.error_tolerance / dt;
     const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };
-    const int np = SLAB_NP, npall = SLAB_NP * G->nranks;
+    const int np = G->np_cur, npall = np * G->nranks;
     const dim3 grid(np), block(PCG_B_THREADS);
     int rc;
     auto seg_upd = [&](int i) { return G->ex[i].gat_upd + (size_t)(G->first + i) * np; };
@@ -446,7 +449,25 @@ static int slab_step(blub_slab_group* G, float dt) {
     int rc;
     const int S = (int)G->slabs.size();
 #define FOR_SLABS(call) for (int i = 0; i < S; ++i) { blub_fluid* h = G->slabs[i]; (void)h; if ((rc = (call)) != BLUB_OK) return rc; }
+    {   // size of this step's PCG grids: every slab contributes the newest fluid-brick count it has (a lagged, non-blocking snapshot) and
+        // all of them use the same grid, from the largest count (one 4-byte gather per step; read after the sync of the exchange below)
+        for (int i = 0; i < S; ++i) {
+            BrickCounts bc{}; bool have = false;
+            if ((rc = latest_counts(G->slabs[i], false, &bc, &have)) != BLUB_OK) return rc;
+            G->cnt_host[G->nranks + i] = have ? (float)bc.n_fluid : 0.0f;
+            HIP_TRY(hipMemcpyAsync(G->ex[i].gat_cnt + (G->first + i), &G->cnt_host[G->nranks + i], sizeof(float), hipMemcpyHostToDevice, G->stream));
+        }
+        if ((rc = slab_gather(G, [G](int i) { return G->ex[i].gat_cnt; }, 1)) != BLUB_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(G->cnt_host, G->ex[0].gat_cnt, (size_t)G->nranks * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+    }
     if ((rc = slab_exchange_particles(G, XFER_GHOST_FULL)) != BLUB_OK) return rc;
+    {
+        float mx = 0.0f; bool all_known = true;
+        for (int k = 0; k < G->nranks; ++k) { mx = std::max(mx, G->cnt_host[k]); all_known = all_known && G->cnt_host[k] > 0.0f; }
+        int np = SLAB_NP_DEFAULT;
+        if (all_known) np = (int)(mx * 9.0f / 8.0f / (float)PCG_BPB) + 8;
+        G->np_cur = std::max(128, std::min(SLAB_NP_MAX, (np + 7) & ~7));
+    }
     FOR_SLABS(stage_transfer(h, dt))
     for (int i = 0; i < S; ++i) G->slabs[i]->num_ghost = 0;   // the velocity ghosts are only needed by the P2G gather
     if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
@@ -496,12 +517,13 @@ static void slab_group_destroy(blub_slab_group* G) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     for (auto& e : G->ex) {
         F(e.leave_idx); F(e.hole_idx); F(e.fill_idx); for (auto p : e.up) F(p); for (auto p : e.dn) F(p);
-        F(e.counts); F(e.recv_counts); F(e.gat_dir); F(e.gat_upd); F(e.gat4[0]); F(e.gat4[1]);
+        F(e.counts); F(e.recv_counts); F(e.gat_dir); F(e.gat_upd); F(e.gat4[0]); F(e.gat4[1]); F(e.gat_cnt);
     }
     for (auto h : G->slabs) destroy(h);
     if (G->counts_host) (void)hipHostFree(G->counts_host);
     if (G->recv_host) (void)hipHostFree(G->recv_host);
     if (G->ctrl_host) (void)hipHostFree(G->ctrl_host);
+    if (G->cnt_host) (void)hipHostFree(G->cnt_host);
     if (G->comm) (void)ncclCommDestroy(G->comm);   // (nullptr after an abort)
     if (G->stream) (void)hipStreamDestroy(G->stream);
     delete G;
@@ -528,7 +550,7 @@ static int slab_calibrate(blub_slab_group* G) {
     }
     blub_fluid* h = G->slabs[0];
     auto& e = G->ex[0];
-    const int np = SLAB_NP;
+    const int np = SLAB_NP_DEFAULT;
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
     float* times = nullptr;
@@ -600,13 +622,16 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         A(dev_alloc_zero(G->stream, &e.leave_idx, P)); A(dev_alloc_zero(G->stream, &e.hole_idx, P)); A(dev_alloc_zero(G->stream, &e.fill_idx, P));
         for (int k = 0; k < 4; ++k) { A(dev_alloc_zero(G->stream, &e.up[k], P)); A(dev_alloc_zero(G->stream, &e.dn[k], P)); }
         A(dev_alloc_zero(G->stream, &e.counts, 1)); A(dev_alloc_zero(G->stream, &e.recv_counts, 2));
-        A(dev_alloc_zero(G->stream, &e.gat_dir, (size_t)nranks * blubk::SLAB_NP)); A(dev_alloc_zero(G->stream, &e.gat_upd, (size_t)nranks * blubk::SLAB_NP));
-        A(dev_alloc_zero(G->stream, &e.gat4[0], (size_t)nranks * blubk::SLAB_NP)); A(dev_alloc_zero(G->stream, &e.gat4[1], (size_t)nranks * blubk::SLAB_NP));
+        A(dev_alloc_zero(G->stream, &e.gat_dir, (size_t)nranks * blubk::SLAB_NP_MAX)); A(dev_alloc_zero(G->stream, &e.gat_upd, (size_t)nranks * blubk::SLAB_NP_MAX));
+        A(dev_alloc_zero(G->stream, &e.gat_cnt, (size_t)nranks));
+        A(dev_alloc_zero(G->stream, &e.gat4[0], (size_t)nranks * blubk::SLAB_NP_MAX)); A(dev_alloc_zero(G->stream, &e.gat4[1], (size_t)nranks * blubk::SLAB_NP_MAX));
         G->ex.push_back(e);
     }
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->counts_host, nlocal * sizeof(blubk::SlabCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->recv_host, 2 * nlocal * sizeof(uint32_t)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->ctrl_host, 2 * sizeof(blubk::PcgCtrl)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK && hipHostMalloc((void**)&G->cnt_host, (size_t)(nranks + nlocal) * sizeof(float)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK) memset(G->cnt_host, 0, (size_t)(nranks + nlocal) * sizeof(float));
     if (rc == BLUB_OK) { memset(G->counts_host, 0, nlocal * sizeof(blubk::SlabCounts)); memset(G->recv_host, 0, 2 * nlocal * sizeof(uint32_t)); memset(G->ctrl_host, 0, 2 * sizeof(blubk::PcgCtrl)); }
     if (rc == BLUB_OK && G->rccl) {
         if (nlocal != 1) rc = set_error(BLUB_ERR_INVALID_ARGUMENT, "RCCL slab groups hold exactly one slab per process");

@@ -501,7 +501,7 @@ def test_z_slab_solve_follows_convergence(schedule):
         slab_fluids = [group.local_fluid(i) for i in range(3)]
         for f in slab_fluids:
             f.update_statistics()
-        full = 4 * 2 + 5 + 2 * solve_ops(33)      # particle exchanges, velocity halos, 2 solves of 33 iterations
+        full = 1 + 4 * 2 + 5 + 2 * solve_ops(33)      # brick-count gather, particle exchanges, velocity halos, 2 solves of 33 iterations
         assert ops[0] == full, (ops, full)           # first step: no previous iteration count
         hist = lambda f, w: [x.iteration_count for x in (f.pressure_solver_stats_velocity() if w == 0 else f.pressure_solver_stats_density())]
         its = []
@@ -515,7 +515,7 @@ def test_z_slab_solve_follows_convergence(schedule):
             assert len(it_g) == 6 and len(it_s) == 6 and all(abs(a - b) <= 4 for a, b in zip(it_s, it_g)), (it_s, it_g)
             assert all(0 < x <= 32 for x in it_g)
         for step in range(1, 6):   # launched per solve = iterations through the later of {previous, this} deciding check + its detection
-            need = 4 * 2 + 5 + sum(solve_ops(min(33, max(its[w][step], its[w][step - 1]) + 2)) for w in (0, 1))
+            need = 1 + 4 * 2 + 5 + sum(solve_ops(min(33, max(its[w][step], its[w][step - 1]) + 2)) for w in (0, 1))
             assert ops[step] == need, (step, ops, need, its)
         d = _match_particles(group.get_particles()[0][:, :3].astype(np.float64), single.get_particles()[0][:, :3].astype(np.float64))
         assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 2e-2, (np.median(d), np.quantile(d, 0.99), d.max())
