@@ -25,11 +25,31 @@
 namespace blubk {
 
 // M^-1 x exactly as the reference's two preconditioner passes write it with the Q1 reading "zero" (pressure_apply_preconditioner.comp:36-82):
-// (x / d) / d with two correctly rounded divisions, d = number of non-SOLID neighbours, skipped for d = 0.  (The two-kernel schedule of
-// blub_pcg.hip.h multiplies by correctly rounded reciprocals instead -- within 1 ulp per factor; its dense mapping is the byte-bound one.)
-__device__ __forceinline__ float precond_exact(float x, int dv) {
-    const float d = (float)(dv & 7);
-    return (dv & 7) > 0 ? (x / d) / d : x;
+// (x / d) / d with two correctly rounded divisions, d = number of non-SOLID neighbours in 0..6, skipped for d = 0.  (The two-kernel
+// schedule of blub_pcg.hip.h multiplies by correctly rounded reciprocals instead -- within 1 ulp per factor.)
+// The iteration kernel is bound by the length of ONE wave's instruction stream and evaluates this ~17 times per thread,
+// so the IEEE division sequence (v_div_scale x2, v_rcp, 4-5 fma, v_div_fmas, v_div_fixup per division) is replaced by division by a
+// CONSTANT: d = m 2^k with m in {1, 3, 5}; scaling by 2^-k is exact, and for the odd part
+//     q0 = RN(y c), r = fma(-m, q0, y) (exact), q = fma(r, c, q0),  c = RN(1/m)
+// is the correctly rounded y / m (Markstein's correction step; checked for every f32 significand by tests/native/div_const_check.c).
+// The results are bit-identical to `(x / d) / d`.
+struct DivConst { float c, nm, sc, pad; };      // per d = 0..7: RN(1/m), -m, 2^-k
+__device__ __forceinline__ void pcg1_fill_div_lut(DivConst* lut) {   // by the first 8 threads of the block; a barrier must follow before the first use
+    if (threadIdx.x < 8) {
+        const int d = (int)threadIdx.x;
+        DivConst e = {1.0f, -1.0f, 1.0f, 0.0f};                       // d = 0, 1 (and the impossible 7): the value itself
+        if (d == 3 || d == 6) { e.c = 0x1.555556p-2f; e.nm = -3.0f; }  // RN(1/3)
+        if (d == 5) { e.c = 0x1.99999ap-3f; e.nm = -5.0f; }            // RN(1/5)
+        if (d == 2 || d == 6) e.sc = 0.5f;
+        if (d == 4) e.sc = 0.25f;
+        lut[d] = e;
+    }
+}
+__device__ __forceinline__ float precond_exact(float x, const DivConst& k) {
+    float y = x * k.sc, q = y * k.c;
+    q = fmaf(fmaf(k.nm, q, y), k.c, q);                               // x / d
+    y = q * k.sc; q = y * k.c;
+    return fmaf(fmaf(k.nm, q, y), k.c, q);                            // (x / d) / d
 }
 
 struct Pcg1Scalars { float gamma[2]; float alpha[2]; };   // gamma_i, alpha_i in slot i & 1 (written by block 0 of K(i), read by K(i+1))
@@ -232,8 +252,10 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                                                                int halo_lo = -1, int halo_hi = -1, int done_first = 0) {
     __shared__ float4 sm4[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
+    __shared__ DivConst div_lut[8];
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    pcg1_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
     // the previous scalars and the partials
     // XCD-contiguous brick order (XMAP, gridDim.x is a multiple of 8): block b runs on XCD b % 8 (observed dispatch order, a speed hint
@@ -275,12 +297,14 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                 if (e >= ST_ROWS * 4 || !st_row_needed(row)) continue;
                 const uint32_t dq = TL.dq[k];
                 float qn[4], rn[4], uu[4];
+                DivConst dc[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int dv = dbyte(dq, j);
+                    dc[j] = div_lut[dv & 7];
                     const float qj = FIRST ? f4(TL.wv[k], j) : f4(TL.wv[k], j) + beta * f4(TL.qv[k], j);
                     const float rj = f4(TL.rv[k], j) - alpha * qj;
-                    const float uj = precond_exact(rj, dv);
+                    const float uj = precond_exact(rj, dc[j]);
                     const bool fl = (dv & 0x80) != 0;
                     qn[j] = fl ? qj : 0.0f; rn[j] = fl ? rj : 0.0f; uu[j] = fl ? uj : 0.0f;
                 }
@@ -293,13 +317,15 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                 if (own) {
                     float dn[4] = {TL.dv4[k].x, TL.dv4[k].y, TL.dv4[k].z, TL.dv4[k].w}, pn[4] = {TL.pv4[k].x, TL.pv4[k].y, TL.pv4[k].z, TL.pv4[k].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < 4; ++j) {                              // (flat selects: a branch per lane costs more than the arithmetic it skips)
                         const int dv = dbyte(dq, j);
-                        if (!(dv & 0x80)) continue;                            // non-FLUID lanes keep their d and p (p = 0 there: pressure_init.comp:45-48)
-                        const float ui = precond_exact(f4(TL.rv[k], j), dv);   // u_i = M^-1 r_i
-                        dn[j] = FIRST ? ui : ui + beta * dn[j];                // pressure_update_search.comp:23
-                        pn[j] = pn[j] + alpha * dn[j];                         // pressure_update_pressure_and_residual.comp:39-40
-                        acc_g += rn[j] * uu[j];
+                        const bool fl = (dv & 0x80) != 0;                      // non-FLUID lanes keep their d and p (p = 0 there: pressure_init.comp:45-48)
+                        const float ui = precond_exact(f4(TL.rv[k], j), dc[j]); // u_i = M^-1 r_i
+                        const float dj = FIRST ? ui : ui + beta * dn[j];       // pressure_update_search.comp:23
+                        const float pj = pn[j] + alpha * dj;                   // pressure_update_pressure_and_residual.comp:39-40
+                        dn[j] = fl ? dj : dn[j];
+                        pn[j] = fl ? pj : pn[j];
+                        acc_g += rn[j] * uu[j];                                // rn = uu = 0 on non-FLUID lanes
                         emax = fmaxf(emax, fabsf(rn[j]));
                     }
                     *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                 if (TL.hin) {
                     const float qj = FIRST ? TL.hw : TL.hw + beta * TL.hq;
                     const float rj = TL.hr - alpha * qj;
-                    uj = (TL.hdv & 0x80) ? precond_exact(rj, TL.hdv) : 0.0f;
+                    uj = (TL.hdv & 0x80) ? precond_exact(rj, div_lut[TL.hdv & 7]) : 0.0f;
                 }
                 T.s[row * ST_ROW + (side ? 20 : 3)] = uj;
                 T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)TL.hdv;

@@ -172,4 +172,6 @@ def test_headline_scene_statistics_track_the_reference_schedule():
         assert abs(ia - ib) <= 0.25 * ia, (w, ia, ib)
         for (ea, na), (eb, nb) in list(zip(a[w], b[w]))[:2]:      # later steps: two chaotic trajectories, see test_gpu_baseline_parity.py
             assert 0.25 < ea / eb < 4.0
-    assert np.abs(a[2].mean(0) - b[2].mean(0)).max() < 5e-3
+    # mean particle position: two runs of the SAME schedule differ by up to 0.008 cells in y after 12 steps (measured with
+    # tools/mean_y_spread.py: atomic list order -> rounding of the gathers -> unconverged density solve), so this is a sanity bound
+    assert np.abs(a[2].mean(0) - b[2].mean(0)).max() < 2.5e-2

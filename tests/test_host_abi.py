@@ -112,3 +112,19 @@ def test_no_cpu_fallback():
     with pytest.raises(BlubError) as e:
         blub_amd.HybridFluid((32, 32, 32), 16)
     assert e.value.status == -7
+
+
+def test_constant_divisor_division_is_correctly_rounded(tmp_path):
+    """The single-reduction PCG kernels divide by d = m 2^k (m in {1, 3, 5}) with a multiply and one fma correction step
+    (blub_pcg1.hip.h, precond_exact).  tests/native/div_const_check.c checks q == y / m for EVERY f32 significand and both signs,
+    plus a sweep over the binades, with the host's fused multiply-add (same IEEE operation as v_fma_f32)."""
+    import shutil
+    import subprocess
+    if "fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("host CPU has no FMA instruction")
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = tmp_path / "div_const_check"
+    subprocess.check_call([gcc, "-O2", "-mfma", "-ffp-contract=off", os.path.join(ROOT, "tests", "native", "div_const_check.c"), "-o", str(exe), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout + out.stderr
