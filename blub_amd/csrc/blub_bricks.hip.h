@@ -24,6 +24,7 @@ constexpr uint32_t STALE_BIT = 0x80000000u;
 struct BrickGeom {
     Grid g;
     int nbx, nby, nbz, nb;
+    uint32_t mx, my;      // ceil(2^32 / nbx), ceil(2^32 / nby): brick index -> coordinates without integer division (brick_coords)
 };
 struct BrickCounts {        // device resident; `seq` tags the asynchronous host read-back of this list build
     uint32_t n_fluid, n_active, n_reset, n_stale;
@@ -33,9 +34,21 @@ struct BrickCounts {        // device resident; `seq` tags the asynchronous host
 __device__ __forceinline__ uint32_t brick_of_cell(const BrickGeom& bg, int x, int y, int z) {
     return (uint32_t)(((z / BZ) * bg.nby + (y / BY)) * bg.nbx + (x / BX));
 }
+// b = (bz * nby + by) * nbx + bx  ->  (bx, by, bz).  A 32-bit division by a run-time value costs ~20 VALU instructions and the
+// latency-bound brick kernels do three per brick; with m = ceil(2^32 / d), umulhi(n, m) == n / d whenever n * d < 2^32
+// (n < nb: checked when the handle is created), d == 1 excepted (its multiplier does not fit).
+__device__ __forceinline__ void brick_coords(const BrickGeom& bg, uint32_t b, int& bx, int& by, int& bz) {
+    const uint32_t q1 = bg.nbx == 1 ? b : __umulhi(b, bg.mx);
+    const uint32_t q2 = bg.nby == 1 ? q1 : __umulhi(q1, bg.my);
+    bx = (int)(b - q1 * (uint32_t)bg.nbx); by = (int)(q1 - q2 * (uint32_t)bg.nby); bz = (int)q2;
+}
+inline void brick_geom_set_magic(BrickGeom& bg) {    // host side
+    bg.mx = bg.nbx > 1 ? (uint32_t)((0x100000000ull + (uint32_t)bg.nbx - 1) / (uint32_t)bg.nbx) : 0u;
+    bg.my = bg.nby > 1 ? (uint32_t)((0x100000000ull + (uint32_t)bg.nby - 1) / (uint32_t)bg.nby) : 0u;
+}
 // thread -> quad of brick b; returns false if the quad lies outside the grid
 __device__ __forceinline__ bool brick_quad(const BrickGeom& bg, uint32_t b, int t, int& x0, int& y, int& z) {
-    const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+    int bx, by, bz; brick_coords(bg, b, bx, by, bz);
     x0 = bx * BX + ((t & 3) << 2);
     y = by * BY + ((t >> 2) & 7);
     z = bz * BZ + (t >> 5);
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
         bool act;
         if (phase == COMPACT_ALL_ACTIVE) act = true;
         else {
-            const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+            int bx, by, bz; brick_coords(bg, b, bx, by, bz);
             uint32_t any = 0;   // all 27 flags are loaded unconditionally (one batch of independent loads, no short-circuit chain)
 #pragma unroll
             for (int dz = -1; dz <= 1; ++dz)
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
         }
         const bool touched = all_touched || brick_touched[b] != 0;
         const bool stale = (phase == COMPACT_STEP_A) && touched && !act;
-        const int bz_own = b / (bg.nbx * bg.nby);
+        int bx_own, by_own, bz_own; brick_coords(bg, b, bx_own, by_own, bz_own); (void)bx_own; (void)by_own;
         const bool own = bz_own >= own_bz_lo && bz_own < own_bz_hi;   // z-slab decomposition: lists of work hold own bricks only
         fl = ((f && own) ? BF_FLUID : 0) | ((act && own) ? BF_ACTIVE : 0) | (stale ? BF_STALE : 0) | ((act || stale) ? BF_RESET : 0);
         brick_flags[b] = (uint8_t)fl;
@@ -254,7 +267,7 @@ __device__ __forceinline__ void gather_velocity_body(GatherShared& sh, uint32_t 
     const uint32_t n = *count;
     for (uint32_t i = first_brick; i < n; i += brick_stride) {
         const uint32_t b = list[i];
-        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;      // :41
         const bool in = live && inb(g, gx, gy, gz);
         const bool border = !live || lx == 0 || ly == 0 || lz == 0;
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
     const uint32_t n = *count;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t b = list[i];
-        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;
         const bool in = live && inb(g, gx, gy, gz);
         const bool border = !live || lx == 0 || ly == 0 || lz == 0;
@@ -438,7 +451,7 @@ __device__ __forceinline__ void gather_velocity_partial_body(GatherPartialsV& sh
     const uint32_t n = *count;
     for (uint32_t i = first_brick; i < n; i += brick_stride) {
         const uint32_t b = list[i];
-        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;      // :41
         const bool in = live && inb(g, gx, gy, gz);
         uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(768) void k_density_gather_p(BrickGeom bg, const ui
     const uint32_t n = *count;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t b = list[i];
-        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;
         const bool in = live && inb(g, gx, gy, gz);
         uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
@@ -724,7 +737,7 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, c
     const uint32_t n = *count;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t b = list[i] & ~STALE_BIT;
-        const int bx = b % bg.nbx, by = (b / bg.nbx) % bg.nby, bz = b / (bg.nbx * bg.nby);
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int tx0 = bx * BX - 4, ty0 = by * BY - 1, tz0 = bz * BZ - 1;     // tile origin (x is dword aligned)
         bool any = false;
         for (int w = threadIdx.x; w < ET_ROWS * (ET_ROW / 4); w += BRICK_THREADS) {

@@ -673,6 +673,8 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->dvol, h->N));
     BrickGeom& bg = h->bg;
     bg.g = h->g; bg.nbx = (h->g.nx + BX - 1) / BX; bg.nby = (h->g.ny + BY - 1) / BY; bg.nbz = (h->g.nz + BZ - 1) / BZ; bg.nb = bg.nbx * bg.nby * bg.nbz;
+    brick_geom_set_magic(bg);
+    if ((unsigned long long)bg.nb * (unsigned long long)std::max(bg.nbx, bg.nby) >= 0x100000000ull) A(set_error(BLUB_ERR_UNSUPPORTED, "grid too large for the brick index arithmetic (brick_coords)"));
     h->brick_grid = std::min(bg.nb, BRICK_GRID_MAX);
     A(dev_alloc_zero(h->stream, &h->brick_fluid, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_active, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_touched, (size_t)bg.nb));
     A(dev_alloc_zero(h->stream, &h->list_fluid, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_active, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_reset, (size_t)bg.nb));

@@ -401,7 +401,8 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_s(BrickGeom bg, const
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = have ? list[i] : 0u;
-        const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+        int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb);
+        const int x0b = bxb * BX, y0b = byb * BY, z0b = bzb * BZ;
         if (have) {
             // phase 1a: the 240 interior quads of the tile
             for (int e = t; e < ST_ROWS * 4; e += BRICK_THREADS) {
@@ -481,7 +482,8 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_s(BrickGeom bg, co
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = have ? list[i] : 0u;
-        const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+        int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb);
+        const int x0b = bxb * BX, y0b = byb * BY, z0b = bzb * BZ;
         UpdLoad L; L.valid = false;
         if (have) {
             int x0, y, z;

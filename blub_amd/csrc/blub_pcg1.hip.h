@@ -33,24 +33,31 @@ namespace blubk {
 //     q0 = RN(y c), r = fma(-m, q0, y) (exact), q = fma(r, c, q0),  c = RN(1/m)
 // is the correctly rounded y / m (Markstein's correction step; checked for every f32 significand by tests/native/div_const_check.c).
 // The results are bit-identical to `(x / d) / d`.
-struct DivConst { float c, nm, sc, pad; };      // per d = 0..7: RN(1/m), -m, 2^-k
+struct DivConst { float c, nm, sc2, pad; };     // per d = 0..7: RN(1/m), -m, 2^-2k  (both power-of-two scalings commute with the roundings: applied at once)
 __device__ __forceinline__ void pcg1_fill_div_lut(DivConst* lut) {   // by the first 8 threads of the block; a barrier must follow before the first use
     if (threadIdx.x < 8) {
         const int d = (int)threadIdx.x;
         DivConst e = {1.0f, -1.0f, 1.0f, 0.0f};                       // d = 0, 1 (and the impossible 7): the value itself
         if (d == 3 || d == 6) { e.c = 0x1.555556p-2f; e.nm = -3.0f; }  // RN(1/3)
         if (d == 5) { e.c = 0x1.99999ap-3f; e.nm = -5.0f; }            // RN(1/5)
-        if (d == 2 || d == 6) e.sc = 0.5f;
-        if (d == 4) e.sc = 0.25f;
+        if (d == 2 || d == 6) e.sc2 = 0.25f;
+        if (d == 4) e.sc2 = 0.0625f;
         lut[d] = e;
     }
 }
 __device__ __forceinline__ float precond_exact(float x, const DivConst& k) {
-    float y = x * k.sc, q = y * k.c;
-    q = fmaf(fmaf(k.nm, q, y), k.c, q);                               // x / d
-    y = q * k.sc; q = y * k.c;
-    return fmaf(fmaf(k.nm, q, y), k.c, q);                            // (x / d) / d
+    const float y = x * k.sc2;
+    float q = y * k.c;
+    q = fmaf(fmaf(k.nm, q, y), k.c, q);                               // 2^-2k x / m
+    float q2 = q * k.c;
+    return fmaf(fmaf(k.nm, q2, q), k.c, q2);                          // ... / m  ==  (x / d) / d
 }
+
+// 32-bit byte offsets from a uniform base pointer: the compiler addresses these as `global_load v, v_off, s[base]` (no 64-bit VALU
+// address arithmetic per access; a volume is < 4 GiB: checked at creation by the brick index bound)
+__device__ __forceinline__ float4 ld4o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off); }
+__device__ __forceinline__ float ld1o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
+__device__ __forceinline__ void st4o(float* base, uint32_t byte_off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 
 struct Pcg1Scalars { float gamma[2]; float alpha[2]; };   // gamma_i, alpha_i in slot i & 1 (written by block 0 of K(i), read by K(i+1))
 
@@ -121,6 +128,30 @@ __device__ __forceinline__ bool pcg1_prologue_finish(const Pcg1PrologueLoads& L,
     return true;
 }
 
+// A u for cell j of a quad whose tile holds u = 0 on every non-FLUID cell (K(i) writes the tile itself): the reference's "minus the
+// FLUID neighbours" (pressure.glsl:34-75) needs no neighbour descriptors then -- subtracting a zero is exact -- which drops six LDS
+// reads and the conditionals of quad_mulA_d from a kernel bound by its instruction stream.  Same operations in the same order.
+__device__ __forceinline__ float quad_mulA_u(uint32_t dc, const QuadValues& v, int j) {
+    float r = 0.0f;
+    r += (float)(dbyte(dc, j) & 7) * f4(v.c, j);
+    r -= (j > 0 ? f4(v.c, j - 1) : v.xm);
+    r -= (j < 3 ? f4(v.c, j + 1) : v.xp);
+    r -= f4(v.ym, j);
+    r -= f4(v.yp, j);
+    r -= f4(v.zm, j);
+    r -= f4(v.zp, j);
+    return r;
+}
+__device__ __forceinline__ uint32_t st_read_quad_u(const StagedTile& T, int t, QuadValues& sv) {
+    const int q = t & 3, yy = (t >> 2) & 7, zz = t >> 5;
+    const int o = ((zz + 1) * (BY + 2) + (yy + 1)) * ST_ROW + 4 + 4 * q;
+    sv.c = *reinterpret_cast<const float4*>(T.s + o);
+    sv.ym = *reinterpret_cast<const float4*>(T.s + o - ST_ROW); sv.yp = *reinterpret_cast<const float4*>(T.s + o + ST_ROW);
+    sv.zm = *reinterpret_cast<const float4*>(T.s + o - (BY + 2) * ST_ROW); sv.zp = *reinterpret_cast<const float4*>(T.s + o + (BY + 2) * ST_ROW);
+    sv.xm = T.s[o - 1]; sv.xp = T.s[o + 4];
+    return *reinterpret_cast<const uint32_t*>(T.d + o);
+}
+
 // w_0 = A u_0 (u_0 = M^-1 r_0 was written to the search volume by k_pcg_init_b) + partials {gamma_0 (block 0 only), delta_0, 0}
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                              const uint8_t* __restrict__ dvol, const float* __restrict__ u, float* __restrict__ w_out,
@@ -138,7 +169,8 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = have ? list[i] : 0u;
-        const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+        int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb);
+        const int x0b = bxb * BX, y0b = byb * BY, z0b = bzb * BZ;
         if (have) {
             for (int e = t; e < ST_ROWS * 4; e += BRICK_THREADS) {
                 const int row = e >> 2, q = e & 3;
@@ -200,7 +232,8 @@ struct Pcg1TileLoads {
 // FLUID cell (measured: see DESIGN.md 6).
 __device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const BrickGeom& bg, uint32_t b, int t, const uint8_t* __restrict__ dvol) {
     const Grid g = bg.g;
-    const int x0b = (int)(b % bg.nbx) * BX, y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+    int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb);
+        const int x0b = bxb * BX, y0b = byb * BY, z0b = bzb * BZ;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int e = t + k * BRICK_THREADS;
@@ -211,14 +244,14 @@ __device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const Bric
         if (!((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx)) continue;
         const int base = cidx(g, gx, gy, gz);
         L.base[k] = base;
-        L.dq[k] = *reinterpret_cast<const uint32_t*>(dvol + base);
+        L.dq[k] = *reinterpret_cast<const uint32_t*>(dvol + (uint32_t)base);
         L.own[k] = gy >= y0b && gy < y0b + BY && gz >= z0b && gz < z0b + BZ;
     }
     L.hin = false; L.hdv = 0; L.hc = -1;
     if (t < BY * BZ * 2) {
         const int side = t & 1, yy = (t >> 1) % BY, zz = (t >> 1) / BY;
         const int gx = side ? x0b + BX : x0b - 1, gy = y0b + yy, gz = z0b + zz;
-        if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { L.hc = cidx(g, gx, gy, gz); L.hin = true; L.hdv = (int)dvol[L.hc]; }
+        if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { L.hc = cidx(g, gx, gy, gz); L.hin = true; L.hdv = (int)dvol[(uint32_t)L.hc]; }
     }
 }
 template <bool FIRST>
@@ -229,13 +262,13 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
     for (int k = 0; k < 2; ++k) {
         L.rv[k] = zero4; L.wv[k] = zero4; L.qv[k] = zero4; L.dv4[k] = zero4; L.pv4[k] = zero4;
         if (L.base[k] < 0 || !any_fluid_d(L.dq[k])) continue;
-        const int base = L.base[k];
-        L.rv[k] = ld4(r_in + base); L.wv[k] = ld4(w_in + base);
-        if (!FIRST) L.qv[k] = ld4(q_in + base);
-        if (L.own[k]) { L.dv4[k] = ld4(dsearch + base); L.pv4[k] = ld4(p + base); }
+        const uint32_t off = (uint32_t)L.base[k] * 4u;
+        L.rv[k] = ld4o(r_in, off); L.wv[k] = ld4o(w_in, off);
+        if (!FIRST) L.qv[k] = ld4o(q_in, off);
+        if (L.own[k]) { L.dv4[k] = ld4o(dsearch, off); L.pv4[k] = ld4o(p, off); }
     }
     L.hr = 0.f; L.hw = 0.f; L.hq = 0.f;
-    if (L.hc >= 0 && (L.hdv & 0x80)) { L.hr = r_in[L.hc]; L.hw = w_in[L.hc]; if (!FIRST) L.hq = q_in[L.hc]; }
+    if (L.hc >= 0 && (L.hdv & 0x80)) { const uint32_t off = (uint32_t)L.hc * 4u; L.hr = ld1o(r_in, off); L.hw = ld1o(w_in, off); if (!FIRST) L.hq = ld1o(q_in, off); }
 }
 
 // K(i): one whole PCG iteration.  HALO (z-slab groups): the block also stores the r_{i+1} / q_i it computed for the ghost plane
@@ -287,7 +320,8 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
         const uint32_t b = first ? b0 : (have ? list[i] : 0u);
         if (!first && have) { pcg1_tile_load_desc(TL, bg, b, t, dvol); pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p); }
         first = false;
-        const int y0b = (int)((b / bg.nbx) % bg.nby) * BY, z0b = (int)(b / (bg.nbx * bg.nby)) * BZ;
+        int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb); (void)bxb;
+        const int y0b = byb * BY, z0b = bzb * BZ;
         if (have) {
             // phase 1a: r_{i+1}, u_{i+1} on the interior quads of the face-halo tile; the own quads also advance q, d, p
 #pragma unroll
@@ -328,15 +362,16 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
                         acc_g += rn[j] * uu[j];                                // rn = uu = 0 on non-FLUID lanes
                         emax = fmaxf(emax, fabsf(rn[j]));
                     }
-                    *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
-                    *reinterpret_cast<float4*>(r_out + base) = make_float4(rn[0], rn[1], rn[2], rn[3]);
-                    *reinterpret_cast<float4*>(dsearch + base) = make_float4(dn[0], dn[1], dn[2], dn[3]);
-                    *reinterpret_cast<float4*>(p + base) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+                    const uint32_t off = (uint32_t)base * 4u;
+                    st4o(q_out, off, make_float4(qn[0], qn[1], qn[2], qn[3]));
+                    st4o(r_out, off, make_float4(rn[0], rn[1], rn[2], rn[3]));
+                    st4o(dsearch, off, make_float4(dn[0], dn[1], dn[2], dn[3]));
+                    st4o(p, off, make_float4(pn[0], pn[1], pn[2], pn[3]));
                 } else if (HALO) {
                     const bool ghost = ((gz == halo_lo - 1 && z0b == halo_lo) || (gz == halo_hi + 1 && z0b + BZ - 1 == halo_hi)) && gy >= y0b && gy < y0b + BY;
                     if (ghost) {
-                        *reinterpret_cast<float4*>(q_out + base) = make_float4(qn[0], qn[1], qn[2], qn[3]);
-                        *reinterpret_cast<float4*>(r_out + base) = make_float4(rn[0], rn[1], rn[2], rn[3]);
+                        st4o(q_out, (uint32_t)base * 4u, make_float4(qn[0], qn[1], qn[2], qn[3]));
+                        st4o(r_out, (uint32_t)base * 4u, make_float4(rn[0], rn[1], rn[2], rn[3]));
                     }
                 }
             }
@@ -359,14 +394,17 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
             // phase 2: w_{i+1} = A u_{i+1} for the own quad from the tile
             int x0, y, z;
             if (brick_quad(bg, b, t, x0, y, z)) {
-                QuadD m; QuadValues sv;
-                st_read_quad(T, t, m, sv);
-                if (any_fluid_d(m.c)) {
-                    float wn[4] = {0.f, 0.f, 0.f, 0.f};
+                QuadValues sv;
+                const uint32_t dcq = st_read_quad_u(T, t, sv);
+                if (any_fluid_d(dcq)) {
+                    float wn[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (dbyte(m.c, j) & 0x80) { wn[j] = quad_mulA_d(m, sv, j); acc_d += wn[j] * f4(sv.c, j); }
-                    *reinterpret_cast<float4*>(w_out + cidx(g, x0, y, z)) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+                    for (int j = 0; j < 4; ++j) {
+                        const float wj = quad_mulA_u(dcq, sv, j);
+                        wn[j] = (dbyte(dcq, j) & 0x80) ? wj : 0.0f;
+                        acc_d += wn[j] * f4(sv.c, j);
+                    }
+                    st4o(w_out, (uint32_t)cidx(g, x0, y, z) * 4u, make_float4(wn[0], wn[1], wn[2], wn[3]));
                 }
             }
         }
