@@ -59,13 +59,44 @@ __device__ __forceinline__ float4 ld4o(const float* base, uint32_t byte_off) { r
 __device__ __forceinline__ float ld1o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
 __device__ __forceinline__ void st4o(float* base, uint32_t byte_off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 
+// Wave-wide reductions on the DPP path (row shifts + the two row broadcasts of gfx9, result read from lane 63 into an SGPR): six
+// dependent VALU instructions where the __shfl_down tree of wave_sum() is six ds_bpermute round trips (~100 cycles each).  The
+// iteration kernel reduces three values twice per launch, and its run time is one wave's dependent instruction stream.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {         // full rows, lanes without a source read 0 (bound_ctrl): folds into v_add_f32_dpp / v_max_f32_dpp
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_bcast(float v) {       // masked rows keep `old` = 0: the identity of + and of max over |.|
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_row<0x111>(v);               // row_shr:1
+    v += dpp_row<0x112>(v);               // row_shr:2
+    v += dpp_row<0x114>(v);               // row_shr:4
+    v += dpp_row<0x118>(v);               // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += dpp_bcast<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v += dpp_bcast<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_abs_dpp(float x) {   // x >= 0: non-negative floats order like their bit patterns (integer max folds into the DPP form)
+    int v = __builtin_bit_cast(int, x);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+}
+
 struct Pcg1Scalars { float gamma[2]; float alpha[2]; };   // gamma_i, alpha_i in slot i & 1 (written by block 0 of K(i), read by K(i+1))
 
 template <int NT>
 __device__ __forceinline__ float4 reduce_partials4(const float4* __restrict__ part, int n, float4* sm4) {
     float g = 0.0f, d = 0.0f, m = 0.0f;
     for (int i = threadIdx.x; i < n; i += NT) { const float4 p = part[i]; g += p.x; d += p.y; m = fmaxf(m, p.z); }
-    g = wave_sum(g); d = wave_sum(d); m = wave_max(m);
+    g = wave_sum_dpp(g); d = wave_sum_dpp(d); m = wave_max_abs_dpp(m);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) sm4[wave] = make_float4(g, d, m, 0.0f);
@@ -104,7 +135,7 @@ __device__ __forceinline__ bool pcg1_prologue_finish(const Pcg1PrologueLoads& L,
 #pragma unroll
     for (int k = 0; k < PCG1_PART_PER_THREAD; ++k) { g += L.pl[k].x; d += L.pl[k].y; m = fmaxf(m, L.pl[k].z); }
     for (int i = (int)threadIdx.x + PCG1_PART_PER_THREAD * NT; i < num_part; i += NT) { const float4 p = part_in[i]; g += p.x; d += p.y; m = fmaxf(m, p.z); }
-    g = wave_sum(g); d = wave_sum(d); m = wave_max(m);
+    g = wave_sum_dpp(g); d = wave_sum_dpp(d); m = wave_max_abs_dpp(m);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) sm4[wave] = make_float4(g, d, m, 0.0f);
@@ -411,7 +442,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
         __syncthreads();   // the tile is rewritten for the next brick
     }
     // one combined block reduction of the three partials
-    acc_g = wave_sum(acc_g); acc_d = wave_sum(acc_d); emax = wave_max(emax);
+    acc_g = wave_sum_dpp(acc_g); acc_d = wave_sum_dpp(acc_d); emax = wave_max_abs_dpp(emax);
     __syncthreads();          // (a block without bricks reaches this point straight from the prologue's reads of sm4)
     if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = make_float4(acc_g, acc_d, emax, 0.0f);
     __syncthreads();
