@@ -117,6 +117,20 @@ __device__ __forceinline__ float quad_mulA_d(const QuadD& m, const QuadValues& v
     if (dbyte(m.zp, j) & 0x80) r -= f4(v.zp, j);
     return r;
 }
+// A u for cell j of a quad whose neighbourhood holds u = 0 on every non-FLUID cell (the caller guarantees it): the reference's "minus the
+// FLUID neighbours" (pressure.glsl:34-75) needs no neighbour descriptors then -- subtracting a zero is exact -- which drops six LDS
+// reads and the conditionals of quad_mulA_d from a kernel bound by its instruction stream.  Same operations in the same order.
+__device__ __forceinline__ float quad_mulA_u(uint32_t dc, const QuadValues& v, int j) {
+    float r = 0.0f;
+    r += (float)(dbyte(dc, j) & 7) * f4(v.c, j);
+    r -= (j > 0 ? f4(v.c, j - 1) : v.xm);
+    r -= (j < 3 ? f4(v.c, j + 1) : v.xp);
+    r -= f4(v.ym, j);
+    r -= f4(v.yp, j);
+    r -= f4(v.zm, j);
+    r -= f4(v.zp, j);
+    return r;
+}
 // 1/d for d = 0..7 in LDS (lut[0] = lut[1] = 1): the direction kernel needs 22 reciprocals per quad, and a table read is two
 // instructions where the select chain of precond_zero_i is fifteen -- in a kernel whose run time is the latency of ONE wave's
 // instruction stream.  The values are the same correctly rounded constants.

@@ -159,20 +159,6 @@ __device__ __forceinline__ bool pcg1_prologue_finish(const Pcg1PrologueLoads& L,
     return true;
 }
 
-// A u for cell j of a quad whose tile holds u = 0 on every non-FLUID cell (K(i) writes the tile itself): the reference's "minus the
-// FLUID neighbours" (pressure.glsl:34-75) needs no neighbour descriptors then -- subtracting a zero is exact -- which drops six LDS
-// reads and the conditionals of quad_mulA_d from a kernel bound by its instruction stream.  Same operations in the same order.
-__device__ __forceinline__ float quad_mulA_u(uint32_t dc, const QuadValues& v, int j) {
-    float r = 0.0f;
-    r += (float)(dbyte(dc, j) & 7) * f4(v.c, j);
-    r -= (j > 0 ? f4(v.c, j - 1) : v.xm);
-    r -= (j < 3 ? f4(v.c, j + 1) : v.xp);
-    r -= f4(v.ym, j);
-    r -= f4(v.yp, j);
-    r -= f4(v.zm, j);
-    r -= f4(v.zp, j);
-    return r;
-}
 __device__ __forceinline__ uint32_t st_read_quad_u(const StagedTile& T, int t, QuadValues& sv) {
     const int q = t & 3, yy = (t >> 2) & 7, zz = t >> 5;
     const int o = ((zz + 1) * (BY + 2) + (yy + 1)) * ST_ROW + 4 + 4 * q;

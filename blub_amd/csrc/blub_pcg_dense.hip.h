@@ -56,7 +56,8 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
                                                     const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[T / 64 + 1];
     __shared__ float4 ls[2][T];
-    __shared__ uint32_t ld[2][T];
+    __shared__ float inv_lut[8];
+    pcg_fill_inv_lut(inv_lut);       // (the prologue's barriers publish it)
     float alpha;
     if (!pcg_upd_prologue<T>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
     const Grid g = gz.g;
@@ -95,9 +96,12 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
         Halo hc; hc.lo = zero4; hc.hi = zero4; hc.dlo = 0; hc.dhi = 0; hc.xm = 0.f; hc.xp = 0.f; hc.dxm = 0; hc.dxp = 0;
         if (valid) {
             const int b0 = z_begin * plane + row_base;
-            s_c = ld4(s + b0); d_c = *reinterpret_cast<const uint32_t*>(dvol + b0);
-            if (z_begin > 0) { s_m = ld4(s + b0 - plane); d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); }
-            if (z_begin + 1 < g.nz) { s_p = ld4(s + b0 + plane); d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane); }
+            // s is only defined on FLUID cells (the reference never writes it elsewhere): every value is zeroed outside the fluid as it
+            // arrives, so that the stencil below needs no per-neighbour tests (quad_mulA_u) -- these kernels are bound by VALU issue as
+            // much as by bytes
+            d_c = *reinterpret_cast<const uint32_t*>(dvol + b0); s_c = sel4(d_c, ld4(s + b0), zero4);
+            if (z_begin > 0) { d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); s_m = sel4(d_m, ld4(s + b0 - plane), zero4); }
+            if (z_begin + 1 < g.nz) { d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane); s_p = sel4(d_p, ld4(s + b0 + plane), zero4); }
             if (any_fluid_d(d_c)) { pc = ld4s<NT>(p + b0); rc = ld4s<NT>(r + b0); }
             hc = load_halo(b0, any_fluid_d(d_c));
         }
@@ -106,39 +110,42 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
             const int buf = z & 1;
             // issue the loads of the planes ahead: they are consumed after this plane's compute
             if (valid && z + 2 < g.nz && z + 1 < z_end) { s_n = ld4(s + base + 2 * plane); d_n = *reinterpret_cast<const uint32_t*>(dvol + base + 2 * plane); }
-            else { s_n = zero4; d_n = 0; }
+            else { s_n = zero4; d_n = 0; }      // (s_n is zeroed outside the fluid when it rotates in, below)
             const bool work_next = valid && z + 1 < z_end && any_fluid_d(d_p);
             if (work_next) { pn = ld4s<NT>(p + base + plane); rn = ld4s<NT>(r + base + plane); }
             const Halo hn = load_halo(base + plane, work_next);
             const bool work = valid && any_fluid_d(d_c);
-            ls[buf][t] = s_c; ld[buf][t] = d_c;
+            ls[buf][t] = s_c;
             // LDS-only barrier: a __syncthreads() would first drain vmcnt, i.e. wait for the planes just requested (the whole point of
             // requesting them ahead); the exchange is double buffered by plane parity, so one barrier per plane suffices
             lds_barrier();
             if (work) {
-                QuadD m; QuadValues sv;
-                m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
-                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = hc.lo; } } else { m.ym = 0; sv.ym = zero4; }
-                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = hc.hi; } } else { m.yp = 0; sv.yp = zero4; }
-                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = hc.xm; } } else { m.xm = 0; sv.xm = 0.f; }
-                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = hc.xp; } } else { m.xp = 0; sv.xp = 0.f; }
+                QuadValues sv;
+                sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
+                if (y > 0) { if (in_lo) sv.ym = ls[buf][t - qpr]; else sv.ym = sel4(hc.dlo, hc.lo, zero4); } else sv.ym = zero4;
+                if (y + 1 < g.ny) { if (in_hi) sv.yp = ls[buf][t + qpr]; else sv.yp = sel4(hc.dhi, hc.hi, zero4); } else sv.yp = zero4;
+                if (x0 > 0) { if (t > 0) sv.xm = ls[buf][t - 1].w; else sv.xm = (hc.dxm & 0x80) ? hc.xm : 0.0f; } else sv.xm = 0.f;
+                if (x0 + 4 < g.nx) { if (t < T - 1) sv.xp = ls[buf][t + 1].x; else sv.xp = (hc.dxp & 0x80) ? hc.xp : 0.0f; } else sv.xp = 0.f;
                 float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {                  // flat selects, no per-lane branches
                     const int dv = dbyte(d_c, j);
-                    if (!(dv & 0x80)) continue;
-                    const float as = quad_mulA_d(m, sv, j);
-                    pp[j] = pp[j] + alpha * f4(s_c, j);
+                    const bool fl = (dv & 0x80) != 0;
+                    const float as = quad_mulA_u(d_c, sv, j);
+                    const float pj = pp[j] + alpha * f4(s_c, j);
                     float res = rr[j];
                     res -= alpha * as;
-                    rr[j] = res;
-                    emax = fmaxf(emax, fabsf(res));
-                    acc += precond_zero(res, (float)(dv & 7)) * res;
+                    pp[j] = fl ? pj : pp[j];
+                    rr[j] = fl ? res : rr[j];
+                    const float inv = inv_lut[dv & 7];
+                    const float zr = ((res * inv) * inv) * res;   // precond_zero(res, d) * res with the same correctly rounded reciprocals
+                    emax = fmaxf(emax, fl ? fabsf(res) : 0.0f);
+                    acc += fl ? zr : 0.0f;
                 }
                 st4s<NT>(p + base, make_float4(pp[0], pp[1], pp[2], pp[3]));
                 st4s<NT>(r + base, make_float4(rr[0], rr[1], rr[2], rr[3]));
             }
-            s_m = s_c; s_c = s_p; s_p = s_n; d_m = d_c; d_c = d_p; d_p = d_n; pc = pn; rc = rn; hc = hn;
+            s_m = s_c; s_c = s_p; s_p = sel4(d_n, s_n, zero4); d_m = d_c; d_c = d_p; d_p = d_n; pc = pn; rc = rn; hc = hn;
         }
         __syncthreads();   // the LDS buffers are reused by the next tile
     }
@@ -156,7 +163,9 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     __shared__ float sm[T / 64 + 1];
     __shared__ float2 sm2[T / 64 + 1];
     __shared__ float4 ls[2][T];
-    __shared__ uint32_t ld[2][T];
+    __shared__ uint32_t ld[2][T];        // descriptor exchange: FIRST only (see below)
+    __shared__ float inv_lut[8];
+    pcg_fill_inv_lut(inv_lut);           // (the prologue's barriers publish it)
     float beta;
     if (!pcg_dir_prologue<T>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     const Grid g = gz.g;
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     // s_new of a quad from global memory (no write)
     auto snew_quad = [&](int b, uint32_t dq) -> float4 {
         if (FIRST) return ld4(s_in + b);
-        return any_fluid_d(dq) ? snew4(dq, ld4(r + b), ld4(s_in + b), beta) : zero4;
+        return any_fluid_d(dq) ? snew4(dq, ld4(r + b), ld4(s_in + b), beta, inv_lut) : zero4;
     };
     const int padded = ((gz.tiles + 7) >> 3) << 3;
     for (int it = blockIdx.x; it < padded; it += gridDim.x) {
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
         auto enter_plane = [&](int b, uint32_t dq, const float4& rr, const float4& so, bool own) -> float4 {
             if (FIRST) return so;
             if (!any_fluid_d(dq)) return zero4;
-            const float4 n = snew4(dq, rr, so, beta);
+            const float4 n = snew4(dq, rr, so, beta, inv_lut);
             if (own) st4s<NT>(s_out + b, sel4(dq, n, so));
             return n;
         };
@@ -229,18 +238,24 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
             }
             const Halo hn = load_halo(base + plane, valid && z + 1 < z_end && any_fluid_d(d_p));
             const bool work = valid && any_fluid_d(d_c);
-            ls[buf][t] = n_c; ld[buf][t] = d_c;
+            // after the first iteration s_new is 0 on every non-FLUID cell (snew_of), so A s needs no neighbour descriptors (quad_mulA_u);
+            // K(0) works on the stored s, which the reference leaves untouched outside the fluid: descriptors travel along
+            ls[buf][t] = n_c;
+            if (FIRST) ld[buf][t] = d_c;
             lds_barrier();   // (see k_pcg_update_z)
             if (work) {
                 QuadD m; QuadValues sv;
                 m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
-                if (y > 0) { if (in_lo) { m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = FIRST ? hc.s_lo : snew4(hc.dlo, hc.r_lo, hc.s_lo, beta); } } else { m.ym = 0; sv.ym = zero4; }
-                if (y + 1 < g.ny) { if (in_hi) { m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = FIRST ? hc.s_hi : snew4(hc.dhi, hc.r_hi, hc.s_hi, beta); } } else { m.yp = 0; sv.yp = zero4; }
-                if (x0 > 0) { if (t > 0) { m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = FIRST ? hc.sxm : snew_of(hc.dxm, hc.rxm, hc.sxm, beta); } } else { m.xm = 0; sv.xm = 0.f; }
-                if (x0 + 4 < g.nx) { if (t < T - 1) { m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = FIRST ? hc.sxp : snew_of(hc.dxp, hc.rxp, hc.sxp, beta); } } else { m.xp = 0; sv.xp = 0.f; }
+                m.ym = 0; m.yp = 0; m.xm = 0; m.xp = 0;
+                if (y > 0) { if (in_lo) { if (FIRST) m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = FIRST ? hc.s_lo : snew4(hc.dlo, hc.r_lo, hc.s_lo, beta, inv_lut); } } else sv.ym = zero4;
+                if (y + 1 < g.ny) { if (in_hi) { if (FIRST) m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = FIRST ? hc.s_hi : snew4(hc.dhi, hc.r_hi, hc.s_hi, beta, inv_lut); } } else sv.yp = zero4;
+                if (x0 > 0) { if (t > 0) { if (FIRST) m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = FIRST ? hc.sxm : snew_of(hc.dxm, hc.rxm, hc.sxm, beta, inv_lut); } } else sv.xm = 0.f;
+                if (x0 + 4 < g.nx) { if (t < T - 1) { if (FIRST) m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = FIRST ? hc.sxp : snew_of(hc.dxp, hc.rxp, hc.sxp, beta, inv_lut); } } else sv.xp = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (dbyte(d_c, j) & 0x80) acc += f4(n_c, j) * quad_mulA_d(m, sv, j);
+                for (int j = 0; j < 4; ++j) {
+                    if (FIRST) { if (dbyte(d_c, j) & 0x80) acc += f4(n_c, j) * quad_mulA_d(m, sv, j); }
+                    else acc += f4(n_c, j) * quad_mulA_u(d_c, sv, j);      // n_c = 0 on non-FLUID lanes: they add an exact zero
+                }
             }
             // plane z+2 enters (its loads have been in flight during the compute above)
             float4 n_n = zero4;
