@@ -183,6 +183,13 @@ __device__ __forceinline__ void load_quad_markers(const int8_t* __restrict__ M, 
 }
 struct QuadValues { float4 c, ym, yp, zm, zp; float xm, xp; };
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// 32-bit byte offsets from a uniform base pointer: the compiler addresses these as `global_load v, v_off, s[base]` (no 64-bit VALU
+// address arithmetic per access; an f32 volume is < 4 GiB for every supported grid)
+__device__ __forceinline__ float4 ld4o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off); }
+__device__ __forceinline__ float ld1o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
+__device__ __forceinline__ void st4o(float* base, uint32_t byte_off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+
+__device__ __forceinline__ uint32_t ldu32o(const uint8_t* base, uint32_t byte_off) { return *reinterpret_cast<const uint32_t*>(base + byte_off); }
 __device__ __forceinline__ void load_quad_values(const float* __restrict__ S, const Grid& g, int base, int x0, int y, int z, QuadValues& v) {
     const int plane = g.nx * g.ny;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);

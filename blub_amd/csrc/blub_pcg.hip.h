@@ -117,6 +117,11 @@ __device__ __forceinline__ float quad_mulA_d(const QuadD& m, const QuadValues& v
     if (dbyte(m.zp, j) & 0x80) r -= f4(v.zp, j);
     return r;
 }
+// FLUID-lane masks as bit operations (all ones / zero from bit 7 of descriptor byte j; v_bfi / v_and): the compiler turns `fluid ? a : b`
+// around an LDS table read back into a branch per lane, which is exactly what the issue-bound kernels cannot afford
+__device__ __forceinline__ uint32_t fluid_mask(uint32_t dq, int j) { return (uint32_t)((int)(dq << (24 - 8 * j)) >> 31); }
+__device__ __forceinline__ float and_mask(float x, uint32_t m) { return __uint_as_float(__float_as_uint(x) & m); }
+__device__ __forceinline__ float blend_mask(float a, float b, uint32_t m) { return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m)); }   // m ? a : b
 // A u for cell j of a quad whose neighbourhood holds u = 0 on every non-FLUID cell (the caller guarantees it): the reference's "minus the
 // FLUID neighbours" (pressure.glsl:34-75) needs no neighbour descriptors then -- subtracting a zero is exact -- which drops six LDS
 // reads and the conditionals of quad_mulA_d from a kernel bound by its instruction stream.  Same operations in the same order.
@@ -144,8 +149,8 @@ __device__ __forceinline__ void pcg_fill_inv_lut(float* lut) {
 }
 __device__ __forceinline__ float snew_of(int dv, float r, float sold, float beta, const float* lut) {   // pressure_update_search.comp:23 on top of M^-1 r
     const float inv = lut[dv & 7];
-    const float sn = (r * inv) * inv + beta * sold;   // evaluated unconditionally: a select, not a branch
-    return (dv & 0x80) ? sn : 0.0f;
+    const float sn = (r * inv) * inv + beta * sold;   // evaluated unconditionally, masked by the FLUID bit (no select: see fluid_mask)
+    return and_mask(sn, fluid_mask((uint32_t)dv, 0));
 }
 // (select-chain variants without a table: the dense 2.5-D kernels are bandwidth-, not issue-bound)
 __device__ __forceinline__ float snew_of(int dv, float r, float sold, float beta) {

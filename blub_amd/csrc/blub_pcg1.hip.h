@@ -53,12 +53,6 @@ __device__ __forceinline__ float precond_exact(float x, const DivConst& k) {
     return fmaf(fmaf(k.nm, q2, q), k.c, q2);                          // ... / m  ==  (x / d) / d
 }
 
-// 32-bit byte offsets from a uniform base pointer: the compiler addresses these as `global_load v, v_off, s[base]` (no 64-bit VALU
-// address arithmetic per access; a volume is < 4 GiB: checked at creation by the brick index bound)
-__device__ __forceinline__ float4 ld4o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off); }
-__device__ __forceinline__ float ld1o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
-__device__ __forceinline__ void st4o(float* base, uint32_t byte_off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v; }
-
 // Wave-wide reductions on the DPP path (row shifts + the two row broadcasts of gfx9, result read from lane 63 into an SGPR): six
 // dependent VALU instructions where the __shfl_down tree of wave_sum() is six ds_bpermute round trips (~100 cycles each).  The
 // iteration kernel reduces three values twice per launch, and its run time is one wave's dependent instruction stream.

@@ -39,14 +39,20 @@ template <bool NT> __device__ __forceinline__ float4 ld4s(const float* p) {
     if (NT) { const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
     return ld4(p);
 }
+template <bool NT> __device__ __forceinline__ float4 ld4so(const float* base, uint32_t byte_off) { return ld4s<NT>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off)); }
 template <bool NT> __device__ __forceinline__ void st4s(float* p, const float4& a) {
     if (NT) { v4f_t v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(p)); }
     else *reinterpret_cast<float4*>(p) = a;
 }
 
+template <bool NT> __device__ __forceinline__ void st4so(float* base, uint32_t byte_off, const float4& a) { st4s<NT>(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off), a); }
+
 __device__ __forceinline__ float4 sel4(uint32_t dq, const float4& a, const float4& fallback) {   // FLUID lanes take a, others fallback
-    return make_float4((dbyte(dq, 0) & 0x80) ? a.x : fallback.x, (dbyte(dq, 1) & 0x80) ? a.y : fallback.y,
-                       (dbyte(dq, 2) & 0x80) ? a.z : fallback.z, (dbyte(dq, 3) & 0x80) ? a.w : fallback.w);
+    return make_float4(blend_mask(a.x, fallback.x, fluid_mask(dq, 0)), blend_mask(a.y, fallback.y, fluid_mask(dq, 1)),
+                       blend_mask(a.z, fallback.z, fluid_mask(dq, 2)), blend_mask(a.w, fallback.w, fluid_mask(dq, 3)));
+}
+__device__ __forceinline__ float4 zero_outside_fluid(uint32_t dq, const float4& a) {
+    return make_float4(and_mask(a.x, fluid_mask(dq, 0)), and_mask(a.y, fluid_mask(dq, 1)), and_mask(a.z, fluid_mask(dq, 2)), and_mask(a.w, fluid_mask(dq, 3)));
 }
 
 // ---- KU: p += alpha s; r -= alpha A s; partial (M^-1 r).r and max|r|  (pressure_update_pressure_and_residual.comp:23-59)
@@ -93,27 +99,30 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
             }
             return h;
         };
-        Halo hc; hc.lo = zero4; hc.hi = zero4; hc.dlo = 0; hc.dhi = 0; hc.xm = 0.f; hc.xp = 0.f; hc.dxm = 0; hc.dxp = 0;
+        // (only the waves at the tile edge have such values: the others skip the loads, the zero fills and the plane rotation of them)
+        const bool wave_halo = __ballot((edge_lo && !in_lo) || (edge_hi && !in_hi) || xm_glob || xp_glob) != 0ull;
+        Halo hc = load_halo(0, false), hn = hc;
         if (valid) {
             const int b0 = z_begin * plane + row_base;
             // s is only defined on FLUID cells (the reference never writes it elsewhere): every value is zeroed outside the fluid as it
             // arrives, so that the stencil below needs no per-neighbour tests (quad_mulA_u) -- these kernels are bound by VALU issue as
             // much as by bytes
-            d_c = *reinterpret_cast<const uint32_t*>(dvol + b0); s_c = sel4(d_c, ld4(s + b0), zero4);
-            if (z_begin > 0) { d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); s_m = sel4(d_m, ld4(s + b0 - plane), zero4); }
-            if (z_begin + 1 < g.nz) { d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane); s_p = sel4(d_p, ld4(s + b0 + plane), zero4); }
+            d_c = *reinterpret_cast<const uint32_t*>(dvol + b0); s_c = zero_outside_fluid(d_c, ld4(s + b0));
+            if (z_begin > 0) { d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); s_m = zero_outside_fluid(d_m, ld4(s + b0 - plane)); }
+            if (z_begin + 1 < g.nz) { d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane); s_p = zero_outside_fluid(d_p, ld4(s + b0 + plane)); }
             if (any_fluid_d(d_c)) { pc = ld4s<NT>(p + b0); rc = ld4s<NT>(r + b0); }
-            hc = load_halo(b0, any_fluid_d(d_c));
+            if (wave_halo) hc = load_halo(b0, any_fluid_d(d_c));
         }
         for (int z = z_begin; z < z_end; ++z) {
             const int base = z * plane + row_base;
             const int buf = z & 1;
             // issue the loads of the planes ahead: they are consumed after this plane's compute
-            if (valid && z + 2 < g.nz && z + 1 < z_end) { s_n = ld4(s + base + 2 * plane); d_n = *reinterpret_cast<const uint32_t*>(dvol + base + 2 * plane); }
+            const uint32_t ub = (uint32_t)base, up = (uint32_t)plane;
+            if (valid && z + 2 < g.nz && z + 1 < z_end) { s_n = ld4o(s, (ub + 2u * up) * 4u); d_n = ldu32o(dvol, ub + 2u * up); }
             else { s_n = zero4; d_n = 0; }      // (s_n is zeroed outside the fluid when it rotates in, below)
             const bool work_next = valid && z + 1 < z_end && any_fluid_d(d_p);
-            if (work_next) { pn = ld4s<NT>(p + base + plane); rn = ld4s<NT>(r + base + plane); }
-            const Halo hn = load_halo(base + plane, work_next);
+            if (work_next) { pn = ld4so<NT>(p, (ub + up) * 4u); rn = ld4so<NT>(r, (ub + up) * 4u); }
+            if (wave_halo) hn = load_halo(base + plane, work_next);
             const bool work = valid && any_fluid_d(d_c);
             ls[buf][t] = s_c;
             // LDS-only barrier: a __syncthreads() would first drain vmcnt, i.e. wait for the planes just requested (the whole point of
@@ -122,30 +131,30 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
             if (work) {
                 QuadValues sv;
                 sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
-                if (y > 0) { if (in_lo) sv.ym = ls[buf][t - qpr]; else sv.ym = sel4(hc.dlo, hc.lo, zero4); } else sv.ym = zero4;
-                if (y + 1 < g.ny) { if (in_hi) sv.yp = ls[buf][t + qpr]; else sv.yp = sel4(hc.dhi, hc.hi, zero4); } else sv.yp = zero4;
-                if (x0 > 0) { if (t > 0) sv.xm = ls[buf][t - 1].w; else sv.xm = (hc.dxm & 0x80) ? hc.xm : 0.0f; } else sv.xm = 0.f;
-                if (x0 + 4 < g.nx) { if (t < T - 1) sv.xp = ls[buf][t + 1].x; else sv.xp = (hc.dxp & 0x80) ? hc.xp : 0.0f; } else sv.xp = 0.f;
+                if (y > 0) { if (in_lo) sv.ym = ls[buf][t - qpr]; else sv.ym = zero_outside_fluid(hc.dlo, hc.lo); } else sv.ym = zero4;
+                if (y + 1 < g.ny) { if (in_hi) sv.yp = ls[buf][t + qpr]; else sv.yp = zero_outside_fluid(hc.dhi, hc.hi); } else sv.yp = zero4;
+                if (x0 > 0) { if (t > 0) sv.xm = ls[buf][t - 1].w; else sv.xm = and_mask(hc.xm, fluid_mask((uint32_t)hc.dxm, 0)); } else sv.xm = 0.f;
+                if (x0 + 4 < g.nx) { if (t < T - 1) sv.xp = ls[buf][t + 1].x; else sv.xp = and_mask(hc.xp, fluid_mask((uint32_t)hc.dxp, 0)); } else sv.xp = 0.f;
                 float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                  // flat selects, no per-lane branches
-                    const int dv = dbyte(d_c, j);
-                    const bool fl = (dv & 0x80) != 0;
+                for (int j = 0; j < 4; ++j) {                  // bit masks, no per-lane branches or selects
+                    const uint32_t mk = fluid_mask(d_c, j);
                     const float as = quad_mulA_u(d_c, sv, j);
                     const float pj = pp[j] + alpha * f4(s_c, j);
                     float res = rr[j];
                     res -= alpha * as;
-                    pp[j] = fl ? pj : pp[j];
-                    rr[j] = fl ? res : rr[j];
-                    const float inv = inv_lut[dv & 7];
+                    pp[j] = blend_mask(pj, pp[j], mk);
+                    rr[j] = blend_mask(res, rr[j], mk);
+                    const float inv = inv_lut[dbyte(d_c, j) & 7];
                     const float zr = ((res * inv) * inv) * res;   // precond_zero(res, d) * res with the same correctly rounded reciprocals
-                    emax = fmaxf(emax, fl ? fabsf(res) : 0.0f);
-                    acc += fl ? zr : 0.0f;
+                    emax = fmaxf(emax, and_mask(fabsf(res), mk));
+                    acc += and_mask(zr, mk);
                 }
-                st4s<NT>(p + base, make_float4(pp[0], pp[1], pp[2], pp[3]));
-                st4s<NT>(r + base, make_float4(rr[0], rr[1], rr[2], rr[3]));
+                st4so<NT>(p, ub * 4u, make_float4(pp[0], pp[1], pp[2], pp[3]));
+                st4so<NT>(r, ub * 4u, make_float4(rr[0], rr[1], rr[2], rr[3]));
             }
-            s_m = s_c; s_c = s_p; s_p = sel4(d_n, s_n, zero4); d_m = d_c; d_c = d_p; d_p = d_n; pc = pn; rc = rn; hc = hn;
+            s_m = s_c; s_c = s_p; s_p = zero_outside_fluid(d_n, s_n); d_m = d_c; d_c = d_p; d_p = d_n; pc = pn; rc = rn;
+            if (wave_halo) hc = hn;
         }
         __syncthreads();   // the LDS buffers are reused by the next tile
     }
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
             if (FIRST) return so;
             if (!any_fluid_d(dq)) return zero4;
             const float4 n = snew4(dq, rr, so, beta, inv_lut);
-            if (own) st4s<NT>(s_out + b, sel4(dq, n, so));
+            if (own) st4so<NT>(s_out, (uint32_t)b * 4u, sel4(dq, n, so));
             return n;
         };
         // raw tile-edge values (converted to s_new when they are used), fetched one plane ahead: see k_pcg_update_z
@@ -231,10 +240,11 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
             // was measured slower: 55.4 vs 52.7 us at 256^3 -- the kernel is not waiting on these loads)
             const bool fetch = valid && z + 1 < z_end && z + 2 < g.nz;
             uint32_t d_n = 0; float4 r_n = zero4, so_n = zero4;
+            const uint32_t un = (uint32_t)base + 2u * (uint32_t)plane;
             if (fetch) {
-                d_n = *reinterpret_cast<const uint32_t*>(dvol + base + 2 * plane);
-                so_n = ld4(s_in + base + 2 * plane);
-                if (!FIRST) r_n = ld4(r + base + 2 * plane);
+                d_n = ldu32o(dvol, un);
+                so_n = ld4o(s_in, un * 4u);
+                if (!FIRST) r_n = ld4o(r, un * 4u);
             }
             const Halo hn = load_halo(base + plane, valid && z + 1 < z_end && any_fluid_d(d_p));
             const bool work = valid && any_fluid_d(d_c);
