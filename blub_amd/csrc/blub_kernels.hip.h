@@ -492,6 +492,7 @@ __device__ __forceinline__ float trilinear_clamp(const Grid& g, Fetch fetch, flo
 // pair are neighbours in memory, so the eight scattered 4-byte loads become four 8-byte ones (the particle kernels are
 // issue-bound on the memory pipe: profiles/r01_pmc_sq_sparse_bench.csv, k_correct).  Same values, same arithmetic.
 typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ float2_a4 ld_pair_o(const float* base, uint32_t cell) { return *reinterpret_cast<const float2_a4*>(reinterpret_cast<const char*>(base) + cell * 4u); }   // 32-bit offset from a uniform base (see ld4o)
 __device__ __forceinline__ float trilinear_clamp_f32(const Grid& g, const float* __restrict__ V, float tx, float ty, float tz) {
     const float ux = tx * (float)g.nx - 0.5f, uy = ty * (float)g.ny - 0.5f, uz = tz * (float)g.nz - 0.5f;
     const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
@@ -503,7 +504,7 @@ __device__ __forceinline__ float trilinear_clamp_f32(const Grid& g, const float*
     const int xbase = min(xa, g.nx - 2);                     // the pair (xbase, xbase + 1) always lies inside the row
     const bool lo_first = xa == xbase, hi_first = xb == xbase;
     auto pair = [&](int y, int z, float& lo, float& hi) {
-        const float2_a4 q = *reinterpret_cast<const float2_a4*>(V + cidx(g, xbase, y, z));
+        const float2_a4 q = ld_pair_o(V, (uint32_t)cidx(g, xbase, y, z));
         lo = lo_first ? q.x : q.y; hi = hi_first ? q.x : q.y;
     };
     float a0, a1, b0, b1, c0, c1, d0, d1;
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
         const int xbase = min(max(min(lo[0], g.nx - 2), 0), g.nx - 2);
         const bool lo_first = lo[0] <= xbase, hi_first = hi[0] <= xbase;
         auto pair = [&](int y, int z, float& a, float& b) {
-            const float2_a4 q = *reinterpret_cast<const float2_a4*>(V + cidx(g, xbase, min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1)));
+            const float2_a4 q = ld_pair_o(V, (uint32_t)cidx(g, xbase, min(max(y, 0), g.ny - 1), min(max(z, 0), g.nz - 1)));
             a = lo_first ? q.x : q.y; b = hi_first ? q.x : q.y;
         };
         pair(lo[1], lo[2], v[0][i], v[1][i]); pair(hi[1], lo[2], v[2][i], v[3][i]);
@@ -608,13 +609,20 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
 #pragma unroll
         for (int k = 0; k < 3; ++k) mv[k] = dir[k] * ms;
         if ((int)op[0] == (int)np[0] && (int)op[1] == (int)np[1] && (int)op[2] == (int)np[2]) {   // :154
-            auto sw = [&](int ax, int ay, int az) -> float { return solid ? solid[cidx(g, ax, ay, az)].w : 0.0f; };
-            const float push[3] = {
-                trilinear_clamp(g, sw, tc[0] - inv[0], tc[1], tc[2]) - trilinear_clamp(g, sw, tc[0] + inv[0], tc[1], tc[2]),
-                trilinear_clamp(g, sw, tc[0], tc[1] - inv[1], tc[2]) - trilinear_clamp(g, sw, tc[0], tc[1] + inv[1], tc[2]),
-                trilinear_clamp(g, sw, tc[0], tc[1], tc[2] - inv[2]) - trilinear_clamp(g, sw, tc[0], tc[1], tc[2] + inv[2])};
+            // push out of the solid along the gradient of the voxelisation's w channel; without solid voxels every sample is 0 and
+            // the six trilinear evaluations (a few hundred instructions for every wave that touches a wall) are skipped
+            if (solid) {
+                auto sw = [&](int ax, int ay, int az) -> float { return solid[cidx(g, ax, ay, az)].w; };
+                const float push[3] = {
+                    trilinear_clamp(g, sw, tc[0] - inv[0], tc[1], tc[2]) - trilinear_clamp(g, sw, tc[0] + inv[0], tc[1], tc[2]),
+                    trilinear_clamp(g, sw, tc[0], tc[1] - inv[1], tc[2]) - trilinear_clamp(g, sw, tc[0], tc[1] + inv[1], tc[2]),
+                    trilinear_clamp(g, sw, tc[0], tc[1], tc[2] - inv[2]) - trilinear_clamp(g, sw, tc[0], tc[1], tc[2] + inv[2])};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) mv[k] += push[k] * (dt * 50.0f);
+                for (int k = 0; k < 3; ++k) mv[k] += push[k] * (dt * 50.0f);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) mv[k] += 0.0f * (dt * 50.0f);      // (0 - 0) * (dt * 50): keeps the sign-of-zero behaviour of the sum
+            }
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { np[k] = op[k] + mv[k]; np[k] = clampf(np[k], 1.001f, gs[k] - 1.001f); nv[k] = (dir[k] * ms) / dt; }
