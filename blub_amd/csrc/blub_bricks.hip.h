@@ -435,6 +435,10 @@ __global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const ui
 // each face adds up the eight partials of the eight lists the reference walks for it.  Per particle the eight weights share their
 // factors (2 x 3 one-dimensional hats), which halves the arithmetic; every product / sum of a particle-face pair is formed exactly
 // as in add_particle(), only the ORDER in which a face's contributions are added differs (list-major instead of round-major).
+#ifndef BLUB_GATHER_CAP_V
+#define BLUB_GATHER_CAP_V 12      // transfer_gather_velocity.comp:61 (other values: timing ablations only)
+#endif
+constexpr int GATHER_CAP_V = BLUB_GATHER_CAP_V;
 constexpr int GP_STRIDE = 768;
 struct GatherPartialsV { float2 part[8][GP_STRIDE]; };     // [corner][list cell] {sum w*d, sum w}: 48 KiB
 struct GatherPartialsD { float part[8][GP_STRIDE]; };      // [corner][list cell] sum w: 24 KiB
@@ -468,8 +472,8 @@ __device__ __forceinline__ void gather_velocity_partial_body(GatherPartialsV& sh
             const float sz0 = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f), sz1 = (float)(gz + 1) + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
             float4 p = pos[cur], r = rows[cur];
             uint32_t nxt = next ? next[cur] : __float_as_uint(p.w);
-            for (int round = 0; round < 12; ++round) {                                           // :61
-                const bool has_n = nxt != INVALID_LL && round + 1 < 12;
+            for (int round = 0; round < GATHER_CAP_V; ++round) {                                           // :61
+                const bool has_n = nxt != INVALID_LL && round + 1 < GATHER_CAP_V;
                 float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
                 if (has_n) { pn = pos[nxt]; rn = rows[nxt]; nn = next ? next[nxt] : __float_as_uint(pn.w); }   // next node in flight during the arithmetic
                 const float tx[2] = {sx0 - p.x, sx1 - p.x}, ty[2] = {sy0 - p.y, sy1 - p.y}, tz[2] = {sz0 - p.z, sz1 - p.z};   // :20
@@ -518,12 +522,23 @@ __device__ __forceinline__ void gather_velocity_partial_body(GatherPartialsV& sh
         }
     }
 }
+// Work mapping: the three component gathers of a brick read the SAME particle positions.  Block b runs on XCD b % 8 (observed dispatch
+// order, a speed hint only); consecutive blocks of one XCD take the three components of one brick slot, so the positions fetched for the
+// first component are L2 hits for the other two.  gridDim.x = 3 * slots, slots a multiple of 8.
+__device__ __forceinline__ void gather3_block_role(uint32_t& slot, uint32_t& slots, int& comp) {
+    const uint32_t b = blockIdx.x, xcd = b & 7u, s = b >> 3;
+    comp = (int)(s % 3u);
+    slot = (s / 3u) * 8u + xcd;
+    slots = gridDim.x / 3u;
+}
 __global__ __launch_bounds__(768) void k_gather_velocity3_p(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                             const int8_t* __restrict__ marker, const float4* __restrict__ pos, GatherArgs3 a) {
     __shared__ GatherPartialsV sh;
-    if (blockIdx.y == 0) gather_velocity_partial_body<0>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[0], pos, a.next[0], a.rows[0], a.out[0], a.gravity_dt[0]);
-    else if (blockIdx.y == 1) gather_velocity_partial_body<1>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[1], pos, a.next[1], a.rows[1], a.out[1], a.gravity_dt[1]);
-    else gather_velocity_partial_body<2>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[2], pos, a.next[2], a.rows[2], a.out[2], a.gravity_dt[2]);
+    uint32_t slot, slots; int comp;
+    gather3_block_role(slot, slots, comp);
+    if (comp == 0) gather_velocity_partial_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], pos, a.next[0], a.rows[0], a.out[0], a.gravity_dt[0]);
+    else if (comp == 1) gather_velocity_partial_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], pos, a.next[1], a.rows[1], a.out[1], a.gravity_dt[1]);
+    else gather_velocity_partial_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], pos, a.next[2], a.rows[2], a.out[2], a.gravity_dt[2]);
 }
 
 // R1 in the same formulation (density_projection_gather_error.comp:41-198): samples are cell centres, the list cap is 32

@@ -262,14 +262,15 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     const dim3 bgrid(h->brick_grid);
     LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, bgrid, dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0], h->ll[1], h->ll[2],
            h->vel[0], h->vel[1], h->vel[2], h->pressure[0], h->pressure[1]);
-    if (h->num_particles + h->num_ghost)
-        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), h->g, h->num_particles + h->num_ghost, h->pos, h->marker,
+    const uint32_t np_all = h->num_particles + h->num_ghost;
+    if (np_all)
+        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, h->marker,
                h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2, (int)(h->solid == nullptr));
     {
         GatherArgs3 a;
         const uint32_t* nexts[3] = {nullptr, h->next1, h->next2};
         for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.next[c] = nexts[c]; a.rows[c] = h->pvel[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
-        if (h->gather_mode == 1) LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, dim3(h->brick_grid, 3), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
+        if (h->gather_mode == 1) LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, dim3(3 * ((h->brick_grid + 7) / 8) * 8), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
         else LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_b, dim3(h->brick_grid, 3), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
     }
     return BLUB_OK;
