@@ -738,97 +738,117 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_position_change_b(BrickGeom b
     BRICK_LOOP_END
 }
 
-// D3: extrapolate_velocity.comp:9-90 (active bricks).  The block stages the marker tile of its brick plus a one-cell ring
-// (18 x 10 x 6 cells, padded to 24 bytes per row) in LDS with ~3 dword loads per thread; every thread then reads the
-// 6 x 3 x 3 marker neighbourhood of its quad from LDS.  Bricks whose tile holds no FLUID cell are skipped after the load
-// (most of the dilated ring); the reference's per-cell logic is evaluated from registers.
+// D3: extrapolate_velocity.comp:9-90 (active bricks).  Every marker test of the shader is "== FLUID", so the block stages its brick plus a
+// one-cell ring (18 x 10 x 6 cells) as ONE BIT per cell: 60 threads each turn a 24-byte marker row (x0-4 .. x0+19) into a 24-bit FLUID mask.
+// A quad's whole 12 x 3 x 3 neighbourhood is then nine shifted row masks in registers, "face has a FLUID side" is an OR of two masks and
+// the shader's skip conditions are bit tests -- the byte-wise version spent ~1 900 VALU instructions per thread on marker extraction and
+// was issue-bound.  Bricks whose tile holds no FLUID cell are skipped after the load (most of the dilated ring).
 constexpr int ET_ROW = 24;                                   // bytes per staged row: x0-4 .. x0+19 (6 dwords)
 constexpr int ET_ROWS = (BY + 2) * (BZ + 2);                 // 60 rows
 __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                  const int8_t* __restrict__ marker, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
-    __shared__ uint32_t tile[ET_ROWS * (ET_ROW / 4)];
+    __shared__ uint32_t rowmask[2][ET_ROWS + 4];             // double buffered by brick parity: one barrier per brick
     const Grid g = bg.g;
     float* vel[3] = {vx, vy, vz};
     const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int plane = g.nx * g.ny;
+    int parity = 0;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x, parity ^= 1) {
         const uint32_t b = list[i] & ~STALE_BIT;
         int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int tx0 = bx * BX - 4, ty0 = by * BY - 1, tz0 = bz * BZ - 1;     // tile origin (x is dword aligned)
+        uint32_t* rm = rowmask[parity];
         bool any = false;
-        for (int w = threadIdx.x; w < ET_ROWS * (ET_ROW / 4); w += BRICK_THREADS) {
-            const int row = w / (ET_ROW / 4), dw = w % (ET_ROW / 4);
-            const int yy = ty0 + row % (BY + 2), zz = tz0 + row / (BY + 2), xx = tx0 + dw * 4;
-            uint32_t v = 0;   // out of bounds reads SOLID (0)
-            if ((unsigned)yy < (unsigned)g.ny && (unsigned)zz < (unsigned)g.nz && xx >= 0 && xx < g.nx) v = *reinterpret_cast<const uint32_t*>(marker + cidx(g, xx, yy, zz));
-            tile[w] = v;
-            any = any || any_fluid4(v);
+        if (threadIdx.x < ET_ROWS) {
+            const int row = threadIdx.x;
+            const int yy = ty0 + row % (BY + 2), zz = tz0 + row / (BY + 2);
+            uint32_t v[ET_ROW / 4];
+#pragma unroll
+            for (int dw = 0; dw < ET_ROW / 4; ++dw) {
+                const int xx = tx0 + dw * 4;
+                v[dw] = 0;   // out of bounds reads SOLID (0)
+                if ((unsigned)yy < (unsigned)g.ny && (unsigned)zz < (unsigned)g.nz && xx >= 0 && xx < g.nx) v[dw] = *reinterpret_cast<const uint32_t*>(marker + cidx(g, xx, yy, zz));
+            }
+            uint32_t mask = 0;
+#pragma unroll
+            for (int dw = 0; dw < ET_ROW / 4; ++dw) {
+                // marker bytes are 0x00 SOLID, 0x01 FLUID, 0xFF AIR: FLUID <=> bit 0 set and bit 7 clear; the multiply gathers the four bits
+                const uint32_t f = v[dw] & ~(v[dw] >> 7) & 0x01010101u;
+                mask |= ((f * 0x10204080u) >> 28) << (4 * dw);
+            }
+            rm[row] = mask;
+            any = mask != 0;
         }
-        if (!__syncthreads_or(any)) continue;     // (the barrier also publishes the tile)
+        if (!__syncthreads_or(any)) continue;     // (the barrier also publishes the masks; the next brick writes the other buffer)
         int x0, y, z;
         const bool valid = brick_quad(bg, b, threadIdx.x, x0, y, z);
-        if (valid) {
-            // the quad's whole marker neighbourhood (x0-4 .. x0+7, y-1 .. y+1, z-1 .. z+1) in ONE batch of 27 independent LDS
-            // reads; every marker test below is then a byte extract from registers (the per-test LDS byte reads this replaces
-            // were ~260 serialised round trips per thread: the kernel was LDS-latency bound)
-            uint32_t win[3][3][3];
+        if (!valid) continue;
+        // F[dz][dy]: bit k = cell (x0 - 4 + k, y + dy - 1, z + dz - 1) is FLUID, k = 0 .. 11; the quad's cells are k = 4 .. 7
+        const int sh = x0 - tx0 - 4, r0 = (z - 1 - tz0) * (BY + 2) + (y - 1 - ty0);
+        uint32_t F[3][3];
 #pragma unroll
-            for (int dz = 0; dz < 3; ++dz)
+        for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < 3; ++dy) F[dz][dy] = (rm[r0 + dz * (BY + 2) + dy] >> sh) & 0xFFFu;
+        uint32_t all = 0;
 #pragma unroll
-                    for (int w = 0; w < 3; ++w)
-                        win[dz][dy][w] = tile[((z + dz - 1 - tz0) * (BY + 2) + (y + dy - 1 - ty0)) * (ET_ROW / 4) + ((x0 - tx0) >> 2) - 1 + w];
-            auto M = [&](int x, int yy, int zz) -> int {
-                const int k = x - x0 + 4;   // 3 .. 8 (compile-time after unrolling)
-                return (int)(int8_t)((win[zz - z + 1][yy - y + 1][k >> 2] >> (8 * (k & 3))) & 0xFFu);
-            };
-            bool near_fluid = false;
+        for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-            for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = 0; dy < 3; ++dy) all |= F[dz][dy];
+        if (!(all & 0x1F8u)) continue;            // no FLUID cell in x0-1 .. x0+4 of the 3 x 3 rows: nothing to extrapolate from
+        // face masks: bit k = the face of cell k towards +comp has a FLUID side (extrapolate_velocity.comp:30-37 validity test)
+        uint32_t X[3][3], Y[3], Z[3];
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
+        for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-                    for (int k = -1; k <= 4; ++k) near_fluid = near_fluid || M(x0 + k, y + dy, z + dz) == CELL_FLUID;
-            if (near_fluid) {
-                const int base = cidx(g, x0, y, z);
+            for (int dy = 0; dy < 3; ++dy) X[dz][dy] = F[dz][dy] | (F[dz][dy] >> 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int x = x0 + j;
-                    if (M(x, y, z) == CELL_FLUID) continue;
+        for (int dz = 0; dz < 3; ++dz) Y[dz] = F[dz][1] | F[dz][2];
 #pragma unroll
-                    for (int comp = 0; comp < 3; ++comp) {
-                        if (M(x + (comp == 0), y + (comp == 1), z + (comp == 2)) == CELL_FLUID) continue;
-                        // validity of the 8 in-plane neighbour faces first (registers/LDS only) ...
-                        bool ok[8]; int ci[8]; int k8 = 0; bool any_ok = false;
+        for (int dy = 0; dy < 3; ++dy) Z[dy] = F[1][dy] | F[2][dy];
+        // cells that take part per component: not FLUID, own face without a FLUID side, at least one valid in-plane neighbour face
+        uint32_t anyok[3];
+        anyok[0] = X[0][0] | X[0][1] | X[0][2] | X[1][0] | X[1][2] | X[2][0] | X[2][1] | X[2][2];
+        anyok[1] = (Y[0] >> 1) | Y[0] | (Y[0] << 1) | (Y[1] >> 1) | (Y[1] << 1) | (Y[2] >> 1) | Y[2] | (Y[2] << 1);
+        anyok[2] = (Z[0] >> 1) | Z[0] | (Z[0] << 1) | (Z[1] >> 1) | (Z[1] << 1) | (Z[2] >> 1) | Z[2] | (Z[2] << 1);
+        const uint32_t own[3] = {X[1][1], Y[1], Z[1]};
+        const int base = cidx(g, x0, y, z);
+        const bool ym_in = y > 0, yp_in = y + 1 < g.ny, zm_in = z > 0, zp_in = z + 1 < g.nz;
 #pragma unroll
-                        for (int b2 = -1; b2 <= 1; ++b2)
+        for (int comp = 0; comp < 3; ++comp) {
+            const uint32_t need = ~F[1][1] & ~own[comp] & anyok[comp] & 0xF0u;
+            if (!need) continue;
 #pragma unroll
-                            for (int a = -1; a <= 1; ++a) {
-                                if (a == 0 && b2 == 0) continue;
-                                int ox, oy, oz;
-                                if (comp == 0) { ox = 0; oy = a; oz = b2; }
-                                else if (comp == 1) { ox = a; oy = 0; oz = b2; }
-                                else { ox = a; oy = b2; oz = 0; }
-                                const int cx = x + ox, cy = y + oy, cz = z + oz;
-                                ok[k8] = M(cx, cy, cz) == CELL_FLUID || M(cx + (comp == 0), cy + (comp == 1), cz + (comp == 2)) == CELL_FLUID;
-                                ci[k8] = inb(g, cx, cy, cz) ? cidx(g, cx, cy, cz) : -1;     // OOB faces read 0 (and are never valid)
-                                any_ok = any_ok || ok[k8];
-                                ++k8;
-                            }
-                        if (!any_ok) continue;
-                        // ... then all loads in one batch (independent, one memory round trip), summed in the reference's order
-                        float val[8];
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 + j;
+                if (!((need >> k) & 1u)) continue;
+                const int x = x0 + j;
+                // the 8 in-plane neighbour faces in the reference's order (b2 outer, a inner): validity from the masks, then all loads in
+                // one batch (independent, one memory round trip), summed in that order
+                bool ok[8]; int ci[8]; int k8 = 0;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) val[k] = (ok[k] && ci[k] >= 0) ? vel[comp][ci[k]] : 0.0f;
-                        float numV = 0.0f, avgV = 0.0f;
+                for (int b2 = -1; b2 <= 1; ++b2)
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) if (ok[k]) { numV += 1.0f; avgV += val[k]; }
-                        vel[comp][base + j] = avgV / numV;
+                    for (int a = -1; a <= 1; ++a) {
+                        if (a == 0 && b2 == 0) continue;
+                        int ox, oy, oz; uint32_t fm;
+                        if (comp == 0) { ox = 0; oy = a; oz = b2; fm = X[1 + b2][1 + a]; }
+                        else if (comp == 1) { ox = a; oy = 0; oz = b2; fm = Y[1 + b2]; }
+                        else { ox = a; oy = b2; oz = 0; fm = Z[1 + b2]; }
+                        ok[k8] = ((fm >> (k + ox)) & 1u) != 0;
+                        const bool in = (ox < 0 ? x > 0 : ox > 0 ? x + 1 < g.nx : true) && (oy < 0 ? ym_in : oy > 0 ? yp_in : true) && (oz < 0 ? zm_in : oz > 0 ? zp_in : true);
+                        ci[k8] = in ? base + j + ox + oy * g.nx + oz * plane : -1;     // OOB faces read 0 (they can still be valid: their inner side may be FLUID)
+                        ++k8;
                     }
-                }
+                float val[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) val[q] = (ok[q] && ci[q] >= 0) ? vel[comp][ci[q]] : 0.0f;
+                float numV = 0.0f, avgV = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (ok[q]) { numV += 1.0f; avgV += val[q]; }
+                vel[comp][base + j] = avgV / numV;
             }
         }
-        __syncthreads();   // the tile is rewritten for the next brick
     }
 }
 
