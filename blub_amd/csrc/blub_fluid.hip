@@ -398,7 +398,17 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     } while (0)
             static const bool xmap = getenv("BLUB_PCG1_XMAP") ? atoi(getenv("BLUB_PCG1_XMAP")) != 0 : true;   // XCD-contiguous list order (+2 % steps/s; needs np % 8 == 0, guaranteed above)
             static const bool done_first_env = getenv("BLUB_PCG1_DONEFIRST") ? atoi(getenv("BLUB_PCG1_DONEFIRST")) != 0 : false;   // (tuning switch)
-            for (int i = 0; i <= maxit; ++i) {
+            // Launch as many iterations as the last few solves needed (+ `tail_margin_checks` check intervals); ONE persistent kernel covers
+            // the rest (k_pcg1_tail_s): it normally finds the solve finished and only publishes the statistics.  Only while the solve is
+            // launch-bound (an iteration inside the tail -- <= 256 blocks, a grid barrier -- costs more than a launched one).
+            int launched1 = maxit + 1;
+            if (h->use_tail && (!have || bc.n_fluid <= 2048u) && freq > 0 && !h->stats_history[which].empty()) {
+                int recent = 0, k = 0;
+                for (auto it2 = h->stats_history[which].rbegin(); it2 != h->stats_history[which].rend() && k < 4; ++it2, ++k) recent = std::max(recent, (int)it2->iteration_count);
+                if (recent >= 0 && recent < maxit) launched1 = std::min(maxit + 1, (recent / freq + h->tail_margin_checks) * freq + 2);   // K(c + 1) forms the verdict of check c
+            }
+            if (h->use_tail && h->tail_first_forced >= 0) launched1 = std::min(maxit + 1, std::max(1, h->tail_first_forced));   // (test hook; K(0) is always launched)
+            for (int i = 0; i < launched1; ++i) {
                 const float4* pin = part[i & 1]; float4* pout = part[(i + 1) & 1];
                 // the first check is iteration `freq`, its verdict is formed by K(freq + 1): K(freq + 2) is the first launch that can find `done` set
                 const int done_first = (done_first_env && freq > 0 && i >= freq + 2) ? 1 : 0;
@@ -407,6 +417,13 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             }
             const int np_final = np;
 #undef BLUB_LAUNCH_K
+            if (launched1 <= maxit) {
+                const dim3 tgrid((unsigned)std::max(8, (std::min(np, h->tail_grid) / 8) * 8));
+                if (xmap) LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_tail_s<true>, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, R[0], R[1], W[0], W[1], Q[0], Q[1], h->search, p,
+                                 part[0], part[1], np_final, ctrl, sc, tol, launched1, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
+                else LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_tail_s<false>, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, R[0], R[1], W[0], W[1], Q[0], Q[1], h->search, p,
+                            part[0], part[1], np_final, ctrl, sc, tol, launched1, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
+            } else
             LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], np_final, maxit, h->solve_seq[which], stat_slot);
             // the residual of a full-length solve ends in R[(maxit + 1) & 1]; keep BLUB_VOLUME_RESIDUAL pointing at it
             if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);

@@ -286,14 +286,16 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
 // below `halo_lo` / above `halo_hi` (own planes of the slab, -1 = none), so only w needs a halo exchange per iteration.
 // EARLY (tuning): 0 = the first brick's loads are issued after the reduction, 1 = its descriptors before / its fields after,
 // 2 = everything before the reduction
-template <bool FIRST, bool HALO = false, int EARLY = 1, bool XMAP = false>
-__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+// (the body of K(i) as a device function: k_pcg1_iter_s runs it once per launch, k_pcg1_tail_s in a loop with grid barriers.
+//  Returns false when the solve is finished -- `done` was set, or this iteration's convergence test succeeded -- and nothing was computed)
+template <bool FIRST, bool HALO, int EARLY, bool XMAP>
+__device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
                                                                const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
                                                                float* __restrict__ q_out, float* __restrict__ dsearch, float* __restrict__ p,
                                                                const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part,
                                                                PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
-                                                               int halo_lo = -1, int halo_hi = -1, int done_first = 0) {
+                                                               int halo_lo, int halo_hi, int done_first) {
     __shared__ float4 sm4[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
     __shared__ DivConst div_lut[8];
@@ -310,16 +312,16 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
     const uint32_t n = *count;
     // (tuning switch `done_first`: test `done` alone before anything else is requested.  Measured: no gain -- a launch of this grid costs
     // ~4.5 us even when every block returns at once, whatever it loads first)
-    if (done_first && ctrl->done) return;      // uniform
+    if (done_first && ctrl->done) return false;      // uniform
     Pcg1PrologueLoads PL;
     pcg1_prologue_load<PCG_B_THREADS, FIRST>(ctrl, sc, part_in, num_part, iteration, PL);
-    if (PL.done) return;      // uniform
+    if (PL.done) return false;      // uniform
     // round trip 2: the first brick's fields, in flight during the reduction
     Pcg1TileLoads TL;
     if (EARLY >= 1 && i0 < n) pcg1_tile_load_desc(TL, bg, b0, t, dvol);
     if (EARLY >= 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
     float alpha, beta;
-    if (!pcg1_prologue_finish<PCG_B_THREADS, FIRST>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return;
+    if (!pcg1_prologue_finish<PCG_B_THREADS, FIRST>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
     if (EARLY < 1 && i0 < n) pcg1_tile_load_desc(TL, bg, b0, t, dvol);
     if (EARLY < 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
     StagedTile& T = tiles[half];
@@ -432,6 +434,20 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
         for (int w = 1; w < PCG_B_THREADS / 64; ++w) { tot.x += sm4[w].x; tot.y += sm4[w].y; tot.z = fmaxf(tot.z, sm4[w].z); }
         part_out[blockIdx.x] = tot;
     }
+    return true;
+}
+
+
+template <bool FIRST, bool HALO = false, int EARLY = 1, bool XMAP = false>
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                               const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
+                                                               const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
+                                                               float* __restrict__ q_out, float* __restrict__ dsearch, float* __restrict__ p,
+                                                               const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part,
+                                                               PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
+                                                               int halo_lo = -1, int halo_hi = -1, int done_first = 0) {
+    (void)pcg1_iteration<FIRST, HALO, EARLY, XMAP>(bg, list, count, dvol, r_in, r_out, w_in, w_out, q_in, q_out, dsearch, p, part_in, part_out, num_part, ctrl, sc, tolerance,
+                                                   iteration, check_prev, halo_lo, halo_hi, done_first);
 }
 
 // After K(max_num_iterations): statistics are written unconditionally if nothing converged before (pressure_reduce.comp:84).
@@ -448,6 +464,43 @@ __global__ __launch_bounds__(256) void k_pcg1_finalize(PcgCtrl* __restrict__ ctr
             __threadfence_system();
             host_snapshot->seq = seq;
         }
+    }
+}
+
+// Persistent tail of a single-reduction solve: the host launches as many K(i) as the last few solves needed plus one check interval
+// (most solves of the headline scene converge after 8-28 of the 33 possible launches, and a launch that only finds `done` set still
+// costs ~2 us); this ONE kernel covers every remaining iteration.  Normally it finds `done` set and only publishes the statistics
+// (k_pcg1_finalize's job); otherwise it runs K(first) .. K(max) itself, separated by bounded agent-scope grid barriers (grid_barrier,
+// blub_pcg.hip.h: every block is co-resident, <= one per CU), and publishes.  Same iteration body, same buffers by iteration parity.
+template <bool XMAP>
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_tail_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint8_t* __restrict__ dvol,
+                                                               float* r0, float* r1, float* w0, float* w1, float* q0, float* q1, float* dsearch, float* p,
+                                                               float4* part0, float4* part1, int num_part_in, PcgCtrl* ctrl, Pcg1Scalars* sc, float tolerance,
+                                                               int first_iteration, int max_iterations, int check_frequency, PcgTailSync* sync, uint32_t seq,
+                                                               PcgCtrl* host_snapshot) {
+    __shared__ float4 sm4f[4];
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    auto publish = [&]() {   // what k_pcg1_finalize does
+        ctrl->seq = seq;
+        if (host_snapshot) { host_snapshot->max_err = ctrl->max_err; host_snapshot->num_iter = ctrl->num_iter; __threadfence_system(); host_snapshot->seq = seq; }
+    };
+    if (ctrl->done) { if (leader) publish(); return; }      // uniform
+    float* R[2] = {r0, r1}; float* W[2] = {w0, w1}; float* Q[2] = {q0, q1}; float4* part[2] = {part0, part1};
+    int num_part = num_part_in;      // the first reduction reads what the LAUNCHED K(first - 1) wrote
+    uint32_t barrier_no = 0;
+    for (int it = first_iteration; it <= max_iterations; ++it) {
+        const int prev = it - 1;
+        const int check_prev = prev > 0 && check_frequency > 0 && prev % check_frequency == 0;
+        const bool ran = pcg1_iteration<false, false, 1, XMAP>(bg, list, count, dvol, R[it & 1], R[(it + 1) & 1], W[it & 1], W[(it + 1) & 1], Q[(it + 1) & 1], Q[it & 1], dsearch, p,
+                                                               part[it & 1], part[(it + 1) & 1], num_part, ctrl, sc, tolerance, it, check_prev, -1, -1, 0);
+        if (!ran) { if (leader) publish(); return; }        // converged at the check of iteration it - 1 (the leader wrote the statistics itself)
+        if (!grid_barrier(&sync->arrivals, gridDim.x * ++barrier_no, &sync->timed_out)) { if (leader) { ctrl->num_iter = -1.0f; ctrl->done = 1; publish(); } return; }
+        num_part = (int)gridDim.x;
+    }
+    // max_num_iterations reached without convergence (pressure_reduce.comp:84)
+    if (blockIdx.x == 0) {
+        const float4 red = reduce_partials4<PCG_B_THREADS>(part[(max_iterations + 1) & 1], num_part, sm4f);
+        if (threadIdx.x == 0) { ctrl->max_err = red.z; ctrl->num_iter = (float)max_iterations; ctrl->done = 1; publish(); }
     }
 }
 

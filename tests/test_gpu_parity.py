@@ -566,26 +566,35 @@ def test_empty_fluid_steps_are_harmless():
         h.close()
 
 
+@pytest.mark.parametrize("schedule", ["reference", "single_reduction"])
 @pytest.mark.parametrize("first", [0, 3, 9])
-def test_pcg_persistent_tail_kernel(first, monkeypatch):
+def test_pcg_persistent_tail_kernel(first, schedule, monkeypatch):
     """Brick-mapped solves hand the iterations the host did not launch to one persistent kernel (grid barriers between the
-    phases).  Forced hand-over after `first` launched iterations: the solve must equal the oracle exactly as the fully
-    launched one does (fixed 14 iterations, and a converging run that stops inside the tail)."""
+    phases; k_pcg_tail_b for the reference schedule, k_pcg1_tail_s for the single-reduction one).  Forced hand-over after `first`
+    launched iterations: the solve must equal the oracle exactly as the fully launched one does (fixed 14 iterations, and a
+    converging run that stops inside the tail)."""
     import blub_amd
-    monkeypatch.setenv("BLUB_PCG_TAIL_FIRST", str(first))
     pos, vel, maxp = util.make_dam(*GRID)
+    full = None
+    if schedule == "single_reduction":      # the same solve with every iteration launched (handle created before the hook is set)
+        _, full = util.new_pair(*GRID, maxp)
+        full.set_pcg_work_mapping("bricks_staged")
+        full.set_pcg_schedule(schedule)
+    monkeypatch.setenv("BLUB_PCG_TAIL_FIRST", str(first))
     o, h = util.new_pair(*GRID, maxp)
     try:
-        h.set_pcg_work_mapping("bricks")
-        h.set_pcg_schedule("reference")
+        h.set_pcg_work_mapping("bricks" if schedule == "reference" else "bricks_staged")
+        h.set_pcg_schedule(schedule)
         o.set_particles(pos, *vel)
         run_until(o, "solve_velocity")
         util.copy_state(o, h)
+        if full is not None:
+            util.copy_state(o, full)
         state = {v: o.read_volume(v) for v in ("residual", "pressure_velocity", "search")}
         fluid = o.read_volume("marker") == 1
         for cfg in (dict(error_tolerance=0.0, max_num_iterations=14, error_check_frequency=4),
                     dict(error_tolerance=0.26, max_num_iterations=64, error_check_frequency=4)):
-            for f in (o, h):
+            for f in (o, h) + ((full,) if full is not None else ()):
                 f.set_solver_config(0, **cfg)
                 for v, a in state.items():
                     f.write_volume(v, a)
@@ -596,9 +605,21 @@ def test_pcg_persistent_tail_kernel(first, monkeypatch):
             eo, io = o.solver_stats(0)
             eh, ih = h.solver_stats(0)
             assert ih == io and ih >= 0, (cfg, (eh, ih), (eo, io))
-            assert abs(eh - eo) <= 2e-3 * eo
+            # the single-reduction schedule rounds differently from the oracle (14 unconverged iterations: ~1e-3 of the scale, see
+            # tests/test_gpu_pcg_schedule.py); what the tail must reproduce tightly is the fully launched solve of the same schedule
+            assert abs(eh - eo) <= (2e-3 if full is None else 2e-2) * eo
             for name in ("pressure_velocity", "residual"):
                 a, b = h.read_volume(name), o.read_volume(name)
-                util.assert_close(name, a[fluid], b[fluid], abs_=3e-4 * np.abs(b[fluid]).max())
+                util.assert_close(name, a[fluid], b[fluid], abs_=(3e-4 if full is None else 3e-3) * np.abs(b[fluid]).max())
+            if full is not None:
+                full.mark_pressure_initialised(0, False)
+                full.run_stage("solve_velocity", util.DT)
+                ef, i_f = full.solver_stats(0)
+                assert i_f == ih and abs(ef - eh) <= 1e-4 * eh, ((ef, i_f), (eh, ih))
+                for name in ("pressure_velocity", "residual", "search"):
+                    a, b = h.read_volume(name), full.read_volume(name)
+                    util.assert_close(name + " (tail vs launched)", a[fluid], b[fluid], abs_=2e-5 * np.abs(b[fluid]).max())
     finally:
         h.close()
+        if full is not None:
+            full.close()
