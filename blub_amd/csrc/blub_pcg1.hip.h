@@ -241,28 +241,47 @@ struct Pcg1TileLoads {
 // of 512), and the kernel is bound by the bytes it pulls through the fabric (every kernel boundary invalidates the L2s), not by
 // the number of dependent loads: the stencil descriptors are fetched first and the five f32 fields only for quads that hold a
 // FLUID cell (measured: see DESIGN.md 6).
-__device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const BrickGeom& bg, uint32_t b, int t, const uint8_t* __restrict__ dvol) {
-    const Grid g = bg.g;
-    int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb);
-        const int x0b = bxb * BX, y0b = byb * BY, z0b = bzb * BZ;
+// What a thread's tile elements need that does NOT depend on the brick: evaluated before the kernel's first wait (the list entry, `done`
+// and the partials are in flight then), so that only two additions per element remain between the arrival of the brick index and the
+// descriptor loads -- the arithmetic below sat on the critical path of a kernel bound by instruction issue.
+struct Pcg1ThreadGeom { int rel[2], ry[2], rz[2], q4[2]; int need[2], own[2]; int hrel, hyy, hzz, hdx; };
+__device__ __forceinline__ void pcg1_thread_geom(Pcg1ThreadGeom& G, const Grid& g, int t) {
+    const int plane = g.nx * g.ny;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int e = t + k * BRICK_THREADS;
         const int row = e >> 2, q = e & 3;
+        const int ry = row % (BY + 2), rz = row / (BY + 2);
+        G.need[k] = (e < ST_ROWS * 4 && st_row_needed(row)) ? 1 : 0;
+        G.ry[k] = ry; G.rz[k] = rz; G.q4[k] = 4 * q;
+        G.rel[k] = (ry - 1) * g.nx + (rz - 1) * plane + 4 * q;
+        G.own[k] = (ry >= 1 && ry <= BY && rz >= 1 && rz <= BZ) ? 1 : 0;
+    }
+    const int side = t & 1, yy = (t >> 1) % BY, zz = (t >> 1) / BY;
+    G.hyy = yy; G.hzz = zz; G.hdx = side ? BX : -1;
+    G.hrel = yy * g.nx + zz * plane + G.hdx;
+    asm volatile("" :: "v"(G.rel[0]), "v"(G.rel[1]), "v"(G.hrel), "v"(G.need[0] | (G.need[1] << 1) | (G.own[0] << 2) | (G.own[1] << 3)));   // not to be sunk below the `done` test
+}
+__device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const Pcg1ThreadGeom& G, const BrickGeom& bg, uint32_t b, int t, const uint8_t* __restrict__ dvol) {
+    const Grid g = bg.g;
+    int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb);
+    const int x0b = bxb * BX, y0b = byb * BY, z0b = bzb * BZ;
+    const int base0 = cidx(g, x0b, y0b, z0b);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
         L.base[k] = -1; L.dq[k] = 0; L.own[k] = false;
-        if (e >= ST_ROWS * 4 || !st_row_needed(row)) continue;
-        const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1, gx = x0b + 4 * q;
+        if (!G.need[k]) continue;
+        const int gy = y0b + G.ry[k] - 1, gz = z0b + G.rz[k] - 1, gx = x0b + G.q4[k];
         if (!((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx)) continue;
-        const int base = cidx(g, gx, gy, gz);
+        const int base = base0 + G.rel[k];
         L.base[k] = base;
         L.dq[k] = *reinterpret_cast<const uint32_t*>(dvol + (uint32_t)base);
-        L.own[k] = gy >= y0b && gy < y0b + BY && gz >= z0b && gz < z0b + BZ;
+        L.own[k] = G.own[k] != 0;
     }
     L.hin = false; L.hdv = 0; L.hc = -1;
     if (t < BY * BZ * 2) {
-        const int side = t & 1, yy = (t >> 1) % BY, zz = (t >> 1) / BY;
-        const int gx = side ? x0b + BX : x0b - 1, gy = y0b + yy, gz = z0b + zz;
-        if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { L.hc = cidx(g, gx, gy, gz); L.hin = true; L.hdv = (int)dvol[(uint32_t)L.hc]; }
+        const int gx = x0b + G.hdx, gy = y0b + G.hyy, gz = z0b + G.hzz;
+        if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { L.hc = base0 + G.hrel; L.hin = true; L.hdv = (int)dvol[(uint32_t)L.hc]; }
     }
 }
 template <bool FIRST>
@@ -315,14 +334,16 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     if (done_first && ctrl->done) return false;      // uniform
     Pcg1PrologueLoads PL;
     pcg1_prologue_load<PCG_B_THREADS, FIRST>(ctrl, sc, part_in, num_part, iteration, PL);
+    Pcg1ThreadGeom TG;
+    pcg1_thread_geom(TG, g, t);       // (in the shadow of the loads above)
     if (PL.done) return false;      // uniform
     // round trip 2: the first brick's fields, in flight during the reduction
     Pcg1TileLoads TL;
-    if (EARLY >= 1 && i0 < n) pcg1_tile_load_desc(TL, bg, b0, t, dvol);
+    if (EARLY >= 1 && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
     if (EARLY >= 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
     float alpha, beta;
     if (!pcg1_prologue_finish<PCG_B_THREADS, FIRST>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
-    if (EARLY < 1 && i0 < n) pcg1_tile_load_desc(TL, bg, b0, t, dvol);
+    if (EARLY < 1 && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
     if (EARLY < 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
     StagedTile& T = tiles[half];
     float acc_g = 0.0f, acc_d = 0.0f, emax = 0.0f;
@@ -331,7 +352,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = first ? b0 : (have ? list[i] : 0u);
-        if (!first && have) { pcg1_tile_load_desc(TL, bg, b, t, dvol); pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p); }
+        if (!first && have) { pcg1_tile_load_desc(TL, TG, bg, b, t, dvol); pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p); }
         first = false;
         int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb); (void)bxb;
         const int y0b = byb * BY, z0b = bzb * BZ;
