@@ -67,13 +67,40 @@ __device__ __forceinline__ float reduce_partials_256(const float* __restrict__ p
 // dual-grid lists (component c: dual cell = ivec3(pos - (0.5 + 0.5 e_c))) and marks FLUID cells.
 // list "next" pointers: component x lives in pos.w (as in the reference), y/z in two extra u32 arrays.
 // =================================================================================================================
-// Wave-aggregated list insertion.  Particles are (re)binned by cell, so neighbouring lanes mostly insert into the SAME
-// list and a per-lane atomicExch serialises on one address.  Instead, every run of adjacent lanes with the same cell
-// is chained in registers (lane -> previous lane of the run) and only the run's LAST lane exchanges the list head; the
-// old head becomes the `next` of the run's FIRST lane.  The result is a valid insertion order of the reference's
-// atomic-exchange list (transfer_build_linkedlist.comp:25) with 1 atomic per run instead of 1 per particle.
-// key < 0: the particle is outside the grid (no insertion, next = invalid).  All 64 lanes must call this.
+// Wave-aggregated list insertion.  A per-lane atomicExch costs a device atomic per particle and list (2.9 M per step on the headline scene:
+// measured 58 us with the particles freshly binned, 114 us sixty steps later, against 36 us for 1/8 of them).  Instead ALL lanes of the wave
+// that insert into the same list are chained in registers, in lane order (lane -> the previous lane of its group), and only the group's LAST
+// lane exchanges the list head; the old head becomes the `next` of the group's FIRST lane.  The result is a valid insertion order of the
+// reference's atomic-exchange list (transfer_build_linkedlist.comp:25).  Groups are found with one ballot per distinct key (a scalar loop,
+// 8-16 rounds for 64 particles of neighbouring cells): unlike runs of ADJACENT equal lanes they survive the decay of the particle order
+// between two rebinnings.  key < 0: the particle is outside the grid (no insertion, next = invalid).  All 64 lanes must call this.
 __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ heads, int key, uint32_t particle) {
+    const int lane = threadIdx.x & 63;
+#ifdef BLUB_NO_WAVE_AGG   // timing ablation only: one atomic per particle
+    unsigned long long mine = 1ull << lane;
+#else
+    unsigned long long remaining = ~0ull, mine = 0ull;
+    while (remaining) {
+        const int k = __shfl(key, __builtin_ctzll(remaining), 64);     // (uniform source lane: a v_readlane)
+        const unsigned long long m = __ballot(key == k);
+        if (key == k) mine = m;
+        remaining &= ~m;
+    }
+#endif
+    const unsigned long long below = mine & ((1ull << lane) - 1ull);
+    const bool is_first = below == 0ull, is_last = (mine >> lane) == 1ull;
+    const int prev_lane = is_first ? lane : 63 - __builtin_clzll(below), last_lane = 63 - __builtin_clzll(mine);
+    uint32_t old = 0;
+    if (is_last && key >= 0) old = atomicExch(heads + key, particle + 1);
+    const uint32_t old_of_group = __shfl(old, last_lane, 64);
+    const uint32_t prev_particle = __shfl(particle, prev_lane, 64);
+    if (key < 0) return INVALID_LL;
+    return is_first ? old_of_group - 1u : prev_particle;
+}
+
+// The cheaper form for kernels whose lists are short-lived and whose wave has other work to hide (k_advect's density list: the group search
+// above made that kernel 5 us slower): only runs of ADJACENT lanes with the same key share an atomic.
+__device__ __forceinline__ uint32_t wave_list_insert_runs(uint32_t* __restrict__ heads, int key, uint32_t particle) {
     const int lane = threadIdx.x & 63;
     const int prev_key = __shfl_up(key, 1, 64), next_key = __shfl_down(key, 1, 64);
     const uint32_t prev_particle = __shfl_up(particle, 1, 64);
@@ -81,7 +108,6 @@ __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ head
     const unsigned long long starts = __ballot(is_start);
     uint32_t old = 0;
     if (is_end && key >= 0) old = atomicExch(heads + key, particle + 1);
-    // the run's last lane = (next run start) - 1
     const unsigned long long above = lane == 63 ? 0ull : (starts >> (lane + 1));
     const int end_lane = above ? lane + __builtin_ctzll(above) : 63;
     const uint32_t old_of_run = __shfl(old, end_lane, 64);
@@ -640,7 +666,7 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
             }
         }
         const int dx = (int)(np[0] - 0.5f), dy = (int)(np[1] - 0.5f), dz = (int)(np[2] - 0.5f);
-        nxt = wave_list_insert(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, pi);
+        nxt = wave_list_insert_runs(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, pi);
     }
     if (!live) return;
     pos[pi] = make_float4(np[0], np[1], np[2], __uint_as_float(nxt));
