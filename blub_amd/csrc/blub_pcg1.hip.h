@@ -244,23 +244,29 @@ struct Pcg1TileLoads {
 // What a thread's tile elements need that does NOT depend on the brick: evaluated before the kernel's first wait (the list entry, `done`
 // and the partials are in flight then), so that only two additions per element remain between the arrival of the brick index and the
 // descriptor loads -- the arithmetic below sat on the critical path of a kernel bound by instruction issue.
-struct Pcg1ThreadGeom { int rel[2], ry[2], rz[2], q4[2]; int need[2], own[2]; int hrel, hyy, hzz, hdx; };
+// Element <-> thread mapping of K(i)'s tile work: pass k = 0 takes the 32 OWN rows of the brick (ry 1..8, rz 1..4: 128 quads, every lane busy,
+// and the own-cell update runs without divergence), pass k = 1 the 24 face-halo rows (y halo: ry in {0, 9}; z halo: rz in {0, 5}; 96 quads),
+// where that update does not exist at all.  (Rows in LDS order, row = rz * 10 + ry, would mix both kinds in every wave: each wave then issues
+// both code paths in both passes.)
+struct Pcg1ThreadGeom { int rel[2], ry[2], rz[2], q4[2]; int need[2], own[2], srow[2]; int hrel, hyy, hzz, hdx; };
 __device__ __forceinline__ void pcg1_thread_geom(Pcg1ThreadGeom& G, const Grid& g, int t) {
     const int plane = g.nx * g.ny;
+    const int q = t & 3, o = t >> 2;                                  // o: 0..31
+    G.ry[0] = 1 + (o & 7); G.rz[0] = 1 + (o >> 3); G.need[0] = 1; G.own[0] = 1;
+    const int hh = o - 8;
+    G.ry[1] = o < 8 ? (o & 1) * (BY + 1) : 1 + (hh & 7);
+    G.rz[1] = o < 8 ? 1 + (o >> 1) : (hh >> 3) * (BZ + 1);
+    G.need[1] = o < 24 ? 1 : 0; G.own[1] = 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int e = t + k * BRICK_THREADS;
-        const int row = e >> 2, q = e & 3;
-        const int ry = row % (BY + 2), rz = row / (BY + 2);
-        G.need[k] = (e < ST_ROWS * 4 && st_row_needed(row)) ? 1 : 0;
-        G.ry[k] = ry; G.rz[k] = rz; G.q4[k] = 4 * q;
-        G.rel[k] = (ry - 1) * g.nx + (rz - 1) * plane + 4 * q;
-        G.own[k] = (ry >= 1 && ry <= BY && rz >= 1 && rz <= BZ) ? 1 : 0;
+        G.q4[k] = 4 * q;
+        G.rel[k] = (G.ry[k] - 1) * g.nx + (G.rz[k] - 1) * plane + 4 * q;
+        G.srow[k] = (G.rz[k] * (BY + 2) + G.ry[k]) * ST_ROW + 4 + 4 * q;      // element offset inside StagedTile::s / ::d
     }
     const int side = t & 1, yy = (t >> 1) % BY, zz = (t >> 1) / BY;
     G.hyy = yy; G.hzz = zz; G.hdx = side ? BX : -1;
     G.hrel = yy * g.nx + zz * plane + G.hdx;
-    asm volatile("" :: "v"(G.rel[0]), "v"(G.rel[1]), "v"(G.hrel), "v"(G.need[0] | (G.need[1] << 1) | (G.own[0] << 2) | (G.own[1] << 3)));   // not to be sunk below the `done` test
+    asm volatile("" :: "v"(G.rel[0]), "v"(G.rel[1]), "v"(G.hrel), "v"(G.srow[0]), "v"(G.srow[1]), "v"(G.need[1]));   // not to be sunk below the `done` test
 }
 __device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const Pcg1ThreadGeom& G, const BrickGeom& bg, uint32_t b, int t, const uint8_t* __restrict__ dvol) {
     const Grid g = bg.g;
@@ -360,9 +366,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
             // phase 1a: r_{i+1}, u_{i+1} on the interior quads of the face-halo tile; the own quads also advance q, d, p
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int e = t + k * BRICK_THREADS;
-                const int row = e >> 2, q = e & 3;
-                if (e >= ST_ROWS * 4 || !st_row_needed(row)) continue;
+                if (!TG.need[k]) continue;
                 const uint32_t dq = TL.dq[k];
                 float qn[4], rn[4], uu[4];
                 DivConst dc[4];
@@ -376,13 +380,12 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
                     const bool fl = (dv & 0x80) != 0;
                     qn[j] = fl ? qj : 0.0f; rn[j] = fl ? rj : 0.0f; uu[j] = fl ? uj : 0.0f;
                 }
-                *reinterpret_cast<float4*>(T.s + row * ST_ROW + 4 + 4 * q) = make_float4(uu[0], uu[1], uu[2], uu[3]);
-                *reinterpret_cast<uint32_t*>(T.d + row * ST_ROW + 4 + 4 * q) = dq;
+                *reinterpret_cast<float4*>(T.s + TG.srow[k]) = make_float4(uu[0], uu[1], uu[2], uu[3]);
+                *reinterpret_cast<uint32_t*>(T.d + TG.srow[k]) = dq;
                 const int base = TL.base[k];
                 if (base < 0 || !any_fluid_d(dq)) continue;
-                const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1;
-                const bool own = gy >= y0b && gy < y0b + BY && gz >= z0b && gz < z0b + BZ;
-                if (own) {
+                const int gy = y0b + TG.ry[k] - 1, gz = z0b + TG.rz[k] - 1;
+                if (k == 0) {                                                  // (pass 0 = the own rows, pass 1 = the halo rows: resolved at compile time)
                     float dn[4] = {TL.dv4[k].x, TL.dv4[k].y, TL.dv4[k].z, TL.dv4[k].w}, pn[4] = {TL.pv4[k].x, TL.pv4[k].y, TL.pv4[k].z, TL.pv4[k].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {                              // (flat selects: a branch per lane costs more than the arithmetic it skips)
