@@ -24,7 +24,7 @@ def test_host_parsers_survive_mutated_inputs(tmp_path):
     scene["static_objects"][0]["animation"]["rotation"] = {"axis": {"x": 0, "y": 1, "z": 0}, "deg_per_sec": 90.0}
     base = tmp_path / "base.json"
     base.write_text(json.dumps(scene))
-    run = subprocess.run([str(exe), str(base), os.path.join(ROOT, "scenes", "models", "unit_cube.obj"), str(tmp_path / "m.obj"), "30000"],
+    run = subprocess.run([str(exe), str(base), os.path.join(ROOT, "scenes", "models", "unit_cube.obj"), str(tmp_path / "m.obj"), "12000"],
                          capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
     accepted, rejected = [int(v) for v in run.stdout.split() if v.isdigit()]

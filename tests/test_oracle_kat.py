@@ -383,7 +383,7 @@ def test_unconverged_cg_is_sensitive_to_dot_product_rounding():
     ONLY difference being whether the PCG dot products are accumulated in f64 or in f32 (the reference's reductions are f32
     trees, pressure_reduce.comp:37-61).  At the reference's operating point (32 iterations, max|r| far above zero) the two runs
     agree closely in step 0 and then drift apart: on dam_halfhalf (1.2 M particles; not run here) step 1 reports 0.554 vs 1.361
-    for the velocity solve.  Here: corner_dams_128-like box, 3 steps; asserted is only that the spread exists AND stays inside
+    for the velocity solve.  Here: corner_dams_128-like box, 2 steps; asserted is only that the spread exists AND stays inside
     the envelope the GPU test grants the engine (errors within 4x, velocity pressure within 5 % rel. L2)."""
     dim = (64, 48, 64)
     rng = np.random.default_rng(2)
@@ -398,7 +398,7 @@ def test_unconverged_cg_is_sensitive_to_dot_product_rounding():
         o.set_particles(pos)
         runs.append(o)
     spread = 0.0
-    for step in range(3):
+    for step in range(2):
         for o in runs:
             o.step(DT)
         a, b = runs
@@ -411,6 +411,6 @@ def test_unconverged_cg_is_sensitive_to_dot_product_rounding():
         pa, pb = a.read_volume("pressure_velocity").astype(np.float64), b.read_volume("pressure_velocity").astype(np.float64)
         assert np.linalg.norm(pa - pb) / np.linalg.norm(pa) < 0.05
     d = np.abs(runs[0].get_particles()[0][:, :3] - runs[1].get_particles()[0][:, :3]).max(axis=1)
-    print("f64 vs f32 dots after 3 steps: largest relative error spread %.3g, positions median %.3g p99 %.3g max %.3g" % (spread, np.median(d), np.quantile(d, 0.99), d.max()))
+    print("f64 vs f32 dots after 2 steps: largest relative error spread %.3g, positions median %.3g p99 %.3g max %.3g" % (spread, np.median(d), np.quantile(d, 0.99), d.max()))
     assert spread > 1e-4          # the two roundings do NOT give the same statistics ...
     assert np.median(d) < 2e-2    # ... while the bulk of the particles stays together (measured: median 6e-3, max 0.06 cells)
