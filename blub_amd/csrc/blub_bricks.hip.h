@@ -748,6 +748,22 @@ constexpr int ET_ROWS = (BY + 2) * (BZ + 2);                 // 60 rows
 __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                  const int8_t* __restrict__ marker, float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz) {
     __shared__ uint32_t rowmask[2][ET_ROWS + 4];             // double buffered by brick parity: one barrier per brick
+    // the mean over n = 1..8 valid neighbour faces as a correctly rounded division by a CONSTANT: n = m 2^k, m in {1, 3, 5, 7}; scaling by 2^-k
+    // is exact and q0 = RN(y c), q = fma(fma(-m, q0, y), c, q0) with c = RN(1/m) is RN(y / m) (checked for every f32 significand by
+    // tests/native/div_const_check.c): bit-identical to `avg / num`, a third of the instructions
+    __shared__ float4 divn[9];
+    if (threadIdx.x < 9) {
+        const int nn = (int)threadIdx.x;
+        float c = 1.0f, nm = -1.0f, sc = 1.0f;
+        if (nn == 3 || nn == 6) { c = 0x1.555556p-2f; nm = -3.0f; }
+        if (nn == 5) { c = 0x1.99999ap-3f; nm = -5.0f; }
+        if (nn == 7) { c = 0x1.24924ap-3f; nm = -7.0f; }
+        if (nn == 2 || nn == 6) sc = 0.5f;
+        if (nn == 4) sc = 0.25f;
+        if (nn == 8) sc = 0.125f;
+        divn[nn] = make_float4(c, nm, sc, 0.0f);
+    }
+    __syncthreads();
     const Grid g = bg.g;
     float* vel[3] = {vx, vy, vz};
     const uint32_t n = *count;
@@ -823,9 +839,9 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, c
                 const int k = 4 + j;
                 if (!((need >> k) & 1u)) continue;
                 const int x = x0 + j;
-                // the 8 in-plane neighbour faces in the reference's order (b2 outer, a inner): validity from the masks, then all loads in
-                // one batch (independent, one memory round trip), summed in that order
-                bool ok[8]; int ci[8]; int k8 = 0;
+                // the 8 in-plane neighbour faces in the reference's order (b2 outer, a inner): validity bits from the masks; every face is
+                // LOADED (an invalid or outside one from the cell itself: same cache lines, no exec-mask juggling per load) and masked to 0
+                uint32_t okm = 0; float val[8]; int k8 = 0;
 #pragma unroll
                 for (int b2 = -1; b2 <= 1; ++b2)
 #pragma unroll
@@ -835,18 +851,21 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, c
                         if (comp == 0) { ox = 0; oy = a; oz = b2; fm = X[1 + b2][1 + a]; }
                         else if (comp == 1) { ox = a; oy = 0; oz = b2; fm = Y[1 + b2]; }
                         else { ox = a; oy = b2; oz = 0; fm = Z[1 + b2]; }
-                        ok[k8] = ((fm >> (k + ox)) & 1u) != 0;
+                        const uint32_t ok = (fm >> (k + ox)) & 1u;
+                        okm |= ok << k8;
                         const bool in = (ox < 0 ? x > 0 : ox > 0 ? x + 1 < g.nx : true) && (oy < 0 ? ym_in : oy > 0 ? yp_in : true) && (oz < 0 ? zm_in : oz > 0 ? zp_in : true);
-                        ci[k8] = in ? base + j + ox + oy * g.nx + oz * plane : -1;     // OOB faces read 0 (they can still be valid: their inner side may be FLUID)
+                        const bool use = ok != 0u && in;                        // (faces outside the grid read 0 but still count when their inner side is FLUID)
+                        const uint32_t cc = (uint32_t)(use ? base + j + ox + oy * g.nx + oz * plane : base + j);
+                        const float v = ld1o(vel[comp], cc * 4u);
+                        val[k8] = use ? v : 0.0f;
                         ++k8;
                     }
-                float val[8];
+                float avgV = 0.0f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) val[q] = (ok[q] && ci[q] >= 0) ? vel[comp][ci[q]] : 0.0f;
-                float numV = 0.0f, avgV = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (ok[q]) { numV += 1.0f; avgV += val[q]; }
-                vel[comp][base + j] = avgV / numV;
+                for (int q = 0; q < 8; ++q) avgV += val[q];                     // invalid faces add an exact 0 (the reference skips them)
+                const float4 dc = divn[__popc(okm)];                            // >= 1: `need` guarantees a valid face
+                const float y = avgV * dc.z, q0 = y * dc.x;
+                st1o(vel[comp], (uint32_t)(base + j) * 4u, fmaf(fmaf(dc.y, q0, y), dc.x, q0));
             }
         }
     }

@@ -215,6 +215,7 @@ __device__ __forceinline__ float4 ld4o(const float* base, uint32_t byte_off) { r
 __device__ __forceinline__ float ld1o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
 __device__ __forceinline__ void st4o(float* base, uint32_t byte_off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 
+__device__ __forceinline__ void st1o(float* base, uint32_t byte_off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 __device__ __forceinline__ uint32_t ldu32o(const uint8_t* base, uint32_t byte_off) { return *reinterpret_cast<const uint32_t*>(base + byte_off); }
 __device__ __forceinline__ void load_quad_values(const float* __restrict__ S, const Grid& g, int base, int x0, int y, int z, QuadValues& v) {
     const int plane = g.nx * g.ny;
