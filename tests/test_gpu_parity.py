@@ -623,3 +623,42 @@ def test_pcg_persistent_tail_kernel(first, schedule, monkeypatch):
         h.close()
         if full is not None:
             full.close()
+
+
+def test_extrapolation_with_every_neighbour_count():
+    """D3 on a random marker field (FLUID / AIR / SOLID mixed cell by cell): faces with 1 .. 8 valid in-plane neighbours all occur, so every
+    entry of the kernel's constant-divisor table (k_extrapolate_b; n = 7 and 8 hardly ever appear in a dam-break scene) is compared
+    bit for bit with the oracle's `avg / num`."""
+    dim = (48, 32, 32)
+    rng = np.random.default_rng(11)
+    o, h = util.new_pair(*dim, 8)
+    try:
+        nz, ny, nx = dim[2], dim[1], dim[0]
+        marker = rng.choice(np.array([1, -1, 0], np.int8), size=(nz, ny, nx), p=[0.45, 0.45, 0.10])
+        marker[0] = marker[-1] = 0; marker[:, 0] = marker[:, -1] = 0; marker[:, :, 0] = marker[:, :, -1] = 0     # the domain shell is SOLID
+        vel = {v: (rng.standard_normal((nz, ny, nx)) * 3).astype(np.float32) for v in ("vel_x", "vel_y", "vel_z")}
+        for f in (o, h):
+            f.write_volume("marker", marker)
+            for v, a in vel.items():
+                f.write_volume(v, a)
+            f.write_volume("pressure_velocity", np.zeros((nz, ny, nx), np.float32))
+        o.run_stage("project", util.DT)
+        h.run_stage("project", util.DT)
+        fl = marker == 1
+        counts = set()
+        for comp, (dz, dy, dx) in enumerate(((0, 0, 1), (0, 1, 0), (1, 0, 0))):
+            a, b = h.read_volume(("vel_x", "vel_y", "vel_z")[comp]), o.read_volume(("vel_x", "vel_y", "vel_z")[comp])
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "component %d differs in %d cells" % (comp, (a != b).sum())
+            # faces with a FLUID side, and per invalid face the number of valid in-plane neighbours (what the divisor table is indexed by)
+            valid = fl | np.roll(fl, (-dz, -dy, -dx), (0, 1, 2))
+            n = np.zeros(marker.shape, np.int32)
+            axes = [ax for ax in range(3) if (dz, dy, dx)[ax] == 0]
+            for s0 in (-1, 0, 1):
+                for s1 in (-1, 0, 1):
+                    if s0 or s1:
+                        n += np.roll(np.roll(valid, s0, axes[0]), s1, axes[1])
+            inner = np.zeros_like(fl); inner[2:-2, 2:-2, 2:-2] = True
+            counts |= set(np.unique(n[inner & ~valid]).tolist())
+        assert set(range(1, 9)) <= counts, counts
+    finally:
+        h.close()

@@ -175,3 +175,37 @@ def test_headline_scene_statistics_track_the_reference_schedule():
     # mean particle position: two runs of the SAME schedule differ by up to 0.008 cells in y after 12 steps (measured with
     # tools/mean_y_spread.py: atomic list order -> rounding of the gathers -> unconverged density solve), so this is a sanity bound
     assert np.abs(a[2].mean(0) - b[2].mean(0)).max() < 2.5e-2
+
+
+@pytest.mark.parametrize("mapping", ["bricks_single", "rows"])
+def test_random_marker_field_exercises_every_diagonal(mapping):
+    """A cell-by-cell random FLUID / AIR / SOLID field: stencil diagonals d = 0 .. 6 all occur (a dam-break scene has almost only 5 and 6),
+    so every entry of the kernels' preconditioner tables -- the constant-divisor division of the single-reduction kernel (d = m 2^k,
+    m in {1, 3, 5}) and the reciprocal table of the dense kernels -- is compared with the oracle's (x / d) / d after 1, 3 and 6 iterations."""
+    import blub_amd
+    dim = (48, 32, 32)
+    rng = np.random.default_rng(5)
+    nz, ny, nx = dim[2], dim[1], dim[0]
+    marker = rng.choice(np.array([1, -1, 0], np.int8), size=(nz, ny, nx), p=[0.5, 0.25, 0.25])
+    marker[0] = marker[-1] = 0; marker[:, 0] = marker[:, -1] = 0; marker[:, :, 0] = marker[:, :, -1] = 0
+    fluid = marker == 1
+    b = (rng.standard_normal((nz, ny, nx)) * fluid).astype(np.float32)
+    nonsolid = np.pad(marker != 0, 1)
+    d = sum(np.roll(nonsolid, s, ax)[1:-1, 1:-1, 1:-1].astype(np.int32) for ax in range(3) for s in (-1, 1))
+    assert set(range(0, 7)) <= set(np.unique(d[fluid]).tolist())
+    for k in (1, 3, 6):
+        o, h = util.new_pair(*dim, 8)
+        try:
+            util.set_mapping(h, mapping)
+            for f in (o, h):
+                f.write_volume("marker", marker); f.write_volume("residual", b)
+                f.set_solver_config(0, error_tolerance=0.0, max_num_iterations=k, error_check_frequency=4)
+            o.run_stage("solve_velocity", util.DT)
+            h.run_stage("solve_velocity", util.DT)
+            for name in ("pressure_velocity", "residual"):
+                x, y = h.read_volume(name), o.read_volume(name)
+                util.assert_close("%s after %d iterations" % (name, k), x[fluid], y[fluid], abs_=1e-4 * np.abs(y[fluid]).max())
+            (eo, io), (eh, ih) = o.solver_stats(0), h.solver_stats(0)
+            assert ih == io == k and abs(eh - eo) <= 1e-4 * eo
+        finally:
+            h.close()
