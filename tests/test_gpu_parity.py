@@ -662,3 +662,36 @@ def test_extrapolation_with_every_neighbour_count():
         assert set(range(1, 9)) <= counts, counts
     finally:
         h.close()
+
+
+def test_transfer_with_shuffled_particle_order():
+    """P2G with the particles in RANDOM memory order (what the order decays to between two rebinnings): the lanes of a wave that insert
+    into the same list are no longer adjacent, so this exercises the wave-wide grouping of wave_list_insert (one atomic per distinct key).
+    The three gathers must agree with the oracle to 1e-5 -- every list member contributes to eight faces, so a lost, duplicated or
+    misplaced list node shows -- and every particle must be on exactly one x list (the engine keeps the three staggered lists at once,
+    the oracle re-uses one volume per component like the reference: the list volumes themselves are not comparable after the stage)."""
+    pos, vel, maxp = util.make_dam(*GRID)
+    rng = np.random.default_rng(21)
+    perm = rng.permutation(len(pos))
+    pos = pos[perm]
+    vel = tuple(v[perm] for v in vel)
+    o, h = util.new_pair(*GRID, maxp)
+    try:
+        o.set_particles(pos, *vel)
+        h.set_particles(pos, *vel)
+        o.run_stage("transfer", util.DT)
+        h.run_stage("transfer", util.DT)
+        assert np.array_equal(h.read_volume("marker"), o.read_volume("marker"))
+        n = len(pos)
+        lh = util.lists_as_sets(h.read_volume("linked_list"), h.get_particles()[0], n)
+        members = np.concatenate([np.fromiter(s, np.int64) for s in lh.values()])
+        assert len(members) == n and len(np.unique(members)) == n            # a partition of the particles
+        dual = np.floor(pos - np.array([1.0, 0.5, 0.5], np.float32)).astype(np.int64)
+        cell_of = (dual[:, 2] * GRID[1] + dual[:, 1]) * GRID[0] + dual[:, 0]
+        for cell, s in list(lh.items())[::97]:
+            assert all(cell_of[i] == cell for i in s)
+        assert max(len(s) for s in lh.values()) <= 12
+        for v in ("vel_x", "vel_y", "vel_z"):
+            util.assert_close(v, h.read_volume(v), o.read_volume(v), rel=1e-5)
+    finally:
+        h.close()
