@@ -18,6 +18,7 @@
 namespace blubk {
 
 constexpr int BX = 16, BY = 8, BZ = 4;        // brick extent in cells (x fastest): 512 cells = 128 quads
+static_assert(BX == 16 && BY == 8 && BZ == 4, "k_advect (blub_kernels.hip.h) marks FLUID bricks with these extents as shifts");
 constexpr int BRICK_THREADS = 128;            // one thread per quad (4 x-consecutive cells)
 constexpr uint32_t STALE_BIT = 0x80000000u;
 

@@ -71,6 +71,7 @@ struct blub_fluid {
     // z-slab decomposition (blub_slab.hip): own planes [slab_z0, slab_z1), ghost particles live at [num_particles, +num_ghost)
     int slab_z0 = 0, slab_z1 = 0;
     uint32_t num_ghost = 0;
+    bool bricks_premarked = false;            // brick_fluid already holds the marks of the current particle positions (set and consumed inside stage_advect)
     float gravity[3] = {0, 0, 0};
     int device = 0;
     hipStream_t stream = nullptr;
@@ -224,6 +225,7 @@ static int build_lists(blub_fluid* h, int phase) {
     // (brick_fluid is all zero here: allocated zeroed, and every build's scatter kernel clears it again)
     if (phase == COMPACT_ALL_ACTIVE)
         hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
+    else if (h->bricks_premarked) h->bricks_premarked = false;     // k_advect marked them (stage_advect)
     else if (h->num_particles + h->num_ghost)
         hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), 0, h->stream, h->bg, h->num_particles + h->num_ghost, (const float4*)h->pos, h->brick_fluid);
     const int nblk = (h->bg.nb + 1023) / 1024;
@@ -529,17 +531,20 @@ static int stage_project(blub_fluid* h) {   // :906-914
            (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
     return stage_extrapolate(h);
 }
-static int stage_advect_particles(blub_fluid* h, float dt, bool insert_lists) {   // :916-926
+static int stage_advect_particles(blub_fluid* h, float dt, bool insert_lists, bool mark_bricks = false) {   // :916-926
+    // mark_bricks: the list build that follows takes its FLUID bricks from this kernel's marks (brick_fluid is all zero here, see build_lists)
     // the reset list (active + stale bricks of this step, own AND ghost bricks) is a superset of the active list
     LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0],
            (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     if (h->num_particles)
         LAUNCH(h, KC_ADVECT, k_advect, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
-               h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, insert_lists ? h->ll[0] : (uint32_t*)nullptr);
+               h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, insert_lists ? h->ll[0] : (uint32_t*)nullptr,
+               mark_bricks ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby);
+    h->bricks_premarked = mark_bricks && h->num_particles != 0;
     return BLUB_OK;
 }
 static int stage_advect(blub_fluid* h, float dt) {   // :916-932
-    int rc = stage_advect_particles(h, dt, true);
+    int rc = stage_advect_particles(h, dt, true, h->num_ghost == 0);
     return rc != BLUB_OK ? rc : build_lists_from_particles(h, COMPACT_STEP_B);
 }
 static int stage_density_gather(blub_fluid* h, float dt) {   // :933-937

@@ -558,7 +558,8 @@ __device__ __forceinline__ void truncate_step(const float* orig, const float* mo
 __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, float dt, float4* __restrict__ pos, float4* __restrict__ pvx,
                                                 float4* __restrict__ pvy, float4* __restrict__ pvz, const float* __restrict__ vx,
                                                 const float* __restrict__ vy, const float* __restrict__ vz, const float4* __restrict__ solid,
-                                                int8_t* __restrict__ marker, uint32_t* __restrict__ heads) {
+                                                int8_t* __restrict__ marker, uint32_t* __restrict__ heads, uint8_t* __restrict__ brick_fluid = nullptr,
+                                                int nbx = 0, int nby = 0) {
     const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
     const bool live = pi < num_particles;          // dead lanes run the (cheap) arithmetic on a dummy particle: the wave-level list insertion needs all lanes
     const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
@@ -670,6 +671,10 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
         nxt = wave_list_insert_runs(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, pi);
     }
     if (!live) return;
+    if (brick_fluid) {   // what k_bricks_mark_particles would do for the list build that follows (one launch less per step): 16 x 8 x 4 bricks
+        const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
+        if (inb(g, x, y, z)) brick_fluid[((z >> 2) * nby + (y >> 3)) * nbx + (x >> 4)] = 1;
+    }
     pos[pi] = make_float4(np[0], np[1], np[2], __uint_as_float(nxt));
     pvx[pi] = make_float4(cx[0], cx[1], cx[2], nv[0]);   // :186-188 (Q2: literal row layout)
     pvy[pi] = make_float4(cy[0], cy[1], cy[2], nv[1]);
