@@ -236,210 +236,25 @@ __global__ __launch_bounds__(256) void k_static_marker_dense(Grid g, const float
     }
 }
 
-// ---- T4 over active bricks: transfer_gather_velocity.comp:39-127 ---------------------------------------------------
-// One workgroup per brick: (16+1)x(8+1)x(4+1) = 765 list cells (brick + one halo layer on the negative sides), each
-// thread walks its own cell's list and publishes the current particle through LDS (24 KiB); a face reads the 7 other
-// lists it needs from LDS.  768 threads = 12 full waves.  The <=12-round loop ends when every list of the tile is empty;
-// the node of round k+1 is fetched from global memory while round k is exchanged through LDS (pointer-chase pipelining).
+// ---- T4 (transfer_gather_velocity.comp:39-127) and R1 (density_projection_gather_error.comp:41-198) over brick lists --------
+// One workgroup per brick: (16+1)x(8+1)x(4+1) = 765 list cells (brick + one halo layer on the negative sides), 768 threads = 12 full waves.
 constexpr int GT_X = BX + 1, GT_Y = BY + 1, GT_Z = BZ + 1, GT_N = GT_X * GT_Y * GT_Z;   // 17 x 9 x 5 = 765
 
-// LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its outstanding global loads, so a prefetched
-// list node stays in flight across the exchange (a __syncthreads() would drain vmcnt first).
+// LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its outstanding global loads, so loads requested ahead
+// stay in flight across the exchange (a __syncthreads() would drain vmcnt first).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct GatherShared {
-    float4 pos[2][GT_N];   // double buffered by round parity: ONE barrier per round (round r+2 rewrites a buffer only
-    float4 vel[2][GT_N];   // after the barrier of round r+1, which every wave reaches after its reads of round r)
-    int any[2][12];
-};
-template <int COMP>
-__device__ __forceinline__ void gather_velocity_body(GatherShared& sh, uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg, const uint32_t* __restrict__ list,
-                                                     const uint32_t* __restrict__ count, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
-                                                     const float4* __restrict__ pos, const uint32_t* __restrict__ next,
-                                                     const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
-    float4 (*sPosB)[GT_N] = sh.pos;
-    float4 (*sVelB)[GT_N] = sh.vel;
-    int (*sAnyB)[12] = sh.any;
-    const Grid g = bg.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool live = tid < GT_N;
-    const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
-    const int a1 = tid - 1, a2 = tid - GT_X, a3 = tid - GT_X - 1, a4 = tid - GT_X * GT_Y, a5 = a4 - 1, a6 = a4 - GT_X, a7 = a4 - GT_X - 1;   // :87-93
-    const uint32_t n = *count;
-    for (uint32_t i = first_brick; i < n; i += brick_stride) {
-        const uint32_t b = list[i];
-        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
-        const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;      // :41
-        const bool in = live && inb(g, gx, gy, gz);
-        const bool border = !live || lx == 0 || ly == 0 || lz == 0;
-        const int mA = in ? (int)marker[cidx(g, gx, gy, gz)] : CELL_SOLID;
-        const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
-        const bool writes = !border && in && (mA == CELL_FLUID || mB == CELL_FLUID);           // :50
-        const bool computes = !border && (mA != CELL_SOLID && mB != CELL_SOLID);                // :51
-        const float sx = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
-        const float sy = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
-        const float sz = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
-        // node of round 0
-        uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
-        bool has = cur != INVALID_LL;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), r = p;
-        uint32_t nxt = INVALID_LL;
-        if (has) { p = pos[cur]; r = rows[cur]; nxt = next ? next[cur] : __float_as_uint(p.w); }
-        float v = 0.0f, wsum = 0.0f;
-        for (int round = 0; round < 12; ++round) {                                               // :61
-            float4* sPos = sPosB[round & 1];
-            float4* sVel = sVelB[round & 1];
-            int* sAny = sAnyB[round & 1];
-            if (has) {
-                if (computes) add_particle(v, wsum, p, r, sx, sy, sz);
-                sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
-                sVel[tid] = r;
-            } else if (live) {
-                sPos[tid].w = 0.0f;
-            }
-            const unsigned long long wave_has = __ballot(has);
-            if (lane == 0) sAny[wave] = wave_has != 0ull;
-            // prefetch the node of the next round: its latency overlaps the LDS exchange below
-            const bool has_n = has && nxt != INVALID_LL && round + 1 < 12;
-            float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
-            if (has_n) { pn = pos[nxt]; rn = rows[nxt]; nn = next ? next[nxt] : __float_as_uint(pn.w); }
-            lds_barrier();
-            int any = 0;
-#pragma unroll
-            for (int w = 0; w < 12; ++w) any |= sAny[w];
-            if (any && computes) {
-                // The neighbours' particles are fetched in two batches of unconditional LDS reads (one wait each) instead of
-                // seven flag-then-data round trips: the exchange is LDS-latency bound, not LDS-bandwidth bound.
-                {
-                    const float4 q1 = sPos[a1], q2 = sPos[a2], q3 = sPos[a3], q4 = sPos[a4];
-                    const float4 r1 = sVel[a1], r2 = sVel[a2], r3 = sVel[a3], r4 = sVel[a4];
-                    if (q1.w != 0.0f) add_particle(v, wsum, q1, r1, sx, sy, sz);
-                    if (q2.w != 0.0f) add_particle(v, wsum, q2, r2, sx, sy, sz);
-                    if (q3.w != 0.0f) add_particle(v, wsum, q3, r3, sx, sy, sz);
-                    if (q4.w != 0.0f) add_particle(v, wsum, q4, r4, sx, sy, sz);
-                }
-                {
-                    const float4 q5 = sPos[a5], q6 = sPos[a6], q7 = sPos[a7];
-                    const float4 r5 = sVel[a5], r6 = sVel[a6], r7 = sVel[a7];
-                    if (q5.w != 0.0f) add_particle(v, wsum, q5, r5, sx, sy, sz);
-                    if (q6.w != 0.0f) add_particle(v, wsum, q6, r6, sx, sy, sz);
-                    if (q7.w != 0.0f) add_particle(v, wsum, q7, r7, sx, sy, sz);
-                }
-            }
-            if (!any) break;
-            has = has_n; p = pn; r = rn; nxt = nn;
-        }
-        lds_barrier();   // the last round's reads are done before the next brick's round 0 rewrites buffer 0
-        if (writes) {
-            if (computes) { if (wsum > 0.0f) v /= wsum; v += gravity_dt; }                       // :117-120
-            else v = 0.0f;                                                                        // :121-124
-            out[cidx(g, gx, gy, gz)] = v;
-        }
-    }
-}
-
-// The three components in ONE launch (blockIdx.y = component): three times the workgroups in flight, so bricks with long lists
-// of one component overlap with cheap bricks of another instead of three separately draining launches.
 struct GatherArgs3 { const uint32_t* heads[3]; const uint32_t* next[3]; const float4* rows[3]; float* out[3]; float gravity_dt[3]; };
-__global__ __launch_bounds__(768) void k_gather_velocity3_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                            const int8_t* __restrict__ marker, const float4* __restrict__ pos, GatherArgs3 a) {
-    __shared__ GatherShared sh;
-    if (blockIdx.y == 0) gather_velocity_body<0>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[0], pos, a.next[0], a.rows[0], a.out[0], a.gravity_dt[0]);
-    else if (blockIdx.y == 1) gather_velocity_body<1>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[1], pos, a.next[1], a.rows[1], a.out[1], a.gravity_dt[1]);
-    else gather_velocity_body<2>(sh, blockIdx.x, gridDim.x, bg, list, count, marker, a.heads[2], pos, a.next[2], a.rows[2], a.out[2], a.gravity_dt[2]);
-}
 
-// ---- R1 over fluid bricks: density_projection_gather_error.comp:41-198 -----------------------------------------------
-__global__ __launch_bounds__(768) void k_density_gather_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                          const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
-                                                          const float4* __restrict__ pos, float* __restrict__ residual, float dt) {
-    __shared__ float4 sPosB[2][GT_N];   // double buffered by round parity, see gather_velocity_body
-    __shared__ int sAnyB[2][12];
-    const Grid g = bg.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool live = tid < GT_N;
-    const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
-    const int a1 = tid - 1, a2 = tid - GT_X, a3 = tid - GT_X - 1, a4 = tid - GT_X * GT_Y, a5 = a4 - 1, a6 = a4 - GT_X, a7 = a4 - GT_X - 1;
-    const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const uint32_t b = list[i];
-        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
-        const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;
-        const bool in = live && inb(g, gx, gy, gz);
-        const bool border = !live || lx == 0 || ly == 0 || lz == 0;
-        const bool writes = !border && in && marker[cidx(g, gx, gy, gz)] == CELL_FLUID;           // :46
-        const float sx = (float)gx + 0.5f, sy = (float)gy + 0.5f, sz = (float)gz + 0.5f;
-        uint32_t cur = in ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
-        bool has = cur != INVALID_LL;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has) p = pos[cur];
-        float density = 0.0f;
-        auto add = [&](const float4& q) {
-            const float ox = satf(1.0f - fabsf(sx - q.x)), oy = satf(1.0f - fabsf(sy - q.y)), oz = satf(1.0f - fabsf(sz - q.z));
-            density += ox * oy * oz;                                                              // :27-31
-        };
-        for (int round = 0; round < 32; ++round) {                                                // :69
-            float4* sPos = sPosB[round & 1];
-            int* sAny = sAnyB[round & 1];
-            uint32_t nxt = INVALID_LL;
-            if (has) {
-                nxt = __float_as_uint(p.w);
-                if (writes) add(p);
-                sPos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
-            } else if (live) {
-                sPos[tid].w = 0.0f;
-            }
-            const unsigned long long wave_has = __ballot(has);
-            if (lane == 0) sAny[wave] = wave_has != 0ull;
-            const bool has_n = has && nxt != INVALID_LL && round + 1 < 32;
-            float4 pn = p;
-            if (has_n) pn = pos[nxt];          // prefetch: overlaps the LDS exchange
-            lds_barrier();
-            int any = 0;
-#pragma unroll
-            for (int w = 0; w < 12; ++w) any |= sAny[w];
-            if (any && writes) {   // all seven neighbours in one batch of LDS reads (one wait), see gather_velocity_body
-                const float4 q1 = sPos[a1], q2 = sPos[a2], q3 = sPos[a3], q4 = sPos[a4], q5 = sPos[a5], q6 = sPos[a6], q7 = sPos[a7];
-                if (q1.w != 0.0f) add(q1);
-                if (q2.w != 0.0f) add(q2);
-                if (q3.w != 0.0f) add(q3);
-                if (q4.w != 0.0f) add(q4);
-                if (q5.w != 0.0f) add(q5);
-                if (q6.w != 0.0f) add(q6);
-                if (q7.w != 0.0f) add(q7);
-            }
-            if (!any) break;
-            has = has_n; p = pn;
-        }
-        lds_barrier();   // see gather_velocity_body
-        if (writes) {
-            const int m[6] = {mk(marker, g, gx + 1, gy, gz), mk(marker, g, gx, gy + 1, gz), mk(marker, g, gx, gy, gz + 1),
-                              mk(marker, g, gx - 1, gy, gz), mk(marker, g, gx, gy - 1, gz), mk(marker, g, gx, gy, gz - 1)};   // :115-120
-            bool anyAir = false;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { if (m[k] == CELL_SOLID) density += 0.5625f; if (m[k] == CELL_AIR) anyAir = true; }   // :167-179
-            if (anyAir) density = fmaxf(8.0f, density);                                           // :182-184
-            density = 1.0f - density / 8.0f;                                                      // :188
-            density = clampf(density, -0.5f, 0.5f);                                               // :192
-            density /= dt;                                                                        // :196
-            residual[cidx(g, gx, gy, gz)] = density;
-        }
-    }
-}
-
-// ---- T4 / R1, "partial sum" formulation ------------------------------------------------------------------------------------
-// The round loop above moves PARTICLES to faces: per round every thread publishes one particle through LDS and reads seven, with
-// a 12-wave barrier per round -- measured LDS-issue / barrier bound, not bound by the list walk.  Transposed: every
+// "Partial sum" formulation.  (Round 1 moved PARTICLES to faces -- per round every thread published one particle through LDS and read
+// seven, with a 12-wave barrier per round: measured LDS-issue / barrier bound; removed.)  Every
 // thread walks its OWN dual cell's list once (<= 12 / 32 nodes, transfer_gather_velocity.comp:61, density_projection_gather_error
 // .comp:69 -- the caps are per list, so the same particles take part) and accumulates, in registers, that list's contribution to the
 // EIGHT samples it reaches (dual cell d feeds the faces d + {0,1}^3); the partial sums are exchanged through LDS ONCE per brick and
 // each face adds up the eight partials of the eight lists the reference walks for it.  Per particle the eight weights share their
 // factors (2 x 3 one-dimensional hats), which halves the arithmetic; every product / sum of a particle-face pair is formed exactly
 // as in add_particle(), only the ORDER in which a face's contributions are added differs (list-major instead of round-major).
-#ifndef BLUB_GATHER_CAP_V
-#define BLUB_GATHER_CAP_V 12      // transfer_gather_velocity.comp:61 (other values: timing ablations only)
-#endif
-constexpr int GATHER_CAP_V = BLUB_GATHER_CAP_V;
+constexpr int GATHER_CAP_V = 12;      // transfer_gather_velocity.comp:61
 constexpr int GP_STRIDE = 768;
 struct GatherPartialsV { float2 part[8][GP_STRIDE]; };     // [corner][list cell] {sum w*d, sum w}: 48 KiB
 struct GatherPartialsD { float part[8][GP_STRIDE]; };      // [corner][list cell] sum w: 24 KiB

@@ -49,13 +49,10 @@ static const char* kKernelClassNames[KC_COUNT] = {
 
 constexpr int PCG_GRID_MAX = 4096;   // upper bound of persistent blocks of the PCG kernels (= number of dot-product partials)
 constexpr int PCG_GRID_DENSE = 2048; // dense rows: 8 blocks of 256 threads per CU
-constexpr int PCG_GRID_BRICKS = 1024;
 constexpr int BRICK_GRID_MAX = 2048; // persistent blocks of the brick-list kernels
 constexpr int STATS_RING = 32;       // pressure_solver.rs:49 NUM_PRESSURE_ERROR_BUFFER
 constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
 constexpr int COUNTS_RING = 8;
-constexpr uint32_t STAGED_PCG_MIN_BRICKS = 512;   // fluid bricks from which the LDS-staged iteration kernels are used: 256^3 / 1 M particles (~1300 bricks) 810 vs 779 steps/s,
-                                                  // dam_halfhalf (~400 bricks) 990 vs 1004, 512^3 (10 k bricks) 243 vs 246
 constexpr float SPARSE_PCG_MAX_FILL = 0.30f;   // fluid bricks / bricks below which the brick-list PCG kernels are used
 
 struct PendingStat { uint32_t seq; int slot; };
@@ -109,8 +106,8 @@ struct blub_fluid {
     uint32_t steps_enqueued = 0;
     uint32_t max_steps_in_flight = 4;
     bool all_touched = false;
-    int force_pcg_path = -1;                  // -1 auto, 0 dense rows, 1 brick lists
-    int gather_mode = 1;                      // P2G / density gathers: 0 = round loop (particles exchanged through LDS), 1 = per-list partial sums (BLUB_GATHER)
+    int force_pcg_path = -1;                  // -1 auto, 0 dense rows, >= 1 brick lists
+    int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
     uint8_t* dvol = nullptr;
     PcgGeom geom{};
@@ -121,15 +118,16 @@ struct blub_fluid {
     uint8_t* tile_flags = nullptr;
     PcgCtrl* ctrl[2] = {nullptr, nullptr};
     // single-reduction schedule (blub_pcg1.hip.h): second buffers of r / w / q (allocated on first use), float4 partials, scalars
-    int pcg_schedule = 1;            // 0: the reference's two-reduction schedule, 1 (default): one kernel per iteration on the brick mapping
+    int pcg_schedule = 0;            // 0 (default): the reference's two-reduction schedule, 1: one kernel per iteration on the brick mapping (opt-in: a different rounding)
     float* cgbuf[3] = {nullptr, nullptr, nullptr};
     float4* part4 = nullptr;
     Pcg1Scalars* pcg1_scalars[2] = {nullptr, nullptr};
     PcgTailSync* tail_sync[2] = {nullptr, nullptr};
-    bool use_tail = true;            // persistent tail kernel for brick-mapped solves (BLUB_PCG_TAIL=0 disables)
+    bool use_tail = true;            // persistent tail kernel of the single-reduction solves (blub_fluid_set_tuning "pcg_tail")
     int tail_margin_checks = 1;
+    int pcg1_max_iterations = 64;    // solves with more iterations run the reference order even when schedule 1 is selected (drift of the recurrence residual)
     int tail_grid = 256;             // co-resident blocks of the tail kernel: occupancy x CUs, at most one per CU (set at creation)
-    int tail_first_forced = -1;      // test hook (BLUB_PCG_TAIL_FIRST): hand over to the tail after exactly this many launched iterations
+    int tail_first_forced = -1;      // test hook (blub_fluid_set_tuning "pcg_tail_first"): hand over to the tail after exactly this many launched iterations
     blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
     bool pressure_initialised[2] = {false, false};
     // statistics read-back ring (pressure_solver.rs:118-126, 148-209)
@@ -272,8 +270,7 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
         GatherArgs3 a;
         const uint32_t* nexts[3] = {nullptr, h->next1, h->next2};
         for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.next[c] = nexts[c]; a.rows[c] = h->pvel[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
-        if (h->gather_mode == 1) LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, dim3(3 * ((h->brick_grid + 7) / 8) * 8), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
-        else LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_b, dim3(h->brick_grid, 3), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
+        LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, dim3(3 * ((h->brick_grid + 7) / 8) * 8), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
     }
     return BLUB_OK;
 }
@@ -303,7 +300,7 @@ static int stage_solve_lod0(blub_fluid* h, int which, float dt) {
     PcgCtrl* ctrl = h->ctrl[which];
     const dim3 grid(h->pcg_grid), block(256);
     const int np = h->pcg_grid;
-    LAUNCH(h, KC_PCG_LOD0, k_pcg_init<false>, grid, block, h->geom, h->marker, p, h->residual, h->search, (float*)nullptr, h->tile_flags);
+    LAUNCH(h, KC_PCG_LOD0, k_pcg_init, grid, block, h->geom, h->marker, p, h->residual, h->search, (float*)nullptr, h->tile_flags);
     LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
     LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->search, (const float*)h->residual, h->part_sigma[0], h->tile_flags, ctrl);
     const int maxit = c.max_num_iterations;
@@ -313,12 +310,12 @@ static int stage_solve_lod0(blub_fluid* h, int which, float dt) {
         LAUNCH(h, KC_PCG_LOD0, k_pcg_apply, grid, block, h->geom, h->marker, h->search, h->part_sas, h->tile_flags, ctrl);
         const int last = (i == maxit);
         const int check = last || (i > 0 && c.error_check_frequency > 0 && i % c.error_check_frequency == 0);   // :672-673
-        LAUNCH(h, KC_PCG_LOD0, k_pcg_update<false>, grid, block, h->geom, h->marker, h->search, p, h->residual, h->part_sas, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl);
+        LAUNCH(h, KC_PCG_LOD0, k_pcg_update, grid, block, h->geom, h->marker, h->search, p, h->residual, h->part_sas, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl);
         if (!last) {
             LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->residual, h->aux_temp, (const float*)nullptr, (float*)nullptr, h->tile_flags, ctrl);
             LAUNCH(h, KC_PCG_LOD0, k_pcg_precond_lod0, grid, block, h->geom, h->marker, h->aux_temp, h->aux, (const float*)h->residual, sig_next, h->tile_flags, ctrl);
         }
-        LAUNCH(h, KC_PCG_LOD0, k_pcg_search<false>, grid, block, h->geom, h->marker, h->aux, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
+        LAUNCH(h, KC_PCG_LOD0, k_pcg_search, grid, block, h->geom, h->marker, h->aux, h->search, sig_cur, sig_next, h->part_max, np, h->tile_flags, ctrl, tol, i, check, last);
         if (last) break;
     }
     LAUNCH(h, KC_PCG_LOD0, k_pcg_tag, dim3(1), dim3(1), ctrl, h->solve_seq[which]);
@@ -333,7 +330,17 @@ static int ensure_pcg1_buffers(blub_fluid* h) {
     return rc;
 }
 
-// PressureSolver::solve, pressure_solver.rs:591-729 (schedule: SURVEY Appendix D), fused two-kernel iteration (blub_pcg.hip.h)
+// Launch grid of the brick-mapped PCG kernels: an ESTIMATE of the number of virtual workgroups (pcg_vblocks) from the newest landed FLUID brick
+// count, with 12 % head room.  It only costs speed when it is off: surplus workgroups exit, missing ones are covered by the others' loops, and
+// the dot-product grouping is fixed by the device-side list alone (blub_pcg.hip.h).
+static int pcg_brick_grid(const blub_fluid* h, bool have, const BrickCounts& bc) {
+    if (h->pcg_grid_forced > 0) return (std::min(h->pcg_grid_forced, PCG_GRID_MAX) + 7) & ~7;
+    int np = std::min((h->bg.nb + PCG_BPB - 1) / PCG_BPB, PCG_VBLOCKS_MAX);
+    if (have) np = std::max(64, std::min(np, (int)((bc.n_fluid * 9u / 8u + 8u + (unsigned)PCG_BPB - 1u) / (unsigned)PCG_BPB)));
+    return (np + 7) & ~7;   // (a multiple of 8: the XCD-contiguous list order of the single-reduction kernels)
+}
+
+// PressureSolver::solve, pressure_solver.rs:591-729 (schedule: SURVEY Appendix D), fused iteration kernels (blub_pcg*.hip.h)
 static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float* p = h->pressure[which];
     const blub_solver_config& c = h->cfg[which];
@@ -371,16 +378,11 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
     float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
     if (sparse) {
-        // grid (= number of dot-product partials) sized from the newest landed FLUID brick count with 12 % head room (the iteration
-        // kernels sweep the fluid list; the init kernel sweeps the larger active list with the same grid and simply strides): the
-        // kernels loop over the device-side list, so a stale count only costs speed, never correctness
-        static const int np_cap = getenv("BLUB_PCG_NP_MAX") ? std::max(64, std::min(PCG_GRID_MAX, atoi(getenv("BLUB_PCG_NP_MAX")))) : PCG_GRID_BRICKS * 2 / PCG_BPB;   // (tuning switch)
-        int np = std::min((h->bg.nb + PCG_BPB - 1) / PCG_BPB, np_cap);
-        if (have) np = std::max(64, std::min(np, (int)((bc.n_fluid * 9u / 8u + 8u + (unsigned)PCG_BPB - 1u) / (unsigned)PCG_BPB)));
-        np = (np + 7) & ~7;   // (a multiple of 8: the single-reduction kernels can hand the list out XCD-contiguously)
+        const int np = pcg_brick_grid(h, have, bc);
         const dim3 grid(np), block(PCG_B_THREADS);
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which]);
-        if (h->pcg_schedule == 1) {
+        const uint32_t* nfl = &h->counts->n_fluid;
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), nfl, 0, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which]);
+        if (h->pcg_schedule == 1 && maxit <= h->pcg1_max_iterations) {
             // ONE kernel per iteration (blub_pcg1.hip.h): r, w = A M^-1 r and q = A d are double buffered by iteration parity,
             // the search direction d (BLUB_VOLUME_SEARCH) and p are updated in place
             if ((rc = ensure_pcg1_buffers(h)) != BLUB_OK) return rc;
@@ -389,17 +391,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             float* Q[2] = {h->aux_temp, h->cgbuf[2]};
             float4* part[2] = {h->part4, h->part4 + PCG_GRID_MAX};
             Pcg1Scalars* sc = h->pcg1_scalars[which];
-            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, np, part[0], 1);
-            static const int early = getenv("BLUB_PCG1_EARLY") ? atoi(getenv("BLUB_PCG1_EARLY")) : 1;   // (tuning switch, see k_pcg1_iter_s)
-#define BLUB_LAUNCH_K(FIRSTV, ...)                                                                                    \
-    do {                                                                                                              \
-        if (xmap) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 1, true>), grid, block, __VA_ARGS__);          \
-        else if (early <= 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 0>), grid, block, __VA_ARGS__);     \
-        else if (early == 1) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 1>), grid, block, __VA_ARGS__);     \
-        else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<FIRSTV, false, 2>), grid, block, __VA_ARGS__);                     \
-    } while (0)
-            static const bool xmap = getenv("BLUB_PCG1_XMAP") ? atoi(getenv("BLUB_PCG1_XMAP")) != 0 : true;   // XCD-contiguous list order (+2 % steps/s; needs np % 8 == 0, guaranteed above)
-            static const bool done_first_env = getenv("BLUB_PCG1_DONEFIRST") ? atoi(getenv("BLUB_PCG1_DONEFIRST")) != 0 : false;   // (tuning switch)
+            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, 0, part[0], 1);
             // Launch as many iterations as the last few solves needed (+ `tail_margin_checks` check intervals); ONE persistent kernel covers
             // the rest (k_pcg1_tail_s): it normally finds the solve finished and only publishes the statistics.  Only while the solve is
             // launch-bound (an iteration inside the tail -- <= 256 blocks, a grid barrier -- costs more than a launched one).
@@ -412,65 +404,31 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             if (h->use_tail && h->tail_first_forced >= 0) launched1 = std::min(maxit + 1, std::max(1, h->tail_first_forced));   // (test hook; K(0) is always launched)
             for (int i = 0; i < launched1; ++i) {
                 const float4* pin = part[i & 1]; float4* pout = part[(i + 1) & 1];
-                // the first check is iteration `freq`, its verdict is formed by K(freq + 1): K(freq + 2) is the first launch that can find `done` set
-                const int done_first = (done_first_env && freq > 0 && i >= freq + 2) ? 1 : 0;
-                if (i == 0) BLUB_LAUNCH_K(true, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, np, ctrl, sc, tol, 0, 0, -1, -1, 0);
-                else BLUB_LAUNCH_K(false, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, np, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1, done_first);
+                if (i == 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, 0, ctrl, sc, tol, 0, 0, -1, -1);
+                else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, 0, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1);
             }
-            const int np_final = np;
-#undef BLUB_LAUNCH_K
             if (launched1 <= maxit) {
-                const dim3 tgrid((unsigned)std::max(8, (std::min(np, h->tail_grid) / 8) * 8));
-                if (xmap) LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_tail_s<true>, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, R[0], R[1], W[0], W[1], Q[0], Q[1], h->search, p,
-                                 part[0], part[1], np_final, ctrl, sc, tol, launched1, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
-                else LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_tail_s<false>, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, R[0], R[1], W[0], W[1], Q[0], Q[1], h->search, p,
-                            part[0], part[1], np_final, ctrl, sc, tol, launched1, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
+                const dim3 tgrid((unsigned)std::min(np, h->tail_grid));     // (tail_grid: a multiple of 8, every block co-resident)
+                LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_tail_s<true>, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, R[0], R[1], W[0], W[1], Q[0], Q[1], h->search, p,
+                       part[0], part[1], ctrl, sc, tol, launched1, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
             } else
-            LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], np_final, maxit, h->solve_seq[which], stat_slot);
+                LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], 0, nfl, maxit, h->solve_seq[which], stat_slot);
             // the residual of a full-length solve ends in R[(maxit + 1) & 1]; keep BLUB_VOLUME_RESIDUAL pointing at it
             if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
             return enqueue_stats_readback(h, which, dt, true);
         }
-        // Launch as many iterations as the last few solves needed (+ one check interval); a persistent tail kernel covers the
-        // rest: a single no-op launch when the solve has converged by then (the rule), a grid-barrier loop otherwise.
-        int launched = maxit + 1;
-        // (only while the solve is launch-bound: with thousands of fluid bricks an iteration inside the tail -- 256 blocks, two grid
-        // barriers -- costs far more than the no-op launches it saves, so a misprediction would be expensive)
-        const bool tail_pays = !have || bc.n_fluid <= 2048u;
-        if (h->use_tail && tail_pays && freq > 0 && !h->stats_history[which].empty()) {
-            int recent = 0, k = 0;
-            for (auto it2 = h->stats_history[which].rbegin(); it2 != h->stats_history[which].rend() && k < 4; ++it2, ++k) recent = std::max(recent, (int)it2->iteration_count);
-            if (recent >= 0 && recent < maxit) launched = std::min(maxit + 1, (recent / freq + h->tail_margin_checks) * freq + 1);   // through `margin` checks past the recent maximum
-        }
-        if (h->use_tail && h->tail_first_forced >= 0) launched = std::min(maxit + 1, h->tail_first_forced);   // (test hook)
-        // from a few hundred fluid bricks on: the LDS-staged variants of the two iteration kernels (same arithmetic, bit-identical results)
-        const bool staged = h->force_pcg_path == 2 || (h->force_pcg_path < 0 && have && bc.n_fluid >= STAGED_PCG_MIN_BRICKS);
-        for (int i = 0; i < launched; ++i) {
-            if (staged) {
-                if (i == 0)
-                    LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
-                           (const float2*)part_upd, part_dir, np, ctrl, tol, i, 0);
-                else
-                    LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<false>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
-                           (const float2*)part_upd, part_dir, np, ctrl, tol, i, (int)is_check(i - 1));
-                LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
-                       (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
-                continue;
-            }
+        // the reference's two-reduction schedule: two kernels per iteration (a finished solve's launches return after one load)
+        for (int i = 0; i <= maxit; ++i) {
             if (i == 0)
-                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<true>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
-                       (const float2*)part_upd, part_dir, np, ctrl, tol, i, 0);
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<true>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
+                       (const float2*)part_upd, part_dir, 0, ctrl, tol, i, 0);
             else
-                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_b<false>, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
-                       (const float2*)part_upd, part_dir, np, ctrl, tol, i, (int)is_check(i - 1));
-            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
-                   (const float*)part_dir, part_upd, np, (const PcgCtrl*)ctrl, i);
+                LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<false>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
+                       (const float2*)part_upd, part_dir, 0, ctrl, tol, i, (int)is_check(i - 1));
+            LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_s, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
+                   (const float*)part_dir, part_upd, 0, (const PcgCtrl*)ctrl, i);
         }
-        if (launched <= maxit)
-            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_tail_b, dim3(std::min(np, h->tail_grid)), block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, h->residual, sbuf[0], sbuf[1], p,
-                   part_upd, part_dir, np, ctrl, tol, launched, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
-        else
-            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, 0, nfl, maxit, h->solve_seq[which], stat_slot);
     } else {
         const int np = h->pcg_grid_z;
         const dim3 grid(np);
@@ -489,12 +447,12 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
                        (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
             }                                                                                                                                                   \
         }
-        static const int nt_mode = getenv("BLUB_PCGZ_NT") ? atoi(getenv("BLUB_PCGZ_NT")) : 1;   // bit 0: p / r of KU non-temporal (default: 66.8 -> 62.5 us at 256^3), bit 1: s_out of KD (no gain)
-        if (h->gz.T == 256) { if (nt_mode == 0) BLUB_LAUNCH_Z(256, false, false) else if (nt_mode == 1) BLUB_LAUNCH_Z(256, true, false) else if (nt_mode == 2) BLUB_LAUNCH_Z(256, false, true) else BLUB_LAUNCH_Z(256, true, true) }
-        else if (h->gz.T == 1024) { if (nt_mode & 1) BLUB_LAUNCH_Z(1024, true, false) else BLUB_LAUNCH_Z(1024, false, false) }
-        else { if (nt_mode & 1) BLUB_LAUNCH_Z(512, true, false) else BLUB_LAUNCH_Z(512, false, false) }
+        // p / r of KU are touched exactly once per kernel: non-temporal (66.8 -> 62.5 us at 256^3); s_out of KD is re-read as a halo: default policy
+        if (h->gz.T == 256) BLUB_LAUNCH_Z(256, true, false)
+        else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024, true, false)
+        else BLUB_LAUNCH_Z(512, true, false)
 #undef BLUB_LAUNCH_Z
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, maxit, h->solve_seq[which], stat_slot);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, (const uint32_t*)nullptr, maxit, h->solve_seq[which], stat_slot);
     }
     // the search direction of a full-length solve ends in sbuf[maxit & 1]; keep BLUB_VOLUME_SEARCH pointing at it
     if (maxit & 1) std::swap(h->search, h->aux);
@@ -548,12 +506,8 @@ static int stage_advect(blub_fluid* h, float dt) {   // :916-932
     return rc != BLUB_OK ? rc : build_lists_from_particles(h, COMPACT_STEP_B);
 }
 static int stage_density_gather(blub_fluid* h, float dt) {   // :933-937
-    if (h->gather_mode == 1)
-        LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_p, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
-               (const float4*)h->pos, h->residual, dt);
-    else
-        LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_b, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
-               (const float4*)h->pos, h->residual, dt);
+    LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_p, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
+           (const float4*)h->pos, h->residual, dt);
     return BLUB_OK;
 }
 static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
@@ -561,9 +515,13 @@ static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
            (const float*)h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
     return stage_extrapolate(h);
 }
-static int stage_correct(blub_fluid* h) {   // :969-973
+// `step_done`: also publish the number of the step this launch completes (run-ahead throttle of blub_fluid_step)
+static int stage_correct(blub_fluid* h, bool step_done = false) {   // :969-973
     if (h->num_particles)
-        LAUNCH(h, KC_CORRECT, k_correct, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2]);
+        LAUNCH(h, KC_CORRECT, k_correct, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2],
+               step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u);
+    else if (step_done)
+        hipLaunchKernelGGL(k_step_done, dim3(1), dim3(1), 0, h->stream, (volatile uint32_t*)h->steps_done_dev, h->steps_enqueued + 1u);
     return BLUB_OK;
 }
 
@@ -585,7 +543,7 @@ static int run_stage(blub_fluid* h, int stage, float dt, bool standalone) {
     case BLUB_STAGE_DENSITY_GATHER: return stage_density_gather(h, dt);
     case BLUB_STAGE_SOLVE_DENSITY: return stage_solve(h, 1, dt, standalone);
     case BLUB_STAGE_POSITION_CHANGE: return stage_position_change(h, dt);
-    case BLUB_STAGE_CORRECT: return stage_correct(h);
+    case BLUB_STAGE_CORRECT: return stage_correct(h, !standalone);
     }
     return set_error(BLUB_ERR_INVALID_ARGUMENT, "unknown stage");
 }
@@ -615,6 +573,21 @@ static void destroy(blub_fluid* h) {
     if (h->prof_origin) (void)hipEventDestroy(h->prof_origin);
     if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+// Tile geometry of the dense 2.5-D PCG kernels (blub_pcg_dense.hip.h).  0 = the measured default for this grid:
+// T = 256 quads x 16 planes at 256^3 (profiles/r01_dense_pcg_sweep.txt: 16 planes amortise the z-halo best, but the chip needs >= ~1000 tiles
+// in flight -- 256 CUs x 4 blocks --, so smaller grids march fewer planes per tile: 128x64x64 at zc = 16 has 32 tiles).
+static void set_dense_geometry(blub_fluid* h, int T, int zc, int grid) {
+    PcgGeomZ& gz = h->gz;
+    const int qpr = h->g.nx / 4, qpp = qpr * h->g.ny;
+    if (T != 256 && T != 512 && T != 1024) T = 256;
+    gz.g = h->g; gz.qpr = qpr; gz.qpp = qpp; gz.T = T; gz.plane_tiles = (qpp + T - 1) / T;
+    if (zc <= 0) { zc = 16; while (zc > 2 && gz.plane_tiles * ((h->g.nz + zc - 1) / zc) < 1024) zc >>= 1; }
+    gz.zc = std::max(2, zc);
+    gz.z_chunks = (h->g.nz + gz.zc - 1) / gz.zc; gz.tiles = gz.plane_tiles * gz.z_chunks;
+    if (grid <= 0) grid = 2048;
+    h->pcg_grid_z = std::min(std::min(grid, PCG_GRID_MAX), ((gz.tiles + 7) / 8) * 8);
 }
 
 static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared_stream = nullptr) {
@@ -656,43 +629,25 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->scan_totals, (h->N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
     PcgGeom& gm = h->geom;
     gm.g = h->g; gm.qpr = h->g.nx / 4; gm.qpp = gm.qpr * h->g.ny; gm.plane_blocks = (gm.qpp + 255) / 256;
-    {   // tile depth / grid size: tuning knobs (environment overrides exist for sweeps only)
-        int zc = 8, grid = PCG_GRID_DENSE;
-        if (const char* e = getenv("BLUB_PCG_ZC")) zc = std::max(1, atoi(e));
-        if (const char* e = getenv("BLUB_PCG_GRID")) grid = std::min(PCG_GRID_MAX, std::max(1, atoi(e)));
-        gm.zc = zc;
-        gm.z_chunks = (h->g.nz + zc - 1) / zc; gm.tiles = gm.plane_blocks * gm.z_chunks;
-        h->pcg_grid = std::min(grid, gm.tiles);
-        PcgGeomZ& gz = h->gz;
-        int T = 256, zcz = 16, gridz = 2048;   // measured on MI355X at 256^3 (profiles/r01_dense_pcg_sweep.txt)
-        if (const char* e = getenv("BLUB_PCGZ_T")) T = atoi(e);
-        if (T != 256 && T != 512 && T != 1024) T = 512;
-        if (const char* e = getenv("BLUB_PCGZ_ZC")) zcz = std::max(1, atoi(e));
-        if (const char* e = getenv("BLUB_PCGZ_GRID")) gridz = std::min(PCG_GRID_MAX, std::max(1, atoi(e)));
-        gz.g = h->g; gz.qpr = gm.qpr; gz.qpp = gm.qpp; gz.T = T; gz.plane_tiles = (gm.qpp + T - 1) / T;
-        // Tile depth: 16 planes amortise the z-halo best (profiles/r01_dense_pcg_sweep.txt), but the chip needs >= ~1000
-        // tiles in flight (256 CUs x 4 blocks): smaller grids march fewer planes per tile (128x64x64 at zc = 16 has 32 tiles).
-        if (!getenv("BLUB_PCGZ_ZC")) while (zcz > 2 && gz.plane_tiles * ((h->g.nz + zcz - 1) / zcz) < 1024) zcz >>= 1;
-        gz.zc = zcz;
-        gz.z_chunks = (h->g.nz + zcz - 1) / zcz; gz.tiles = gz.plane_tiles * gz.z_chunks;
-        h->pcg_grid_z = std::min(gridz, ((gz.tiles + 7) / 8) * 8);
-    }
+    gm.zc = 8;   // LOD0 reading (literal kernel sequence, dense rows): 8 planes per tile, 8 blocks of 256 threads per CU
+    gm.z_chunks = (h->g.nz + gm.zc - 1) / gm.zc; gm.tiles = gm.plane_blocks * gm.z_chunks;
+    h->pcg_grid = std::min(PCG_GRID_DENSE, gm.tiles);
+    set_dense_geometry(h, 0, 0, 0);
     A(dev_alloc_zero(h->stream, &h->part_sas, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[0], 2 * PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->part_sigma[1], PCG_GRID_MAX));
-    A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, (size_t)std::max(gm.tiles, h->gz.tiles) + 8));
+    {   // tile flags: one per dense tile of ANY tile geometry blub_fluid_set_tuning can select (the smallest tile: 256 quads x 2 planes)
+        const size_t max_tiles = (size_t)((gm.qpp + 255) / 256) * (size_t)((h->g.nz + 1) / 2);
+        A(dev_alloc_zero(h->stream, &h->part_max, PCG_GRID_MAX)); A(dev_alloc_zero(h->stream, &h->tile_flags, std::max<size_t>(std::max<size_t>(gm.tiles, max_tiles), (size_t)h->gz.tiles) + 8));
+    }
     A(dev_alloc_zero(h->stream, &h->ctrl[0], 1)); A(dev_alloc_zero(h->stream, &h->ctrl[1], 1));
     A(dev_alloc_zero(h->stream, &h->tail_sync[0], 1)); A(dev_alloc_zero(h->stream, &h->tail_sync[1], 1));
-    {   // the tail kernel's grid barrier needs every block resident at once: bound the grid by what the device can hold
+    {   // the tail kernel's grid barrier needs every block resident at once: bound its grid by what the device holds of THAT kernel
+        // (round-2 ADVICE: the bound used to come from another kernel with a smaller footprint)
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_tail_b, PCG_B_THREADS, 0) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
-            h->tail_grid = std::max(1, std::min(256, cus));          // one block per CU: always fits when per_cu >= 1
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg1_tail_s<true>, PCG_B_THREADS, 0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus >= 8)
+            h->tail_grid = (std::min(256, cus) / 8) * 8;             // at most one block per CU (always co-resident when per_cu >= 1), a multiple of 8
         else h->use_tail = false;
     }
-    if (const char* e = getenv("BLUB_PCG_SCHEDULE")) h->pcg_schedule = atoi(e) == 1 ? 1 : 0;
-    if (const char* e = getenv("BLUB_GATHER")) h->gather_mode = atoi(e) == 0 ? 0 : 1;
-    if (const char* e = getenv("BLUB_PCG_TAIL")) h->use_tail = atoi(e) != 0;
-    if (const char* e = getenv("BLUB_PCG_TAIL_FIRST")) h->tail_first_forced = atoi(e);
-    if (const char* e = getenv("BLUB_PCG_TAIL_MARGIN")) h->tail_margin_checks = std::max(0, atoi(e));
     A(dev_alloc_zero(h->stream, &h->dvol, h->N));
     BrickGeom& bg = h->bg;
     bg.g = h->g; bg.nbx = (h->g.nx + BX - 1) / BX; bg.nby = (h->g.ny + BY - 1) / BY; bg.nbz = (h->g.nz + BZ - 1) / BZ; bg.nb = bg.nbx * bg.nby * bg.nbz;
@@ -848,8 +803,7 @@ int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
         if ((rc = blub::run_stage(h, BLUB_STAGE_BINNING, dt, false)) != BLUB_OK) return rc;
     for (int s : after_binning) if ((rc = blub::run_stage(h, s, dt, false)) != BLUB_OK) return rc;
     h->step_counter += 1;   // :976
-    h->steps_enqueued += 1;
-    hipLaunchKernelGGL(blubk::k_step_done, dim3(1), dim3(1), 0, h->stream, (volatile uint32_t*)h->steps_done_dev, h->steps_enqueued);
+    h->steps_enqueued += 1;   // (k_correct, the last kernel of the step, publishes this number: stage_correct)
     (void)blub::poll_stats(h, false);   // the reference polls old read-backs inside solve (:612)
     return blub::check_launch(h);
 }
@@ -1022,6 +976,23 @@ int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode) {
     return BLUB_OK;
 }
 int blub_fluid_get_pcg_schedule(const blub_fluid* h) { return h ? h->pcg_schedule : BLUB_ERR_INVALID_ARGUMENT; }
+// Performance knobs and test hooks by name: none changes results beyond the rounding of a dot-product tree; the library never reads the
+// environment.  (Benchmarks and sweeps call this; nothing of the HybridFluid surface does.)
+int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
+    REQUIRE_HANDLE(h);
+    if (!name) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    const std::string k(name);
+    if (k == "pcg_tail") h->use_tail = value != 0 && h->tail_grid >= 8;
+    else if (k == "pcg_tail_first") h->tail_first_forced = value;
+    else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
+    else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
+    else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);
+    else if (k == "dense_tile_quads" || k == "dense_tile_planes" || k == "dense_grid") {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        blub::set_dense_geometry(h, k == "dense_tile_quads" ? value : h->gz.T, k == "dense_tile_planes" ? value : (k == "dense_tile_quads" ? 0 : h->gz.zc), k == "dense_grid" ? value : 0);
+    } else return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "unknown tuning knob");
+    return BLUB_OK;
+}
 int blub_fluid_set_max_steps_in_flight(blub_fluid* h, uint32_t m) { if (!h) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); h->max_steps_in_flight = m; return BLUB_OK; }
 int blub_fluid_get_brick_counts(blub_fluid* h, uint32_t out[6]) {
     REQUIRE_HANDLE(h);

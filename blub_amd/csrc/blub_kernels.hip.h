@@ -76,9 +76,6 @@ __device__ __forceinline__ float reduce_partials_256(const float* __restrict__ p
 // between two rebinnings.  key < 0: the particle is outside the grid (no insertion, next = invalid).  All 64 lanes must call this.
 __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ heads, int key, uint32_t particle) {
     const int lane = threadIdx.x & 63;
-#ifdef BLUB_NO_WAVE_AGG   // timing ablation only: one atomic per particle
-    unsigned long long mine = 1ull << lane;
-#else
     unsigned long long remaining = ~0ull, mine = 0ull;
     while (remaining) {
         const int k = __shfl(key, __builtin_ctzll(remaining), 64);     // (uniform source lane: a v_readlane)
@@ -86,7 +83,6 @@ __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ head
         if (key == k) mine = m;
         remaining &= ~m;
     }
-#endif
     const unsigned long long below = mine & ((1ull << lane) - 1ull);
     const bool is_first = below == 0ull, is_last = (mine >> lane) == 1ull;
     const int prev_lane = is_first ? lane : 63 - __builtin_clzll(below), last_lane = 63 - __builtin_clzll(mine);
@@ -245,22 +241,6 @@ __device__ __forceinline__ float quad_mulA(const QuadMarkers& m, const QuadValue
     if (mZ1 == CELL_FLUID) r -= f4(v.zp, j);
     return r;
 }
-// "zero" reading of pressure_apply_preconditioner.comp:36-82 applied twice (pass0 then pass1): (r / d) / d with
-// d in {0..6}.  Evaluated as (r * (1/d)) * (1/d) with a correctly rounded reciprocal: <= 1 ulp per factor away from a
-// correctly rounded division, i.e. inside the 2.5 ulp the GLSL/Vulkan precision contract grants the reference's own `/`,
-// and ~10x cheaper than two IEEE divisions (the fused direction kernel evaluates this 22 times per quad).
-// The reciprocal is picked by a flat chain of selects (v_cmp + v_cndmask): the nested form compiled to ~8 exec-mask branches
-// per cell, 280 branches per thread in the direction kernel, which made that kernel issue- instead of latency-bound.
-__device__ __forceinline__ float precond_zero_i(float r, int di) {
-    float inv = 1.0f;
-    inv = di == 2 ? 0.5f : inv;
-    inv = di == 3 ? (1.0f / 3.0f) : inv;
-    inv = di == 4 ? 0.25f : inv;
-    inv = di == 5 ? 0.2f : inv;
-    inv = di >= 6 ? (1.0f / 6.0f) : inv;
-    return (r * inv) * inv;
-}
-__device__ __forceinline__ float precond_zero(float r, float d) { return precond_zero_i(r, (int)d); }
 __device__ __forceinline__ float eps_div(float num, float den) { return num / (den + (den < 0.0f ? -1e-10f : 1e-10f)); }   // pressure_reduce.comp:71-77
 
 #define PCG_TILE_LOOP_BEGIN(geom)                                                                            \
@@ -272,9 +252,8 @@ __device__ __forceinline__ float eps_div(float num, float den) { return num / (d
         const int z_begin = zc * (geom).zc, z_end = min(z_begin + (geom).zc, (geom).g.nz);
 #define PCG_TILE_LOOP_END }
 
-// S0 (pressure_init.comp:19-84) fused with the initial preconditioner + s.r partials (pressure_solver.rs:630-648).
-// PRECOND_ZERO: s = (r/d)/d and sigma partial here.  LOD0: only r and p are updated (generic passes follow).
-template <bool ZERO_MODE>
+// The kernels below are the LITERAL kernel sequence of the LOD0 preconditioner reading (dense rows, marker based; stage_solve_lod0).
+// S0 (pressure_init.comp:19-84): only r and p are updated (the generic preconditioner passes follow).
 __global__ __launch_bounds__(256) void k_pcg_init(PcgGeom geom, const int8_t* __restrict__ marker, float* __restrict__ p, float* __restrict__ r,
                                                   float* __restrict__ s, float* __restrict__ part_sigma, uint8_t* __restrict__ tile_flags) {
     __shared__ float sm[8];
@@ -295,7 +274,6 @@ __global__ __launch_bounds__(256) void k_pcg_init(PcgGeom geom, const int8_t* __
                     QuadValues pv; load_quad_values(p, geom.g, base, x0, y, z, pv);
                     float4 rc = ld4(r + base);
                     float rr[4] = {rc.x, rc.y, rc.z, rc.w};
-                    float ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (mbyte(mc, j) != CELL_FLUID) continue;
@@ -311,18 +289,8 @@ __global__ __launch_bounds__(256) void k_pcg_init(PcgGeom geom, const int8_t* __
                         if (mZ0 == CELL_FLUID) res += f4(pv.zm, j);
                         if (mZ1 == CELL_FLUID) res += f4(pv.zp, j);
                         rr[j] = res;
-                        if (ZERO_MODE) { ss[j] = precond_zero(res, d); acc += ss[j] * res; }
                     }
                     *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
-                    if (ZERO_MODE) {
-                        // the reference never writes s outside FLUID cells; keep those values untouched
-                        float4 so = ld4(s + base);
-                        if (mbyte(mc, 0) == CELL_FLUID) so.x = ss[0];
-                        if (mbyte(mc, 1) == CELL_FLUID) so.y = ss[1];
-                        if (mbyte(mc, 2) == CELL_FLUID) so.z = ss[2];
-                        if (mbyte(mc, 3) == CELL_FLUID) so.w = ss[3];
-                        *reinterpret_cast<float4*>(s + base) = so;
-                    }
                 }
                 // pressure_init.comp:45-48: p := 0 outside the fluid
                 bool dirty = false;
@@ -368,8 +336,7 @@ __global__ __launch_bounds__(256) void k_pcg_apply(PcgGeom geom, const int8_t* _
     if (threadIdx.x == 0) part_sas[blockIdx.x] = tot;
 }
 
-// K2: pressure_update_pressure_and_residual.comp:23-59 (+ preconditioner and z.r partial when ZERO_MODE)
-template <bool ZERO_MODE>
+// K2: pressure_update_pressure_and_residual.comp:23-59
 __global__ __launch_bounds__(256) void k_pcg_update(PcgGeom geom, const int8_t* __restrict__ marker, const float* __restrict__ s, float* __restrict__ p,
                                                     float* __restrict__ r, const float* __restrict__ part_sas, const float* __restrict__ part_sigma,
                                                     float* __restrict__ part_sigma_next, float* __restrict__ part_max, int num_part,
@@ -399,7 +366,6 @@ __global__ __launch_bounds__(256) void k_pcg_update(PcgGeom geom, const int8_t* 
                 res -= alpha * as;                                                      // :52
                 rr[j] = res;
                 emax = fmaxf(emax, fabsf(res));                                         // :55
-                if (ZERO_MODE) acc += precond_zero(res, d) * res;
             }
             *reinterpret_cast<float4*>(p + base) = make_float4(pp[0], pp[1], pp[2], pp[3]);
             *reinterpret_cast<float4*>(r + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
@@ -407,7 +373,8 @@ __global__ __launch_bounds__(256) void k_pcg_update(PcgGeom geom, const int8_t* 
     PCG_TILE_LOOP_END
     const float tot = block_reduce_256<false>(acc, sm);
     const float mx = block_reduce_256<true>(emax, sm);
-    if (threadIdx.x == 0) { if (ZERO_MODE) part_sigma_next[blockIdx.x] = tot; part_max[blockIdx.x] = mx; }
+    (void)tot; (void)part_sigma_next;
+    if (threadIdx.x == 0) part_max[blockIdx.x] = mx;
 }
 
 // Generic preconditioner pass for the LOD0 reading: pressure_apply_preconditioner.comp:36-82 (both passes use the
@@ -451,7 +418,6 @@ __global__ __launch_bounds__(256) void k_pcg_precond_lod0(PcgGeom geom, const in
 
 // K5: pressure_update_search.comp:13-24 + the MAX_ERROR / BETA modes of pressure_reduce.comp:63-95.
 // check: this iteration compared max|r| against the tolerance; last: i == max_num_iterations.
-template <bool ZERO_MODE>
 __global__ __launch_bounds__(256) void k_pcg_search(PcgGeom geom, const int8_t* __restrict__ marker, const float* __restrict__ r_or_z, float* __restrict__ s,
                                                     const float* __restrict__ part_sigma, const float* __restrict__ part_sigma_next,
                                                     const float* __restrict__ part_max, int num_part, const uint8_t* __restrict__ tile_flags,
@@ -474,20 +440,13 @@ __global__ __launch_bounds__(256) void k_pcg_search(PcgGeom geom, const int8_t* 
             const int base = cidx(geom.g, x0, y, z);
             QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
             if (!any_fluid4(m.c)) continue;
-            if (ZERO_MODE) load_quad_markers(marker, geom.g, base, x0, y, z, m);
             const float4 zc4 = ld4(r_or_z + base);
             float4 sc = ld4(s + base);
             float ss[4] = {sc.x, sc.y, sc.z, sc.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (mbyte(m.c, j) != CELL_FLUID) continue;
-                float zval = f4(zc4, j);
-                if (ZERO_MODE) {
-                    const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
-                    const float d = (float)(mX0 != 0) + (float)(mX1 != 0) + (float)(mbyte(m.ym, j) != 0) + (float)(mbyte(m.yp, j) != 0) +
-                                    (float)(mbyte(m.zm, j) != 0) + (float)(mbyte(m.zp, j) != 0);
-                    zval = precond_zero(zval, d);
-                }
+                const float zval = f4(zc4, j);
                 ss[j] = zval + beta * ss[j];                                            // :23
             }
             *reinterpret_cast<float4*>(s + base) = make_float4(ss[0], ss[1], ss[2], ss[3]);
@@ -684,8 +643,12 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
 // =================================================================================================================
 // R3: density_projection_correct_particles.comp:25-73
 // =================================================================================================================
+// step_done_host / step_number: the run-ahead throttle of blub_fluid_step (a counter in pinned host memory; this is the last kernel of a
+// step, and its last workgroup is dispatched when nearly all others have retired -- the throttle needs no more than that)
 __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles, float4* __restrict__ pos, const int8_t* __restrict__ marker,
-                                                 const float* __restrict__ vx, const float* __restrict__ vy, const float* __restrict__ vz) {
+                                                 const float* __restrict__ vx, const float* __restrict__ vy, const float* __restrict__ vz,
+                                                 volatile uint32_t* step_done_host = nullptr, uint32_t step_number = 0) {
+    if (step_done_host && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *step_done_host = step_number;
     const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
     if (pi >= num_particles) return;
     const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
@@ -806,5 +769,8 @@ __global__ __launch_bounds__(256) void k_bin_rewrite(Grid g, uint32_t num_partic
     const uint32_t dst = inc - __float_as_uint(p.w) - 1u;                               // particle_binning_rewrite_particles.comp:15, 0-based (Q4)
     if (dst < max_particles) new_pos[dst] = p;
 }
+
+// end-of-step marker for steps without particles (otherwise k_correct writes it)
+__global__ void k_step_done(volatile uint32_t* host_counter, uint32_t step_number) { *host_counter = step_number; }
 
 }  // namespace blubk

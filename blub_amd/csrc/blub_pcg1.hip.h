@@ -24,35 +24,6 @@
 
 namespace blubk {
 
-// M^-1 x exactly as the reference's two preconditioner passes write it with the Q1 reading "zero" (pressure_apply_preconditioner.comp:36-82):
-// (x / d) / d with two correctly rounded divisions, d = number of non-SOLID neighbours in 0..6, skipped for d = 0.  (The two-kernel
-// schedule of blub_pcg.hip.h multiplies by correctly rounded reciprocals instead -- within 1 ulp per factor.)
-// The iteration kernel is bound by the length of ONE wave's instruction stream and evaluates this ~17 times per thread,
-// so the IEEE division sequence (v_div_scale x2, v_rcp, 4-5 fma, v_div_fmas, v_div_fixup per division) is replaced by division by a
-// CONSTANT: d = m 2^k with m in {1, 3, 5}; scaling by 2^-k is exact, and for the odd part
-//     q0 = RN(y c), r = fma(-m, q0, y) (exact), q = fma(r, c, q0),  c = RN(1/m)
-// is the correctly rounded y / m (Markstein's correction step; checked for every f32 significand by tests/native/div_const_check.c).
-// The results are bit-identical to `(x / d) / d`.
-struct DivConst { float c, nm, sc2, pad; };     // per d = 0..7: RN(1/m), -m, 2^-2k  (both power-of-two scalings commute with the roundings: applied at once)
-__device__ __forceinline__ void pcg1_fill_div_lut(DivConst* lut) {   // by the first 8 threads of the block; a barrier must follow before the first use
-    if (threadIdx.x < 8) {
-        const int d = (int)threadIdx.x;
-        DivConst e = {1.0f, -1.0f, 1.0f, 0.0f};                       // d = 0, 1 (and the impossible 7): the value itself
-        if (d == 3 || d == 6) { e.c = 0x1.555556p-2f; e.nm = -3.0f; }  // RN(1/3)
-        if (d == 5) { e.c = 0x1.99999ap-3f; e.nm = -5.0f; }            // RN(1/5)
-        if (d == 2 || d == 6) e.sc2 = 0.25f;
-        if (d == 4) e.sc2 = 0.0625f;
-        lut[d] = e;
-    }
-}
-__device__ __forceinline__ float precond_exact(float x, const DivConst& k) {
-    const float y = x * k.sc2;
-    float q = y * k.c;
-    q = fmaf(fmaf(k.nm, q, y), k.c, q);                               // 2^-2k x / m
-    float q2 = q * k.c;
-    return fmaf(fmaf(k.nm, q2, q), k.c, q2);                          // ... / m  ==  (x / d) / d
-}
-
 // Wave-wide reductions on the DPP path (row shifts + the two row broadcasts of gfx9, result read from lane 63 into an SGPR): six
 // dependent VALU instructions where the __shfl_down tree of wave_sum() is six ds_bpermute round trips (~100 cycles each).  The
 // iteration kernel reduces three values twice per launch, and its run time is one wave's dependent instruction stream.
@@ -102,33 +73,31 @@ __device__ __forceinline__ float4 reduce_partials4(const float4* __restrict__ pa
 }
 
 // The prologue is split in two so that everything the kernel needs from memory is requested in TWO dependent round trips:
-//   (1) `done`, the previous scalars, this thread's share of the partial array -- together with the list length and the block's
-//       list entry (the caller issues those in the same batch);
-//   (2) the field loads of the block's first brick, issued by the caller between the two halves: they are in flight while the
+//   (1) `done`, the previous scalars, this thread's share of the partial array (spec_partials_load, blub_pcg.hip.h) -- together with the
+//       list length and the block's list entry (the caller issues those in the same batch);
+//   (2) the descriptor loads of the block's first brick, issued by the caller between the two halves: they are in flight while the
 //       partials are reduced.
 // The kernels are latency-bound: each saved round trip is ~1.5 us of a ~9 us kernel.
-constexpr int PCG1_PART_PER_THREAD = 4;   // 4 x 256 threads >= the 1024 partials a brick-mapped solve can have
-struct Pcg1PrologueLoads { int done; float g_prev, a_prev; float4 pl[PCG1_PART_PER_THREAD]; };
-template <int NT, bool FIRST>
-__device__ __forceinline__ void pcg1_prologue_load(const PcgCtrl* __restrict__ ctrl, const Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in, int num_part,
+struct Pcg1PrologueLoads { int done; float g_prev, a_prev; int spec; SpecPartials<float4> sp; };
+template <bool FIRST>
+__device__ __forceinline__ void pcg1_prologue_load(const PcgCtrl* __restrict__ ctrl, const Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in, int num_part_in,
                                                    int iteration, Pcg1PrologueLoads& L) {
     L.done = ctrl->done;
     L.g_prev = 0.0f; L.a_prev = 0.0f;
     if (!FIRST) { L.g_prev = sc->gamma[(iteration + 1) & 1]; L.a_prev = sc->alpha[(iteration + 1) & 1]; }
-#pragma unroll
-    for (int k = 0; k < PCG1_PART_PER_THREAD; ++k) {
-        const int i = (int)threadIdx.x + k * NT;
-        L.pl[k] = i < num_part ? part_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    L.spec = spec_bound(num_part_in);
+    spec_partials_load(part_in, L.spec, L.sp);
 }
 // Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
-template <int NT, bool FIRST>
-__device__ __forceinline__ bool pcg1_prologue_finish(const Pcg1PrologueLoads& L, PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in,
+template <bool FIRST>
+__device__ __forceinline__ bool pcg1_prologue_finish(Pcg1PrologueLoads& L, PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in,
                                                      int num_part, float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta) {
+    constexpr int NT = PCG_B_THREADS;
+    spec_partials_fix(part_in, L.spec, num_part, L.sp);
     float g = 0.0f, d = 0.0f, m = 0.0f;
 #pragma unroll
-    for (int k = 0; k < PCG1_PART_PER_THREAD; ++k) { g += L.pl[k].x; d += L.pl[k].y; m = fmaxf(m, L.pl[k].z); }
-    for (int i = (int)threadIdx.x + PCG1_PART_PER_THREAD * NT; i < num_part; i += NT) { const float4 p = part_in[i]; g += p.x; d += p.y; m = fmaxf(m, p.z); }
+    for (int k = 0; k < PCG_PART_PER_THREAD; ++k) { g += L.sp.v[k].x; d += L.sp.v[k].y; m = fmaxf(m, L.sp.v[k].z); }
+    for (int i = (int)threadIdx.x + PCG_VBLOCKS_MAX; i < num_part; i += NT) { const float4 p = part_in[i]; g += p.x; d += p.y; m = fmaxf(m, p.z); }
     g = wave_sum_dpp(g); d = wave_sum_dpp(d); m = wave_max_abs_dpp(m);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
@@ -163,71 +132,56 @@ __device__ __forceinline__ uint32_t st_read_quad_u(const StagedTile& T, int t, Q
     return *reinterpret_cast<const uint32_t*>(T.d + o);
 }
 
-// w_0 = A u_0 (u_0 = M^-1 r_0 was written to the search volume by k_pcg_init_b) + partials {gamma_0 (block 0 only), delta_0, 0}
-__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+// w_0 = A u_0 (u_0 = M^-1 r_0 was written to the search volume by k_pcg_init_b) + partials {gamma_0 (virtual block 0 only), delta_0, 0}
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
                                                              const uint8_t* __restrict__ dvol, const float* __restrict__ u, float* __restrict__ w_out,
-                                                             const float2* __restrict__ part_init, int num_part, float4* __restrict__ part_out, int gamma_owner) {
+                                                             const float2* __restrict__ part_init, int num_part_in, float4* __restrict__ part_out, int gamma_owner) {
     __shared__ float sm[8];
     __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
     const Grid g = bg.g;
     const uint32_t n = *count;
+    const int V = pcg_vblocks(n, vb_force);
+    if ((int)blockIdx.x >= V) return;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
-    const float2 red0 = reduce_partials2<PCG_B_THREADS>(part_init, num_part, sm2);
+    const float2 red0 = reduce_partials2<PCG_B_THREADS>(part_init, num_part_in > 0 ? num_part_in : V, sm2);
     StagedTile& T = tiles[half];
-    float acc = 0.0f;
-    for (uint32_t ib = blockIdx.x; ib * PCG_BPB < n; ib += gridDim.x) {
-        const uint32_t i = ib * PCG_BPB + half;
-        const bool have = i < n;
-        const uint32_t b = have ? list[i] : 0u;
-        int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb);
-        const int x0b = bxb * BX, y0b = byb * BY, z0b = bzb * BZ;
-        if (have) {
-            for (int e = t; e < ST_ROWS * 4; e += BRICK_THREADS) {
-                const int row = e >> 2, q = e & 3;
-                if (!st_row_needed(row)) continue;
-                const int gy = y0b + row % (BY + 2) - 1, gz = z0b + row / (BY + 2) - 1, gx = x0b + 4 * q;
-                float4 uv = make_float4(0.f, 0.f, 0.f, 0.f);
-                uint32_t dq = 0;
-                if ((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx) {
-                    const int base = cidx(g, gx, gy, gz);
-                    dq = *reinterpret_cast<const uint32_t*>(dvol + base);
-                    uv = ld4(u + base);
-                }
-                *reinterpret_cast<float4*>(T.s + row * ST_ROW + 4 + 4 * q) = uv;
-                *reinterpret_cast<uint32_t*>(T.d + row * ST_ROW + 4 + 4 * q) = dq;
-            }
-            for (int e = t; e < BY * BZ * 2; e += BRICK_THREADS) {
-                const int side = e & 1, yy = (e >> 1) % BY, zz = (e >> 1) / BY;
-                const int row = (zz + 1) * (BY + 2) + (yy + 1);
-                const int gx = side ? x0b + BX : x0b - 1, gy = y0b + yy, gz = z0b + zz;
-                float uv = 0.0f; int dv = 0;
-                if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { const int c = cidx(g, gx, gy, gz); dv = (int)dvol[c]; uv = u[c]; }
-                T.s[row * ST_ROW + (side ? 20 : 3)] = uv;
-                T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)dv;
-            }
-        }
-        __syncthreads();
-        if (have) {
-            int x0, y, z;
-            if (brick_quad(bg, b, t, x0, y, z)) {
-                QuadD m; QuadValues sv;
-                st_read_quad(T, t, m, sv);
-                if (any_fluid_d(m.c)) {
-                    float wn[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int vb = blockIdx.x; vb < V; vb += gridDim.x) {
+        float acc = 0.0f;
+        for (uint32_t ib = (uint32_t)vb; ib * PCG_BPB < n; ib += (uint32_t)V) {
+            const uint32_t i = ib * PCG_BPB + half;
+            const bool have = i < n;
+            const uint32_t b = have ? list[i] : 0u;
+            if (have)
+                st_fill(T, bg, b, t,
+                    [&](int base, bool inside, bool, int, int, uint32_t& dq) -> float4 {
+                        if (!inside) return make_float4(0.f, 0.f, 0.f, 0.f);
+                        dq = *reinterpret_cast<const uint32_t*>(dvol + base);
+                        return ld4(u + base);
+                    },
+                    [&](int c, bool inside, int& dv) -> float { if (!inside) return 0.0f; dv = (int)dvol[c]; return u[c]; });
+            __syncthreads();
+            if (have) {
+                int x0, y, z;
+                if (brick_quad(bg, b, t, x0, y, z)) {
+                    QuadD m; QuadValues sv;
+                    st_read_quad(T, t, m, sv);
+                    if (any_fluid_d(m.c)) {
+                        float wn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (dbyte(m.c, j) & 0x80) { wn[j] = quad_mulA_d(m, sv, j); acc += wn[j] * f4(sv.c, j); }
-                    *reinterpret_cast<float4*>(w_out + cidx(g, x0, y, z)) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+                        for (int j = 0; j < 4; ++j)
+                            if (dbyte(m.c, j) & 0x80) { wn[j] = quad_mulA_d(m, sv, j); acc += wn[j] * f4(sv.c, j); }
+                        *reinterpret_cast<float4*>(w_out + cidx(g, x0, y, z)) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+        const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
+        // gamma_0 (already reduced over ALL partials of the init kernels) enters the partial array exactly once: virtual block 0 of the one
+        // domain, or of the first slab of a z-slab group
+        if (threadIdx.x == 0) part_out[vb] = make_float4((vb == 0 && gamma_owner) ? red0.x : 0.0f, tot, 0.0f, 0.0f);
     }
-    const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
-    // gamma_0 (already reduced over ALL partials of the init kernels) enters the partial array exactly once: block 0 of the one
-    // domain, or of the first slab of a z-slab group
-    if (threadIdx.x == 0) part_out[blockIdx.x] = make_float4((blockIdx.x == 0 && gamma_owner) ? red0.x : 0.0f, tot, 0.0f, 0.0f);
 }
 
 // Raw loads of one brick's face-halo tile for K(i), held in registers: two passes over the 240 interior quads (thread t takes
@@ -309,52 +263,59 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
 
 // K(i): one whole PCG iteration.  HALO (z-slab groups): the block also stores the r_{i+1} / q_i it computed for the ghost plane
 // below `halo_lo` / above `halo_hi` (own planes of the slab, -1 = none), so only w needs a halo exchange per iteration.
-// EARLY (tuning): 0 = the first brick's loads are issued after the reduction, 1 = its descriptors before / its fields after,
-// 2 = everything before the reduction
 // (the body of K(i) as a device function: k_pcg1_iter_s runs it once per launch, k_pcg1_tail_s in a loop with grid barriers.
-//  Returns false when the solve is finished -- `done` was set, or this iteration's convergence test succeeded -- and nothing was computed)
-template <bool FIRST, bool HALO, int EARLY, bool XMAP>
-__device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+//  Returns false when the solve is finished -- `done` was set, or this iteration's convergence test succeeded -- and nothing was computed.)
+// Work and partials are organised in VIRTUAL workgroups (pcg_vblocks, blub_pcg.hip.h): the result does not depend on the launch grid.
+// SURPLUS_EXITS: launched workgroups beyond the virtual ones return at once (the tail kernel's must stay: they take part in its grid barriers).
+// vb_force / num_part_in: z-slab groups (the virtual-workgroup count every rank agreed on / the gathered partials of all slabs); 0 otherwise.
+template <bool FIRST, bool HALO, bool XMAP, bool SURPLUS_EXITS>
+__device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
                                                                const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
                                                                float* __restrict__ q_out, float* __restrict__ dsearch, float* __restrict__ p,
-                                                               const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part,
+                                                               const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part_in,
                                                                PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
-                                                               int halo_lo, int halo_hi, int done_first) {
+                                                               int halo_lo, int halo_hi) {
     __shared__ float4 sm4[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
     __shared__ DivConst div_lut[8];
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
-    pcg1_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
+    pcg_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
-    // the previous scalars and the partials
-    // XCD-contiguous brick order (XMAP, gridDim.x is a multiple of 8): block b runs on XCD b % 8 (observed dispatch order, a speed hint
-    // only), so XCD k takes the contiguous list range [k * grid / 8, (k + 1) * grid / 8): neighbouring bricks share an L2 for their halos
-    const uint32_t blk = XMAP ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const uint32_t i0 = blk * PCG_BPB + half;
-    const uint32_t b0 = i0 < (uint32_t)bg.nb ? list[i0] : 0u;
+    // the previous scalars and the partials.  The first list entry is requested for virtual workgroup blockIdx.x BEFORE the list length
+    // (hence V) is known: with the XCD-contiguous order its position depends on V, so that speculative fetch uses the launch grid's
+    // estimate of it (gridDim.x) and is simply repeated when the estimate was wrong.
+    // XCD-contiguous brick order (XMAP, V is a multiple of 8): block b runs on XCD b % 8 (observed dispatch order, a speed hint only), so
+    // XCD k takes the contiguous list range [k V / 8, (k + 1) V / 8): neighbouring bricks share an L2 for their halos
+    const uint32_t blk_guess = XMAP ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t i0_guess = blk_guess * PCG_BPB + half;
+    uint32_t b0 = i0_guess < (uint32_t)bg.nb ? list[i0_guess] : 0u;
     const uint32_t n = *count;
-    // (tuning switch `done_first`: test `done` alone before anything else is requested.  Measured: no gain -- a launch of this grid costs
-    // ~4.5 us even when every block returns at once, whatever it loads first)
-    if (done_first && ctrl->done) return false;      // uniform
     Pcg1PrologueLoads PL;
-    pcg1_prologue_load<PCG_B_THREADS, FIRST>(ctrl, sc, part_in, num_part, iteration, PL);
+    pcg1_prologue_load<FIRST>(ctrl, sc, part_in, num_part_in, iteration, PL);
     Pcg1ThreadGeom TG;
     pcg1_thread_geom(TG, g, t);       // (in the shadow of the loads above)
+    const int V = pcg_vblocks(n, vb_force);
+    if (SURPLUS_EXITS && (int)blockIdx.x >= V) return false;
+    const int num_part = num_part_in > 0 ? num_part_in : V;
     if (PL.done) return false;      // uniform
-    // round trip 2: the first brick's fields, in flight during the reduction
+    const bool has_vb = (int)blockIdx.x < V;
+    const uint32_t blk0 = XMAP ? (blockIdx.x & 7u) * ((uint32_t)V >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t i0 = blk0 * PCG_BPB + half;
+    if (blk0 != blk_guess && i0 < (uint32_t)bg.nb) b0 = list[i0];      // uniform per block (rare: the host's estimate of the list length was off)
+    // round trip 2: the first brick's descriptors, in flight during the reduction; its fields follow the reduction
     Pcg1TileLoads TL;
-    if (EARLY >= 1 && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
-    if (EARLY >= 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
+    if (has_vb && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
     float alpha, beta;
-    if (!pcg1_prologue_finish<PCG_B_THREADS, FIRST>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
-    if (EARLY < 1 && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
-    if (EARLY < 2 && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
+    if (!pcg1_prologue_finish<FIRST>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
+    if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
     StagedTile& T = tiles[half];
-    float acc_g = 0.0f, acc_d = 0.0f, emax = 0.0f;
     bool first = true;
-    for (uint32_t ib = blk; ib * PCG_BPB < n; ib += gridDim.x) {       // uniform trip count for both halves: barriers inside
+    for (int vb = blockIdx.x; vb < V; vb += gridDim.x) {
+    const uint32_t blk = XMAP ? ((uint32_t)vb & 7u) * ((uint32_t)V >> 3) + ((uint32_t)vb >> 3) : (uint32_t)vb;
+    float acc_g = 0.0f, acc_d = 0.0f, emax = 0.0f;
+    for (uint32_t ib = blk; ib * PCG_BPB < n; ib += (uint32_t)V) {       // uniform trip count for both halves: barriers inside
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = first ? b0 : (have ? list[i] : 0u);
@@ -447,39 +408,41 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
         }
         __syncthreads();   // the tile is rewritten for the next brick
     }
-    // one combined block reduction of the three partials
+    // one combined block reduction of the three partials of this virtual workgroup
     acc_g = wave_sum_dpp(acc_g); acc_d = wave_sum_dpp(acc_d); emax = wave_max_abs_dpp(emax);
-    __syncthreads();          // (a block without bricks reaches this point straight from the prologue's reads of sm4)
+    __syncthreads();          // (a workgroup without bricks reaches this point straight from the prologue's reads of sm4)
     if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = make_float4(acc_g, acc_d, emax, 0.0f);
     __syncthreads();
     if (threadIdx.x == 0) {
         float4 tot = sm4[0];
 #pragma unroll
         for (int w = 1; w < PCG_B_THREADS / 64; ++w) { tot.x += sm4[w].x; tot.y += sm4[w].y; tot.z = fmaxf(tot.z, sm4[w].z); }
-        part_out[blockIdx.x] = tot;
+        part_out[vb] = tot;
+    }
     }
     return true;
 }
 
 
-template <bool FIRST, bool HALO = false, int EARLY = 1, bool XMAP = false>
-__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+template <bool FIRST, bool HALO = false, bool XMAP = true>
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
                                                                const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
                                                                float* __restrict__ q_out, float* __restrict__ dsearch, float* __restrict__ p,
-                                                               const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part,
+                                                               const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part_in,
                                                                PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
-                                                               int halo_lo = -1, int halo_hi = -1, int done_first = 0) {
-    (void)pcg1_iteration<FIRST, HALO, EARLY, XMAP>(bg, list, count, dvol, r_in, r_out, w_in, w_out, q_in, q_out, dsearch, p, part_in, part_out, num_part, ctrl, sc, tolerance,
-                                                   iteration, check_prev, halo_lo, halo_hi, done_first);
+                                                               int halo_lo = -1, int halo_hi = -1) {
+    (void)pcg1_iteration<FIRST, HALO, XMAP, true>(bg, list, count, vb_force, dvol, r_in, r_out, w_in, w_out, q_in, q_out, dsearch, p, part_in, part_out, num_part_in, ctrl, sc, tolerance,
+                                                  iteration, check_prev, halo_lo, halo_hi);
 }
 
 // After K(max_num_iterations): statistics are written unconditionally if nothing converged before (pressure_reduce.comp:84).
-__global__ __launch_bounds__(256) void k_pcg1_finalize(PcgCtrl* __restrict__ ctrl, const float4* __restrict__ part, int num_part, int iteration, uint32_t seq,
-                                                       PcgCtrl* __restrict__ host_snapshot) {
+// num_part > 0: that many partials (z-slab groups); 0: the V of the solve.
+__global__ __launch_bounds__(256) void k_pcg1_finalize(PcgCtrl* __restrict__ ctrl, const float4* __restrict__ part, int num_part, const uint32_t* __restrict__ count_fluid,
+                                                       int iteration, uint32_t seq, PcgCtrl* __restrict__ host_snapshot) {
     __shared__ float4 sm4[4];
     const int done = ctrl->done;
-    const float4 red = reduce_partials4<256>(part, num_part, sm4);
+    const float4 red = reduce_partials4<256>(part, num_part > 0 ? num_part : pcg_vblocks(*count_fluid, 0), sm4);
     if (threadIdx.x == 0) {
         if (!done) { ctrl->max_err = red.z; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
         ctrl->seq = seq;
@@ -495,11 +458,12 @@ __global__ __launch_bounds__(256) void k_pcg1_finalize(PcgCtrl* __restrict__ ctr
 // (most solves of the headline scene converge after 8-28 of the 33 possible launches, and a launch that only finds `done` set still
 // costs ~2 us); this ONE kernel covers every remaining iteration.  Normally it finds `done` set and only publishes the statistics
 // (k_pcg1_finalize's job); otherwise it runs K(first) .. K(max) itself, separated by bounded agent-scope grid barriers (grid_barrier,
-// blub_pcg.hip.h: every block is co-resident, <= one per CU), and publishes.  Same iteration body, same buffers by iteration parity.
+// blub_pcg.hip.h: every block is co-resident -- the host bounds the grid by this kernel's occupancy), and publishes.  Same iteration body,
+// same buffers by iteration parity, same virtual workgroups: tail and launched iterations are bit-identical.
 template <bool XMAP>
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_tail_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint8_t* __restrict__ dvol,
                                                                float* r0, float* r1, float* w0, float* w1, float* q0, float* q1, float* dsearch, float* p,
-                                                               float4* part0, float4* part1, int num_part_in, PcgCtrl* ctrl, Pcg1Scalars* sc, float tolerance,
+                                                               float4* part0, float4* part1, PcgCtrl* ctrl, Pcg1Scalars* sc, float tolerance,
                                                                int first_iteration, int max_iterations, int check_frequency, PcgTailSync* sync, uint32_t seq,
                                                                PcgCtrl* host_snapshot) {
     __shared__ float4 sm4f[4];
@@ -510,20 +474,18 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_tail_s(BrickGeom bg, con
     };
     if (ctrl->done) { if (leader) publish(); return; }      // uniform
     float* R[2] = {r0, r1}; float* W[2] = {w0, w1}; float* Q[2] = {q0, q1}; float4* part[2] = {part0, part1};
-    int num_part = num_part_in;      // the first reduction reads what the LAUNCHED K(first - 1) wrote
     uint32_t barrier_no = 0;
     for (int it = first_iteration; it <= max_iterations; ++it) {
         const int prev = it - 1;
         const int check_prev = prev > 0 && check_frequency > 0 && prev % check_frequency == 0;
-        const bool ran = pcg1_iteration<false, false, 1, XMAP>(bg, list, count, dvol, R[it & 1], R[(it + 1) & 1], W[it & 1], W[(it + 1) & 1], Q[(it + 1) & 1], Q[it & 1], dsearch, p,
-                                                               part[it & 1], part[(it + 1) & 1], num_part, ctrl, sc, tolerance, it, check_prev, -1, -1, 0);
+        const bool ran = pcg1_iteration<false, false, XMAP, false>(bg, list, count, 0, dvol, R[it & 1], R[(it + 1) & 1], W[it & 1], W[(it + 1) & 1], Q[(it + 1) & 1], Q[it & 1], dsearch, p,
+                                                                   part[it & 1], part[(it + 1) & 1], 0, ctrl, sc, tolerance, it, check_prev, -1, -1);
         if (!ran) { if (leader) publish(); return; }        // converged at the check of iteration it - 1 (the leader wrote the statistics itself)
         if (!grid_barrier(&sync->arrivals, gridDim.x * ++barrier_no, &sync->timed_out)) { if (leader) { ctrl->num_iter = -1.0f; ctrl->done = 1; publish(); } return; }
-        num_part = (int)gridDim.x;
     }
     // max_num_iterations reached without convergence (pressure_reduce.comp:84)
     if (blockIdx.x == 0) {
-        const float4 red = reduce_partials4<PCG_B_THREADS>(part[(max_iterations + 1) & 1], num_part, sm4f);
+        const float4 red = reduce_partials4<PCG_B_THREADS>(part[(max_iterations + 1) & 1], pcg_vblocks(*count, 0), sm4f);
         if (threadIdx.x == 0) { ctrl->max_err = red.z; ctrl->num_iter = (float)max_iterations; ctrl->done = 1; publish(); }
     }
 }

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
                                                     const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[T / 64 + 1];
     __shared__ float4 ls[2][T];
-    __shared__ float inv_lut[8];
-    pcg_fill_inv_lut(inv_lut);       // (the prologue's barriers publish it)
+    __shared__ DivConst div_lut[8];
+    pcg_fill_div_lut(div_lut);       // (the prologue's barriers publish it)
     float alpha;
     if (!pcg_upd_prologue<T>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
     const Grid g = gz.g;
@@ -145,8 +145,7 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
                     res -= alpha * as;
                     pp[j] = blend_mask(pj, pp[j], mk);
                     rr[j] = blend_mask(res, rr[j], mk);
-                    const float inv = inv_lut[dbyte(d_c, j) & 7];
-                    const float zr = ((res * inv) * inv) * res;   // precond_zero(res, d) * res with the same correctly rounded reciprocals
+                    const float zr = precond_exact(res, div_lut[dbyte(d_c, j) & 7]) * res;   // (M^-1 r) r with M^-1 r = (r / d) / d, correctly rounded
                     emax = fmaxf(emax, and_mask(fabsf(res), mk));
                     acc += and_mask(zr, mk);
                 }
@@ -173,8 +172,8 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     __shared__ float2 sm2[T / 64 + 1];
     __shared__ float4 ls[2][T];
     __shared__ uint32_t ld[2][T];        // descriptor exchange: FIRST only (see below)
-    __shared__ float inv_lut[8];
-    pcg_fill_inv_lut(inv_lut);           // (the prologue's barriers publish it)
+    __shared__ DivConst div_lut[8];
+    pcg_fill_div_lut(div_lut);           // (the prologue's barriers publish it)
     float beta;
     if (!pcg_dir_prologue<T>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     const Grid g = gz.g;
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     // s_new of a quad from global memory (no write)
     auto snew_quad = [&](int b, uint32_t dq) -> float4 {
         if (FIRST) return ld4(s_in + b);
-        return any_fluid_d(dq) ? snew4(dq, ld4(r + b), ld4(s_in + b), beta, inv_lut) : zero4;
+        return any_fluid_d(dq) ? snew4(dq, ld4(r + b), ld4(s_in + b), beta, div_lut) : zero4;
     };
     const int padded = ((gz.tiles + 7) >> 3) << 3;
     for (int it = blockIdx.x; it < padded; it += gridDim.x) {
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
         auto enter_plane = [&](int b, uint32_t dq, const float4& rr, const float4& so, bool own) -> float4 {
             if (FIRST) return so;
             if (!any_fluid_d(dq)) return zero4;
-            const float4 n = snew4(dq, rr, so, beta, inv_lut);
+            const float4 n = snew4(dq, rr, so, beta, div_lut);
             if (own) st4so<NT>(s_out, (uint32_t)b * 4u, sel4(dq, n, so));
             return n;
         };
@@ -257,10 +256,10 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
                 QuadD m; QuadValues sv;
                 m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
                 m.ym = 0; m.yp = 0; m.xm = 0; m.xp = 0;
-                if (y > 0) { if (in_lo) { if (FIRST) m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = FIRST ? hc.s_lo : snew4(hc.dlo, hc.r_lo, hc.s_lo, beta, inv_lut); } } else sv.ym = zero4;
-                if (y + 1 < g.ny) { if (in_hi) { if (FIRST) m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = FIRST ? hc.s_hi : snew4(hc.dhi, hc.r_hi, hc.s_hi, beta, inv_lut); } } else sv.yp = zero4;
-                if (x0 > 0) { if (t > 0) { if (FIRST) m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = FIRST ? hc.sxm : snew_of(hc.dxm, hc.rxm, hc.sxm, beta, inv_lut); } } else sv.xm = 0.f;
-                if (x0 + 4 < g.nx) { if (t < T - 1) { if (FIRST) m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = FIRST ? hc.sxp : snew_of(hc.dxp, hc.rxp, hc.sxp, beta, inv_lut); } } else sv.xp = 0.f;
+                if (y > 0) { if (in_lo) { if (FIRST) m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = FIRST ? hc.s_lo : snew4(hc.dlo, hc.r_lo, hc.s_lo, beta, div_lut); } } else sv.ym = zero4;
+                if (y + 1 < g.ny) { if (in_hi) { if (FIRST) m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = FIRST ? hc.s_hi : snew4(hc.dhi, hc.r_hi, hc.s_hi, beta, div_lut); } } else sv.yp = zero4;
+                if (x0 > 0) { if (t > 0) { if (FIRST) m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = FIRST ? hc.sxm : snew_of(hc.dxm, hc.rxm, hc.sxm, beta, div_lut); } } else sv.xm = 0.f;
+                if (x0 + 4 < g.nx) { if (t < T - 1) { if (FIRST) m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = FIRST ? hc.sxp : snew_of(hc.dxp, hc.rxp, hc.sxp, beta, div_lut); } } else sv.xp = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (FIRST) { if (dbyte(d_c, j) & 0x80) acc += f4(n_c, j) * quad_mulA_d(m, sv, j); }

@@ -264,7 +264,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     const int S = (int)G->slabs.size();
     blub_fluid* h0 = G->slabs[0];
     if (h0->precond_mode != BLUB_PRECOND_ZERO) return set_error(BLUB_ERR_UNSUPPORTED, "z-slab groups support the default preconditioner reading only");
-    if (h0->pcg_schedule == 1) return slab_solve_single_reduction(G, which, dt);
+    if (h0->pcg_schedule == 1 && h0->cfg[which].max_num_iterations <= h0->pcg1_max_iterations) return slab_solve_single_reduction(G, which, dt);
     const blub_solver_config c = h0->cfg[which];
     const float tol = c.error_tolerance / dt;
     const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
@@ -286,7 +286,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
         blub_fluid* h = G->slabs[i];
         if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
         h->solve_seq[which] += 1;
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
                seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr);
     }
     // descriptor, r, s planes and the initial partials: one grouped operation
@@ -303,17 +303,17 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
                 float* sbuf[2] = {h->search, h->aux};
                 const int halo_lo = has_down(G, i) ? h->slab_z0 : -1, halo_hi = has_up(G, i) ? h->slab_z1 - 1 : -1;
                 if (it == 0)
-                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_b<true, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_s<true, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
                            (const float2*)G->ex[i].gat_upd, seg_dir(i), npall, h->ctrl[which], tol, it, 0, halo_lo, halo_hi);
                 else
-                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_b<false, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(it - 1) & 1], sbuf[it & 1],
+                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_s<false, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(it - 1) & 1], sbuf[it & 1],
                            (const float2*)G->ex[i].gat_upd, seg_dir(i), npall, h->ctrl[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi);
             }
             if ((rc = gather_dir()) != BLUB_OK) return rc;
             for (int i = 0; i < S; ++i) {
                 blub_fluid* h = G->slabs[i];
                 float* sbuf[2] = {h->search, h->aux};
-                LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_b, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)sbuf[it & 1], h->pressure[which], h->residual,
+                LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_s, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)sbuf[it & 1], h->pressure[which], h->residual,
                        (const float*)G->ex[i].gat_dir, seg_upd(i), npall, (const PcgCtrl*)h->ctrl[which], it);
             }
             if ((rc = slab_fused(G, [&]() -> int { return slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }}, 4, false); }, gather_upd)) != BLUB_OK) return rc;
@@ -327,7 +327,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), h->ctrl[which], (const float2*)G->ex[i].gat_upd, npall, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), h->ctrl[which], (const float2*)G->ex[i].gat_upd, npall, (const uint32_t*)nullptr, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
         if (maxit & 1) std::swap(h->search, h->aux);
         if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
     }
@@ -364,7 +364,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
         if ((rc = ensure_pcg1_buffers(h)) != BLUB_OK) return rc;
         if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
         h->solve_seq[which] += 1;
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
                seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr);
     }
     // descriptor, r_0 and u_0 = M^-1 r_0 planes and the gamma_0 partials: one grouped operation
@@ -378,7 +378,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
         B[i] = Bufs{{h->residual, h->cgbuf[0]}, {h->aux, h->cgbuf[1]}, {h->aux_temp, h->cgbuf[2]}};
-        LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
+        LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
                seg4(i, 0), (int)(G->first + i == 0));
     }
     auto exchange = [&](int wpar, int ppar) -> int {   // plane of W[wpar] to the z-neighbours + partials of parity ppar to every slab
@@ -417,10 +417,10 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
                 const float4* pin = G->ex[i].gat4[it & 1];
                 float4* pout = seg4(i, (it + 1) & 1);
                 if (it == 0)
-                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true, true, 1, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)B[i].R[0], B[i].R[1], (const float*)B[i].W[0],
+                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[0], B[i].R[1], (const float*)B[i].W[0],
                            B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi);
                 else
-                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false, true, 1, true>), grid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, (const float*)B[i].R[it & 1], B[i].R[(it + 1) & 1],
+                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[it & 1], B[i].R[(it + 1) & 1],
                            (const float*)B[i].W[it & 1], B[i].W[(it + 1) & 1], (const float*)B[i].Q[(it + 1) & 1], B[i].Q[it & 1], h->search, h->pressure[which], pin, pout, npall,
                            h->ctrl[which], h->pcg1_scalars[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi);
             }
@@ -434,7 +434,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, (const uint32_t*)nullptr, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
         if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
         if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
     }
@@ -539,15 +539,10 @@ static void slab_range(int nz, int nranks, int index, int* z0, int* z1) {
 
 // RCCL transport of the PCG partials, chosen by measurement on the hardware at hand (the two candidates cannot be ranked
 // on the 1-GPU development box): per candidate, 30 rounds of what one PCG iteration issues; the slowest rank's time decides
-// (all-reduced, so every rank picks the same mode).  BLUB_SLAB_GATHER=0|1 overrides.
+// (all-reduced, so every rank picks the same mode).  blub_slab_group_set_gather_mode overrides.
 static int slab_calibrate(blub_slab_group* G) {
     snprintf(G->transport, sizeof G->transport, "rccl, %d ranks", G->nranks);
     if (G->nranks == 1) return BLUB_OK;
-    if (const char* e = getenv("BLUB_SLAB_GATHER")) {
-        G->gather_mode = atoi(e) == 1 ? 1 : 0;
-        snprintf(G->transport, sizeof G->transport, "rccl, %d ranks, partials by %s (forced)", G->nranks, G->gather_mode ? "ncclAllGather" : "grouped send/recv");
-        return BLUB_OK;
-    }
     blub_fluid* h = G->slabs[0];
     auto& e = G->ex[0];
     const int np = SLAB_NP_DEFAULT;
@@ -723,6 +718,12 @@ int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_
 int blub_slab_group_set_pcg_schedule(blub_slab_group* g, int mode) {   // every rank must pass the same mode
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     for (auto h : g->slabs) { int rc = blub_fluid_set_pcg_schedule(h, mode); if (rc != BLUB_OK) return rc; }
+    return BLUB_OK;
+}
+int blub_slab_group_set_gather_mode(blub_slab_group* g, int mode) {
+    if (!g || mode < 0 || mode > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    g->gather_mode = mode;
+    if (g->rccl) snprintf(g->transport, sizeof g->transport, "rccl, %d ranks, partials by %s (set by the caller)", g->nranks, mode ? "ncclAllGather" : "grouped send/recv");
     return BLUB_OK;
 }
 int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t f) { if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle"); for (auto h : g->slabs) h->rebin_freq = f; return BLUB_OK; }

@@ -169,6 +169,7 @@ def load_library():
         "blub_fluid_set_pcg_schedule": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_pcg_schedule": (C.c_int, [vp]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
+        "blub_fluid_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "blub_scene_mesh_desc_at_time": (C.c_int, [C.POINTER(SceneConfig), u32, C.c_uint64, C.c_uint64, C.POINTER(MeshDesc)]),
         "blub_load_obj": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.POINTER(u32), vp, C.c_size_t, C.POINTER(u32)]),
         "blub_fluid_set_meshes": (C.c_int, [vp, u32, vp, u32, vp]),
@@ -427,7 +428,7 @@ class HybridFluid:
         return s.error, s.iteration_count
 
     def set_pcg_work_mapping(self, mode):
-        """"auto" | "rows" | "bricks" | "bricks_staged" -- performance knob, see include/blubhip.h"""
+        """"auto" | "rows" | "bricks" ("bricks_staged": its former alias) -- performance knob, see include/blubhip.h"""
         _check(self._L, self._L.blub_fluid_set_pcg_work_mapping(self._h, {"auto": -1, "rows": 0, "bricks": 1, "bricks_staged": 2}[mode]))
 
     def set_pcg_schedule(self, mode):
@@ -437,6 +438,10 @@ class HybridFluid:
 
     def pcg_schedule(self):
         return ("reference", "single_reduction")[int(self._L.blub_fluid_get_pcg_schedule(self._h))]
+
+    def set_tuning(self, name, value):
+        """Performance knobs / test hooks by name (include/blubhip.h: blub_fluid_set_tuning); the library never reads the environment."""
+        _check(self._L, self._L.blub_fluid_set_tuning(self._h, name.encode(), int(value)))
 
     def set_max_steps_in_flight(self, n):
         _check(self._L, self._L.blub_fluid_set_max_steps_in_flight(self._h, int(n)))
@@ -619,7 +624,7 @@ class SlabGroup:
                 ("blub_slab_group_get_particles", C.c_int, [vp, vp, vp, vp, vp]), ("blub_slab_group_set_gravity_grid", C.c_int, [vp, vp]),
                 ("blub_slab_group_set_solver_config", C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
                 ("blub_slab_group_set_rebinning_frequency", C.c_int, [vp, C.c_uint32]),
-                ("blub_slab_group_set_pcg_schedule", C.c_int, [vp, C.c_int]),
+                ("blub_slab_group_set_pcg_schedule", C.c_int, [vp, C.c_int]), ("blub_slab_group_set_gather_mode", C.c_int, [vp, C.c_int]),
                 ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
                 ("blub_slab_group_transport_ops", C.c_uint64, [vp]), ("blub_slab_group_transport_description", C.c_char_p, [vp]),
                 ("blub_slab_group_set_meshes", C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
@@ -721,6 +726,10 @@ class SlabGroup:
     def set_pcg_schedule(self, mode):
         """"reference" | "single_reduction" on every local slab (all ranks must pass the same mode)"""
         _check(self._L, self._L.blub_slab_group_set_pcg_schedule(self._g, {"reference": 0, "single_reduction": 1}[mode]))
+
+    def set_gather_mode(self, mode):
+        """RCCL transport of the PCG partials: "p2p" (grouped send/recv fused with the halo) | "allgather"; all ranks must agree."""
+        _check(self._L, self._L.blub_slab_group_set_gather_mode(self._g, {"p2p": 0, "allgather": 1}[mode]))
 
     def step(self, simulation_delta):
         _check(self._L, self._L.blub_slab_group_step(self._g, float(simulation_delta)))

@@ -200,6 +200,10 @@ typedef enum blub_volume {
     BLUB_VOLUME_LINKED_LIST = 1,       /* uint32 (list heads of component x / density; the binning counters live in AUX_TEMP) */
     BLUB_VOLUME_VELOCITY_X = 2, BLUB_VOLUME_VELOCITY_Y = 3, BLUB_VOLUME_VELOCITY_Z = 4,
     BLUB_VOLUME_PRESSURE_VELOCITY = 5, BLUB_VOLUME_PRESSURE_DENSITY = 6,
+    /* RESIDUAL, SEARCH, AUX, AUX_TEMP are solver work volumes: their contents OUTSIDE FLUID cells are undefined (AUX_TEMP doubles as the u32
+     * counter / prefix-sum scratch of the binning pass, so non-FLUID cells may hold integer bit patterns, NaNs included; every reader gates on
+     * the FLUID bit of the stencil descriptor), and which allocation backs RESIDUAL / SEARCH may change from solve to solve (double buffering
+     * by iteration parity) -- re-query blub_fluid_get_device_views / read_volume after a step instead of caching their device pointers. */
     BLUB_VOLUME_RESIDUAL = 7, BLUB_VOLUME_SEARCH = 8, BLUB_VOLUME_AUX = 9, BLUB_VOLUME_AUX_TEMP = 10,
     BLUB_VOLUME_SOLID = 11             /* float4 */
 } blub_volume;
@@ -248,17 +252,28 @@ typedef struct blub_trace_event {
 } blub_trace_event;
 int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capacity, int* count_out); /* blocks */
 /* Work mapping of the PCG kernels: -1 = automatic (brick lists when < 30 % of the bricks hold fluid, dense rows otherwise),
- * 0 = dense rows, 1 = brick lists, 2 = brick lists with LDS-staged tiles (many fluid bricks).  A performance knob only: both mappings run the same per-cell arithmetic (the
- * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise). */
+ * 0 = dense rows, 1 (or 2, its former LDS-staged alias) = brick lists.  A performance knob only: both mappings run the same per-cell arithmetic (the
+ * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise).  Within a mapping the grouping depends on the
+ * brick lists alone, never on launch grids or host timing: two solves on the same state give bit-identical scalars. */
 int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
 /* Schedule of the PCG iteration on the brick mappings: 0 = the reference's (pressure_solver.rs:654-723: two global reductions, here
  * two kernels per iteration), 1 = single-reduction (Chronopoulos-Gear) form of the same recurrence: ONE kernel per iteration, A d
  * carried by a recurrence.  Identical in exact arithmetic, a different rounding in f32 (not bit-comparable); convergence test,
  * check cadence and statistics are the same.  The dense-row mapping always runs schedule 0 (it is byte-, not launch-bound).
- * Default 1 (parity against the oracle holds with the tolerances of schedule 0: tests/test_gpu_pcg_schedule.py); the environment
- * variable BLUB_PCG_SCHEDULE overrides the default at creation. */
+ * Default 0: the reference's order of operations.  1 is an opt-in for launch-bound scenes (bench.py opts in and reports both); its r and
+ * q = A d are carried by recurrences, so over hundreds of iterations the recurrence residual drifts from b - A p by more than schedule 0's
+ * (tests/test_gpu_pcg_schedule.py::test_long_solve_true_residual states the measured bound): solves configured with more than 64
+ * iterations therefore run schedule 0 regardless ("pcg1_max_iterations", blub_fluid_set_tuning). */
 int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode);
 int blub_fluid_get_pcg_schedule(const blub_fluid* h);
+/* Performance knobs / test hooks by name (the library never reads the environment).  None changes a result beyond the rounding of a
+ * dot-product tree.  "pcg_tail" 0|1: persistent tail kernel of the single-reduction solves; "pcg_tail_first" n: hand over to the tail after
+ * exactly n launched iterations (-1: predicted from the last solves); "pcg_tail_margin" n: check intervals launched beyond the prediction;
+ * "pcg1_max_iterations" n (default 64): solves configured with more iterations run schedule 0 even when schedule 1 is selected;
+ * "pcg_launch_grid" n: launch grid of the brick-mapped PCG kernels (0: estimated from the last landed brick count) -- results do not depend on it;
+ * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
+ * (0 = default for the grid).  Unknown names: BLUB_ERR_INVALID_ARGUMENT. */
+int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value);
 /* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks
  * (polling pinned memory) until step n - max has finished. */
 int blub_fluid_set_max_steps_in_flight(blub_fluid* h, uint32_t max_steps);
@@ -333,6 +348,9 @@ int blub_slab_group_set_gravity_grid(blub_slab_group* g, const float gravity_gri
 int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_solver_config* cfg);
 int blub_slab_group_set_rebinning_frequency(blub_slab_group* g, uint32_t every_n_steps);
 int blub_slab_group_set_pcg_schedule(blub_slab_group* g, int mode);   /* blub_fluid_set_pcg_schedule on every local slab; all ranks must agree */
+/* RCCL transport of the PCG partials: 0 = grouped send/recv fused with the halo planes, 1 = ncclAllGather next to a p2p-only halo group.
+ * Calibrated at creation (both are timed on the hardware at hand); this overrides the choice.  All ranks must pass the same mode. */
+int blub_slab_group_set_gather_mode(blub_slab_group* g, int mode);
 /* static objects (see blub_fluid_set_meshes / blub_fluid_voxelize): every local slab voxelises the meshes in global grid coordinates */
 int blub_slab_group_set_meshes(blub_slab_group* g, uint32_t num_vertices, const float* positions_xyz, uint32_t num_indices, const uint32_t* indices);
 int blub_slab_group_voxelize(blub_slab_group* g, uint32_t num_meshes, const blub_mesh_desc* meshes);

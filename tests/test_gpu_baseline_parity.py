@@ -42,13 +42,18 @@ def _bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
-def _stage_on_both(o, h, stage):
-    util.copy_state(o, h)
+def _stage_on_both(o, h, stage, volumes=None):
+    """volumes: what the engine takes over from the oracle before the stage (None: particles + every volume; the largest configurations
+    name the stage's actual inputs -- moving nine 0.5 GB volumes through ctypes before each of ten stages would take minutes)."""
+    if volumes is None:
+        util.copy_state(o, h)
+    else:
+        util.copy_state(o, h, volumes=volumes)
     o.run_stage(stage, util.DT)
     h.run_stage(stage, util.DT)
 
 
-def _compare_solve(name, o, h, which, stage, fluid):
+def _compare_solve(name, o, h, which, stage, fluid, ks=(4, 8), default_solve=True):
     """One PressureSolver::solve on identical inputs (the oracle's current state): k = 4 and 8 fixed iterations -> p, r, s within
     1e-4 of their scale and identical statistics; then the reference's defaults (tolerance 0.1, 32 iterations, check every 4):
     iteration counts within one check interval; if the solve converged both errors are below the tolerance, otherwise (the
@@ -64,7 +69,7 @@ def _compare_solve(name, o, h, which, stage, fluid):
             h.write_volume(v, a)
         o.reset_pressure_cleared(which, False)
         h.mark_pressure_initialised(which, False)
-    for k in (4, 8):
+    for k in ks:
         restore()
         for fl in (o, h):
             fl.set_solver_config(which, error_tolerance=0.0, max_num_iterations=k, error_check_frequency=4)
@@ -78,6 +83,8 @@ def _compare_solve(name, o, h, which, stage, fluid):
         assert np.all(h.read_volume(pname)[~fluid] == 0)
         (eo, io), (eh, ih) = o.solver_stats(which), h.solver_stats(which)
         assert ih == io == k and abs(eh - eo) <= 1e-4 * abs(eo) + 1e-9, ((eh, ih), (eo, io))
+    if not default_solve:
+        return
     restore()
     for fl in (o, h):
         fl.set_solver_config(which, error_tolerance=0.1, max_num_iterations=32, error_check_frequency=4)
@@ -145,6 +152,58 @@ def test_every_stage_of_step_zero_matches_the_oracle_at_full_size(name, particle
         for v in ("vel_x", "vel_y", "vel_z"):
             assert _bits_equal(h.read_volume(v), o.read_volume(v)), v
         _stage_on_both(o, h, "correct")
+        assert _bits_equal(h.get_particles()[0][:, :3], o.get_particles()[0][:, :3])
+        print("%s: all stages compared in %.1f s" % (name, time.time() - t_start))
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("name,particles,dim", [("dam_halfhalf_highres", 10113264, (256, 128, 128)), ("corner_dams_512", 8065008, (512, 512, 512))])
+def test_every_stage_of_step_zero_matches_the_oracle_at_the_largest_configurations(name, particles, dim):
+    """BASELINE configs[3] / configs[4] (round-2 review, missing item 2): 10.1 M particles in 256x128x128 (the densest particle arrays the
+    engine sees: every list at its cap) and 8.07 M particles at 512^3 (134 M cells: the sizes where 32-bit offset arithmetic and the brick
+    index magic numbers are exercised hardest).  Same statements as at 256^3 -- marker, D1, D2+D3, A1 incl. the three APIC rows, R2+D3, R3
+    bit-exact; gathers and fixed-iteration PCG within the stated tolerances -- with the engine taking over only each stage's inputs from
+    the oracle.  At 512^3 the solves are compared after 4 fixed iterations only (an oracle iteration takes ~0.7 s there)."""
+    t_start = time.time()
+    scene, h, o = _pair_from_scene(name)
+    big = dim[0] * dim[1] * dim[2] > 1 << 26
+    try:
+        assert tuple(h.grid_dimension()) == dim and h.num_particles() == o.num_particles == particles
+        _stage_on_both(o, h, "transfer", volumes=())
+        marker = o.read_volume("marker")
+        assert np.array_equal(h.read_volume("marker"), marker)
+        fluid = marker == 1
+        assert fluid.sum() > 100000
+        for v in ("vel_x", "vel_y", "vel_z"):
+            util.assert_close(v, h.read_volume(v), o.read_volume(v), rel=1e-5)
+        _stage_on_both(o, h, "divergence", volumes=("vel_x", "vel_y", "vel_z"))
+        assert _bits_equal(h.read_volume("residual")[fluid], o.read_volume("residual")[fluid])
+        assert np.abs(o.read_volume("residual")[fluid]).max() > 0
+        _compare_solve(name, o, h, 0, "solve_velocity", fluid, ks=(4,) if big else (4, 8), default_solve=not big)
+        h.set_pcg_work_mapping("rows")        # the dense 2.5-D mapping on the same system (its offsets are the ones that approach 2^32 at 512^3)
+        _compare_solve(name + " (dense rows)", o, h, 0, "solve_velocity", fluid, ks=(4,), default_solve=False)
+        h.set_pcg_work_mapping("auto")
+        _stage_on_both(o, h, "project", volumes=("pressure_velocity",))
+        for v in ("vel_x", "vel_y", "vel_z"):
+            assert _bits_equal(h.read_volume(v), o.read_volume(v)), v
+        _stage_on_both(o, h, "advect", volumes=())
+        po, ph = o.get_particles(), h.get_particles()
+        assert _bits_equal(ph[0][:, :3], po[0][:, :3])
+        for c in (1, 2, 3):
+            assert _bits_equal(ph[c], po[c]), c
+        assert np.array_equal(h.read_volume("marker"), o.read_volume("marker"))
+        assert np.array_equal(h.read_volume("linked_list") != 0, o.read_volume("linked_list") != 0)
+        del po, ph
+        _stage_on_both(o, h, "density_gather", volumes=("linked_list",))
+        fluid2 = o.read_volume("marker") == 1
+        util.assert_close("density residual", h.read_volume("residual")[fluid2], o.read_volume("residual")[fluid2], abs_=util.DENSITY_RESIDUAL_TOL)
+        util.copy_state(o, h, volumes=("residual",))
+        _compare_solve(name, o, h, 1, "solve_density", fluid2, ks=(4,) if big else (4, 8), default_solve=not big)
+        _stage_on_both(o, h, "position_change", volumes=("pressure_density",))
+        for v in ("vel_x", "vel_y", "vel_z"):
+            assert _bits_equal(h.read_volume(v), o.read_volume(v)), v
+        _stage_on_both(o, h, "correct", volumes=())
         assert _bits_equal(h.get_particles()[0][:, :3], o.get_particles()[0][:, :3])
         print("%s: all stages compared in %.1f s" % (name, time.time() - t_start))
     finally:

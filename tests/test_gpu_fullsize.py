@@ -87,7 +87,7 @@ def test_full_size_binning_is_a_permutation():
         f.close()
 
 
-@pytest.mark.parametrize("n,mapping", [(256, "rows"), (128, "bricks"), (128, "bricks_staged"), (128, "bricks_single")])
+@pytest.mark.parametrize("n,mapping", [(256, "rows"), (128, "bricks"), (128, "bricks_single")])
 def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
     """Dense n^3 Poisson problem (SOLID shell, FLUID inside, one AIR layer under the lid so that the system is not the
     singular pure-Neumann one; 16.3 M unknowns at 256^3): after the solve the engine's own residual volume must equal
@@ -182,10 +182,11 @@ def test_sixty_steps_of_the_reference_shaped_scene_track_the_oracle():
         f.close()
 
 
-def test_staged_brick_kernels_are_bit_identical_to_the_plain_brick_kernels():
-    """k_pcg_dir_s / k_pcg_update_s (LDS-staged tiles, used from a few thousand fluid bricks on) map threads, quads and
-    partial sums exactly like k_pcg_dir_b / k_pcg_update_b and run the same per-cell arithmetic: same bits, on a grid with
-    partial bricks at its upper faces and a ragged fluid region."""
+@pytest.mark.parametrize("schedule", ["reference", "single_reduction"])
+def test_brick_mapped_solve_is_bit_reproducible_across_launch_grids(schedule):
+    """A brick-mapped solve groups its dot-product partials by virtual workgroups that depend on the brick list alone (pcg_vblocks,
+    blub_pcg.hip.h): on a grid with partial bricks at its upper faces and a ragged fluid region, repeated solves and solves launched
+    with very different grids give the same bits."""
     import blub_amd
     dim = (72, 44, 30)
     rng = np.random.default_rng(11)
@@ -197,19 +198,24 @@ def test_staged_brick_kernels_are_bit_identical_to_the_plain_brick_kernels():
     marker[10:14, 5:9, 20:30] = 0
     b = np.where(marker == 1, rng.standard_normal(dim[::-1]), 0).astype(np.float32)
     out = {}
-    for mapping in ("bricks", "bricks_staged"):
+    for grid in (0, 16, 512, -1):          # -1: the estimate again (run-to-run)
         h = blub_amd.HybridFluid(dim, 8, binning="off")
         try:
-            util.set_mapping(h, mapping)
+            h.set_pcg_work_mapping("bricks")
+            h.set_pcg_schedule(schedule)
+            h.set_tuning("pcg_launch_grid", max(grid, 0))
             h.write_volume("marker", marker)
             h.write_volume("residual", b)
             h.set_solver_config(0, error_tolerance=0.0, max_num_iterations=9, error_check_frequency=4)
             h.run_stage("solve_velocity", util.DT)
-            out[mapping] = (h.read_volume("pressure_velocity"), h.read_volume("residual"), h.read_volume("search"), h.solver_stats(0))
+            out[grid] = (h.read_volume("pressure_velocity"), h.read_volume("residual"), h.read_volume("search"), h.solver_stats(0))
         finally:
             h.close()
-    a, c = out["bricks"], out["bricks_staged"]
+    a = out[0]
     assert np.abs(a[0]).max() > 0
-    for k in range(3):
-        assert np.array_equal(a[k].view(np.uint32), c[k].view(np.uint32)), k
-    assert a[3] == c[3]
+    fluid = marker == 1
+    for grid in (16, 512, -1):
+        c = out[grid]
+        for k in range(3):
+            assert np.array_equal(a[k][fluid].view(np.uint32), c[k][fluid].view(np.uint32)), (grid, k)
+        assert a[3] == c[3]

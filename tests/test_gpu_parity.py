@@ -63,7 +63,7 @@ def test_elementwise_grid_stage_bit_exact(pair, stage, outputs):
     assert any(np.abs(o.read_volume(v)).max() > 0 for v in outputs)
 
 
-@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged", "bricks_single"])
+@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_single"])
 @pytest.mark.parametrize("iters", [0, 1, 4, 7, 8])
 def test_pcg_fixed_iterations(pair, iters, mapping):
     """Fixed iteration count (tolerance 0): p, r, s after k iterations. Only the dot-product summation order differs;
@@ -89,7 +89,7 @@ def test_pcg_fixed_iterations(pair, iters, mapping):
     assert abs(eh - eo) <= 1e-4 * abs(eo) + 1e-9
 
 
-@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_staged", "bricks_single"])
+@pytest.mark.parametrize("mapping", ["rows", "bricks", "bricks_single"])
 @pytest.mark.parametrize("which,stage", [(0, "solve_velocity"), (1, "solve_density")])
 def test_pcg_default_config(pair, which, stage, mapping):
     """The reference's operating point (32 iterations, check every 4) stops far from convergence (max|r| ~ 12), where
@@ -231,7 +231,7 @@ def test_full_step_loose_solver(pair):
     po, ph = o.get_particles(), h.get_particles()
     d = np.abs(ph[0][:, :3] - po[0][:, :3]).max(axis=1)
     print("deviation quantiles (cells): median %.3g  p99 %.3g  max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
-    assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 5e-3 and d.max() < 0.3       # (max: one particle at the free surface, see test_gpu_pcg_schedule.py)
+    assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 5e-3 and d.max() < 0.15      # (the engine's default is the reference's schedule; the single-reduction opt-in: test_gpu_pcg_schedule.py)
     for w in (0, 1):
         eo, io = o.solver_stats(w)
         eh, ih = h.solver_stats(w)
@@ -566,63 +566,85 @@ def test_empty_fluid_steps_are_harmless():
         h.close()
 
 
-@pytest.mark.parametrize("schedule", ["reference", "single_reduction"])
-@pytest.mark.parametrize("first", [0, 3, 9])
-def test_pcg_persistent_tail_kernel(first, schedule, monkeypatch):
-    """Brick-mapped solves hand the iterations the host did not launch to one persistent kernel (grid barriers between the
-    phases; k_pcg_tail_b for the reference schedule, k_pcg1_tail_s for the single-reduction one).  Forced hand-over after `first`
-    launched iterations: the solve must equal the oracle exactly as the fully launched one does (fixed 14 iterations, and a
-    converging run that stops inside the tail)."""
-    import blub_amd
+@pytest.mark.parametrize("first", [1, 3, 9])
+def test_pcg_persistent_tail_kernel(first):
+    """Single-reduction solves hand the iterations the host did not launch to ONE persistent kernel (k_pcg1_tail_s: the same iteration
+    body, grid barriers in between).  Forced hand-over after `first` launched iterations: same iteration counts as the oracle, and
+    BIT-IDENTICAL to the fully launched solve (tail and launched kernels share the virtual-workgroup grouping of the dot products:
+    fixed 14 iterations, and a converging run that stops inside the tail)."""
     pos, vel, maxp = util.make_dam(*GRID)
-    full = None
-    if schedule == "single_reduction":      # the same solve with every iteration launched (handle created before the hook is set)
-        _, full = util.new_pair(*GRID, maxp)
-        full.set_pcg_work_mapping("bricks_staged")
-        full.set_pcg_schedule(schedule)
-    monkeypatch.setenv("BLUB_PCG_TAIL_FIRST", str(first))
+    _, full = util.new_pair(*GRID, maxp)
     o, h = util.new_pair(*GRID, maxp)
     try:
-        h.set_pcg_work_mapping("bricks" if schedule == "reference" else "bricks_staged")
-        h.set_pcg_schedule(schedule)
+        for f in (full, h):
+            f.set_pcg_work_mapping("bricks")
+            f.set_pcg_schedule("single_reduction")
+        full.set_tuning("pcg_tail", 0)
+        h.set_tuning("pcg_tail_first", first)
         o.set_particles(pos, *vel)
         run_until(o, "solve_velocity")
         util.copy_state(o, h)
-        if full is not None:
-            util.copy_state(o, full)
+        util.copy_state(o, full)
         state = {v: o.read_volume(v) for v in ("residual", "pressure_velocity", "search")}
         fluid = o.read_volume("marker") == 1
         for cfg in (dict(error_tolerance=0.0, max_num_iterations=14, error_check_frequency=4),
                     dict(error_tolerance=0.26, max_num_iterations=64, error_check_frequency=4)):
-            for f in (o, h) + ((full,) if full is not None else ()):
+            for f in (o, h, full):
                 f.set_solver_config(0, **cfg)
                 for v, a in state.items():
                     f.write_volume(v, a)
             o.reset_pressure_cleared(0, False)
             h.mark_pressure_initialised(0, False)
+            full.mark_pressure_initialised(0, False)
             o.run_stage("solve_velocity", util.DT)
             h.run_stage("solve_velocity", util.DT)
+            full.run_stage("solve_velocity", util.DT)
             eo, io = o.solver_stats(0)
             eh, ih = h.solver_stats(0)
+            ef, i_f = full.solver_stats(0)
             assert ih == io and ih >= 0, (cfg, (eh, ih), (eo, io))
-            # the single-reduction schedule rounds differently from the oracle (14 unconverged iterations: ~1e-3 of the scale, see
-            # tests/test_gpu_pcg_schedule.py); what the tail must reproduce tightly is the fully launched solve of the same schedule
-            assert abs(eh - eo) <= (2e-3 if full is None else 2e-2) * eo
-            for name in ("pressure_velocity", "residual"):
-                a, b = h.read_volume(name), o.read_volume(name)
-                util.assert_close(name, a[fluid], b[fluid], abs_=(3e-4 if full is None else 3e-3) * np.abs(b[fluid]).max())
-            if full is not None:
-                full.mark_pressure_initialised(0, False)
-                full.run_stage("solve_velocity", util.DT)
-                ef, i_f = full.solver_stats(0)
-                assert i_f == ih and abs(ef - eh) <= 1e-4 * eh, ((ef, i_f), (eh, ih))
-                for name in ("pressure_velocity", "residual", "search"):
-                    a, b = h.read_volume(name), full.read_volume(name)
-                    util.assert_close(name + " (tail vs launched)", a[fluid], b[fluid], abs_=2e-5 * np.abs(b[fluid]).max())
+            assert abs(eh - eo) <= 2e-2 * eo          # a different rounding of the recurrence than the oracle's (tests/test_gpu_pcg_schedule.py)
+            assert (ef, i_f) == (eh, ih), ((ef, i_f), (eh, ih))
+            for name in ("pressure_velocity", "residual", "search"):
+                a, b = h.read_volume(name), full.read_volume(name)
+                assert np.array_equal(a[fluid], b[fluid]), name + ": tail and launched solve differ"
     finally:
         h.close()
-        if full is not None:
-            full.close()
+        full.close()
+
+
+@pytest.mark.parametrize("schedule", ["reference", "single_reduction"])
+def test_pcg_results_do_not_depend_on_the_launch_grid(schedule):
+    """The launch grid of the brick-mapped PCG kernels is an estimate from a lagged, asynchronous snapshot of the brick counts (round-2
+    review: results moved with the host's timing).  The dot-product partials are grouped by VIRTUAL workgroups -- a function of the
+    device-side brick list alone (pcg_vblocks, blub_pcg.hip.h) --, so the same solve launched with too few, about right and far too many
+    workgroups gives bit-identical fields and statistics."""
+    pos, vel, maxp = util.make_dam(*GRID)
+    o, h = util.new_pair(*GRID, maxp)
+    try:
+        h.set_pcg_work_mapping("bricks")
+        h.set_pcg_schedule(schedule)
+        h.set_tuning("pcg_tail", 0)
+        o.set_particles(pos, *vel)
+        run_until(o, "solve_velocity")
+        util.copy_state(o, h)
+        state = {v: o.read_volume(v) for v in ("residual", "pressure_velocity", "search")}
+        fluid = o.read_volume("marker") == 1
+        h.set_solver_config(0, error_tolerance=0.05, max_num_iterations=40, error_check_frequency=4)
+        results = []
+        for grid in (0, 8, 24, 64, 1024):
+            h.set_tuning("pcg_launch_grid", grid)
+            for v, a in state.items():
+                h.write_volume(v, a)
+            h.mark_pressure_initialised(0, False)
+            h.run_stage("solve_velocity", util.DT)
+            results.append((h.solver_stats(0), h.read_volume("pressure_velocity")[fluid].copy(), h.read_volume("residual")[fluid].copy()))
+        for stats, p, r in results[1:]:
+            assert stats == results[0][0], (stats, results[0][0])
+            assert np.array_equal(p, results[0][1]) and np.array_equal(r, results[0][2])
+        assert 0 < results[0][0][1] <= 40
+    finally:
+        h.close()
 
 
 def test_extrapolation_with_every_neighbour_count():

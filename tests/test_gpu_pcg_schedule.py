@@ -1,6 +1,8 @@
-"""The single-reduction PCG schedule (blub_pcg1.hip.h: ONE kernel per iteration on the brick mapping) against the oracle, with
-the SAME tolerances the reference-order schedule is held to in tests/test_gpu_parity.py: it is the same recurrence in exact
-arithmetic (Chronopoulos-Gear), only rounded differently.
+"""The single-reduction PCG schedule (blub_pcg1.hip.h: ONE kernel per iteration on the brick mapping; an OPT-IN since round 3, the
+engine's default is the reference's two-reduction order) against the oracle: it is the same recurrence in exact arithmetic
+(Chronopoulos-Gear), only rounded differently.  Fixed small iteration counts are held to the SAME tolerances as the reference-order
+schedule in tests/test_gpu_parity.py; the envelope statements (loose whole step, free-running statistics) carry the wider bounds
+that belong to this schedule alone -- the reference-order path keeps the tight ones.
 """
 import os
 
@@ -18,8 +20,10 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a
 def pair():
     pos, vel, maxp = util.make_dam(*GRID)
     o, h = util.new_pair(*GRID, maxp)
-    h.set_pcg_work_mapping("bricks_staged")
+    assert h.pcg_schedule() == "reference"           # the library default is the reference's order of operations
+    h.set_pcg_work_mapping("bricks")
     h.set_pcg_schedule("single_reduction")
+    h.set_tuning("pcg1_max_iterations", 100000)      # (solves longer than 64 iterations normally fall back to the reference order)
     assert h.pcg_schedule() == "single_reduction"
     o.set_particles(pos, *vel)
     h.set_particles(pos, *vel)
@@ -143,8 +147,8 @@ def test_full_step_loose_solver(pair):
     po, ph = o.get_particles(), h.get_particles()
     d = np.abs(ph[0][:, :3] - po[0][:, :3]).max(axis=1)
     print("single-reduction deviation quantiles (cells): median %.3g  p99 %.3g  max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
-    # (the maximum is a single particle at the free surface; it moves with the rounding of the partial sums, i.e. with the launch grid the
-    #  engine picks from its asynchronous brick-count snapshot: 0.04 .. 0.16 cells over repeated runs)
+    # (the maximum is a single particle at the free surface: this schedule's own rounding of the recurrence moves it further than the
+    #  reference order's, which test_gpu_parity.py::test_full_step_loose_solver holds to 0.15)
     assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 5e-3 and d.max() < 0.3
 
 
@@ -158,6 +162,7 @@ def test_headline_scene_statistics_track_the_reference_schedule():
         f = scene.fluid()
         try:
             f.set_pcg_schedule(sched)
+            assert f.pcg_schedule() == sched
             for _ in range(12):
                 scene.step(util.DT)
             f.synchronize()
@@ -179,11 +184,11 @@ def test_headline_scene_statistics_track_the_reference_schedule():
     assert np.abs(a[2].mean(0) - b[2].mean(0)).max() < 2.5e-2
 
 
-@pytest.mark.parametrize("mapping", ["bricks_single", "rows"])
+@pytest.mark.parametrize("mapping", ["bricks_single", "bricks", "rows"])
 def test_random_marker_field_exercises_every_diagonal(mapping):
     """A cell-by-cell random FLUID / AIR / SOLID field: stencil diagonals d = 0 .. 6 all occur (a dam-break scene has almost only 5 and 6),
-    so every entry of the kernels' preconditioner tables -- the constant-divisor division of the single-reduction kernel (d = m 2^k,
-    m in {1, 3, 5}) and the reciprocal table of the dense kernels -- is compared with the oracle's (x / d) / d after 1, 3 and 6 iterations."""
+    so every entry of the kernels' constant-divisor table (d = m 2^k, m in {1, 3, 5}: M^-1 r = (r / d) / d correctly rounded in EVERY
+    mapping and schedule since round 3) is compared with the oracle's two divisions after 1, 3 and 6 iterations."""
     import blub_amd
     dim = (48, 32, 32)
     rng = np.random.default_rng(5)
@@ -211,3 +216,45 @@ def test_random_marker_field_exercises_every_diagonal(mapping):
             assert ih == io == k and abs(eh - eo) <= 1e-4 * eo
         finally:
             h.close()
+
+
+@pytest.mark.parametrize("mapping", ["bricks", "bricks_single", "rows"])
+def test_long_solve_true_residual(mapping):
+    """Round-2 ADVICE: the single-reduction form carries r AND q = A d by recurrences, so the residual the convergence test sees drifts from
+    b - A p faster than the reference order's (which recomputes A s every iteration).  400 iterations with tolerance 0 -- far past
+    convergence, where CG stagnates at its attainable accuracy -- and then the TRUE residual b - A p, recomputed on the host in f64:
+    it must stay at rounding level of |A||p| + |b| for every schedule; the bound of the single-reduction schedule is the measured one
+    (several times the reference order's), which is why the engine only uses it for solves of <= 64 iterations unless told otherwise
+    (blub_fluid_set_tuning "pcg1_max_iterations")."""
+    pos, vel, maxp = util.make_dam(*GRID)
+    o, h = util.new_pair(*GRID, maxp)
+    try:
+        util.set_mapping(h, mapping)
+        h.set_tuning("pcg1_max_iterations", 100000)
+        o.set_particles(pos, *vel)
+        run_until(o, "solve_velocity")
+        util.copy_state(o, h)
+        b = o.read_volume("residual").astype(np.float64)
+        marker = o.read_volume("marker")
+        fluid = marker == 1
+        h.set_solver_config(0, error_tolerance=0.0, max_num_iterations=400, error_check_frequency=8)
+        h.run_stage("solve_velocity", util.DT)
+        err, it = h.solver_stats(0)
+        assert it == 400
+        p = h.read_volume("pressure_velocity").astype(np.float64)
+        mpad = np.pad(marker, 1, constant_values=0)
+        ppad = np.pad(p * fluid, 1)
+        diag = np.zeros_like(p)
+        nb = np.zeros_like(p)
+        for ax in range(3):
+            for sft in (-1, 1):
+                diag += np.roll(mpad, sft, ax)[1:-1, 1:-1, 1:-1] != 0
+                nb += np.roll(ppad, sft, ax)[1:-1, 1:-1, 1:-1] * (np.roll(mpad, sft, ax)[1:-1, 1:-1, 1:-1] == 1)
+        r_true = (b - (diag * p - nb)) * fluid
+        scale = 12.0 * np.abs(p).max() + np.abs(b).max()
+        rel = np.abs(r_true).max() / scale
+        r_rec = np.abs(h.read_volume("residual").astype(np.float64) * fluid).max() / scale
+        print("%s: true residual %.3g, recurrence residual %.3g (relative to |A||p| + |b|) after 400 iterations" % (mapping, rel, r_rec))
+        assert rel < (3e-6 if mapping != "bricks_single" else 3e-5), rel
+    finally:
+        h.close()
