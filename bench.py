@@ -20,7 +20,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = os.path.join("profiles", "r02_pmc_dense_pcg_256.json")   # FETCH_SIZE / WRITE_SIZE capture of the dense PCG benchmark
+PMC_FILES = {256: os.path.join("profiles", "r03_pmc_dense_pcg_256.json"),   # FETCH_SIZE / WRITE_SIZE captures of the dense PCG benchmark (tools/dense_pmc.sh),
+             512: os.path.join("profiles", "r03_pmc_dense_pcg_512.json")}   # stamped with the hash of the sources they were taken from
 
 
 def algorithmic_bytes(kernel, F, P, A, Fb):
@@ -46,10 +47,13 @@ def algorithmic_bytes(kernel, F, P, A, Fb):
     return float(table.get(kernel, 0))
 
 
-def dense_pcg_benchmark(n=256, iterations=32):
-    """M3 of BASELINE.md: SOLID shell + all-FLUID interior, b = sin*sin*sin, fixed iteration count, per-kernel HIP-event timing."""
+def dense_pcg_benchmark(n=256, iterations=32, tuning=None):
+    """M3 of BASELINE.md: SOLID shell + all-FLUID interior, b = sin*sin*sin, fixed iteration count, per-kernel HIP-event timing.
+    tuning: {knob: value} for blub_fluid_set_tuning (tile-geometry sweeps, tools/dense_sweep.sh)."""
     import blub_amd
     h = blub_amd.HybridFluid((n, n, n), 16, binning="off")
+    for k_, v_ in (tuning or {}).items():
+        h.set_tuning(k_, v_)
     marker = np.zeros((n, n, n), np.int8)
     marker[1:-1, 1:-1, 1:-1] = 1
     ax = np.sin(2 * np.pi * (np.arange(n) + 0.5) / n).astype(np.float32)
@@ -76,19 +80,25 @@ def dense_pcg_benchmark(n=256, iterations=32):
     iter_us = sum(out[k]["avg_us"] for k in out)
     err, iters = h.solver_stats(0)
     h.close()
-    pmc = {}
+    pmc, pmc_file = {}, PMC_FILES.get(n)
     try:   # HBM bytes per launch from the committed PMC capture of this same benchmark (rocprofv3 cannot run inside bench.py)
-        pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
-    except (OSError, ValueError):
+        pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+    except (OSError, ValueError, TypeError):
         pass
+    from blub_amd.build import source_hash
+    stamp, now = pmc.get("kernel_source_sha16"), source_hash()
     for k in out:
-        out[k]["traffic_bytes_pmc"] = pmc.get(k, {}).get("traffic") if n == 256 else None
-        out[k]["traffic_source"] = ("committed rocprofv3 --pmc capture of this benchmark: %s (counters cannot be read from inside bench.py)" % PMC_FILE) if out[k]["traffic_bytes_pmc"] else None
+        out[k]["traffic_bytes_pmc"] = pmc.get(k, {}).get("traffic")
+        out[k]["traffic_source"] = ("committed rocprofv3 --pmc capture of this benchmark: %s (counters cannot be read from inside bench.py)" % pmc_file) if out[k]["traffic_bytes_pmc"] else None
+        # the capture is a file: say whether it was taken from the sources this run was built from
+        out[k]["traffic_capture_matches_sources"] = (stamp == now) if out[k]["traffic_bytes_pmc"] else None
+        if out[k]["traffic_bytes_pmc"] and stamp != now:
+            out[k]["traffic_warning"] = "PMC capture stamped %s, sources are %s: traffic is from an older code state" % (stamp, now)
         out[k]["algorithmic_bytes"] = algorithmic_bytes(k, F, 0, N, N)
     # one iteration = pcg_dir + pcg_update.  "iter_bytes" is SURVEY 8(d)'s figure for the UNFUSED three-phase iteration
     # (3N + 36F); the fused pair itself only has to move 2N + 32F ("iter_bytes_fused"), both fractions are reported.
     fused = 2 * N + 32 * F
-    return {"grid": "%d^3" % n, "fluid_cells": F, "iterations": iters, "us_per_iteration_kernels": round(iter_us, 1),
+    return {"grid": "%d^3" % n, "fluid_cells": F, "iterations": iters, "us_per_iteration_kernels": round(iter_us, 1), "kernel_source_sha16": now,
             "iter_bytes": 3 * N + 36 * F, "iter_GBs": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9, 1),
             "iter_frac": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "iter_bytes_fused": fused, "iter_frac_fused": round(fused / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
@@ -197,10 +207,19 @@ METRIC = "simulation steps/sec, 1M particles @ 256^3 grid"
 
 
 def roofline_object(dense, where):
-    ku = dense["kernels"]["pcg_update"]
-    return {"bound": "hbm", "kernel": "k_pcg_update_z (PCG stencil update, dense 256^3 micro-benchmark M3, %s)" % where, "achieved": ku["achieved_GBs"],
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"], "traffic": ku["traffic_bytes_pmc"],
-            "traffic_source": ku.get("traffic_source"), "algorithmic_bytes": ku["algorithmic_bytes"], "avg_us": ku["avg_us"], "launches": ku["launches"]}
+    """The dominant kernel of the dense PCG iteration (the update kernel: N + 20F of the 2N + 32F the fused pair moves), timed live with HIP
+    events on the engine's own stream; the direction kernel rides along as `second_kernel`."""
+    ku, kd = dense["kernels"]["pcg_update"], dense["kernels"]["pcg_dir"]
+    obj = {"bound": "hbm", "kernel": "k_pcg_update_z (PCG stencil update, dense %s micro-benchmark M3, %s)" % (dense["grid"], where), "achieved": ku["achieved_GBs"],
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ku["frac"], "traffic": ku["traffic_bytes_pmc"],
+           "traffic_source": ku.get("traffic_source"), "traffic_capture_matches_sources": ku.get("traffic_capture_matches_sources"),
+           "algorithmic_bytes": ku["algorithmic_bytes"], "avg_us": ku["avg_us"], "launches": ku["launches"],
+           "second_kernel": {"kernel": "k_pcg_dir_z", "achieved": kd["achieved_GBs"], "frac": kd["frac"], "avg_us": kd["avg_us"], "algorithmic_bytes": kd["algorithmic_bytes"],
+                             "traffic": kd["traffic_bytes_pmc"]},
+           "iteration_frac_fused_pair": dense["iter_frac_fused"]}
+    if ku.get("traffic_warning"):
+        obj["traffic_warning"] = ku["traffic_warning"]
+    return obj
 
 
 def multi_gpu(args, torch, dist, rank, world, dev, ctl):
@@ -238,6 +257,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev)
         if group is not None:
             group.set_gravity_grid(gravity)
+            group.set_pcg_schedule(args.pcg_schedule)   # (opt-in like the single-GPU headline run; every rank passes the same flag)
             group.set_particles(pos)
         del pos
     except Exception as e:   # all ranks must take the same path
@@ -297,7 +317,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling if transport != "loopback" else args.scaling + "-emulated-on-one-gpu", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "grid": list(dim), "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
-                       "parallelism": parallelism},
+                       "parallelism": parallelism, "pcg_schedule": args.pcg_schedule},
             "pcg_iters_per_step": round((it1 - it0) / args.steps, 2), "transport_ops_per_step": round(ops_per_step, 1),
             "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}
     dist.barrier()
@@ -321,10 +341,15 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: split ONE domain (default) or stack N copies along z")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-pcg", action="store_true")
+    ap.add_argument("--no-dense-512", action="store_true", help="skip the 512^3 repetition of the dense PCG micro-benchmark (roofline_512)")
+    ap.add_argument("--pcg-schedule", default="single_reduction", choices=["single_reduction", "reference"], help="schedule of the headline window (the other one is timed beside it)")
     ap.add_argument("--no-fast-forward", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--dense-only", action="store_true", help="only run the dense PCG micro-benchmark (tuning)")
     ap.add_argument("--dense-size", type=int, default=256)
+    ap.add_argument("--dense-tile-quads", type=int, default=0, help="--dense-only: tile width of the dense PCG kernels (256 | 512 | 1024 quads; tuning)")
+    ap.add_argument("--dense-tile-planes", type=int, default=0, help="--dense-only: planes marched per tile (tuning)")
+    ap.add_argument("--dense-grid", type=int, default=0, help="--dense-only: launch grid of the dense PCG kernels (tuning)")
     ap.add_argument("--pcg-mapping", default="auto", choices=["auto", "rows", "bricks", "bricks_staged"], help="work mapping of the PCG kernels (tuning)")
     ap.add_argument("--transfer-only", action="store_true", help="only run the 256^3 transfer micro-benchmark M4 (65 M particles)")
     args = ap.parse_args()
@@ -333,7 +358,10 @@ def main():
     import blub_amd
 
     if args.dense_only:
-        print(json.dumps(dense_pcg_benchmark(args.dense_size, 32)))
+        tuning = {k_: v_ for k_, v_ in (("dense_tile_quads", args.dense_tile_quads), ("dense_tile_planes", args.dense_tile_planes), ("dense_grid", args.dense_grid)) if v_}
+        res = dense_pcg_benchmark(args.dense_size, 32, tuning)
+        res["tuning"] = tuning
+        print(json.dumps(res))
         return
     if args.transfer_only:
         print(json.dumps(transfer_microbenchmark(256)))
@@ -365,9 +393,18 @@ def main():
 
     scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
     dt = blub_amd.default_simulation_delta()
-    scene = blub_amd.Scene(path=scene_path, device=dev)
-    fluid = scene.fluid()
-    fluid.set_pcg_work_mapping(args.pcg_mapping)
+
+    def new_scene(schedule):
+        sc_ = blub_amd.Scene(path=scene_path, device=dev)
+        fl_ = sc_.fluid()
+        fl_.set_pcg_work_mapping(args.pcg_mapping)
+        fl_.set_pcg_schedule(schedule)
+        return sc_, fl_
+
+    # The library's default PCG schedule is the reference's (two global reductions per iteration, pressure_solver.rs:654-723).  The headline
+    # run OPTS IN to the single-reduction form of the same recurrence (one kernel per iteration; include/blubhip.h: blub_fluid_set_pcg_schedule)
+    # and the same window is timed again with the reference's order: both numbers are printed.
+    scene, fluid = new_scene(args.pcg_schedule)
     step, sync = (lambda: scene.step(dt)), fluid.synchronize
     nx, ny, nz = fluid.grid_dimension()
     N = nx * ny * nz
@@ -412,14 +449,36 @@ def main():
         dist.destroy_process_group()
         return
 
+    def timed_window(schedule, rebinning=None):
+        """A fresh scene, the same warm-up and the same K steps, timed like the headline window."""
+        sc_, fl_ = new_scene(schedule)
+        if rebinning is not None:
+            fl_.particle_rebinning_step_frequency = rebinning
+        for _ in range(args.warmup):
+            sc_.step(dt)
+        fl_.synchronize()
+        i0 = fl_.total_solver_iterations()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            sc_.step(dt)
+        fl_.synchronize()
+        el = time.perf_counter() - t0_
+        i1 = fl_.total_solver_iterations()
+        fl_.close()
+        return el, i1 - i0
+
+    # ---- the same window with the OTHER schedule (round-2 review: the cost of the literal order of operations must be visible)
+    other = "reference" if args.pcg_schedule == "single_reduction" else "single_reduction"
+    el_o, it_o = timed_window(other)
+    by_schedule = {args.pcg_schedule: {"steps_per_s": round(args.steps / elapsed, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2)},
+                   other: {"steps_per_s": round(args.steps / el_o, 3), "ms_per_step": round(el_o / args.steps * 1e3, 4), "pcg_iters_per_step": round(it_o / args.steps, 2)}}
+
     # ---- fast-forward through the native scheduler (simulation_controller.rs:96-157): the reference's own way of timing steps.
     # Same window as the timed region above (a fresh scene, the same warm-up), no Python in the stepping loop, a wait every 16 steps.
     fast_forward = None
     if not args.no_fast_forward:
         from blub_amd.simulation_controller import SimulationController
-        scene_ff = blub_amd.Scene(path=scene_path, device=dev)
-        fluid_ff = scene_ff.fluid()
-        fluid_ff.set_pcg_work_mapping(args.pcg_mapping)
+        scene_ff, fluid_ff = new_scene(args.pcg_schedule)
         sc = SimulationController()
         if args.warmup:
             sc.fast_forward_steps_fluid(fluid_ff, args.warmup * sc.simulation_delta_ns)
@@ -437,23 +496,15 @@ def main():
     if not args.no_fast_forward:
         rebinning_tuned = {"note": "informational: same scene and window with particle_rebinning_step_frequency (a tunable of the reference, default 60) changed", "runs": []}
         for freq_r in (8, 16):
-            scene_rb = blub_amd.Scene(path=scene_path, device=dev)
-            fluid_rb = scene_rb.fluid()
-            fluid_rb.set_pcg_work_mapping(args.pcg_mapping)
-            fluid_rb.particle_rebinning_step_frequency = freq_r
-            for _ in range(args.warmup):
-                scene_rb.step(dt)
-            fluid_rb.synchronize()
-            t0r = time.perf_counter()
-            for _ in range(args.steps):
-                scene_rb.step(dt)
-            fluid_rb.synchronize()
-            rebinning_tuned["runs"].append({"frequency": freq_r, "steps_per_s": round(args.steps / (time.perf_counter() - t0r), 3)})
-            fluid_rb.close()
+            el_r, _ = timed_window(args.pcg_schedule, rebinning=freq_r)
+            rebinning_tuned["runs"].append({"frequency": freq_r, "steps_per_s": round(args.steps / el_r, 3)})
 
-    # ---- instrumented pass: per-kernel-class HIP-event timing on the engine's own stream -----------------------------
+    # ---- instrumented pass: per-kernel-class HIP-event timing on the engine's own stream.  Every profiled launch carries an event pair
+    # whose own cost (measured: profile_event_overhead_us) is part of what the pair reports; it is subtracted per launch, so the classes sum
+    # to the GPU-busy part of a step (<= ms_per_step).  The per-kernel table of record is the rocprofv3 trace under profiles/.
     roofline_workload, breakdown, pcg_ms = None, None, 0.0
     if args.profile_steps > 0:
+        ev_us = fluid.profile_event_overhead_us()
         fluid.profile_enable(True)
         fluid.profile_reset()
         for _ in range(args.profile_steps):
@@ -461,6 +512,8 @@ def main():
         fluid.synchronize()
         prof = fluid.profile_read()
         fluid.profile_enable(False)
+        for v in prof.values():
+            v["total_ms"] = max(v["total_ms"] - v["launches"] * ev_us * 1e-3, 0.05 * v["total_ms"])
         F = int((fluid.read_volume("marker") == 1).sum())
         bc = fluid.brick_counts()
         A, Fb = bc["active"] * bc["cells_per_brick"], bc["fluid"] * bc["cells_per_brick"]
@@ -473,14 +526,23 @@ def main():
                              "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F, "active_brick_cells": A, "fluid_brick_cells": Fb,
                              "launches_per_step": round(prof[dominant]["launches"] / args.profile_steps, 1)}
         pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
-        breakdown = {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        breakdown = {"us_per_step": {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
+                     "sum_us_per_step": round(total_ms / args.profile_steps * 1e3, 1), "launches_per_step": round(sum(v["launches"] for v in prof.values()) / args.profile_steps, 1),
+                     "event_pair_overhead_us_subtracted_per_launch": round(ev_us, 2),
+                     "window": "the %d steps after the timed window (steps %d..%d of the scene): later, i.e. costlier, steps than the timed ones" % (args.profile_steps, args.warmup + args.steps, args.warmup + args.steps + args.profile_steps)}
 
     result = {
         "metric": METRIC, "value": round(args.steps / elapsed, 3), "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.scene, "grid": [nx, ny, nz], "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4",
-                   "rebinning": 60, "parallelism": "single GPU", "pcg_schedule": fluid.pcg_schedule()},
+                   "rebinning": 60, "parallelism": "single GPU", "pcg_schedule": fluid.pcg_schedule(),
+                   "pcg_schedule_note": "opt-in: the library default is the reference's two-reduction order, timed beside it as value_reference_schedule",
+                   "window": "steps %d..%d of the scene after %d warm-up steps; the dams break and spread (256 -> ~1400 fluid bricks over the first 130 steps), so steps/s depends on the window: "
+                             "the no-flag default (10 + 120) is the representative figure, a 5 + 20 window sees only the cheapest phase" % (args.warmup, args.warmup + args.steps, args.warmup)},
+        "value_reference_schedule": by_schedule["reference"]["steps_per_s"],
+        "value_single_reduction_schedule": by_schedule["single_reduction"]["steps_per_s"],
+        "by_schedule": by_schedule,
         "pcg_iters_per_sec": round((it1 - it0) / elapsed, 1),
         "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
         "pcg_iters_per_sec_in_solver": round((it1 - it0) / args.steps * args.profile_steps / (pcg_ms * 1e-3), 1) if pcg_ms > 0 else None,
@@ -488,16 +550,22 @@ def main():
         "rebinning_tuned": rebinning_tuned,
         "roofline": None,
         "roofline_workload": roofline_workload,
-        "kernel_us_per_step": breakdown,
+        "kernel_breakdown": breakdown,
     }
+    scene._fluid.close()
+    scene._fluid = None
     if not args.no_dense_pcg:
         # The HBM roofline is defined on the PCG stencil at 256^3: dense fill, every byte from HBM/MALL.
         # Dominant kernel of an iteration = the update kernel (N + 20F algorithmic bytes of the 2N + 32F the fused pair moves).
-        scene._fluid.close()
-        scene._fluid = None
         dense = dense_pcg_benchmark(256, 32)
         result["roofline_pcg_dense"] = dense
         result["roofline"] = roofline_object(dense, "same process")
+        if not args.no_dense_512:
+            # 256^3 is not a clean HBM number (the iteration's working set is about the size of the 256 MiB Infinity Cache): the same benchmark at
+            # 512^3, where every byte comes from HBM
+            dense512 = dense_pcg_benchmark(512, 32)
+            result["roofline_512"] = roofline_object(dense512, "same process")
+            result["roofline_pcg_dense_512"] = dense512
     if not args.no_cpu_baseline:   # rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(scene_path, dt)
     print(json.dumps(result))

@@ -14,6 +14,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel / host sources and the public header: stamps measured artefacts (the PMC captures under
+    profiles/) with the code state they were taken from; bench.py reports whether the stamp matches the sources it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC)) + [os.path.join(ROOT, "include", "blubhip.h")]:
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

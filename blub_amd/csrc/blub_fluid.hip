@@ -1012,6 +1012,28 @@ int blub_fluid_profile_reset(blub_fluid* h) {
     if (h->prof_origin) { h->prof_pool.push_back(h->prof_origin); h->prof_origin = nullptr; }
     return rc;
 }
+// What one profiled launch's event pair adds to the figure it reports: the elapsed time between two events recorded back to back on the
+// handle's (idle) stream, averaged over 64 pairs.  blub_fluid_profile_read's totals contain launches x this.
+int blub_fluid_profile_event_overhead_us(blub_fluid* h, double* out_us) {
+    REQUIRE_HANDLE(h);
+    if (!out_us) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    constexpr int PAIRS = 64;
+    hipEvent_t ev[2 * PAIRS];
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    for (int rep = 0; rep < 2; ++rep) {      // (first repetition warms the event objects up)
+        for (int k = 0; k < PAIRS; ++k) {
+            HIP_TRY(hipEventRecord(ev[2 * k], h->stream)); HIP_TRY(hipEventRecord(ev[2 * k + 1], h->stream));
+            hipLaunchKernelGGL(blubk::k_pcg_tag, dim3(1), dim3(1), 0, h->stream, h->ctrl[0], h->solve_seq[0]);   // (a kernel between the pairs, as in a profiled step)
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    double sum = 0.0;
+    for (int k = 0; k < PAIRS; ++k) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1])); sum += ms; }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *out_us = sum / PAIRS * 1e3;
+    return BLUB_OK;
+}
 int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capacity, int* count_out) {
     REQUIRE_HANDLE(h);
     if (!count_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");

@@ -242,6 +242,9 @@ typedef struct blub_prof_entry {
 int blub_fluid_profile_enable(blub_fluid* h, int enabled);
 int blub_fluid_profile_reset(blub_fluid* h);
 int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacity, int* count_out); /* blocks */
+/* Mean elapsed time (us) between two events recorded back to back on the handle's stream: what the event pair of ONE profiled launch adds
+ * to the totals of blub_fluid_profile_read (which therefore over-state short kernels by launches x this).  Blocks. */
+int blub_fluid_profile_event_overhead_us(blub_fluid* h, double* out_us);
 /* Per-launch timeline of the profiled launches since the last reset (the data behind the reference's chrome-trace dump,
  * gui/mod.rs:487-491 / wgpu-profiler): start relative to the first profiled launch, both in microseconds. */
 typedef struct blub_trace_event {

@@ -31,7 +31,10 @@ def main(size, d, stats_csv, out):
             continue
         parts = line.rsplit(",", 8)
         dur[parts[0]] = (float(parts[3]), int(parts[1]))
-    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --dense-only --dense-size %d (tools/dense_pmc.sh)" % n,
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blub_amd.build import source_hash
+    res = {"kernel_source_sha16": source_hash(), "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --dense-only --dense-size %d (tools/dense_pmc.sh)" % n,
            "unit": "bytes per launch; FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section), counters are KiB"}
     lines = ["# dense %d^3 PCG micro-benchmark: N = %d cells, F = %d FLUID; traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch" % (n, N, F),
              "kernel                         launches  avg_us  FETCH raw [MB]  x2 [MB]  WRITE [MB]  traffic [MB]  algorithmic [MB]  traffic/alg  alg GB/s  frac of 8 TB/s"]

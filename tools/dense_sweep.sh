@@ -1,13 +1,11 @@
 #!/bin/bash
-# usage: tools/dense_sweep.sh SIZE "ENV=VAL ..." ...   -- dense PCG micro-benchmark per variant (2 repetitions each)
-size=$1; shift
-for rep in 1 2; do
-  for v in "$@"; do
-    out=$(env $v python bench.py --dense-only --dense-size $size 2>/dev/null | python -c "
+# Tile-geometry sweep of the dense 2.5-D PCG kernels on the GPU box: one line per configuration.
+# usage: tools/dense_sweep.sh SIZE "T:ZC T:ZC ..."        (T = tile width in quads, ZC = planes per tile, 0 = default)
+size=${1:-256}; shift
+for cfg in ${@:-0:0}; do
+  t=${cfg%%:*}; zc=${cfg##*:}
+  python bench.py --dense-only --dense-size $size --dense-tile-quads $t --dense-tile-planes $zc 2>/dev/null | grep '^{' | python -c "
 import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); k=d['kernels']; print('iter %.1f us frac %.4f fused %.4f | dir %.2f us %.4f | upd %.2f us %.4f' % (d['us_per_iteration_kernels'], d['iter_frac'], d['iter_frac_fused'], k['pcg_dir']['avg_us'], k['pcg_dir']['frac'], k['pcg_update']['avg_us'], k['pcg_update']['frac']))")
-    echo "[$size $v] $out"
-  done
+d=json.loads(sys.stdin.read()); k=d['kernels']
+print('dense %s T=%s zc=%s : KD %.2f us (%.3f)  KU %.2f us (%.3f)  iter %.1f us  fused frac %.3f' % (d['grid'], '$t', '$zc', k['pcg_dir']['avg_us'], k['pcg_dir']['frac'], k['pcg_update']['avg_us'], k['pcg_update']['frac'], d['us_per_iteration_kernels'], d['iter_frac_fused']))"
 done
