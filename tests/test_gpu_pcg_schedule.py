@@ -223,9 +223,9 @@ def test_long_solve_true_residual(mapping):
     """Round-2 ADVICE: the single-reduction form carries r AND q = A d by recurrences, so the residual the convergence test sees drifts from
     b - A p faster than the reference order's (which recomputes A s every iteration).  400 iterations with tolerance 0 -- far past
     convergence, where CG stagnates at its attainable accuracy -- and then the TRUE residual b - A p, recomputed on the host in f64:
-    it must stay at rounding level of |A||p| + |b| for every schedule; the bound of the single-reduction schedule is the measured one
-    (several times the reference order's), which is why the engine only uses it for solves of <= 64 iterations unless told otherwise
-    (blub_fluid_set_tuning "pcg1_max_iterations")."""
+    it must stay at rounding level of |A||p| + |b| for every schedule.  Measured (48x40x32 dam, MI355X): 5.4e-7 reference order on bricks,
+    4.5e-7 single-reduction, 3.9e-7 dense rows -- no drift beyond the reference order's on this problem; the engine nevertheless keeps the
+    single-reduction form to solves of <= 64 iterations unless told otherwise (blub_fluid_set_tuning "pcg1_max_iterations")."""
     pos, vel, maxp = util.make_dam(*GRID)
     o, h = util.new_pair(*GRID, maxp)
     try:
@@ -255,6 +255,6 @@ def test_long_solve_true_residual(mapping):
         rel = np.abs(r_true).max() / scale
         r_rec = np.abs(h.read_volume("residual").astype(np.float64) * fluid).max() / scale
         print("%s: true residual %.3g, recurrence residual %.3g (relative to |A||p| + |b|) after 400 iterations" % (mapping, rel, r_rec))
-        assert rel < (3e-6 if mapping != "bricks_single" else 3e-5), rel
+        assert rel < 3e-6, rel
     finally:
         h.close()
