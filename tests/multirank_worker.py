@@ -1,0 +1,81 @@
+"""One rank of a multi-process z-slab group (tests/test_gpu_multirank.py starts N of these with tests/native/libfake_rccl.so LD_PRELOADed,
+all on the one GPU of the test box).  usage: multirank_worker.py MODE RANK WORLD WORKDIR SCHEDULE GATHER"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def scene():
+    """The blob of tests/test_gpu_parity.py::test_z_slab_decomposition_matches_single_domain: it straddles every slab interface and shears
+    across them, so every exchange carries data."""
+    dim = (32, 32, 48)
+    rng = np.random.default_rng(4)
+    cells = np.stack(np.meshgrid(np.arange(6, 26), np.arange(8, 20), np.arange(6, 42), indexing="ij"), -1).reshape(-1, 3)
+    pos = (cells[:, None, :] + rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
+    vel = [np.zeros((pos.shape[0], 4), np.float32) for _ in range(3)]
+    vel[2][:, 3] = 6.0 * np.sin(pos[:, 0] * 0.4)
+    cfg = dict(error_tolerance=0.0, max_num_iterations=120, error_check_frequency=8)   # far past convergence, no convergence DECISION (see the loopback test)
+    return dim, pos, vel, cfg
+
+
+def main():
+    mode, rank, world, workdir, schedule, gather = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+    try:
+        ctypes.CDLL(None).fake_rccl_marker
+    except AttributeError:
+        raise SystemExit("tests/native/libfake_rccl.so is not preloaded: this worker must not run against the real RCCL on a shared GPU")
+    import blub_amd
+    from tests import util
+    uid_path = os.path.join(workdir, "uid")
+    if rank == 0:
+        uid = blub_amd.SlabGroup.unique_id()
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(uid_path + ".tmp", uid_path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(uid_path):
+            if time.time() - t0 > 60:
+                raise SystemExit("no unique id from rank 0")
+            time.sleep(0.01)
+        uid = open(uid_path, "rb").read()
+    dim, pos, vel, cfg = scene()
+    group = blub_amd.SlabGroup(dim, pos.shape[0], rank=rank, world=world, unique_id=uid, device=0, binning="off")
+    out = {"description": group.transport_description(), "range": group.local_range(0)}
+    try:
+        if gather != "calibrated":
+            group.set_gather_mode(gather)
+        group.set_pcg_schedule(schedule)
+        group.local_fluid(0).set_tuning("pcg1_max_iterations", 1000)     # (120 single-reduction iterations: the engine would otherwise switch to the reference order)
+        group.set_gravity_grid((0.0, -981.0, 0.0))
+        group.set_particles(pos, *vel)
+        for w in (0, 1):
+            group.set_solver_config(w, **cfg)
+        fluid = group.local_fluid(0)
+        out["count0"] = fluid.num_particles()
+        steps = 3
+        for step in range(steps):
+            if mode == "kill" and rank == 1 and step == 1:
+                os._exit(17)            # a rank disappears in the middle of the run
+            ops0 = group.transport_ops()
+            group.step(util.DT)
+            group.synchronize()
+            out["pos%d" % step] = group.get_particles()[0][:, :3]
+            out["ops%d" % step] = group.transport_ops() - ops0
+        out["stats"] = np.array([fluid.solver_stats(0), fluid.solver_stats(1)], np.float64)
+        out["marker"] = fluid.read_volume("marker")
+        out["status"] = "ok"
+    except blub_amd.hybrid_fluid.BlubError as e:
+        out["status"] = "error %d: %s" % (e.status, e)
+    np.savez(os.path.join(workdir, "rank%d.npz" % rank), **out)
+    group.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+"""The z-slab group's RCCL transport with MORE THAN ONE RANK (round-2 review, missing item 1): N real processes, one slab each, all on
+the one GPU of the test box.  RCCL itself refuses two ranks on one device, so tests/native/libfake_rccl.so -- the ~12 RCCL entry points
+blub_slab.inc.hip uses, host-staged between processes; TEST INFRASTRUCTURE, see its header -- is LD_PRELOADed into the workers: the same
+libblubhip.so and the same protocol code run rank sequencing, grouped send / receive, partial gathers (both spellings), calibration with
+its all-reduce, migration between processes and the abort path.  Results are compared with the single-domain engine exactly like the
+loopback test (tests/test_gpu_parity.py::test_z_slab_decomposition_matches_single_domain)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.conftest import ROOT, has_gpu
+from tests.multirank_worker import scene
+from tests.test_gpu_parity import _match_particles
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+SRC = os.path.join(ROOT, "tests", "native", "fake_rccl.cpp")
+LIB = os.path.join(ROOT, "tests", "native", "libfake_rccl.so")
+
+
+def _fake_rccl():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-fPIC", "-shared", "-std=c++17", SRC, "-o", LIB])
+    return LIB
+
+
+def _launch(mode, world, workdir, schedule="reference", gather="calibrated", timeout=300):
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = _fake_rccl() + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
+    env["FAKE_RCCL_DIR"] = str(workdir)
+    env["FAKE_RCCL_TIMEOUT_S"] = "20"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), mode, str(r), str(world), str(workdir), schedule, gather],
+                              env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung:\n" + "\n".join(outs))
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.parametrize("world,schedule,gather", [(2, "reference", "calibrated"), (2, "single_reduction", "p2p"), (2, "single_reduction", "allgather"),
+                                                   (4, "reference", "p2p"), (4, "single_reduction", "calibrated")])
+def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedule, gather, tmp_path):
+    import blub_amd
+    rcs, outs = _launch("compare", world, tmp_path, schedule, gather)
+    assert all(rc == 0 for rc in rcs), "\n".join(outs)
+    ranks = [np.load(os.path.join(tmp_path, "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
+    assert all(str(d["status"]) == "ok" for d in ranks), [str(d["status"]) for d in ranks]
+    dim, pos, vel, cfg = scene()
+    # every rank reports the same transport (the calibration's verdict is all-reduced) and the ranges tile the domain in rank order
+    desc = [str(d["description"]) for d in ranks]
+    assert all(x == desc[0] for x in desc) and ("%d ranks" % world) in desc[0], desc
+    print("transport:", desc[0])
+    rng_ = [tuple(int(v) for v in d["range"]) for d in ranks]
+    assert rng_[0][0] == 0 and rng_[-1][1] == dim[2] and all(a[1] == b[0] for a, b in zip(rng_, rng_[1:]))
+    counts0 = [int(d["count0"]) for d in ranks]
+    assert sum(counts0) == pos.shape[0] and all(c > 0 for c in counts0)
+    single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
+    try:
+        single.set_pcg_schedule(schedule)
+        single.set_tuning("pcg1_max_iterations", 1000)
+        single.set_gravity_grid((0.0, -981.0, 0.0))
+        single.set_particles(pos, *vel)
+        for w in (0, 1):
+            single.set_solver_config(w, **cfg)
+        for step in range(3):
+            single.step(util.DT)
+            ps = single.get_particles()[0][:, :3].astype(np.float64)
+            pg = np.concatenate([d["pos%d" % step] for d in ranks]).astype(np.float64)
+            assert pg.shape == ps.shape                                   # no particle lost or duplicated between the processes
+            for d, (z0, z1) in zip(ranks, rng_):                          # every rank only holds particles of its own z-range
+                z = d["pos%d" % step][:, 2]
+                assert np.all(z >= z0) and np.all(z < z1)
+            dd = _match_particles(pg, ps)
+            q = (np.median(dd), np.quantile(dd, 0.99), np.quantile(dd, 0.999), dd.max())
+            print("step %d  %d processes vs single domain: median %.3g p99 %.3g p99.9 %.3g max %.3g" % ((step, world) + q))
+            bounds = (3e-5, 4e-4, 1.5e-3, 3e-3) if step == 0 else (2e-4, 3e-3, 3e-2, 0.1)     # (the loopback test's envelope)
+            for a, b in zip(q, bounds):
+                assert a <= b, (step, q, bounds)
+            ops = [int(d["ops%d" % step]) for d in ranks]
+            assert all(o == ops[0] for o in ops) and ops[0] > 0, ops      # every rank issued the same sequence of transport operations
+        assert [d["pos2"].shape[0] for d in ranks] != counts0, "no particle migrated between the processes"
+        st = [d["stats"] for d in ranks]
+        assert all(np.array_equal(x, st[0]) for x in st)                  # identical solver statistics on every rank (gathered partials, fixed order)
+        m_single = single.read_volume("marker")
+        m_group = np.zeros_like(m_single)
+        for d, (z0, z1) in zip(ranks, rng_):
+            m_group[z0:z1] = d["marker"][z0:z1]
+        assert (m_group != m_single).mean() < 2e-3
+    finally:
+        single.close()
+
+
+def test_a_rank_that_dies_gives_its_peers_a_communication_error_instead_of_a_hang(tmp_path):
+    """Rank 1 of 3 exits abruptly before its second step.  Its z-neighbours are blocked in a grouped send / receive with it; they must
+    come back with BLUB_ERR_COMM (and abort the communicator, so that THEIR peers fail too) rather than block forever."""
+    rcs, outs = _launch("kill", 3, tmp_path, timeout=180)
+    assert rcs[1] == 17, outs[1]
+    for r in (0, 2):
+        assert rcs[r] == 0, outs[r]
+        d = np.load(os.path.join(tmp_path, "rank%d.npz" % r), allow_pickle=True)
+        status = str(d["status"])
+        assert status.startswith("error -8") and "communicator aborted" in status, status      # BLUB_ERR_COMM
+        assert "pos0" in d.files and "pos1" not in d.files                                      # step 0 completed, step 1 failed
+
+
+def test_bench_gpus_2_runs_the_slab_path(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per "GPU"), control plane over gloo, data plane through
+    the preloaded fake: the z-slab path must produce the JSON line itself -- not the replicas fallback."""
+    import json
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = _fake_rccl()
+    env["FAKE_RCCL_DIR"] = str(tmp_path)
+    env["BLUB_BENCH_BACKEND"] = "gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scene", "corner_dams_128", "--no-dense-pcg"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert res.returncode == 0 and lines, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] is not None and d["value"] > 0, d
+    assert "rccl, 2 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
