@@ -188,11 +188,12 @@ struct ProfScope {
         h->prof_pending.push_back({a, b, kc, h->cur_stage, h->step_counter});
     }
 };
-#define LAUNCH(h, kc, kernel, grid, block, ...)                                  \
-    do {                                                                         \
-        ProfScope _ps((h), (kc));                                                \
-        hipLaunchKernelGGL(kernel, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+#define LAUNCH_LDS(h, kc, kernel, grid, block, lds_bytes, ...)                            \
+    do {                                                                                  \
+        ProfScope _ps((h), (kc));                                                         \
+        hipLaunchKernelGGL(kernel, grid, block, (lds_bytes), (h)->stream, __VA_ARGS__);   \
     } while (0)
+#define LAUNCH(h, kc, kernel, grid, block, ...) LAUNCH_LDS(h, kc, kernel, grid, block, 0, __VA_ARGS__)
 
 static unsigned particle_blocks(uint32_t n) { return (n + 255) / 256; }
 static unsigned stream_blocks(size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, 2048); }
@@ -368,6 +369,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         const float max_fill = h->N <= (size_t)1 << 20 ? 0.70f : SPARSE_PCG_MAX_FILL;
         sparse = (have && (float)bc.n_fluid < max_fill * (float)h->bg.nb) || h->gz.tiles < 256;   // tiny grids: too few dense tiles to fill the chip
     }
+    if (2 * h->gz.qpr > h->gz.T) sparse = true;   // rows wider than 2048 cells: the dense tiles cannot hold their halo rows (k_pcg_dir_z)
     const int maxit = c.max_num_iterations;
     const int freq = c.error_check_frequency;
     auto is_check = [&](int j) { return j > 0 && freq > 0 && j % freq == 0; };   // :672-673 (the i == max case is k_pcg_finalize)
@@ -432,16 +434,17 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     } else {
         const int np = h->pcg_grid_z;
         const dim3 grid(np);
+        const size_t lds_dir = dense_dir_lds_bytes(h->gz.T, h->gz.qpr);
 #define BLUB_LAUNCH_Z(TT, NTU, NTD)                                                                                                                             \
         {                                                                                                                                                       \
             const dim3 block(TT);                                                                                                                               \
             LAUNCH(h, KC_PCG_INIT, k_pcg_init_z<TT>, grid, block, h->gz, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags, ctrl);   \
             for (int i = 0; i <= maxit; ++i) {                                                                                                                  \
                 if (i == 0)                                                                                                                                     \
-                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true, NTD>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
+                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true, NTD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);                                              \
                 else                                                                                                                                            \
-                    LAUNCH(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
+                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));                           \
                 LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,     \
                        (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
@@ -582,6 +585,7 @@ static void set_dense_geometry(blub_fluid* h, int T, int zc, int grid) {
     PcgGeomZ& gz = h->gz;
     const int qpr = h->g.nx / 4, qpp = qpr * h->g.ny;
     if (T != 256 && T != 512 && T != 1024) T = 256;
+    while (T < 2 * qpr && T < 1024) T *= 2;      // a tile holds at least two rows (its halo rows are filled by its first 2 qpr threads)
     gz.g = h->g; gz.qpr = qpr; gz.qpp = qpp; gz.T = T; gz.plane_tiles = (qpp + T - 1) / T;
     if (zc <= 0) { zc = 16; while (zc > 2 && gz.plane_tiles * ((h->g.nz + zc - 1) / zc) < 1024) zc >>= 1; }
     gz.zc = std::max(2, zc);

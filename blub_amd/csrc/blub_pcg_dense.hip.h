@@ -163,115 +163,123 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
 }
 
 // ---- KD: [convergence test] beta; s = M^-1 r + beta s; partial s.As  (pressure_update_search.comp + pressure_apply_coeff.comp)
-// Registers hold s_new of planes z-1, z, z+1; s_new of a plane is computed (and written to s_out) when the plane enters.
+// Round-3 formulation (the round-2 kernel issued 335 VALU instructions per quad and plane -- zero fills, 64-bit address arithmetic and a
+// dozen exec-mask branches around the tile-edge cases -- and was bound by that, not by bytes: DESIGN.md 5d):
+//   * the exchange buffer in LDS holds the tile's T quads of the current plane PLUS the qpr quads before and after them in memory order
+//     (one row of halo either side; slot i <-> quad q0 - qpr + i).  Every thread then finds all four in-plane neighbours at FIXED
+//     offsets from its own slot -- y-1 at [t], x-1 at [t + qpr - 1], x+1 at [t + qpr + 1], y+1 at [t + 2 qpr] -- with no case analysis:
+//     row ends are two loop-invariant bit masks; the domain's y ends and a ragged last tile are zeros their writers put there;
+//   * the 2 qpr halo quads are owned by the first 2 qpr threads (whole waves when qpr is a multiple of 64): they carry one extra quad's
+//     raw loads through the same one-plane-ahead pipeline, convert it to s_new when it arrives and publish it next to their own value;
+//   * loads are unconditional (lanes without a quad read the plane's first quad and mask the descriptor): no exec-mask branches around them;
+//   * addresses: one 32-bit in-plane byte offset per thread (+ one per halo quad) against plane base pointers that advance in SGPRs;
+//   * registers hold s_new of planes z-1, z, z+1; s_new of a plane is computed (and written to s_out) when the plane enters;
+//   * s_new is 0 on every non-FLUID cell, so A s needs no neighbour descriptors (quad_mulA_u).  K(0) reads the stored s, which the
+//     reference leaves untouched outside the fluid: it is zeroed outside the fluid as it arrives, which gives the same sums.
+// Requires 2 qpr <= T (set_dense_geometry picks T accordingly; grids wider than 2048 cells use the brick mapping).
+// Dynamic LDS: 2 x (T + 2 qpr) float4 (dense_dir_lds_bytes).
+__host__ __device__ inline size_t dense_dir_lds_bytes(int T, int qpr) { return (size_t)2 * (size_t)(T + 2 * qpr) * 16u; }
 template <int T, bool FIRST, bool NT = false>
 __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
                                                  float* __restrict__ s_out, const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
                                                  const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
+    extern __shared__ float4 ext[];      // [2][T + 2 qpr]
     __shared__ float sm[T / 64 + 1];
     __shared__ float2 sm2[T / 64 + 1];
-    __shared__ float4 ls[2][T];
-    __shared__ uint32_t ld[2][T];        // descriptor exchange: FIRST only (see below)
     __shared__ DivConst div_lut[8];
     pcg_fill_div_lut(div_lut);           // (the prologue's barriers publish it)
     float beta;
     if (!pcg_dir_prologue<T>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     const Grid g = gz.g;
-    const int t = threadIdx.x, plane = g.nx * g.ny, qpr = gz.qpr;
+    const int t = threadIdx.x, qpr = gz.qpr;
+    const size_t plane = (size_t)g.nx * (size_t)g.ny;
+    const int ext_n = T + 2 * qpr;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float acc = 0.0f;
-    // s_new of a quad from global memory (no write)
-    auto snew_quad = [&](int b, uint32_t dq) -> float4 {
-        if (FIRST) return ld4(s_in + b);
-        return any_fluid_d(dq) ? snew4(dq, ld4(r + b), ld4(s_in + b), beta, div_lut) : zero4;
+    auto snew = [&](uint32_t dq, const float4& rr, const float4& so) -> float4 {      // s_new of a quad from its raw loads
+        if (FIRST) return zero_outside_fluid(dq, so);
+        return snew4(dq, rr, so, beta, div_lut);
     };
     const int padded = ((gz.tiles + 7) >> 3) << 3;
     for (int it = blockIdx.x; it < padded; it += gridDim.x) {
         const int tile = xcd_tile(it, gz.tiles);
         if (tile >= gz.tiles || !tile_flags[tile]) continue;
         const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
-        const int q = pt * T + t;
+        const int q0 = pt * T, q = q0 + t;
         const bool valid = q < gz.qpp;
-        const int x0 = (q % qpr) << 2, y = q / qpr;
+        const int x0 = (q % qpr) << 2;
         const int z_begin = zci * gz.zc, z_end = min(z_begin + gz.zc, g.nz);
-        const int row_base = valid ? (y * g.nx + x0) : 0;
-        const bool edge_lo = valid && (t < qpr) && y > 0, edge_hi = valid && (t >= T - qpr || q + qpr >= gz.qpp) && y + 1 < g.ny;
-        const bool in_lo = t >= qpr, in_hi = (t + qpr < T) && (q + qpr < gz.qpp);
-        const bool xm_glob = valid && x0 > 0 && t == 0, xp_glob = valid && x0 + 4 < g.nx && (t == T - 1);
-        float4 n_m = zero4, n_c = zero4, n_p = zero4;   // s_new of planes z-1, z, z+1 (own quad)
-        uint32_t d_m = 0, d_c = 0, d_p = 0;
-        // s_new of an owned plane from its raw loads; written to s_out (FLUID lanes only) when `own`
-        auto enter_plane = [&](int b, uint32_t dq, const float4& rr, const float4& so, bool own) -> float4 {
-            if (FIRST) return so;
-            if (!any_fluid_d(dq)) return zero4;
-            const float4 n = snew4(dq, rr, so, beta, div_lut);
-            if (own) st4so<NT>(s_out, (uint32_t)b * 4u, sel4(dq, n, so));
-            return n;
-        };
-        // raw tile-edge values (converted to s_new when they are used), fetched one plane ahead: see k_pcg_update_z
-        struct Halo { float4 s_lo, s_hi, r_lo, r_hi; uint32_t dlo, dhi; float sxm, sxp, rxm, rxp; int dxm, dxp; };
-        auto load_halo = [&](int base, bool cond) -> Halo {
-            Halo h; h.s_lo = zero4; h.s_hi = zero4; h.r_lo = zero4; h.r_hi = zero4; h.dlo = 0; h.dhi = 0; h.sxm = 0.f; h.sxp = 0.f; h.rxm = 0.f; h.rxp = 0.f; h.dxm = 0; h.dxp = 0;
-            if (cond) {
-                if (edge_lo && !in_lo) { h.dlo = *reinterpret_cast<const uint32_t*>(dvol + base - g.nx); h.s_lo = ld4(s_in + base - g.nx); if (!FIRST) h.r_lo = ld4(r + base - g.nx); }
-                if (edge_hi && !in_hi) { h.dhi = *reinterpret_cast<const uint32_t*>(dvol + base + g.nx); h.s_hi = ld4(s_in + base + g.nx); if (!FIRST) h.r_hi = ld4(r + base + g.nx); }
-                if (xm_glob) { h.dxm = dvol[base - 1]; h.sxm = s_in[base - 1]; if (!FIRST) h.rxm = r[base - 1]; }
-                if (xp_glob) { h.dxp = dvol[base + 4]; h.sxp = s_in[base + 4]; if (!FIRST) h.rxp = r[base + 4]; }
+        const uint32_t goff = valid ? (uint32_t)q * 16u : 0u;                     // byte offset of the own quad inside a plane of an f32 volume
+        const uint32_t vmask = valid ? 0xFFFFFFFFu : 0u;
+        const uint32_t mxm = (valid && x0 > 0) ? 0xFFFFFFFFu : 0u, mxp = (valid && x0 + 4 < g.nx) ? 0xFFFFFFFFu : 0u;
+        // halo quad of this thread (threads 0 .. 2 qpr - 1): one row before the tile's first quad / one row after its last
+        const bool halo_thread = t < 2 * qpr;
+        const int hq = t < qpr ? q0 - qpr + t : q0 + T + (t - qpr);
+        const bool halo_valid = halo_thread && hq >= 0 && hq < gz.qpp;
+        const uint32_t hoff = halo_valid ? (uint32_t)hq * 16u : 0u;
+        const uint32_t hmask = halo_valid ? 0xFFFFFFFFu : 0u;
+        const int halo_slot = t < qpr ? t : T + t;                                // upper halo: T + qpr + (t - qpr)
+        float4 n_m, n_c, n_p, h_c;               // s_new of planes z-1, z, z+1 (own quad); s_new of the halo quad at plane z
+        uint32_t d_c, d_p;                       // descriptors of planes z, z+1 (own quad)
+        {   // ---- planes z_begin - 1, z_begin, z_begin + 1 of the own quad, plane z_begin of the halo quad
+            const uint8_t* dv = dvol + (size_t)z_begin * plane;
+            const float* sp = s_in + (size_t)z_begin * plane;
+            const float* rp = r + (size_t)z_begin * plane;
+            const bool has_m = z_begin > 0, has_p = z_begin + 1 < g.nz;          // uniform
+            uint32_t dq_m = 0, dq_p = 0;
+            float4 r_m = zero4, r_p = zero4, s_m = zero4, s_p = zero4, r_c = zero4, r_h = zero4;
+            const uint32_t dq_c = ldu32o(dv, goff >> 2) & vmask;
+            const float4 s_c = ld4o(sp, goff);
+            if (!FIRST) r_c = ld4o(rp, goff);
+            if (has_m) { dq_m = ldu32o(dv - plane, goff >> 2) & vmask; s_m = ld4o(sp - plane, goff); if (!FIRST) r_m = ld4o(rp - plane, goff); }
+            if (has_p) { dq_p = ldu32o(dv + plane, goff >> 2) & vmask; s_p = ld4o(sp + plane, goff); if (!FIRST) r_p = ld4o(rp + plane, goff); }
+            uint32_t dq_h = 0; float4 s_h = zero4;
+            if (halo_thread) { dq_h = ldu32o(dv, hoff >> 2) & hmask; s_h = ld4o(sp, hoff); if (!FIRST) r_h = ld4o(rp, hoff); }
+            n_m = snew(dq_m, r_m, s_m);                                           // z-halo plane: not written
+            n_c = snew(dq_c, r_c, s_c);
+            n_p = snew(dq_p, r_p, s_p);
+            h_c = snew(dq_h, r_h, s_h);
+            d_c = dq_c; d_p = dq_p;
+            if (!FIRST && valid) {
+                float* so = s_out + (size_t)z_begin * plane;
+                st4so<NT>(so, goff, n_c);
+                if (z_begin + 1 < z_end) st4so<NT>(so + plane, goff, n_p);
             }
-            return h;
-        };
-        Halo hc = load_halo(0, false);
-        if (valid) {
-            const int b0 = z_begin * plane + row_base;
-            d_c = *reinterpret_cast<const uint32_t*>(dvol + b0);
-            n_c = enter_plane(b0, d_c, FIRST ? zero4 : ld4(r + b0), ld4(s_in + b0), true);
-            if (z_begin > 0) { d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); n_m = snew_quad(b0 - plane, d_m); }   // halo plane: not written
-            if (z_begin + 1 < g.nz) {
-                d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane);
-                n_p = enter_plane(b0 + plane, d_p, FIRST ? zero4 : ld4(r + b0 + plane), ld4(s_in + b0 + plane), z_begin + 1 < z_end);
-            }
-            hc = load_halo(b0, any_fluid_d(d_c));
         }
         for (int z = z_begin; z < z_end; ++z) {
-            const int base = z * plane + row_base;
-            const int buf = z & 1;
-            // raw loads of plane z+2 are issued now and consumed after this plane's compute (requesting them a whole iteration earlier
-            // was measured slower: 55.4 vs 52.7 us at 256^3 -- the kernel is not waiting on these loads)
-            const bool fetch = valid && z + 1 < z_end && z + 2 < g.nz;
-            uint32_t d_n = 0; float4 r_n = zero4, so_n = zero4;
-            const uint32_t un = (uint32_t)base + 2u * (uint32_t)plane;
-            if (fetch) {
-                d_n = ldu32o(dvol, un);
-                so_n = ld4o(s_in, un * 4u);
-                if (!FIRST) r_n = ld4o(r, un * 4u);
+            // raw loads of plane z + 2 (own quad) and of plane z + 1 (halo quad): issued now, consumed after this plane's stencil
+            const bool next_plane = z + 1 < z_end;                               // uniform
+            const bool fetch_own = next_plane && z + 2 < g.nz;                   // uniform
+            uint32_t dq_n = 0, dq_hn = 0;
+            float4 r_n = zero4, s_n = zero4, r_hn = zero4, s_hn = zero4;
+            if (fetch_own) {
+                const size_t pb = (size_t)(z + 2) * plane;
+                dq_n = ldu32o(dvol + pb, goff >> 2) & vmask; s_n = ld4o(s_in + pb, goff); if (!FIRST) r_n = ld4o(r + pb, goff);
             }
-            const Halo hn = load_halo(base + plane, valid && z + 1 < z_end && any_fluid_d(d_p));
-            const bool work = valid && any_fluid_d(d_c);
-            // after the first iteration s_new is 0 on every non-FLUID cell (snew_of), so A s needs no neighbour descriptors (quad_mulA_u);
-            // K(0) works on the stored s, which the reference leaves untouched outside the fluid: descriptors travel along
-            ls[buf][t] = n_c;
-            if (FIRST) ld[buf][t] = d_c;
-            lds_barrier();   // (see k_pcg_update_z)
-            if (work) {
-                QuadD m; QuadValues sv;
-                m.c = d_c; m.zm = d_m; m.zp = d_p; sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
-                m.ym = 0; m.yp = 0; m.xm = 0; m.xp = 0;
-                if (y > 0) { if (in_lo) { if (FIRST) m.ym = ld[buf][t - qpr]; sv.ym = ls[buf][t - qpr]; } else { m.ym = hc.dlo; sv.ym = FIRST ? hc.s_lo : snew4(hc.dlo, hc.r_lo, hc.s_lo, beta, div_lut); } } else sv.ym = zero4;
-                if (y + 1 < g.ny) { if (in_hi) { if (FIRST) m.yp = ld[buf][t + qpr]; sv.yp = ls[buf][t + qpr]; } else { m.yp = hc.dhi; sv.yp = FIRST ? hc.s_hi : snew4(hc.dhi, hc.r_hi, hc.s_hi, beta, div_lut); } } else sv.yp = zero4;
-                if (x0 > 0) { if (t > 0) { if (FIRST) m.xm = dbyte(ld[buf][t - 1], 3); sv.xm = ls[buf][t - 1].w; } else { m.xm = hc.dxm; sv.xm = FIRST ? hc.sxm : snew_of(hc.dxm, hc.rxm, hc.sxm, beta, div_lut); } } else sv.xm = 0.f;
-                if (x0 + 4 < g.nx) { if (t < T - 1) { if (FIRST) m.xp = dbyte(ld[buf][t + 1], 0); sv.xp = ls[buf][t + 1].x; } else { m.xp = hc.dxp; sv.xp = FIRST ? hc.sxp : snew_of(hc.dxp, hc.rxp, hc.sxp, beta, div_lut); } } else sv.xp = 0.f;
+            if (next_plane && halo_thread) {
+                const size_t pb = (size_t)(z + 1) * plane;
+                dq_hn = ldu32o(dvol + pb, hoff >> 2) & hmask; s_hn = ld4o(s_in + pb, hoff); if (!FIRST) r_hn = ld4o(r + pb, hoff);
+            }
+            // exchange of plane z (double buffered by plane parity: one LDS-only barrier per plane, see k_pcg_update_z)
+            float4* const eb = ext + ((z - z_begin) & 1) * ext_n;
+            eb[t + qpr] = n_c;
+            if (halo_thread) eb[halo_slot] = h_c;
+            lds_barrier();
+            {
+                QuadValues sv;
+                sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
+                sv.ym = eb[t]; sv.yp = eb[t + 2 * qpr];
+                sv.xm = and_mask(eb[t + qpr - 1].w, mxm); sv.xp = and_mask(eb[t + qpr + 1].x, mxp);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (FIRST) { if (dbyte(d_c, j) & 0x80) acc += f4(n_c, j) * quad_mulA_d(m, sv, j); }
-                    else acc += f4(n_c, j) * quad_mulA_u(d_c, sv, j);      // n_c = 0 on non-FLUID lanes: they add an exact zero
-                }
+                for (int j = 0; j < 4; ++j) acc += f4(n_c, j) * quad_mulA_u(d_c, sv, j);      // n_c = 0 on non-FLUID lanes: they add an exact zero
             }
-            // plane z+2 enters (its loads have been in flight during the compute above)
-            float4 n_n = zero4;
-            if (fetch) n_n = enter_plane(base + 2 * plane, d_n, r_n, so_n, z + 2 < z_end);
-            n_m = n_c; n_c = n_p; n_p = n_n; d_m = d_c; d_c = d_p; d_p = d_n; hc = hn;
+            // planes z + 2 (own) / z + 1 (halo) enter: their loads were in flight during the stencil above
+            const float4 n_n = snew(dq_n, r_n, s_n);
+            const float4 h_n = snew(dq_hn, r_hn, s_hn);
+            if (!FIRST && fetch_own && z + 2 < z_end && valid) st4so<NT>(s_out + (size_t)(z + 2) * plane, goff, n_n);
+            n_m = n_c; n_c = n_p; n_p = n_n; d_c = d_p; d_p = dq_n; h_c = h_n;
         }
-        __syncthreads();
+        __syncthreads();   // the LDS buffers are reused by the next tile
     }
     const float tot = block_reduce<T, false>(acc, sm);
     if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
