@@ -47,12 +47,13 @@ def algorithmic_bytes(kernel, F, P, A, Fb):
     return float(table.get(kernel, 0))
 
 
-def dense_pcg_benchmark(n=256, iterations=32, tuning=None):
+def dense_pcg_benchmark(n=256, iterations=32, tuning=None, repeats=1):
     """M3 of BASELINE.md: SOLID shell + all-FLUID interior, b = sin*sin*sin, fixed iteration count, per-kernel HIP-event timing.
     tuning: {knob: value} for blub_fluid_set_tuning (tile-geometry sweeps, tools/dense_sweep.sh)."""
     import blub_amd
-    h = blub_amd.HybridFluid((n, n, n), 16, binning="off")
-    for k_, v_ in (tuning or {}).items():
+    tuning = dict(tuning or {})
+    h = blub_amd.HybridFluid((n, n, n), 16, binning="off", volume_shift_kib=tuning.pop("volume_shift_kib", 0))
+    for k_, v_ in tuning.items():
         h.set_tuning(k_, v_)
     marker = np.zeros((n, n, n), np.int8)
     marker[1:-1, 1:-1, 1:-1] = 1
@@ -63,14 +64,17 @@ def dense_pcg_benchmark(n=256, iterations=32, tuning=None):
     h.set_solver_config(0, error_tolerance=0.0, max_num_iterations=iterations, error_check_frequency=4)
     dt = blub_amd.default_simulation_delta()
     N, F = n ** 3, int((marker == 1).sum())
-    for rep in range(2):   # first repetition warms up
+    per_repeat = []
+    for rep in range(1 + max(1, repeats)):   # first repetition warms up
         h.write_volume("residual", b)
         h.mark_pressure_initialised(0, False)
-        h.profile_enable(rep == 1)
+        h.profile_enable(rep >= 1)
         h.profile_reset()
         h.run_stage("solve_velocity", dt)
         h.synchronize()
-    prof = h.profile_read()
+        if rep >= 1:
+            prof = h.profile_read()
+            per_repeat.append({k: round(prof[k]["total_ms"] / prof[k]["launches"] * 1e3, 2) for k in ("pcg_dir", "pcg_update")})
     h.profile_enable(False)
     out = {}
     for k in ("pcg_dir", "pcg_update"):
@@ -98,7 +102,7 @@ def dense_pcg_benchmark(n=256, iterations=32, tuning=None):
     # one iteration = pcg_dir + pcg_update.  "iter_bytes" is SURVEY 8(d)'s figure for the UNFUSED three-phase iteration
     # (3N + 36F); the fused pair itself only has to move 2N + 32F ("iter_bytes_fused"), both fractions are reported.
     fused = 2 * N + 32 * F
-    return {"grid": "%d^3" % n, "fluid_cells": F, "iterations": iters, "us_per_iteration_kernels": round(iter_us, 1), "kernel_source_sha16": now,
+    return {"grid": "%d^3" % n, "fluid_cells": F, "iterations": iters, "us_per_iteration_kernels": round(iter_us, 1), "kernel_source_sha16": now, "per_repeat_avg_us": per_repeat if repeats > 1 else None,
             "iter_bytes": 3 * N + 36 * F, "iter_GBs": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9, 1),
             "iter_frac": round((3 * N + 36 * F) / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "iter_bytes_fused": fused, "iter_frac_fused": round(fused / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
@@ -349,6 +353,9 @@ def main():
     ap.add_argument("--dense-size", type=int, default=256)
     ap.add_argument("--dense-tile-quads", type=int, default=0, help="--dense-only: tile width of the dense PCG kernels (256 | 512 | 1024 quads; tuning)")
     ap.add_argument("--dense-tile-planes", type=int, default=0, help="--dense-only: planes marched per tile (tuning)")
+    ap.add_argument("--dense-ku-variant", type=int, default=0)
+    ap.add_argument("--volume-shift-kib", type=int, default=0, help="--dense-only: blub_fluid_desc::volume_shift_kib (0 = default 64, -1 = one allocation per volume; placement study)")
+    ap.add_argument("--dense-repeats", type=int, default=1, help="--dense-only: timed repetitions of the solve on the same allocation (variance study)")
     ap.add_argument("--dense-grid", type=int, default=0, help="--dense-only: launch grid of the dense PCG kernels (tuning)")
     ap.add_argument("--pcg-mapping", default="auto", choices=["auto", "rows", "bricks", "bricks_staged"], help="work mapping of the PCG kernels (tuning)")
     ap.add_argument("--transfer-only", action="store_true", help="only run the 256^3 transfer micro-benchmark M4 (65 M particles)")
@@ -358,8 +365,10 @@ def main():
     import blub_amd
 
     if args.dense_only:
-        tuning = {k_: v_ for k_, v_ in (("dense_tile_quads", args.dense_tile_quads), ("dense_tile_planes", args.dense_tile_planes), ("dense_grid", args.dense_grid)) if v_}
-        res = dense_pcg_benchmark(args.dense_size, 32, tuning)
+        tuning = {k_: v_ for k_, v_ in (("dense_tile_quads", args.dense_tile_quads), ("dense_tile_planes", args.dense_tile_planes), ("dense_grid", args.dense_grid), ("dense_ku_variant", args.dense_ku_variant)) if v_}
+        if args.volume_shift_kib:
+            tuning["volume_shift_kib"] = args.volume_shift_kib
+        res = dense_pcg_benchmark(args.dense_size, 32, tuning, repeats=args.dense_repeats)
         res["tuning"] = tuning
         print(json.dumps(res))
         return

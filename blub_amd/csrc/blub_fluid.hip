@@ -71,6 +71,7 @@ struct blub_fluid {
     bool bricks_premarked = false;            // brick_fluid already holds the marks of the current particle positions (set and consumed inside stage_advect)
     float gravity[3] = {0, 0, 0};
     int device = 0;
+    char* slab = nullptr; size_t slab_bytes = 0, slab_used = 0, slab_shift = 0; int slab_count = 0;   // grid volumes from one allocation (see vol_alloc)
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     uint32_t precond_mode = BLUB_PRECOND_ZERO, binning_mode = BLUB_BINNING_FIXED;
@@ -107,6 +108,7 @@ struct blub_fluid {
     uint32_t max_steps_in_flight = 4;
     bool all_touched = false;
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, >= 1 brick lists
+    int dense_ku_variant = 0;                 // (measurement only, to be removed: 1 = round-2 update kernel)
     int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
     uint8_t* dvol = nullptr;
@@ -204,6 +206,24 @@ template <class T>
 static int dev_alloc_zero(hipStream_t stream, T** p, size_t count) {
     HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
     HIP_TRY(hipMemsetAsync(*p, 0, count * sizeof(T), stream));
+    return BLUB_OK;
+}
+// Grid volumes are carved from ONE allocation, volume i shifted by i x 64 KiB against its 2 MiB-aligned slot.  Measured at 512^3
+// (profiles/r03_volume_placement_512.txt): with one hipMalloc per volume -- all 2 MiB aligned, i.e. every concurrent stream of a stencil
+// kernel (r, s, p, descriptor at the same in-plane offset) starts in the same channel / bank phase -- the dense PCG update kernel takes
+// 513, 578 or 600-608 us per launch depending on the physical frames a process happens to get (constant within a process); from one
+// allocation the time is a deterministic function of the relative shift: 602 us at 0, 535-540 us at 32 .. 64 KiB per volume, 575-588 us
+// at 128 / 224 KiB.  256^3 does not care (its working set lives in the Infinity Cache).  blub_fluid_desc::volume_shift_kib overrides.
+template <class T>
+static int vol_alloc(blub_fluid* h, T** p, size_t count) {
+    if (!h->slab) return dev_alloc_zero(h->stream, p, count);
+    const size_t bytes = count * sizeof(T);
+    size_t at = (h->slab_used + 0x1FFFFFull) & ~0x1FFFFFull;      // 2 MiB aligned ...
+    at += ((size_t)h->slab_count * h->slab_shift) & 0x1FFFFFull;   // ... plus the shift of this volume
+    if (at + bytes > h->slab_bytes) return set_error(BLUB_ERR_OUT_OF_MEMORY, "volume slab exhausted");
+    *p = reinterpret_cast<T*>(h->slab + at);
+    h->slab_used = at + bytes; h->slab_count += 1;
+    HIP_TRY(hipMemsetAsync(*p, 0, bytes, h->stream));
     return BLUB_OK;
 }
 static int copy_sync(blub_fluid* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
@@ -446,8 +466,12 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
                 else                                                                                                                                            \
                     LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));                           \
-                LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,     \
-                       (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
+                if (h->dense_ku_variant == 0)                                                                                                                   \
+                    LAUNCH_LDS(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual, \
+                               (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                   \
+                else                                                                                                                                            \
+                    LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z_r2<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual, \
+                           (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                       \
             }                                                                                                                                                   \
         }
         // p / r of KU are touched exactly once per kernel: non-temporal (66.8 -> 62.5 us at 256^3); s_out of KD is re-read as a halo: default policy
@@ -562,7 +586,7 @@ static void destroy(blub_fluid* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    auto F = [h](void* p) { if (p && !(h->slab && (char*)p >= h->slab && (char*)p < h->slab + h->slab_bytes)) (void)hipFree(p); };
     F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->next1); F(h->next2); F(h->marker); for (auto p : h->ll) F(p);
     for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
@@ -574,6 +598,7 @@ static void destroy(blub_fluid* h) {
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->prof_origin) (void)hipEventDestroy(h->prof_origin);
+    if (h->slab) (void)hipFree(h->slab);
     if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -626,10 +651,17 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->pos, P)); A(dev_alloc_zero(h->stream, &h->pos_tmp, P));
     for (int c = 0; c < 3; ++c) A(dev_alloc_zero(h->stream, &h->pvel[c], P));
     A(dev_alloc_zero(h->stream, &h->next1, P)); A(dev_alloc_zero(h->stream, &h->next2, P));
-    A(dev_alloc_zero(h->stream, &h->marker, h->N));
-    for (int c = 0; c < 3; ++c) { A(dev_alloc_zero(h->stream, &h->ll[c], h->N)); A(dev_alloc_zero(h->stream, &h->vel[c], h->N)); }
-    for (int w = 0; w < 2; ++w) A(dev_alloc_zero(h->stream, &h->pressure[w], h->N));
-    A(dev_alloc_zero(h->stream, &h->residual, h->N)); A(dev_alloc_zero(h->stream, &h->search, h->N)); A(dev_alloc_zero(h->stream, &h->aux, h->N)); A(dev_alloc_zero(h->stream, &h->aux_temp, h->N));
+    if (d->volume_shift_kib != 0xFFFFFFFFu) {      // (0xFFFFFFFF: one allocation per volume)
+        h->slab_shift = (size_t)(d->volume_shift_kib ? d->volume_shift_kib : 64u) * 1024u;
+        const size_t per = ((h->N * 4 + 0x1FFFFFull) & ~0x1FFFFFull) + 0x400000ull;      // 2 MiB alignment + up to 2 MiB of shift
+        h->slab_bytes = 18 * per;                                                          // 16 volumes (two of them bytes) + head room
+        if (hipMalloc((void**)&h->slab, h->slab_bytes) != hipSuccess) { h->slab = nullptr; h->slab_bytes = 0; (void)hipGetLastError(); }   // (fall back to separate allocations)
+    }
+    A(vol_alloc(h, &h->residual, h->N)); A(vol_alloc(h, &h->search, h->N)); A(vol_alloc(h, &h->aux, h->N)); A(vol_alloc(h, &h->aux_temp, h->N));
+    for (int w = 0; w < 2; ++w) A(vol_alloc(h, &h->pressure[w], h->N));
+    A(vol_alloc(h, &h->dvol, h->N));
+    A(vol_alloc(h, &h->marker, h->N));
+    for (int c = 0; c < 3; ++c) { A(vol_alloc(h, &h->ll[c], h->N)); A(vol_alloc(h, &h->vel[c], h->N)); }
     A(dev_alloc_zero(h->stream, &h->scan_totals, (h->N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
     PcgGeom& gm = h->geom;
     gm.g = h->g; gm.qpr = h->g.nx / 4; gm.qpp = gm.qpr * h->g.ny; gm.plane_blocks = (gm.qpp + 255) / 256;
@@ -652,7 +684,6 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
             h->tail_grid = (std::min(256, cus) / 8) * 8;             // at most one block per CU (always co-resident when per_cu >= 1), a multiple of 8
         else h->use_tail = false;
     }
-    A(dev_alloc_zero(h->stream, &h->dvol, h->N));
     BrickGeom& bg = h->bg;
     bg.g = h->g; bg.nbx = (h->g.nx + BX - 1) / BX; bg.nby = (h->g.ny + BY - 1) / BY; bg.nbz = (h->g.nz + BZ - 1) / BZ; bg.nb = bg.nbx * bg.nby * bg.nbz;
     brick_geom_set_magic(bg);
@@ -730,7 +761,6 @@ extern "C" {
 
 const char* blub_last_error_string(void) { return blub::g_last_error.c_str(); }
 const char* blub_version_string(void) { return "blubhip 0.1 (gfx950)"; }
-
 int blub_fluid_create(const blub_fluid_desc* desc, blub_fluid** out) { return blub::create(desc, out); }
 void blub_fluid_destroy(blub_fluid* h) { blub::destroy(h); }
 
@@ -990,6 +1020,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_tail_first") h->tail_first_forced = value;
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
+    else if (k == "dense_ku_variant") h->dense_ku_variant = value;
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);
     else if (k == "dense_tile_quads" || k == "dense_tile_planes" || k == "dense_grid") {
         HIP_TRY(hipStreamSynchronize(h->stream));

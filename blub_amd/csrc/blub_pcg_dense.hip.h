@@ -57,7 +57,7 @@ __device__ __forceinline__ float4 zero_outside_fluid(uint32_t dq, const float4& 
 
 // ---- KU: p += alpha s; r -= alpha A s; partial (M^-1 r).r and max|r|  (pressure_update_pressure_and_residual.comp:23-59)
 template <int T, bool NT = false>
-__global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+__global__ __launch_bounds__(T) void k_pcg_update_z_r2(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
                                                     float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
                                                     const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[T / 64 + 1];
@@ -176,9 +176,101 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
 //   * registers hold s_new of planes z-1, z, z+1; s_new of a plane is computed (and written to s_out) when the plane enters;
 //   * s_new is 0 on every non-FLUID cell, so A s needs no neighbour descriptors (quad_mulA_u).  K(0) reads the stored s, which the
 //     reference leaves untouched outside the fluid: it is zeroed outside the fluid as it arrives, which gives the same sums.
+//   * the kernel is bound by the bytes it keeps IN FLIGHT, not by instruction issue (the first version of this formulation halved the
+//     VALU count and got slower: one plane ahead = 36 B per thread at 4 waves per SIMD is ~46 KB per CU, Little's law wants that for
+//     6 TB/s at 2 us).  Raw loads are therefore requested TWO planes ahead (own quad: plane z + 3 while plane z is computed; halo quad:
+//     plane z + 2), in two register sets that alternate (the plane loop is unrolled by two), unconditionally and in a fixed order, so
+//     that the compiler's s_waitcnt counts them exactly: planes that are not needed are read from the tile's first plane (cache hits)
+//     with their descriptors masked.  Waves that own halo quads and waves that do not run two instantiations of the loop (HALO) for the
+//     same reason -- a conditional load between the two sets would force vmcnt(0) at every use.
 // Requires 2 qpr <= T (set_dense_geometry picks T accordingly; grids wider than 2048 cells use the brick mapping).
 // Dynamic LDS: 2 x (T + 2 qpr) float4 (dense_dir_lds_bytes).
 __host__ __device__ inline size_t dense_dir_lds_bytes(int T, int qpr) { return (size_t)2 * (size_t)(T + 2 * qpr) * 16u; }
+
+struct DirRaw { uint32_t dq; float4 s, r; };
+template <bool FIRST>
+__device__ __forceinline__ void dir_raw_load(DirRaw& R, const uint8_t* __restrict__ dv, const float* __restrict__ sp, const float* __restrict__ rp, uint32_t off, uint32_t mask) {
+    R.dq = ldu32o(dv, off >> 2) & mask;
+    R.s = ld4o(sp, off);
+    if (!FIRST) R.r = ld4o(rp, off); else R.r = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <bool FIRST>
+__device__ __forceinline__ float4 dir_snew(const DirRaw& R, float beta, const DivConst* lut) {      // s_new of a quad from its raw loads
+    if (FIRST) return zero_outside_fluid(R.dq, R.s);
+    return snew4(R.dq, R.r, R.s, beta, lut);
+}
+struct DirTile {      // per-thread constants of a tile
+    uint32_t goff, vmask, mxm, mxp, hoff, hmask;
+    int halo_slot, z_begin, z_end;
+    bool valid, halo_thread;
+};
+// the plane march of one tile; HALO: this wave owns halo quads
+template <int T, bool FIRST, bool NT, bool HALO>
+__device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, float4* __restrict__ ext, const uint8_t* __restrict__ dvol, const float* __restrict__ r,
+                                          const float* __restrict__ s_in, float* __restrict__ s_out, float beta, const DivConst* lut, float& acc) {
+    const Grid g = gz.g;
+    const int t = threadIdx.x, qpr = gz.qpr, ext_n = T + 2 * qpr;
+    const size_t plane = (size_t)g.nx * (size_t)g.ny;
+    const int zb = K.z_begin, ze = K.z_end;
+    // (uniform) base of plane `zz` if it exists and is wanted, else of the tile's first plane with a zero descriptor mask
+    auto plane_of = [&](int zz, bool wanted, uint32_t& pm) -> size_t { const bool ok = wanted && zz >= 0 && zz < g.nz; pm = ok ? 0xFFFFFFFFu : 0u; return (size_t)(ok ? zz : zb) * plane; };
+    float4 n_m, n_c, n_p, h_c = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t d_c, d_p;
+    DirRaw A, B, HA, HB;                       // own planes z + 2 / z + 3 and halo planes z + 1 / z + 2, alternating roles
+    HA.dq = 0; HB.dq = 0; HA.s = HA.r = HB.s = HB.r = make_float4(0.f, 0.f, 0.f, 0.f);
+    {   // ---- planes zb - 1, zb, zb + 1 of the own quad and plane zb of the halo quad: loaded and converted at once
+        uint32_t pm_m, pm_c, pm_p;
+        const size_t b_m = plane_of(zb - 1, true, pm_m), b_c = plane_of(zb, true, pm_c), b_p = plane_of(zb + 1, true, pm_p);
+        DirRaw M, C, P, H;
+        if (HALO) dir_raw_load<FIRST>(H, dvol + b_c, s_in + b_c, r + b_c, K.hoff, K.hmask);
+        dir_raw_load<FIRST>(M, dvol + b_m, s_in + b_m, r + b_m, K.goff, K.vmask & pm_m);
+        dir_raw_load<FIRST>(C, dvol + b_c, s_in + b_c, r + b_c, K.goff, K.vmask & pm_c);
+        dir_raw_load<FIRST>(P, dvol + b_p, s_in + b_p, r + b_p, K.goff, K.vmask & pm_p);
+        // ... and the first set of the pipeline: own plane zb + 2, halo plane zb + 1
+        uint32_t pm_a, pm_ha;
+        const size_t b_a = plane_of(zb + 2, zb + 1 < ze, pm_a), b_ha = plane_of(zb + 1, zb + 1 < ze, pm_ha);
+        if (HALO) dir_raw_load<FIRST>(HA, dvol + b_ha, s_in + b_ha, r + b_ha, K.hoff, K.hmask & pm_ha);
+        dir_raw_load<FIRST>(A, dvol + b_a, s_in + b_a, r + b_a, K.goff, K.vmask & pm_a);
+        n_m = dir_snew<FIRST>(M, beta, lut);                                      // z-halo plane: not written
+        n_c = dir_snew<FIRST>(C, beta, lut);
+        n_p = dir_snew<FIRST>(P, beta, lut);
+        if (HALO) h_c = dir_snew<FIRST>(H, beta, lut);
+        d_c = C.dq; d_p = P.dq;
+        if (!FIRST && K.valid) {
+            st4so<NT>(s_out + b_c, K.goff, n_c);
+            if (zb + 1 < ze) st4so<NT>(s_out + (size_t)(zb + 1) * plane, K.goff, n_p);
+        }
+    }
+    // one plane: request `issue` / `hissue` (own plane z + 3, halo plane z + 2), stencil of plane z, then `use` / `huse` (own plane z + 2, halo plane z + 1) enter
+    auto body = [&](int z, DirRaw& issue, DirRaw& hissue, DirRaw& use, DirRaw& huse) {
+        uint32_t pm_o, pm_h;
+        const size_t b_o = plane_of(z + 3, z + 2 < ze, pm_o), b_h = plane_of(z + 2, z + 2 < ze, pm_h);
+        if (HALO) dir_raw_load<FIRST>(hissue, dvol + b_h, s_in + b_h, r + b_h, K.hoff, K.hmask & pm_h);
+        dir_raw_load<FIRST>(issue, dvol + b_o, s_in + b_o, r + b_o, K.goff, K.vmask & pm_o);
+        // exchange of plane z (double buffered by plane parity: one LDS-only barrier per plane, see k_pcg_update_z)
+        float4* const eb = ext + ((z - zb) & 1) * ext_n;
+        eb[t + qpr] = n_c;
+        if (HALO) { if (K.halo_thread) eb[K.halo_slot] = h_c; }
+        lds_barrier();
+        {
+            QuadValues sv;
+            sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
+            sv.ym = eb[t]; sv.yp = eb[t + 2 * qpr];
+            sv.xm = and_mask(eb[t + qpr - 1].w, K.mxm); sv.xp = and_mask(eb[t + qpr + 1].x, K.mxp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += f4(n_c, j) * quad_mulA_u(d_c, sv, j);      // n_c = 0 on non-FLUID lanes: they add an exact zero
+        }
+        const float4 n_n = dir_snew<FIRST>(use, beta, lut);
+        if (HALO) h_c = dir_snew<FIRST>(huse, beta, lut);
+        if (!FIRST && z + 2 < ze && K.valid) st4so<NT>(s_out + (size_t)(z + 2) * plane, K.goff, n_n);
+        n_m = n_c; n_c = n_p; n_p = n_n; d_c = d_p; d_p = use.dq;
+    };
+    for (int z = zb; z < ze; z += 2) {
+        body(z, B, HB, A, HA);
+        if (z + 1 < ze) body(z + 1, A, HA, B, HB);
+    }
+}
+
 template <int T, bool FIRST, bool NT = false>
 __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
                                                  float* __restrict__ s_out, const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
@@ -192,97 +284,162 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     if (!pcg_dir_prologue<T>(ctrl, part_upd, num_part, tolerance, iteration, check_prev, sm2, beta)) return;
     const Grid g = gz.g;
     const int t = threadIdx.x, qpr = gz.qpr;
-    const size_t plane = (size_t)g.nx * (size_t)g.ny;
-    const int ext_n = T + 2 * qpr;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool halo_wave = (t & ~63) < 2 * qpr;            // wave-uniform
     float acc = 0.0f;
-    auto snew = [&](uint32_t dq, const float4& rr, const float4& so) -> float4 {      // s_new of a quad from its raw loads
-        if (FIRST) return zero_outside_fluid(dq, so);
-        return snew4(dq, rr, so, beta, div_lut);
-    };
     const int padded = ((gz.tiles + 7) >> 3) << 3;
     for (int it = blockIdx.x; it < padded; it += gridDim.x) {
         const int tile = xcd_tile(it, gz.tiles);
         if (tile >= gz.tiles || !tile_flags[tile]) continue;
         const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
         const int q0 = pt * T, q = q0 + t;
-        const bool valid = q < gz.qpp;
+        DirTile K;
+        K.valid = q < gz.qpp;
         const int x0 = (q % qpr) << 2;
-        const int z_begin = zci * gz.zc, z_end = min(z_begin + gz.zc, g.nz);
-        const uint32_t goff = valid ? (uint32_t)q * 16u : 0u;                     // byte offset of the own quad inside a plane of an f32 volume
-        const uint32_t vmask = valid ? 0xFFFFFFFFu : 0u;
-        const uint32_t mxm = (valid && x0 > 0) ? 0xFFFFFFFFu : 0u, mxp = (valid && x0 + 4 < g.nx) ? 0xFFFFFFFFu : 0u;
+        K.z_begin = zci * gz.zc; K.z_end = min(K.z_begin + gz.zc, g.nz);
+        K.goff = K.valid ? (uint32_t)q * 16u : 0u;                                // byte offset of the own quad inside a plane of an f32 volume
+        K.vmask = K.valid ? 0xFFFFFFFFu : 0u;
+        K.mxm = (K.valid && x0 > 0) ? 0xFFFFFFFFu : 0u; K.mxp = (K.valid && x0 + 4 < g.nx) ? 0xFFFFFFFFu : 0u;
         // halo quad of this thread (threads 0 .. 2 qpr - 1): one row before the tile's first quad / one row after its last
-        const bool halo_thread = t < 2 * qpr;
+        K.halo_thread = t < 2 * qpr;
         const int hq = t < qpr ? q0 - qpr + t : q0 + T + (t - qpr);
-        const bool halo_valid = halo_thread && hq >= 0 && hq < gz.qpp;
-        const uint32_t hoff = halo_valid ? (uint32_t)hq * 16u : 0u;
-        const uint32_t hmask = halo_valid ? 0xFFFFFFFFu : 0u;
-        const int halo_slot = t < qpr ? t : T + t;                                // upper halo: T + qpr + (t - qpr)
-        float4 n_m, n_c, n_p, h_c;               // s_new of planes z-1, z, z+1 (own quad); s_new of the halo quad at plane z
-        uint32_t d_c, d_p;                       // descriptors of planes z, z+1 (own quad)
-        {   // ---- planes z_begin - 1, z_begin, z_begin + 1 of the own quad, plane z_begin of the halo quad
-            const uint8_t* dv = dvol + (size_t)z_begin * plane;
-            const float* sp = s_in + (size_t)z_begin * plane;
-            const float* rp = r + (size_t)z_begin * plane;
-            const bool has_m = z_begin > 0, has_p = z_begin + 1 < g.nz;          // uniform
-            uint32_t dq_m = 0, dq_p = 0;
-            float4 r_m = zero4, r_p = zero4, s_m = zero4, s_p = zero4, r_c = zero4, r_h = zero4;
-            const uint32_t dq_c = ldu32o(dv, goff >> 2) & vmask;
-            const float4 s_c = ld4o(sp, goff);
-            if (!FIRST) r_c = ld4o(rp, goff);
-            if (has_m) { dq_m = ldu32o(dv - plane, goff >> 2) & vmask; s_m = ld4o(sp - plane, goff); if (!FIRST) r_m = ld4o(rp - plane, goff); }
-            if (has_p) { dq_p = ldu32o(dv + plane, goff >> 2) & vmask; s_p = ld4o(sp + plane, goff); if (!FIRST) r_p = ld4o(rp + plane, goff); }
-            uint32_t dq_h = 0; float4 s_h = zero4;
-            if (halo_thread) { dq_h = ldu32o(dv, hoff >> 2) & hmask; s_h = ld4o(sp, hoff); if (!FIRST) r_h = ld4o(rp, hoff); }
-            n_m = snew(dq_m, r_m, s_m);                                           // z-halo plane: not written
-            n_c = snew(dq_c, r_c, s_c);
-            n_p = snew(dq_p, r_p, s_p);
-            h_c = snew(dq_h, r_h, s_h);
-            d_c = dq_c; d_p = dq_p;
-            if (!FIRST && valid) {
-                float* so = s_out + (size_t)z_begin * plane;
-                st4so<NT>(so, goff, n_c);
-                if (z_begin + 1 < z_end) st4so<NT>(so + plane, goff, n_p);
-            }
-        }
-        for (int z = z_begin; z < z_end; ++z) {
-            // raw loads of plane z + 2 (own quad) and of plane z + 1 (halo quad): issued now, consumed after this plane's stencil
-            const bool next_plane = z + 1 < z_end;                               // uniform
-            const bool fetch_own = next_plane && z + 2 < g.nz;                   // uniform
-            uint32_t dq_n = 0, dq_hn = 0;
-            float4 r_n = zero4, s_n = zero4, r_hn = zero4, s_hn = zero4;
-            if (fetch_own) {
-                const size_t pb = (size_t)(z + 2) * plane;
-                dq_n = ldu32o(dvol + pb, goff >> 2) & vmask; s_n = ld4o(s_in + pb, goff); if (!FIRST) r_n = ld4o(r + pb, goff);
-            }
-            if (next_plane && halo_thread) {
-                const size_t pb = (size_t)(z + 1) * plane;
-                dq_hn = ldu32o(dvol + pb, hoff >> 2) & hmask; s_hn = ld4o(s_in + pb, hoff); if (!FIRST) r_hn = ld4o(r + pb, hoff);
-            }
-            // exchange of plane z (double buffered by plane parity: one LDS-only barrier per plane, see k_pcg_update_z)
-            float4* const eb = ext + ((z - z_begin) & 1) * ext_n;
-            eb[t + qpr] = n_c;
-            if (halo_thread) eb[halo_slot] = h_c;
-            lds_barrier();
-            {
-                QuadValues sv;
-                sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
-                sv.ym = eb[t]; sv.yp = eb[t + 2 * qpr];
-                sv.xm = and_mask(eb[t + qpr - 1].w, mxm); sv.xp = and_mask(eb[t + qpr + 1].x, mxp);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc += f4(n_c, j) * quad_mulA_u(d_c, sv, j);      // n_c = 0 on non-FLUID lanes: they add an exact zero
-            }
-            // planes z + 2 (own) / z + 1 (halo) enter: their loads were in flight during the stencil above
-            const float4 n_n = snew(dq_n, r_n, s_n);
-            const float4 h_n = snew(dq_hn, r_hn, s_hn);
-            if (!FIRST && fetch_own && z + 2 < z_end && valid) st4so<NT>(s_out + (size_t)(z + 2) * plane, goff, n_n);
-            n_m = n_c; n_c = n_p; n_p = n_n; d_c = d_p; d_p = dq_n; h_c = h_n;
-        }
+        const bool halo_valid = K.halo_thread && hq >= 0 && hq < gz.qpp;
+        K.hoff = halo_valid ? (uint32_t)hq * 16u : 0u;
+        K.hmask = halo_valid ? 0xFFFFFFFFu : 0u;
+        K.halo_slot = t < qpr ? t : T + t;                                        // upper halo: T + qpr + (t - qpr)
+        if (halo_wave) dir_march<T, FIRST, NT, true>(gz, K, ext, dvol, r, s_in, s_out, beta, div_lut, acc);
+        else dir_march<T, FIRST, NT, false>(gz, K, ext, dvol, r, s_in, s_out, beta, div_lut, acc);
         __syncthreads();   // the LDS buffers are reused by the next tile
     }
     const float tot = block_reduce<T, false>(acc, sm);
     if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
+}
+
+// ---- KU, round-3 formulation: the same pipeline as k_pcg_dir_z (halo rows in the exchange buffer, raw loads two planes ahead in two
+// alternating register sets, unconditional and in a fixed order) for p += alpha s; r -= alpha A s; partial (M^-1 r).r and max|r|
+// (pressure_update_pressure_and_residual.comp:23-59).  p and r have no halo and are touched exactly once per kernel: non-temporal.
+struct UpdRaw { uint32_t dq; float4 s, p, r; };      // s and descriptor of plane k, p and r of plane k - 1
+template <bool NT>
+__device__ __forceinline__ void upd_raw_load(UpdRaw& R, const uint8_t* __restrict__ dv, const float* __restrict__ sp, const float* __restrict__ pp, const float* __restrict__ rp,
+                                             uint32_t off, uint32_t mask) {
+    R.dq = ldu32o(dv, off >> 2) & mask;
+    R.s = ld4o(sp, off);
+    R.p = ld4so<NT>(pp, off);
+    R.r = ld4so<NT>(rp, off);
+}
+struct HaloRaw { uint32_t dq; float4 s; };
+template <int T, bool NT, bool HALO>
+__device__ __forceinline__ void upd_march(const PcgGeomZ& gz, const DirTile& K, float4* __restrict__ ext, const uint8_t* __restrict__ dvol, const float* __restrict__ s,
+                                          float* __restrict__ p, float* __restrict__ r, float alpha, const DivConst* lut, float& acc, float& emax) {
+    const Grid g = gz.g;
+    const int t = threadIdx.x, qpr = gz.qpr, ext_n = T + 2 * qpr;
+    const size_t plane = (size_t)g.nx * (size_t)g.ny;
+    const int zb = K.z_begin, ze = K.z_end;
+    auto plane_of = [&](int zz, bool wanted, uint32_t& pm) -> size_t { const bool ok = wanted && zz >= 0 && zz < g.nz; pm = ok ? 0xFFFFFFFFu : 0u; return (size_t)(ok ? zz : zb) * plane; };
+    float4 s_m, s_c, s_p, pc, rc, h_c = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t d_c, d_p;
+    UpdRaw A, B;
+    HaloRaw HA, HB;
+    HA.dq = 0; HB.dq = 0; HA.s = HB.s = make_float4(0.f, 0.f, 0.f, 0.f);
+    {   // ---- s of planes zb - 1, zb, zb + 1, p and r of plane zb, the halo quad's s of plane zb; then the first set of the pipeline
+        uint32_t pm_m, pm_c, pm_p, pm_a, pm_ha;
+        const size_t b_m = plane_of(zb - 1, true, pm_m), b_c = plane_of(zb, true, pm_c), b_p = plane_of(zb + 1, true, pm_p);
+        HaloRaw H; H.dq = 0; H.s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HALO) { H.dq = ldu32o(dvol + b_c, K.hoff >> 2) & K.hmask; H.s = ld4o(s + b_c, K.hoff); }
+        const uint32_t dq_m = ldu32o(dvol + b_m, K.goff >> 2) & (K.vmask & pm_m); const float4 sm_ = ld4o(s + b_m, K.goff);
+        UpdRaw C; upd_raw_load<NT>(C, dvol + b_c, s + b_c, p + b_c, r + b_c, K.goff, K.vmask & pm_c);
+        const uint32_t dq_p = ldu32o(dvol + b_p, K.goff >> 2) & (K.vmask & pm_p); const float4 sp_ = ld4o(s + b_p, K.goff);
+        const size_t b_a = plane_of(zb + 2, zb + 1 < ze, pm_a), b_ha = plane_of(zb + 1, zb + 1 < ze, pm_ha);
+        if (HALO) { HA.dq = ldu32o(dvol + b_ha, K.hoff >> 2) & (K.hmask & pm_ha); HA.s = ld4o(s + b_ha, K.hoff); }
+        upd_raw_load<NT>(A, dvol + b_a, s + b_a, p + b_ha, r + b_ha, K.goff, K.vmask & pm_a);      // s of plane zb + 2, p / r of plane zb + 1
+        // s is only defined on FLUID cells (the reference never writes it elsewhere): zeroed outside the fluid as it arrives, so that the
+        // stencil needs no per-neighbour tests (quad_mulA_u)
+        s_m = zero_outside_fluid(dq_m, sm_); s_c = zero_outside_fluid(C.dq, C.s); s_p = zero_outside_fluid(dq_p, sp_);
+        if (HALO) h_c = zero_outside_fluid(H.dq, H.s);
+        d_c = C.dq; d_p = dq_p; pc = C.p; rc = C.r;
+    }
+    auto body = [&](int z, UpdRaw& issue, HaloRaw& hissue, UpdRaw& use, HaloRaw& huse) {
+        uint32_t pm_o, pm_h;
+        const size_t b_o = plane_of(z + 3, z + 2 < ze, pm_o), b_h = plane_of(z + 2, z + 2 < ze, pm_h);
+        if (HALO) { hissue.dq = ldu32o(dvol + b_h, K.hoff >> 2) & (K.hmask & pm_h); hissue.s = ld4o(s + b_h, K.hoff); }
+        upd_raw_load<NT>(issue, dvol + b_o, s + b_o, p + b_h, r + b_h, K.goff, K.vmask & pm_o);      // s of plane z + 3, p / r of plane z + 2
+        float4* const eb = ext + ((z - zb) & 1) * ext_n;
+        eb[t + qpr] = s_c;
+        if (HALO) { if (K.halo_thread) eb[K.halo_slot] = h_c; }
+        lds_barrier();
+        {
+            QuadValues sv;
+            sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
+            sv.ym = eb[t]; sv.yp = eb[t + 2 * qpr];
+            sv.xm = and_mask(eb[t + qpr - 1].w, K.mxm); sv.xp = and_mask(eb[t + qpr + 1].x, K.mxp);
+            float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                  // bit masks, no per-lane branches or selects
+                const uint32_t mk = fluid_mask(d_c, j);
+                const float as = quad_mulA_u(d_c, sv, j);
+                const float pj = pp[j] + alpha * f4(s_c, j);
+                float res = rr[j];
+                res -= alpha * as;
+                pp[j] = blend_mask(pj, pp[j], mk);
+                rr[j] = blend_mask(res, rr[j], mk);
+                const float zr = precond_exact(res, lut[dbyte(d_c, j) & 7]) * res;   // (M^-1 r) r with M^-1 r = (r / d) / d, correctly rounded
+                emax = fmaxf(emax, and_mask(fabsf(res), mk));
+                acc += and_mask(zr, mk);
+            }
+            if (K.valid) {
+                const size_t b_z = (size_t)z * plane;
+                st4so<NT>(p + b_z, K.goff, make_float4(pp[0], pp[1], pp[2], pp[3]));
+                st4so<NT>(r + b_z, K.goff, make_float4(rr[0], rr[1], rr[2], rr[3]));
+            }
+        }
+        s_m = s_c; s_c = s_p; s_p = zero_outside_fluid(use.dq, use.s); d_c = d_p; d_p = use.dq; pc = use.p; rc = use.r;
+        if (HALO) h_c = zero_outside_fluid(huse.dq, huse.s);
+    };
+    for (int z = zb; z < ze; z += 2) {
+        body(z, B, HB, A, HA);
+        if (z + 1 < ze) body(z + 1, A, HA, B, HB);
+    }
+}
+
+template <int T, bool NT = false>
+__global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+                                                    float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
+                                                    const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
+    extern __shared__ float4 ext[];      // [2][T + 2 qpr]
+    __shared__ float sm[T / 64 + 1];
+    __shared__ DivConst div_lut[8];
+    pcg_fill_div_lut(div_lut);       // (the prologue's barriers publish it)
+    float alpha;
+    if (!pcg_upd_prologue<T>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
+    const Grid g = gz.g;
+    const int t = threadIdx.x, qpr = gz.qpr;
+    const bool halo_wave = (t & ~63) < 2 * qpr;            // wave-uniform
+    float acc = 0.0f, emax = 0.0f;
+    const int padded = ((gz.tiles + 7) >> 3) << 3;
+    for (int it = blockIdx.x; it < padded; it += gridDim.x) {
+        const int tile = xcd_tile(it, gz.tiles);
+        if (tile >= gz.tiles || !tile_flags[tile]) continue;
+        const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
+        const int q0 = pt * T, q = q0 + t;
+        DirTile K;
+        K.valid = q < gz.qpp;
+        const int x0 = (q % qpr) << 2;
+        K.z_begin = zci * gz.zc; K.z_end = min(K.z_begin + gz.zc, g.nz);
+        K.goff = K.valid ? (uint32_t)q * 16u : 0u;
+        K.vmask = K.valid ? 0xFFFFFFFFu : 0u;
+        K.mxm = (K.valid && x0 > 0) ? 0xFFFFFFFFu : 0u; K.mxp = (K.valid && x0 + 4 < g.nx) ? 0xFFFFFFFFu : 0u;
+        K.halo_thread = t < 2 * qpr;
+        const int hq = t < qpr ? q0 - qpr + t : q0 + T + (t - qpr);
+        const bool halo_valid = K.halo_thread && hq >= 0 && hq < gz.qpp;
+        K.hoff = halo_valid ? (uint32_t)hq * 16u : 0u;
+        K.hmask = halo_valid ? 0xFFFFFFFFu : 0u;
+        K.halo_slot = t < qpr ? t : T + t;
+        if (halo_wave) upd_march<T, NT, true>(gz, K, ext, dvol, s, p, r, alpha, div_lut, acc, emax);
+        else upd_march<T, NT, false>(gz, K, ext, dvol, s, p, r, alpha, div_lut, acc, emax);
+        __syncthreads();   // the LDS buffers are reused by the next tile
+    }
+    const float tot = block_reduce<T, false>(acc, sm);
+    const float mx = block_reduce<T, true>(emax, sm);
+    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, mx);
 }
 
 // init for this mapping: same per-quad body as the row kernel, tile flags indexed by the z-march tiles

@@ -41,7 +41,7 @@ class _SolverStats(C.Structure):
 
 class _FluidDesc(C.Structure):
     _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("max_num_particles", C.c_uint32),
-                ("device", C.c_int32), ("precond_mode", C.c_uint32), ("binning_mode", C.c_uint32), ("reserved", C.c_uint32)]
+                ("device", C.c_int32), ("precond_mode", C.c_uint32), ("binning_mode", C.c_uint32), ("volume_shift_kib", C.c_uint32)]
 
 
 class StaticObjectConfig(C.Structure):
@@ -242,7 +242,7 @@ class HybridFluid:
 
     PARTICLES_PER_GRID_CELL = 8  # hybrid_fluid.rs:90
 
-    def __init__(self, grid_dimension, max_num_particles, device=-1, precond="zero", binning="fixed", _handle=None):
+    def __init__(self, grid_dimension, max_num_particles, device=-1, precond="zero", binning="fixed", _handle=None, volume_shift_kib=0):
         """HybridFluid::new (hybrid_fluid.rs:92-100). grid_dimension = (x, y, z)."""
         self._L = load_library()
         self._h = C.c_void_p()
@@ -250,7 +250,7 @@ class HybridFluid:
             self._h = _handle
         else:
             d = _FluidDesc(int(grid_dimension[0]), int(grid_dimension[1]), int(grid_dimension[2]), int(max_num_particles),
-                           int(device), PRECOND[precond], BINNING[binning], 0)
+                           int(device), PRECOND[precond], BINNING[binning], int(volume_shift_kib) & 0xFFFFFFFF)
             _check(self._L, self._L.blub_fluid_create(C.byref(d), C.byref(self._h)))
         dim = (C.c_uint32 * 3)()
         _check(self._L, self._L.blub_fluid_grid_dimension(self._h, dim))

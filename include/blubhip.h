@@ -71,7 +71,8 @@ typedef struct blub_fluid_desc {
     int32_t device;                /* HIP device ordinal; -1 = current device */
     uint32_t precond_mode;         /* blub_precond_mode */
     uint32_t binning_mode;         /* blub_binning_mode */
-    uint32_t reserved;
+    uint32_t volume_shift_kib;     /* placement of the grid volumes inside the engine's one allocation: volume i is shifted by i x this many KiB against its
+                                    * 2 MiB-aligned slot (0 = default 64; 0xFFFFFFFF = one allocation per volume).  A performance knob: see vol_alloc in blub_fluid.hip */
 } blub_fluid_desc;
 
 /* ---- scene JSON: src/scene/mod.rs:19-43 (SceneConfig / FluidConfig / Box) -- host only, no device needed -------- */
