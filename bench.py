@@ -353,7 +353,6 @@ def main():
     ap.add_argument("--dense-size", type=int, default=256)
     ap.add_argument("--dense-tile-quads", type=int, default=0, help="--dense-only: tile width of the dense PCG kernels (256 | 512 | 1024 quads; tuning)")
     ap.add_argument("--dense-tile-planes", type=int, default=0, help="--dense-only: planes marched per tile (tuning)")
-    ap.add_argument("--dense-ku-variant", type=int, default=0)
     ap.add_argument("--volume-shift-kib", type=int, default=0, help="--dense-only: blub_fluid_desc::volume_shift_kib (0 = default 64, -1 = one allocation per volume; placement study)")
     ap.add_argument("--dense-repeats", type=int, default=1, help="--dense-only: timed repetitions of the solve on the same allocation (variance study)")
     ap.add_argument("--dense-grid", type=int, default=0, help="--dense-only: launch grid of the dense PCG kernels (tuning)")
@@ -365,7 +364,7 @@ def main():
     import blub_amd
 
     if args.dense_only:
-        tuning = {k_: v_ for k_, v_ in (("dense_tile_quads", args.dense_tile_quads), ("dense_tile_planes", args.dense_tile_planes), ("dense_grid", args.dense_grid), ("dense_ku_variant", args.dense_ku_variant)) if v_}
+        tuning = {k_: v_ for k_, v_ in (("dense_tile_quads", args.dense_tile_quads), ("dense_tile_planes", args.dense_tile_planes), ("dense_grid", args.dense_grid)) if v_}
         if args.volume_shift_kib:
             tuning["volume_shift_kib"] = args.volume_shift_kib
         res = dense_pcg_benchmark(args.dense_size, 32, tuning, repeats=args.dense_repeats)

@@ -188,6 +188,104 @@ __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uin
     }
 }
 
+// Passes 1 + 2 in ONE launch (the headline scene is bound by its number of dependent launches: two list builds per step).  Every block
+// classifies its 1024 bricks, publishes its four counts followed by a sequence-tagged ready flag (release), waits until the flags of ALL
+// blocks carry this build's sequence number (every block of the grid is co-resident: the host only uses this kernel while the grid has at
+// most one block per CU) and scatters with the same deterministic offsets as k_bricks_scatter.  Lists, counts and snapshot are identical
+// to the two-kernel build.
+__global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, int all_touched, int own_bz_lo, int own_bz_hi, uint8_t* __restrict__ brick_fluid,
+                                                       uint8_t* __restrict__ brick_active, uint8_t* __restrict__ brick_touched, uint32_t* block_counts4 /* 4 per block */,
+                                                       uint32_t* block_ready, uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
+                                                       uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq, BrickCounts* __restrict__ host_snapshot) {
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t base[4], total[4];
+    __shared__ uint32_t wtot[16];
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    const int nblocks = gridDim.x;
+    uint32_t fl = 0;
+    if (b < bg.nb) {
+        const bool f = brick_fluid[b] != 0;
+        bool act;
+        if (phase == COMPACT_ALL_ACTIVE) act = true;
+        else {
+            int bx, by, bz; brick_coords(bg, b, bx, by, bz);
+            uint32_t any = 0;   // all 27 flags are loaded unconditionally (one batch of independent loads, no short-circuit chain)
+#pragma unroll
+            for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int qx = bx + dx, qy = by + dy, qz = bz + dz;
+                        const bool inside = (unsigned)qx < (unsigned)bg.nbx && (unsigned)qy < (unsigned)bg.nby && (unsigned)qz < (unsigned)bg.nbz;
+                        any |= (uint32_t)brick_fluid[inside ? (qz * bg.nby + qy) * bg.nbx + qx : b] & (inside ? 0xFFu : 0u);
+                    }
+            act = any != 0;
+            if (phase == COMPACT_STEP_B) act = act || brick_active[b] != 0;
+        }
+        const bool touched = all_touched || brick_touched[b] != 0;
+        const bool stale = (phase == COMPACT_STEP_A) && touched && !act;
+        int bx_own, by_own, bz_own; brick_coords(bg, b, bx_own, by_own, bz_own); (void)bx_own; (void)by_own;
+        const bool own = bz_own >= own_bz_lo && bz_own < own_bz_hi;   // z-slab decomposition: lists of work hold own bricks only
+        fl = ((f && own) ? BF_FLUID : 0) | ((act && own) ? BF_ACTIVE : 0) | (stale ? BF_STALE : 0) | ((act || stale) ? BF_RESET : 0);
+        brick_active[b] = act;
+        if (phase == COMPACT_STEP_A) brick_touched[b] = act;
+        else if (act) brick_touched[b] = 1;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bf = __ballot((fl & BF_FLUID) != 0), ba = __ballot((fl & BF_ACTIVE) != 0), br = __ballot((fl & BF_RESET) != 0), bs = __ballot((fl & BF_STALE) != 0);
+    if (lane == 0) { wtot[wave] = (uint32_t)__popcll(bf) | ((uint32_t)__popcll(ba) << 8) | ((uint32_t)__popcll(br) << 16); sm[wave] = (uint32_t)__popcll(bs); }
+    __syncthreads();      // (also: every thread of the block has read its 27 neighbour flags before any of them is cleared below -- for THIS block's bricks;
+                          //  other blocks' flags are cleared by their owners only after the grid-wide wait that follows)
+    if (threadIdx.x == 0) {
+        uint32_t tf = 0, ta = 0, tr = 0, ts = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t q = wtot[w]; tf += q & 0xFFu; ta += (q >> 8) & 0xFFu; tr += (q >> 16) & 0xFFu; ts += sm[w]; }
+        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 0, tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 1, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 2, tr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 3, ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(block_ready + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {   // one wave waits for all blocks and sums their counts: lanes stride over the blocks in order
+        uint32_t before[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};
+        for (int k = threadIdx.x; k < nblocks; k += 64) {
+            while (__hip_atomic_load(block_ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            uint32_t c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = __hip_atomic_load(block_counts4 + 4 * k + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { all[q] += c[q]; if (k < (int)blockIdx.x) before[q] += c[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { before[q] += __shfl_down(before[q], off, 64); all[q] += __shfl_down(all[q], off, 64); }
+        if (threadIdx.x == 0) for (int q = 0; q < 4; ++q) { base[q] = before[q]; total[q] = all[q]; }
+    }
+    __syncthreads();
+    // every block has classified by now (its flag is set after its classification): the marks are consumed, clear them for the next build
+    if (b < bg.nb) brick_fluid[b] = 0;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t of = (uint32_t)__popcll(bf & below), oa = (uint32_t)__popcll(ba & below), orr = (uint32_t)__popcll(br & below);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t q = w < wave ? wtot[w] : 0u; of += q & 0xFFu; oa += (q >> 8) & 0xFFu; orr += (q >> 16) & 0xFFu; }
+    if (fl & BF_FLUID) list_fluid[base[0] + of] = (uint32_t)b;
+    if (fl & BF_ACTIVE) list_active[base[1] + oa] = (uint32_t)b;
+    if (fl & BF_RESET) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        BrickCounts c; c.n_fluid = total[0]; c.n_active = total[1]; c.n_reset = total[2]; c.n_stale = total[3]; c.seq = seq; c.pad0 = 0; c.pad1 = 0; c.seq_check = seq;
+        *counts = c;
+        if (host_snapshot) {   // pinned host ring slot (path selection only): payload first, tags last
+            host_snapshot->n_fluid = c.n_fluid; host_snapshot->n_active = c.n_active; host_snapshot->n_reset = c.n_reset; host_snapshot->n_stale = c.n_stale;
+            __threadfence_system();
+            host_snapshot->seq = seq; host_snapshot->seq_check = seq;
+        }
+    }
+}
+
 // ---- static marker pattern: transfer_clear.comp:10-14 + transfer_set_boundary_marker.comp:11-19 --------------------
 __device__ __forceinline__ uint32_t static_marker_quad(const Grid& g, const float4* __restrict__ solid, int base, int x0, int y, int z) {
     const bool shell_yz = (y == 0) | (z == 0) | (y == g.ny - 1) | (z == g.nz - 1);

@@ -97,6 +97,8 @@ struct blub_fluid {
     uint32_t *list_fluid = nullptr, *list_active = nullptr, *list_reset = nullptr;
     uint8_t* brick_flags = nullptr;
     uint4* brick_block_counts = nullptr;
+    uint32_t* brick_block_ready = nullptr;    // per block of k_bricks_build: sequence number of the last build it has classified
+    int num_cus = 0;
     BrickCounts* counts = nullptr;            // device
     BrickCounts* counts_host = nullptr;       // pinned ring of COUNTS_RING snapshots (path selection only), tagged by seq
     BrickCounts* counts_host_dev = nullptr;   // the same ring as the device sees it (kernels write the snapshots directly)
@@ -108,7 +110,6 @@ struct blub_fluid {
     uint32_t max_steps_in_flight = 4;
     bool all_touched = false;
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, >= 1 brick lists
-    int dense_ku_variant = 0;                 // (measurement only, to be removed: 1 = round-2 update kernel)
     int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
     uint8_t* dvol = nullptr;
@@ -250,6 +251,13 @@ static int build_lists(blub_fluid* h, int phase) {
     const int nblk = (h->bg.nb + 1023) / 1024;
     const int all_touched = (phase == COMPACT_ALL_ACTIVE) ? 1 : (int)h->all_touched;
     h->counts_seq += 1;
+    if (nblk <= h->num_cus) {      // every block co-resident: classification and scatter in ONE launch (k_bricks_build)
+        hipLaunchKernelGGL(k_bricks_build, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, h->brick_fluid, h->brick_active,
+                           h->brick_touched, reinterpret_cast<uint32_t*>(h->brick_block_counts), h->brick_block_ready, h->list_fluid, h->list_active, h->list_reset, h->counts,
+                           h->counts_seq, h->counts_host_dev + (h->counts_seq % COUNTS_RING));
+        if (phase == COMPACT_STEP_A) h->all_touched = false;
+        return BLUB_OK;
+    }
     hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, (const uint8_t*)h->brick_fluid, h->brick_active,
                        h->brick_touched, h->brick_flags, h->brick_block_counts);
     hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
@@ -258,6 +266,13 @@ static int build_lists(blub_fluid* h, int phase) {
     return BLUB_OK;
 }
 static int build_lists_from_particles(blub_fluid* h, int phase) { return build_lists(h, phase); }
+// particles were changed from outside a step (or a stage ran on its own): marks a kernel left for the next list build are void
+static int drop_brick_marks(blub_fluid* h) {
+    if (!h->bricks_premarked) return BLUB_OK;
+    h->bricks_premarked = false;
+    HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
+    return BLUB_OK;
+}
 static int build_lists_from_marker(blub_fluid* h) { return build_lists(h, COMPACT_ALL_ACTIVE); }
 // newest snapshot of the brick counts that has landed (never waits unless `block`): only steers a performance choice
 static int latest_counts(blub_fluid* h, bool block, BrickCounts* out, bool* have) {
@@ -466,12 +481,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
                 else                                                                                                                                            \
                     LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));                           \
-                if (h->dense_ku_variant == 0)                                                                                                                   \
-                    LAUNCH_LDS(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual, \
-                               (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                   \
-                else                                                                                                                                            \
-                    LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z_r2<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual, \
-                           (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                       \
+                LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,     \
+                       (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
             }                                                                                                                                                   \
         }
         // p / r of KU are touched exactly once per kernel: non-temporal (66.8 -> 62.5 us at 256^3); s_out of KD is re-read as a halo: default policy
@@ -543,10 +554,15 @@ static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
     return stage_extrapolate(h);
 }
 // `step_done`: also publish the number of the step this launch completes (run-ahead throttle of blub_fluid_step)
+// Inside blub_fluid_step the kernel also marks the FLUID bricks for the NEXT step's first list build (brick_fluid is all zero here: the
+// list build after advection consumed and cleared it), one launch less per step; every entry point that changes particles drops the marks.
 static int stage_correct(blub_fluid* h, bool step_done = false) {   // :969-973
-    if (h->num_particles)
+    const bool mark = step_done && h->num_ghost == 0;
+    if (h->num_particles) {
         LAUNCH(h, KC_CORRECT, k_correct, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2],
-               step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u);
+               step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u, mark ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby);
+        h->bricks_premarked = mark;
+    }
     else if (step_done)
         hipLaunchKernelGGL(k_step_done, dim3(1), dim3(1), 0, h->stream, (volatile uint32_t*)h->steps_done_dev, h->steps_enqueued + 1u);
     return BLUB_OK;
@@ -557,6 +573,7 @@ static int stage_correct(blub_fluid* h, bool step_done = false) {   // :969-973
 static int run_stage(blub_fluid* h, int stage, float dt, bool standalone) {
     int rc;
     h->cur_stage = BLUB_STAGE_COUNT;
+    if (standalone && (rc = drop_brick_marks(h)) != BLUB_OK) return rc;
     if (standalone && stage != BLUB_STAGE_TRANSFER && stage != BLUB_STAGE_BINNING)
         if ((rc = build_lists_from_marker(h)) != BLUB_OK) return rc;
     h->cur_stage = stage;
@@ -589,7 +606,7 @@ static void destroy(blub_fluid* h) {
     auto F = [h](void* p) { if (p && !(h->slab && (char*)p >= h->slab && (char*)p < h->slab + h->slab_bytes)) (void)hipFree(p); };
     F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->next1); F(h->next2); F(h->marker); for (auto p : h->ll) F(p);
     for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
-    F(h->brick_flags); F(h->brick_block_counts); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
+    F(h->brick_flags); F(h->brick_block_counts); F(h->brick_block_ready); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
     if (h->steps_done_host) (void)hipHostFree((void*)h->steps_done_host);
     F(h->tail_sync[0]); F(h->tail_sync[1]); for (auto q : h->cgbuf) F(q); F(h->part4); F(h->pcg1_scalars[0]); F(h->pcg1_scalars[1]); F(h->mesh_positions); F(h->mesh_indices);
@@ -603,16 +620,18 @@ static void destroy(blub_fluid* h) {
     delete h;
 }
 
-// Tile geometry of the dense 2.5-D PCG kernels (blub_pcg_dense.hip.h).  0 = the measured default for this grid:
-// T = 256 quads x 16 planes at 256^3 (profiles/r01_dense_pcg_sweep.txt: 16 planes amortise the z-halo best, but the chip needs >= ~1000 tiles
-// in flight -- 256 CUs x 4 blocks --, so smaller grids march fewer planes per tile: 128x64x64 at zc = 16 has 32 tiles).
+// Tile geometry of the dense 2.5-D PCG kernels (blub_pcg_dense.hip.h).  0 = the measured default for this grid
+// (profiles/r03_dense_sweep_*.txt, all under the deterministic volume placement of vol_alloc): tiles of 512 quads from 256^2-cell planes on
+// (8 rows at nx = 256, 4 at nx = 512: y-halo factor 1.25 / 1.5), 256 quads below; as many planes per tile (<= 32: the z-halo factor 1 + 2 / zc)
+// as leave >= 4096 waves of tiles for the 256 CUs -- 16 at 256^3 (KD 42.0 / KU 59.2 us against 43.9 / 59.6 with 256-quad tiles), 32 at 512^3
+// (KD 328 / KU 545 us against 379 / 539 with 256 x 16).
 static void set_dense_geometry(blub_fluid* h, int T, int zc, int grid) {
     PcgGeomZ& gz = h->gz;
     const int qpr = h->g.nx / 4, qpp = qpr * h->g.ny;
-    if (T != 256 && T != 512 && T != 1024) T = 256;
+    if (T != 256 && T != 512 && T != 1024) T = qpp >= 16384 ? 512 : 256;
     while (T < 2 * qpr && T < 1024) T *= 2;      // a tile holds at least two rows (its halo rows are filled by its first 2 qpr threads)
     gz.g = h->g; gz.qpr = qpr; gz.qpp = qpp; gz.T = T; gz.plane_tiles = (qpp + T - 1) / T;
-    if (zc <= 0) { zc = 16; while (zc > 2 && gz.plane_tiles * ((h->g.nz + zc - 1) / zc) < 1024) zc >>= 1; }
+    if (zc <= 0) { zc = 32; while (zc > 2 && (size_t)gz.plane_tiles * (size_t)((h->g.nz + zc - 1) / zc) * (size_t)(T / 64) < 4096) zc >>= 1; }
     gz.zc = std::max(2, zc);
     gz.z_chunks = (h->g.nz + gz.zc - 1) / gz.zc; gz.tiles = gz.plane_tiles * gz.z_chunks;
     if (grid <= 0) grid = 2048;
@@ -693,6 +712,8 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->list_fluid, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_active, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->list_reset, (size_t)bg.nb));
     A(dev_alloc_zero(h->stream, &h->counts, 1));
     A(dev_alloc_zero(h->stream, &h->brick_flags, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_block_counts, (size_t)(bg.nb + 1023) / 1024));
+    A(dev_alloc_zero(h->stream, &h->brick_block_ready, (size_t)(bg.nb + 1023) / 1024));
+    if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) h->num_cus = 0;
     if (rc == BLUB_OK) {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&h->steps_done_dev, hp, 0) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
@@ -785,6 +806,7 @@ int blub_fluid_create_from_scene(const blub_scene_config* sc, int32_t device, bl
 
 int blub_fluid_add_fluid_cube(blub_fluid* h, const float mn[3], const float mx[3]) {
     REQUIRE_HANDLE(h);
+    { int rc0 = blub::drop_brick_marks(h); if (rc0 != BLUB_OK) return rc0; }
     if (!mn || !mx) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     const uint32_t dim[3] = {(uint32_t)h->g.nx, (uint32_t)h->g.ny, (uint32_t)h->g.nz};
     uint32_t count = 0, demand = 0;
@@ -941,6 +963,7 @@ int blub_fluid_voxelize(blub_fluid* h, uint32_t num_meshes, const blub_mesh_desc
 int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz) {
     REQUIRE_HANDLE(h);
     if (n > h->max_particles) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "more particles than max_num_particles");
+    { int rc0 = blub::drop_brick_marks(h); if (rc0 != BLUB_OK) return rc0; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->num_particles = n;
     if (n == 0) return BLUB_OK;
@@ -1020,7 +1043,6 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_tail_first") h->tail_first_forced = value;
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
-    else if (k == "dense_ku_variant") h->dense_ku_variant = value;
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);
     else if (k == "dense_tile_quads" || k == "dense_tile_planes" || k == "dense_grid") {
         HIP_TRY(hipStreamSynchronize(h->stream));

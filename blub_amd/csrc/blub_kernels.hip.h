@@ -647,7 +647,8 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
 // step, and its last workgroup is dispatched when nearly all others have retired -- the throttle needs no more than that)
 __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles, float4* __restrict__ pos, const int8_t* __restrict__ marker,
                                                  const float* __restrict__ vx, const float* __restrict__ vy, const float* __restrict__ vz,
-                                                 volatile uint32_t* step_done_host = nullptr, uint32_t step_number = 0) {
+                                                 volatile uint32_t* step_done_host = nullptr, uint32_t step_number = 0,
+                                                 uint8_t* __restrict__ brick_fluid = nullptr, int nbx = 0, int nby = 0) {
     if (step_done_host && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *step_done_host = step_number;
     const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
     if (pi >= num_particles) return;
@@ -683,6 +684,10 @@ __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles,
         for (int k = 0; k < 3; ++k) { np[k] = op[k] + dir[k] * ms; np[k] = clampf(np[k], 1.001f, gs[k] - 1.001f); }
     }
     pos[pi] = make_float4(np[0], np[1], np[2], p0.w);
+    if (brick_fluid) {   // what k_bricks_mark_particles would do for the next step's first list build (16 x 8 x 4 bricks, see k_advect)
+        const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
+        if (inb(g, x, y, z)) brick_fluid[((z >> 2) * nby + (y >> 3)) * nbx + (x >> 4)] = 1;
+    }
 }
 
 // =================================================================================================================

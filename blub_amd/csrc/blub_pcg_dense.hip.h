@@ -56,8 +56,11 @@ __device__ __forceinline__ float4 zero_outside_fluid(uint32_t dq, const float4& 
 }
 
 // ---- KU: p += alpha s; r -= alpha A s; partial (M^-1 r).r and max|r|  (pressure_update_pressure_and_residual.comp:23-59)
+// (Round 3 also built this kernel in the formulation of k_pcg_dir_z below -- halo rows in the exchange buffer, raw loads two planes
+//  ahead -- and measured it under deterministic placement: 61.1 vs 59.6 us at 256^3, 538-558 vs 539-558 us at 512^3.  This kernel moves 21 B
+//  per cell of mixed read / write traffic at 6.0 TB/s already; more bytes in flight do not help it.  Removed again.)
 template <int T, bool NT = false>
-__global__ __launch_bounds__(T) void k_pcg_update_z_r2(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+__global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
                                                     float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
                                                     const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
     __shared__ float sm[T / 64 + 1];
@@ -312,134 +315,6 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     }
     const float tot = block_reduce<T, false>(acc, sm);
     if (threadIdx.x == 0) part_dir[blockIdx.x] = tot;
-}
-
-// ---- KU, round-3 formulation: the same pipeline as k_pcg_dir_z (halo rows in the exchange buffer, raw loads two planes ahead in two
-// alternating register sets, unconditional and in a fixed order) for p += alpha s; r -= alpha A s; partial (M^-1 r).r and max|r|
-// (pressure_update_pressure_and_residual.comp:23-59).  p and r have no halo and are touched exactly once per kernel: non-temporal.
-struct UpdRaw { uint32_t dq; float4 s, p, r; };      // s and descriptor of plane k, p and r of plane k - 1
-template <bool NT>
-__device__ __forceinline__ void upd_raw_load(UpdRaw& R, const uint8_t* __restrict__ dv, const float* __restrict__ sp, const float* __restrict__ pp, const float* __restrict__ rp,
-                                             uint32_t off, uint32_t mask) {
-    R.dq = ldu32o(dv, off >> 2) & mask;
-    R.s = ld4o(sp, off);
-    R.p = ld4so<NT>(pp, off);
-    R.r = ld4so<NT>(rp, off);
-}
-struct HaloRaw { uint32_t dq; float4 s; };
-template <int T, bool NT, bool HALO>
-__device__ __forceinline__ void upd_march(const PcgGeomZ& gz, const DirTile& K, float4* __restrict__ ext, const uint8_t* __restrict__ dvol, const float* __restrict__ s,
-                                          float* __restrict__ p, float* __restrict__ r, float alpha, const DivConst* lut, float& acc, float& emax) {
-    const Grid g = gz.g;
-    const int t = threadIdx.x, qpr = gz.qpr, ext_n = T + 2 * qpr;
-    const size_t plane = (size_t)g.nx * (size_t)g.ny;
-    const int zb = K.z_begin, ze = K.z_end;
-    auto plane_of = [&](int zz, bool wanted, uint32_t& pm) -> size_t { const bool ok = wanted && zz >= 0 && zz < g.nz; pm = ok ? 0xFFFFFFFFu : 0u; return (size_t)(ok ? zz : zb) * plane; };
-    float4 s_m, s_c, s_p, pc, rc, h_c = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t d_c, d_p;
-    UpdRaw A, B;
-    HaloRaw HA, HB;
-    HA.dq = 0; HB.dq = 0; HA.s = HB.s = make_float4(0.f, 0.f, 0.f, 0.f);
-    {   // ---- s of planes zb - 1, zb, zb + 1, p and r of plane zb, the halo quad's s of plane zb; then the first set of the pipeline
-        uint32_t pm_m, pm_c, pm_p, pm_a, pm_ha;
-        const size_t b_m = plane_of(zb - 1, true, pm_m), b_c = plane_of(zb, true, pm_c), b_p = plane_of(zb + 1, true, pm_p);
-        HaloRaw H; H.dq = 0; H.s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (HALO) { H.dq = ldu32o(dvol + b_c, K.hoff >> 2) & K.hmask; H.s = ld4o(s + b_c, K.hoff); }
-        const uint32_t dq_m = ldu32o(dvol + b_m, K.goff >> 2) & (K.vmask & pm_m); const float4 sm_ = ld4o(s + b_m, K.goff);
-        UpdRaw C; upd_raw_load<NT>(C, dvol + b_c, s + b_c, p + b_c, r + b_c, K.goff, K.vmask & pm_c);
-        const uint32_t dq_p = ldu32o(dvol + b_p, K.goff >> 2) & (K.vmask & pm_p); const float4 sp_ = ld4o(s + b_p, K.goff);
-        const size_t b_a = plane_of(zb + 2, zb + 1 < ze, pm_a), b_ha = plane_of(zb + 1, zb + 1 < ze, pm_ha);
-        if (HALO) { HA.dq = ldu32o(dvol + b_ha, K.hoff >> 2) & (K.hmask & pm_ha); HA.s = ld4o(s + b_ha, K.hoff); }
-        upd_raw_load<NT>(A, dvol + b_a, s + b_a, p + b_ha, r + b_ha, K.goff, K.vmask & pm_a);      // s of plane zb + 2, p / r of plane zb + 1
-        // s is only defined on FLUID cells (the reference never writes it elsewhere): zeroed outside the fluid as it arrives, so that the
-        // stencil needs no per-neighbour tests (quad_mulA_u)
-        s_m = zero_outside_fluid(dq_m, sm_); s_c = zero_outside_fluid(C.dq, C.s); s_p = zero_outside_fluid(dq_p, sp_);
-        if (HALO) h_c = zero_outside_fluid(H.dq, H.s);
-        d_c = C.dq; d_p = dq_p; pc = C.p; rc = C.r;
-    }
-    auto body = [&](int z, UpdRaw& issue, HaloRaw& hissue, UpdRaw& use, HaloRaw& huse) {
-        uint32_t pm_o, pm_h;
-        const size_t b_o = plane_of(z + 3, z + 2 < ze, pm_o), b_h = plane_of(z + 2, z + 2 < ze, pm_h);
-        if (HALO) { hissue.dq = ldu32o(dvol + b_h, K.hoff >> 2) & (K.hmask & pm_h); hissue.s = ld4o(s + b_h, K.hoff); }
-        upd_raw_load<NT>(issue, dvol + b_o, s + b_o, p + b_h, r + b_h, K.goff, K.vmask & pm_o);      // s of plane z + 3, p / r of plane z + 2
-        float4* const eb = ext + ((z - zb) & 1) * ext_n;
-        eb[t + qpr] = s_c;
-        if (HALO) { if (K.halo_thread) eb[K.halo_slot] = h_c; }
-        lds_barrier();
-        {
-            QuadValues sv;
-            sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
-            sv.ym = eb[t]; sv.yp = eb[t + 2 * qpr];
-            sv.xm = and_mask(eb[t + qpr - 1].w, K.mxm); sv.xp = and_mask(eb[t + qpr + 1].x, K.mxp);
-            float pp[4] = {pc.x, pc.y, pc.z, pc.w}, rr[4] = {rc.x, rc.y, rc.z, rc.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                  // bit masks, no per-lane branches or selects
-                const uint32_t mk = fluid_mask(d_c, j);
-                const float as = quad_mulA_u(d_c, sv, j);
-                const float pj = pp[j] + alpha * f4(s_c, j);
-                float res = rr[j];
-                res -= alpha * as;
-                pp[j] = blend_mask(pj, pp[j], mk);
-                rr[j] = blend_mask(res, rr[j], mk);
-                const float zr = precond_exact(res, lut[dbyte(d_c, j) & 7]) * res;   // (M^-1 r) r with M^-1 r = (r / d) / d, correctly rounded
-                emax = fmaxf(emax, and_mask(fabsf(res), mk));
-                acc += and_mask(zr, mk);
-            }
-            if (K.valid) {
-                const size_t b_z = (size_t)z * plane;
-                st4so<NT>(p + b_z, K.goff, make_float4(pp[0], pp[1], pp[2], pp[3]));
-                st4so<NT>(r + b_z, K.goff, make_float4(rr[0], rr[1], rr[2], rr[3]));
-            }
-        }
-        s_m = s_c; s_c = s_p; s_p = zero_outside_fluid(use.dq, use.s); d_c = d_p; d_p = use.dq; pc = use.p; rc = use.r;
-        if (HALO) h_c = zero_outside_fluid(huse.dq, huse.s);
-    };
-    for (int z = zb; z < ze; z += 2) {
-        body(z, B, HB, A, HA);
-        if (z + 1 < ze) body(z + 1, A, HA, B, HB);
-    }
-}
-
-template <int T, bool NT = false>
-__global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
-                                                    float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part,
-                                                    const uint8_t* __restrict__ tile_flags, const PcgCtrl* __restrict__ ctrl, int iteration) {
-    extern __shared__ float4 ext[];      // [2][T + 2 qpr]
-    __shared__ float sm[T / 64 + 1];
-    __shared__ DivConst div_lut[8];
-    pcg_fill_div_lut(div_lut);       // (the prologue's barriers publish it)
-    float alpha;
-    if (!pcg_upd_prologue<T>(ctrl, part_dir, num_part, iteration, sm, alpha)) return;
-    const Grid g = gz.g;
-    const int t = threadIdx.x, qpr = gz.qpr;
-    const bool halo_wave = (t & ~63) < 2 * qpr;            // wave-uniform
-    float acc = 0.0f, emax = 0.0f;
-    const int padded = ((gz.tiles + 7) >> 3) << 3;
-    for (int it = blockIdx.x; it < padded; it += gridDim.x) {
-        const int tile = xcd_tile(it, gz.tiles);
-        if (tile >= gz.tiles || !tile_flags[tile]) continue;
-        const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
-        const int q0 = pt * T, q = q0 + t;
-        DirTile K;
-        K.valid = q < gz.qpp;
-        const int x0 = (q % qpr) << 2;
-        K.z_begin = zci * gz.zc; K.z_end = min(K.z_begin + gz.zc, g.nz);
-        K.goff = K.valid ? (uint32_t)q * 16u : 0u;
-        K.vmask = K.valid ? 0xFFFFFFFFu : 0u;
-        K.mxm = (K.valid && x0 > 0) ? 0xFFFFFFFFu : 0u; K.mxp = (K.valid && x0 + 4 < g.nx) ? 0xFFFFFFFFu : 0u;
-        K.halo_thread = t < 2 * qpr;
-        const int hq = t < qpr ? q0 - qpr + t : q0 + T + (t - qpr);
-        const bool halo_valid = K.halo_thread && hq >= 0 && hq < gz.qpp;
-        K.hoff = halo_valid ? (uint32_t)hq * 16u : 0u;
-        K.hmask = halo_valid ? 0xFFFFFFFFu : 0u;
-        K.halo_slot = t < qpr ? t : T + t;
-        if (halo_wave) upd_march<T, NT, true>(gz, K, ext, dvol, s, p, r, alpha, div_lut, acc, emax);
-        else upd_march<T, NT, false>(gz, K, ext, dvol, s, p, r, alpha, div_lut, acc, emax);
-        __syncthreads();   // the LDS buffers are reused by the next tile
-    }
-    const float tot = block_reduce<T, false>(acc, sm);
-    const float mx = block_reduce<T, true>(emax, sm);
-    if (threadIdx.x == 0) part_upd[blockIdx.x] = make_float2(tot, mx);
 }
 
 // init for this mapping: same per-quad body as the row kernel, tile flags indexed by the z-march tiles

@@ -4,8 +4,8 @@
 size=${1:-256}; shift
 for cfg in ${@:-0:0}; do
   IFS=: read t zc kv <<< "$cfg"; kv=${kv:-0}
-  python bench.py --dense-only --dense-size $size --dense-tile-quads $t --dense-tile-planes $zc --dense-ku-variant $kv 2>/dev/null | grep '^{' | python -c "
+  python bench.py --dense-only --dense-size $size --dense-tile-quads $t --dense-tile-planes $zc 2>/dev/null | grep '^{' | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels']
-print('dense %s T=%s zc=%s ku=%s : KD %.2f us (%.3f)  KU %.2f us (%.3f)  iter %.1f us  fused frac %.3f' % (d['grid'], '$t', '$zc', '$kv', k['pcg_dir']['avg_us'], k['pcg_dir']['frac'], k['pcg_update']['avg_us'], k['pcg_update']['frac'], d['us_per_iteration_kernels'], d['iter_frac_fused']))"
+print('dense %s T=%s zc=%s : KD %.2f us (%.3f)  KU %.2f us (%.3f)  iter %.1f us  fused frac %.3f' % (d['grid'], '$t', '$zc', k['pcg_dir']['avg_us'], k['pcg_dir']['frac'], k['pcg_update']['avg_us'], k['pcg_update']['frac'], d['us_per_iteration_kernels'], d['iter_frac_fused']))"
 done
