@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-pcg", action="store_true")
     ap.add_argument("--no-dense-512", action="store_true", help="skip the 512^3 repetition of the dense PCG micro-benchmark (roofline_512)")
+    ap.add_argument("--tune", action="append", default=[], help="name=value for blub_fluid_set_tuning on every scene of the run (A/B measurements)")
     ap.add_argument("--pcg-schedule", default="single_reduction", choices=["single_reduction", "reference"], help="schedule of the headline window (the other one is timed beside it)")
     ap.add_argument("--no-fast-forward", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
@@ -407,6 +408,9 @@ def main():
         fl_ = sc_.fluid()
         fl_.set_pcg_work_mapping(args.pcg_mapping)
         fl_.set_pcg_schedule(schedule)
+        for kv in args.tune:
+            k_, v_ = kv.split("=")
+            fl_.set_tuning(k_, int(v_))
         return sc_, fl_
 
     # The library's default PCG schedule is the reference's (two global reductions per iteration, pressure_solver.rs:654-723).  The headline

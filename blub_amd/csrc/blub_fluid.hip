@@ -129,7 +129,7 @@ struct blub_fluid {
     bool use_tail = true;            // persistent tail kernel of the single-reduction solves (blub_fluid_set_tuning "pcg_tail")
     int tail_margin_checks = 1;
     int pcg1_max_iterations = 64;    // solves with more iterations run the reference order even when schedule 1 is selected (drift of the recurrence residual)
-    int tail_grid = 256;             // co-resident blocks of the tail kernel: occupancy x CUs, at most one per CU (set at creation)
+    int tail_grid = 256, tail_grid_max = 256;   // co-resident blocks of the tail kernel: occupancy x CUs (set at creation)
     int tail_first_forced = -1;      // test hook (blub_fluid_set_tuning "pcg_tail_first"): hand over to the tail after exactly this many launched iterations
     blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
     bool pressure_initialised[2] = {false, false};
@@ -696,12 +696,15 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->ctrl[0], 1)); A(dev_alloc_zero(h->stream, &h->ctrl[1], 1));
     A(dev_alloc_zero(h->stream, &h->tail_sync[0], 1)); A(dev_alloc_zero(h->stream, &h->tail_sync[1], 1));
     {   // the tail kernel's grid barrier needs every block resident at once: bound its grid by what the device holds of THAT kernel
-        // (round-2 ADVICE: the bound used to come from another kernel with a smaller footprint)
+        // (round-2 ADVICE: the bound used to come from another kernel with a smaller footprint).  tail_grid_max = every co-resident block, but
+        // the default stays at one block per CU: with ~1000 blocks on the one barrier counter an iteration inside the tail costs 3x as much
+        // (measured, round 3: 483-510 steps/s against 929-953 with the tail forced in after 6 iterations)
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg1_tail_s<true>, PCG_B_THREADS, 0) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus >= 8)
-            h->tail_grid = (std::min(256, cus) / 8) * 8;             // at most one block per CU (always co-resident when per_cu >= 1), a multiple of 8
-        else h->use_tail = false;
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus >= 8) {
+            h->tail_grid_max = ((per_cu * cus) / 8) * 8;
+            h->tail_grid = std::min(h->tail_grid_max, (std::min(256, cus) / 8) * 8);
+        } else h->use_tail = false;
     }
     BrickGeom& bg = h->bg;
     bg.g = h->g; bg.nbx = (h->g.nx + BX - 1) / BX; bg.nby = (h->g.ny + BY - 1) / BY; bg.nbz = (h->g.nz + BZ - 1) / BZ; bg.nb = bg.nbx * bg.nby * bg.nbz;
@@ -1040,6 +1043,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     if (!name) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     const std::string k(name);
     if (k == "pcg_tail") h->use_tail = value != 0 && h->tail_grid >= 8;
+    else if (k == "pcg_tail_grid") h->tail_grid = std::max(8, (std::min(value, h->tail_grid_max) / 8) * 8);
     else if (k == "pcg_tail_first") h->tail_first_forced = value;
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
