@@ -511,12 +511,11 @@ def main():
             el_r, _ = timed_window(args.pcg_schedule, rebinning=freq_r)
             rebinning_tuned["runs"].append({"frequency": freq_r, "steps_per_s": round(args.steps / el_r, 3)})
 
-    # ---- instrumented pass: per-kernel-class HIP-event timing on the engine's own stream.  Every profiled launch carries an event pair
-    # whose own cost (measured: profile_event_overhead_us) is part of what the pair reports; it is subtracted per launch, so the classes sum
-    # to the GPU-busy part of a step (<= ms_per_step).  The per-kernel table of record is the rocprofv3 trace under profiles/.
+    # ---- instrumented pass: per-kernel-class HIP-event timing on the engine's own stream.  The events ride inside the dispatches
+    # (hipExtLaunchKernelGGL: the kernels' own start / end time stamps), so the classes sum to the GPU-busy part of a step (<= ms_per_step);
+    # the per-kernel table of record is the rocprofv3 trace under profiles/.
     roofline_workload, breakdown, pcg_ms = None, None, 0.0
     if args.profile_steps > 0:
-        ev_us = fluid.profile_event_overhead_us()
         fluid.profile_enable(True)
         fluid.profile_reset()
         for _ in range(args.profile_steps):
@@ -524,8 +523,6 @@ def main():
         fluid.synchronize()
         prof = fluid.profile_read()
         fluid.profile_enable(False)
-        for v in prof.values():
-            v["total_ms"] = max(v["total_ms"] - v["launches"] * ev_us * 1e-3, 0.05 * v["total_ms"])
         F = int((fluid.read_volume("marker") == 1).sum())
         bc = fluid.brick_counts()
         A, Fb = bc["active"] * bc["cells_per_brick"], bc["fluid"] * bc["cells_per_brick"]
@@ -540,7 +537,6 @@ def main():
         pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
         breakdown = {"us_per_step": {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
                      "sum_us_per_step": round(total_ms / args.profile_steps * 1e3, 1), "launches_per_step": round(sum(v["launches"] for v in prof.values()) / args.profile_steps, 1),
-                     "event_pair_overhead_us_subtracted_per_launch": round(ev_us, 2),
                      "window": "the %d steps after the timed window (steps %d..%d of the scene): later, i.e. costlier, steps than the timed ones" % (args.profile_steps, args.warmup + args.steps, args.warmup + args.steps + args.profile_steps)}
 
     result = {

@@ -3,6 +3,7 @@
 // PressureField) of the reference; the kernels live in blub_kernels.hip.h.  There is no CPU fallback: without a HIP
 // device every device entry point returns BLUB_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <time.h>
 
@@ -191,10 +192,21 @@ struct ProfScope {
         h->prof_pending.push_back({a, b, kc, h->cur_stage, h->step_counter});
     }
 };
-#define LAUNCH_LDS(h, kc, kernel, grid, block, lds_bytes, ...)                            \
-    do {                                                                                  \
-        ProfScope _ps((h), (kc));                                                         \
-        hipLaunchKernelGGL(kernel, grid, block, (lds_bytes), (h)->stream, __VA_ARGS__);   \
+// Profiled kernel launches carry their events INSIDE the dispatch (hipExtLaunchKernelGGL: the events take the kernel's own start / end
+// time stamps), so the reported durations are the kernels' -- an event pair recorded around a launch adds ~2 us of its own to each of them
+// (round 2: the classes summed to more than the step; round-2 review).  Copies / memsets keep the recorded pair (ProfScope).
+static void prof_events(blub_fluid* h, hipEvent_t* a, hipEvent_t* b) {
+    if (h->prof_pending.size() >= 8192) prof_flush(h);
+    auto get = [&]() { hipEvent_t e; if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    *a = get(); *b = get();
+}
+#define LAUNCH_LDS(h, kc, kernel, grid, block, lds_bytes, ...)                                                         \
+    do {                                                                                                               \
+        if ((h)->prof_enabled) {                                                                                       \
+            hipEvent_t _a, _b; prof_events((h), &_a, &_b);                                                             \
+            hipExtLaunchKernelGGL(kernel, grid, block, (lds_bytes), (h)->stream, _a, _b, 0, __VA_ARGS__);              \
+            (h)->prof_pending.push_back({_a, _b, (kc), (h)->cur_stage, (h)->step_counter});                            \
+        } else hipLaunchKernelGGL(kernel, grid, block, (lds_bytes), (h)->stream, __VA_ARGS__);                         \
     } while (0)
 #define LAUNCH(h, kc, kernel, grid, block, ...) LAUNCH_LDS(h, kc, kernel, grid, block, 0, __VA_ARGS__)
 
@@ -458,10 +470,10 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         for (int i = 0; i <= maxit; ++i) {
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<true>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
-                       (const float2*)part_upd, part_dir, 0, ctrl, tol, i, 0);
+                       (const float2*)part_upd, part_dir, 0, ctrl, tol, i, 0, -1, -1);
             else
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<false>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1],
-                       (const float2*)part_upd, part_dir, 0, ctrl, tol, i, (int)is_check(i - 1));
+                       (const float2*)part_upd, part_dir, 0, ctrl, tol, i, (int)is_check(i - 1), -1, -1);
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_s, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
                    (const float*)part_dir, part_upd, 0, (const PcgCtrl*)ctrl, i);
         }
@@ -503,18 +515,22 @@ static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
     // anyway.  Here list heads are only re-zeroed inside the reset-list bricks, so the per-cell counters / prefix sums live in a
     // volume that is scratch at this point of the step instead (aux_temp: only ever read inside a solve, after being rewritten) and
     // ll[0] keeps the invariant "zero outside the touched bricks".
+    // BLUB_BINNING_LITERAL (Q4): the dispatches cover ceil(P / 64) * 64 threads without a guard -- the records behind the live range
+    // (zeros, or what an earlier pass left there) are binned too --, destinations are 1-based, and the WHOLE buffer is copied back.
+    const bool literal = h->binning_mode == BLUB_BINNING_LITERAL;
+    const uint32_t T = literal ? std::min<uint32_t>((h->num_particles + 63u) / 64u * 64u, h->max_particles) : h->num_particles;
     uint32_t* counters = reinterpret_cast<uint32_t*>(h->aux_temp);
     HIP_TRY(hipMemsetAsync(counters, 0, h->N * sizeof(uint32_t), h->stream));   // clear_texture :858
-    LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, counters);
+    LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(T)), dim3(256), h->g, T, h->pos, counters);
     const int n = (int)h->N, nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     LAUNCH(h, KC_BIN_SCAN, k_scan_block_totals, dim3(nblocks), dim3(1024), (const uint32_t*)counters, n, h->scan_totals);
     LAUNCH(h, KC_BIN_SCAN, k_scan_totals, dim3(1), dim3(1024), h->scan_totals, nblocks);
     LAUNCH(h, KC_BIN_SCAN, k_scan_apply, dim3(nblocks), dim3(1024), counters, n, (const uint32_t*)h->scan_totals);
-    LAUNCH(h, KC_BIN_REWRITE, k_bin_rewrite, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->max_particles,
-           (const float4*)h->pos, h->pos_tmp, (const uint32_t*)counters);
+    LAUNCH(h, KC_BIN_REWRITE, k_bin_rewrite, dim3(particle_blocks(T)), dim3(256), h->g, T, h->max_particles,
+           (const float4*)h->pos, h->pos_tmp, (const uint32_t*)counters, (int)literal);
     {
-        ProfScope ps(h, KC_COPY);   // :885-891 (only the live range; the rest of the buffer is never read)
-        HIP_TRY(hipMemcpyAsync(h->pos, h->pos_tmp, (size_t)h->num_particles * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        ProfScope ps(h, KC_COPY);   // :885-891 ("fixed": only the live range; the rest of the buffer is never read)
+        HIP_TRY(hipMemcpyAsync(h->pos, h->pos_tmp, (size_t)(literal ? h->max_particles : h->num_particles) * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
     }
     return BLUB_OK;
 }
@@ -646,7 +662,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     const uint64_t N64 = (uint64_t)d->nx * d->ny * d->nz;
     if (N64 <= 16384) return set_error(BLUB_ERR_UNSUPPORTED, "grid must have more than 16384 cells (pressure_solver.rs:551)");
     if (N64 >= (1ull << 31)) return set_error(BLUB_ERR_UNSUPPORTED, "grid must have fewer than 2^31 cells");
-    if (d->precond_mode > BLUB_PRECOND_LOD0 || (d->binning_mode != BLUB_BINNING_FIXED && d->binning_mode != BLUB_BINNING_OFF))
+    if (d->precond_mode > BLUB_PRECOND_LOD0 || d->binning_mode > BLUB_BINNING_OFF)
         return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad quirk mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(BLUB_ERR_NO_DEVICE, "no HIP device (libblubhip has no CPU fallback)");
@@ -1072,28 +1088,6 @@ int blub_fluid_profile_reset(blub_fluid* h) {
     h->prof_trace.clear();
     if (h->prof_origin) { h->prof_pool.push_back(h->prof_origin); h->prof_origin = nullptr; }
     return rc;
-}
-// What one profiled launch's event pair adds to the figure it reports: the elapsed time between two events recorded back to back on the
-// handle's (idle) stream, averaged over 64 pairs.  blub_fluid_profile_read's totals contain launches x this.
-int blub_fluid_profile_event_overhead_us(blub_fluid* h, double* out_us) {
-    REQUIRE_HANDLE(h);
-    if (!out_us) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    constexpr int PAIRS = 64;
-    hipEvent_t ev[2 * PAIRS];
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-    for (int rep = 0; rep < 2; ++rep) {      // (first repetition warms the event objects up)
-        for (int k = 0; k < PAIRS; ++k) {
-            HIP_TRY(hipEventRecord(ev[2 * k], h->stream)); HIP_TRY(hipEventRecord(ev[2 * k + 1], h->stream));
-            hipLaunchKernelGGL(blubk::k_pcg_tag, dim3(1), dim3(1), 0, h->stream, h->ctrl[0], h->solve_seq[0]);   // (a kernel between the pairs, as in a profiled step)
-        }
-        HIP_TRY(hipStreamSynchronize(h->stream));
-    }
-    double sum = 0.0;
-    for (int k = 0; k < PAIRS; ++k) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1])); sum += ms; }
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    *out_us = sum / PAIRS * 1e3;
-    return BLUB_OK;
 }
 int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capacity, int* count_out) {
     REQUIRE_HANDLE(h);

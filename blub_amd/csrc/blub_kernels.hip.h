@@ -764,15 +764,16 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ coun
     if (base + 3 < n) *reinterpret_cast<uint4*>(counters + base) = make_uint4(c[0], c[1], c[2], c[3]);
     else for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) counters[base + k] = c[k];
 }
+// one_based: the literal Q4 reading (BLUB_BINNING_LITERAL) -- destination `inclusive - slot` as the shader writes it, slot 0 never written
 __global__ __launch_bounds__(256) void k_bin_rewrite(Grid g, uint32_t num_particles, uint32_t max_particles, const float4* __restrict__ old_pos,
-                                                     float4* __restrict__ new_pos, const uint32_t* __restrict__ inclusive) {
+                                                     float4* __restrict__ new_pos, const uint32_t* __restrict__ inclusive, int one_based) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= num_particles) return;
     const float4 p = old_pos[i];
     const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
     const uint32_t inc = inb(g, x, y, z) ? inclusive[cidx(g, x, y, z)] : 0u;
-    const uint32_t dst = inc - __float_as_uint(p.w) - 1u;                               // particle_binning_rewrite_particles.comp:15, 0-based (Q4)
-    if (dst < max_particles) new_pos[dst] = p;
+    const uint32_t dst = inc - __float_as_uint(p.w) - (one_based ? 0u : 1u);            // particle_binning_rewrite_particles.comp:15; "fixed": 0-based (Q4)
+    if (dst < max_particles) new_pos[dst] = p;                                          // (an out-of-bounds store is dropped)
 }
 
 // end-of-step marker for steps without particles (otherwise k_correct writes it)

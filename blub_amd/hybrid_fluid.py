@@ -17,7 +17,7 @@ STAGES = {"transfer": 0, "divergence": 1, "solve_velocity": 2, "binning": 3, "pr
 STEP_ORDER = ["transfer", "divergence", "solve_velocity", "binning", "project", "advect", "density_gather",
               "solve_density", "position_change", "correct"]
 PRECOND = {"zero": 0, "lod0": 1}
-BINNING = {"fixed": 0, "off": 2}
+BINNING = {"fixed": 0, "literal": 1, "off": 2}
 SOLVER_VELOCITY, SOLVER_DENSITY = 0, 1
 MAX_CUBES = 64
 MAX_STATIC_OBJECTS = 16
@@ -170,7 +170,6 @@ def load_library():
         "blub_fluid_get_pcg_schedule": (C.c_int, [vp]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
         "blub_fluid_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
-        "blub_fluid_profile_event_overhead_us": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "blub_scene_mesh_desc_at_time": (C.c_int, [C.POINTER(SceneConfig), u32, C.c_uint64, C.c_uint64, C.POINTER(MeshDesc)]),
         "blub_load_obj": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.POINTER(u32), vp, C.c_size_t, C.POINTER(u32)]),
         "blub_fluid_set_meshes": (C.c_int, [vp, u32, vp, u32, vp]),
@@ -457,12 +456,6 @@ class HybridFluid:
 
     def profile_enable(self, enabled=True):
         _check(self._L, self._L.blub_fluid_profile_enable(self._h, int(bool(enabled))))
-
-    def profile_event_overhead_us(self):
-        """What the event pair of one profiled launch adds to profile_read()'s totals (us)."""
-        v = C.c_double(0.0)
-        _check(self._L, self._L.blub_fluid_profile_event_overhead_us(self._h, C.byref(v)))
-        return v.value
 
     def profile_reset(self):
         _check(self._L, self._L.blub_fluid_profile_reset(self._h))

@@ -62,6 +62,9 @@ typedef enum blub_precond_mode {
 } blub_precond_mode;
 typedef enum blub_binning_mode {
     BLUB_BINNING_FIXED = 0, /* Q4: guarded, 0-based permutation (default) */
+    BLUB_BINNING_LITERAL = 1, /* Q4 as the reference's shaders run it: no i < NumParticles guard (threads up to ceil(P/64)*64 bin stale / zero
+                             * records), 1-based destinations (slot 0 is never written), the whole buffer copied back: every pass replaces
+                             * pad + 1 real particles by stale / zero records (particle_binning_count.comp:9-13, _rewrite_particles.comp:8-16, hybrid_fluid.rs:885-891) */
     BLUB_BINNING_OFF = 2    /* never rebin */
 } blub_binning_mode;
 
@@ -243,9 +246,6 @@ typedef struct blub_prof_entry {
 int blub_fluid_profile_enable(blub_fluid* h, int enabled);
 int blub_fluid_profile_reset(blub_fluid* h);
 int blub_fluid_profile_read(blub_fluid* h, blub_prof_entry* entries, int capacity, int* count_out); /* blocks */
-/* Mean elapsed time (us) between two events recorded back to back on the handle's stream: what the event pair of ONE profiled launch adds
- * to the totals of blub_fluid_profile_read (which therefore over-state short kernels by launches x this).  Blocks. */
-int blub_fluid_profile_event_overhead_us(blub_fluid* h, double* out_us);
 /* Per-launch timeline of the profiled launches since the last reset (the data behind the reference's chrome-trace dump,
  * gui/mod.rs:487-491 / wgpu-profiler): start relative to the first profiled launch, both in microseconds. */
 typedef struct blub_trace_event {

@@ -197,6 +197,52 @@ def test_binning_is_cell_ordered_permutation(pair):
             h2.close()
 
 
+def test_literal_binning_mode_matches_the_oracles_literal_mode():
+    """BLUB_BINNING_LITERAL: Q4 as the reference's three shaders run it (particle_binning_count.comp:9-13 without an i < NumParticles guard,
+    1-based destinations in _rewrite_particles.comp:8-16, whole-buffer copy hybrid_fluid.rs:885-891), against the oracle's `literal` mode
+    (itself checked against a numpy emulation of the shaders, tests/test_oracle_crosscheck.py).  The slot a particle gets inside its cell is
+    an atomic race in the reference and in the engine (ascending index in the oracle), so records are compared as multisets per cell; the
+    cell at which the live range ends may keep different members of its particles on the two sides -- only its COUNT is compared."""
+    import blub_amd
+    from oracle.oracle import Oracle
+    pos, vel, maxp = util.make_dam(*GRID, seed=7)
+    rng = np.random.default_rng(3)
+    pos = pos[rng.permutation(pos.shape[0])][:pos.shape[0] - 37]          # not a multiple of 64
+    n = pos.shape[0]
+    pad = (n + 63) // 64 * 64 - n
+    o = Oracle(*GRID, n + 200)
+    o.set_quirks(binning="literal")
+    h = blub_amd.HybridFluid(GRID, n + 200, binning="literal")
+    try:
+        for rounds in range(2):            # the second pass bins what the first one left behind the live range as well
+            if rounds == 0:
+                o.set_particles(pos)
+                h.set_particles(pos)
+            o.run_stage("binning", util.DT)
+            h.run_stage("binning", util.DT)
+            po, ph = o.get_particles()[0][:, :3], h.get_particles()[0][:, :3]
+            assert po.shape == ph.shape == (n, 3)
+            lin = lambda a: ((a[:, 2].astype(np.int64) * GRID[1] + a[:, 1].astype(np.int64)) * GRID[0] + a[:, 0].astype(np.int64))
+            co, ch = lin(po), lin(ph)
+            # slot 0 is never written (it keeps what it held), slots 1 .. n - 1 are cell-contiguous in linear order on both sides
+            assert np.array_equal(ph[0], po[0])
+            assert np.all(np.diff(ch[1:]) >= 0) and np.all(np.diff(co[1:]) >= 0)
+            uo, cnt_o = np.unique(co, return_counts=True)
+            uh, cnt_h = np.unique(ch, return_counts=True)
+            assert np.array_equal(uo, uh) and np.array_equal(cnt_o, cnt_h)          # every cell keeps the same NUMBER of records
+            last_cell = co[-1]                                                        # the cell the live range ends in
+            rec = lambda a, c: np.sort(np.ascontiguousarray(a[c != last_cell]).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).reshape(-1), order=("x", "y", "z"))
+            assert np.array_equal(rec(ph, ch), rec(po, co))
+            if rounds == 0:
+                # pad zero records were binned into the live range and pad + 1 real particles fell off its end
+                assert int((np.abs(ph).sum(axis=1) == 0).sum()) == pad + 1               # slot 0 (never written) + the pad zero records
+                orig = np.sort(np.ascontiguousarray(pos[:, :3]).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).reshape(-1), order=("x", "y", "z"))
+                kept = np.sort(np.ascontiguousarray(ph).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).reshape(-1), order=("x", "y", "z"))
+                assert len(orig) - np.isin(orig, kept).sum() == pad + 1
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("mapping", ["auto", "rows"])
 def test_full_step_converged_solver(pair, mapping):
     """With both pressure solves run to convergence the solution no longer depends on CG rounding: one whole step
