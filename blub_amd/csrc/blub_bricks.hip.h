@@ -57,7 +57,9 @@ __device__ __forceinline__ bool brick_quad(const BrickGeom& bg, uint32_t b, int 
 }
 
 // ---- list construction ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bricks_mark_particles(BrickGeom bg, uint32_t num_particles, const float4* __restrict__ pos, uint8_t* __restrict__ brick_fluid) {
+__global__ __launch_bounds__(256) void k_bricks_mark_particles(BrickGeom bg, uint32_t num_particles, const float4* __restrict__ pos, uint8_t* __restrict__ brick_fluid,
+                                                               const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
+    num_particles = particle_count(num_particles, n_dev, n_sel);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= num_particles) return;
     const float4 p = pos[i];

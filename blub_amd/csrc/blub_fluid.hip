@@ -69,6 +69,9 @@ struct blub_fluid {
     // z-slab decomposition (blub_slab.hip): own planes [slab_z0, slab_z1), ghost particles live at [num_particles, +num_ghost)
     int slab_z0 = 0, slab_z1 = 0;
     uint32_t num_ghost = 0;
+    // z-slab groups without host synchronisation (blub_slab.inc.hip): the particle counts live on the device ({own, ghost}); num_particles /
+    // num_ghost are then the BOUNDS launch grids are sized for, and the exact values only come back on request (slab_refresh_counts)
+    uint32_t* n_dev = nullptr;
     bool bricks_premarked = false;            // brick_fluid already holds the marks of the current particle positions (set and consumed inside stage_advect)
     float gravity[3] = {0, 0, 0};
     int device = 0;
@@ -211,6 +214,7 @@ static void prof_events(blub_fluid* h, hipEvent_t* a, hipEvent_t* b) {
 #define LAUNCH(h, kc, kernel, grid, block, ...) LAUNCH_LDS(h, kc, kernel, grid, block, 0, __VA_ARGS__)
 
 static unsigned particle_blocks(uint32_t n) { return (n + 255) / 256; }
+constexpr uint32_t N_OWN = 1u, N_GHOST = 2u, N_ALL = 3u;      // particle_count() selectors (blub_kernels.hip.h)
 static unsigned stream_blocks(size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, 2048); }
 
 // NOTE: the handle's stream is non-blocking, i.e. NOT ordered against the null stream: every memset / copy of this
@@ -259,7 +263,8 @@ static int build_lists(blub_fluid* h, int phase) {
         hipLaunchKernelGGL(k_bricks_mark_from_marker, dim3(h->bg.nb), dim3(BRICK_THREADS), 0, h->stream, h->bg, (const int8_t*)h->marker, h->brick_fluid);
     else if (h->bricks_premarked) h->bricks_premarked = false;     // k_advect marked them (stage_advect)
     else if (h->num_particles + h->num_ghost)
-        hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), 0, h->stream, h->bg, h->num_particles + h->num_ghost, (const float4*)h->pos, h->brick_fluid);
+        hipLaunchKernelGGL(k_bricks_mark_particles, dim3(particle_blocks(h->num_particles + h->num_ghost)), dim3(256), 0, h->stream, h->bg, h->num_particles + h->num_ghost, (const float4*)h->pos, h->brick_fluid,
+                           (const uint32_t*)h->n_dev, N_ALL);
     const int nblk = (h->bg.nb + 1023) / 1024;
     const int all_touched = (phase == COMPACT_ALL_ACTIVE) ? 1 : (int)h->all_touched;
     h->counts_seq += 1;
@@ -313,7 +318,7 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     const uint32_t np_all = h->num_particles + h->num_ghost;
     if (np_all)
         LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, h->marker,
-               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2, (int)(h->solid == nullptr));
+               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2, (int)(h->solid == nullptr), (const uint32_t*)h->n_dev, N_ALL);
     {
         GatherArgs3 a;
         const uint32_t* nexts[3] = {nullptr, h->next1, h->next2};
@@ -521,13 +526,13 @@ static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
     const uint32_t T = literal ? std::min<uint32_t>((h->num_particles + 63u) / 64u * 64u, h->max_particles) : h->num_particles;
     uint32_t* counters = reinterpret_cast<uint32_t*>(h->aux_temp);
     HIP_TRY(hipMemsetAsync(counters, 0, h->N * sizeof(uint32_t), h->stream));   // clear_texture :858
-    LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(T)), dim3(256), h->g, T, h->pos, counters);
+    LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(T)), dim3(256), h->g, T, h->pos, counters, (const uint32_t*)h->n_dev, N_OWN);
     const int n = (int)h->N, nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     LAUNCH(h, KC_BIN_SCAN, k_scan_block_totals, dim3(nblocks), dim3(1024), (const uint32_t*)counters, n, h->scan_totals);
     LAUNCH(h, KC_BIN_SCAN, k_scan_totals, dim3(1), dim3(1024), h->scan_totals, nblocks);
     LAUNCH(h, KC_BIN_SCAN, k_scan_apply, dim3(nblocks), dim3(1024), counters, n, (const uint32_t*)h->scan_totals);
     LAUNCH(h, KC_BIN_REWRITE, k_bin_rewrite, dim3(particle_blocks(T)), dim3(256), h->g, T, h->max_particles,
-           (const float4*)h->pos, h->pos_tmp, (const uint32_t*)counters, (int)literal);
+           (const float4*)h->pos, h->pos_tmp, (const uint32_t*)counters, (int)literal, (const uint32_t*)h->n_dev, N_OWN);
     {
         ProfScope ps(h, KC_COPY);   // :885-891 ("fixed": only the live range; the rest of the buffer is never read)
         HIP_TRY(hipMemcpyAsync(h->pos, h->pos_tmp, (size_t)(literal ? h->max_particles : h->num_particles) * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
@@ -551,7 +556,7 @@ static int stage_advect_particles(blub_fluid* h, float dt, bool insert_lists, bo
     if (h->num_particles)
         LAUNCH(h, KC_ADVECT, k_advect, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
                h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, insert_lists ? h->ll[0] : (uint32_t*)nullptr,
-               mark_bricks ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby);
+               mark_bricks ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby, (const uint32_t*)h->n_dev, N_OWN);
     h->bricks_premarked = mark_bricks && h->num_particles != 0;
     return BLUB_OK;
 }
@@ -576,7 +581,8 @@ static int stage_correct(blub_fluid* h, bool step_done = false) {   // :969-973
     const bool mark = step_done && h->num_ghost == 0;
     if (h->num_particles) {
         LAUNCH(h, KC_CORRECT, k_correct, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2],
-               step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u, mark ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby);
+               step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u, mark ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby,
+               (const uint32_t*)h->n_dev, N_OWN);
         h->bricks_premarked = mark;
     }
     else if (step_done)

@@ -15,6 +15,14 @@ constexpr uint32_t INVALID_LL = 0xFFFFFFFFu;
 
 struct Grid { int nx, ny, nz; };
 
+// Particle kernels take their particle count from the host argument or -- z-slab groups, whose counts change on the device without the host
+// looking (blub_slab.inc.hip) -- from device memory: n_dev = {own particles, ghost particles}, sel bit 0 / 1 = count the own / the ghosts;
+// the host argument is then only the bound the launch grid was sized for.
+__device__ __forceinline__ uint32_t particle_count(uint32_t n_host, const uint32_t* __restrict__ n_dev, uint32_t sel) {
+    if (!n_dev) return n_host;
+    const uint32_t n = ((sel & 1u) ? n_dev[0] : 0u) + ((sel & 2u) ? n_dev[1] : 0u);
+    return n < n_host ? n : n_host;
+}
 __device__ __forceinline__ bool inb(const Grid& g, int x, int y, int z) {
     return (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
 }
@@ -113,7 +121,10 @@ __device__ __forceinline__ uint32_t wave_list_insert_runs(uint32_t* __restrict__
 
 __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_particles, float4* __restrict__ pos, int8_t* __restrict__ marker,
                                                      uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
-                                                     uint32_t* __restrict__ next1, uint32_t* __restrict__ next2, int no_solid_voxels) {
+                                                     uint32_t* __restrict__ next1, uint32_t* __restrict__ next2, int no_solid_voxels,
+                                                     const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
+    num_particles = particle_count(num_particles, n_dev, n_sel);
+    if (blockIdx.x * 256u >= num_particles) return;      // (uniform)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < num_particles;          // no early return: the wave-level insertion needs every lane
     float4 p = make_float4(-8.f, -8.f, -8.f, 0.f);
@@ -517,8 +528,10 @@ __device__ __forceinline__ void truncate_step(const float* orig, const float* mo
 __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, float dt, float4* __restrict__ pos, float4* __restrict__ pvx,
                                                 float4* __restrict__ pvy, float4* __restrict__ pvz, const float* __restrict__ vx,
                                                 const float* __restrict__ vy, const float* __restrict__ vz, const float4* __restrict__ solid,
-                                                int8_t* __restrict__ marker, uint32_t* __restrict__ heads, uint8_t* __restrict__ brick_fluid = nullptr,
-                                                int nbx = 0, int nby = 0) {
+                                                int8_t* __restrict__ marker, uint32_t* __restrict__ heads, uint8_t* __restrict__ brick_fluid,
+                                                int nbx, int nby, const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
+    num_particles = particle_count(num_particles, n_dev, n_sel);
+    if (blockIdx.x * 256u >= num_particles) return;      // (uniform)
     const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
     const bool live = pi < num_particles;          // dead lanes run the (cheap) arithmetic on a dummy particle: the wave-level list insertion needs all lanes
     const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
@@ -647,9 +660,10 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
 // step, and its last workgroup is dispatched when nearly all others have retired -- the throttle needs no more than that)
 __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles, float4* __restrict__ pos, const int8_t* __restrict__ marker,
                                                  const float* __restrict__ vx, const float* __restrict__ vy, const float* __restrict__ vz,
-                                                 volatile uint32_t* step_done_host = nullptr, uint32_t step_number = 0,
-                                                 uint8_t* __restrict__ brick_fluid = nullptr, int nbx = 0, int nby = 0) {
+                                                 volatile uint32_t* step_done_host, uint32_t step_number,
+                                                 uint8_t* __restrict__ brick_fluid, int nbx, int nby, const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
     if (step_done_host && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *step_done_host = step_number;
+    num_particles = particle_count(num_particles, n_dev, n_sel);
     const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
     if (pi >= num_particles) return;
     const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
@@ -696,7 +710,9 @@ __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles,
 // counters (block totals -> scan of totals -> rescan + offset) instead of the reference's block scan + one global
 // atomic per block, so cells are laid out in linear-index order (a legal instance of the reference's "sloppy" order).
 // =================================================================================================================
-__global__ __launch_bounds__(256) void k_bin_count(Grid g, uint32_t num_particles, float4* __restrict__ pos, uint32_t* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_bin_count(Grid g, uint32_t num_particles, float4* __restrict__ pos, uint32_t* __restrict__ counters,
+                                                   const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
+    num_particles = particle_count(num_particles, n_dev, n_sel);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= num_particles) return;
     const float4 p = pos[i];
@@ -766,7 +782,9 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ coun
 }
 // one_based: the literal Q4 reading (BLUB_BINNING_LITERAL) -- destination `inclusive - slot` as the shader writes it, slot 0 never written
 __global__ __launch_bounds__(256) void k_bin_rewrite(Grid g, uint32_t num_particles, uint32_t max_particles, const float4* __restrict__ old_pos,
-                                                     float4* __restrict__ new_pos, const uint32_t* __restrict__ inclusive, int one_based) {
+                                                     float4* __restrict__ new_pos, const uint32_t* __restrict__ inclusive, int one_based,
+                                                     const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
+    num_particles = particle_count(num_particles, n_dev, n_sel);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= num_particles) return;
     const float4 p = old_pos[i];

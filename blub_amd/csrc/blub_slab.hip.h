@@ -35,8 +35,11 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t* __restrict__ counter, b
 // would otherwise all hit the one counter.
 __global__ __launch_bounds__(256) void k_slab_select(uint32_t n, const float4* __restrict__ pos, const float4* __restrict__ vx, const float4* __restrict__ vy,
                                                      const float4* __restrict__ vz, float zlo, float zhi, uint32_t capacity, uint32_t* __restrict__ counter,
-                                                     float4* __restrict__ out_pos, float4* __restrict__ out_vx, float4* __restrict__ out_vy, float4* __restrict__ out_vz) {
+                                                     float4* __restrict__ out_pos, float4* __restrict__ out_vx, float4* __restrict__ out_vy, float4* __restrict__ out_vz,
+                                                     const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t wcount[4], wbase;
+    n = particle_count(n, n_dev, 1u);
+    if (blockIdx.x * 256u >= n) return;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(256) void k_slab_migrate_mark(uint32_t n, const flo
                                                            const float4* __restrict__ vz, float z0, float z1, uint32_t capacity, SlabCounts* __restrict__ counts,
                                                            float4* __restrict__ up_pos, float4* __restrict__ up_vx, float4* __restrict__ up_vy, float4* __restrict__ up_vz,
                                                            float4* __restrict__ dn_pos, float4* __restrict__ dn_vx, float4* __restrict__ dn_vy, float4* __restrict__ dn_vz,
-                                                           uint32_t* __restrict__ leave_idx) {
+                                                           uint32_t* __restrict__ leave_idx, const uint32_t* __restrict__ n_dev) {
+    n = particle_count(n, n_dev, 1u);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -81,7 +85,9 @@ __global__ __launch_bounds__(256) void k_slab_migrate_mark(uint32_t n, const flo
     if (up || down) leave_idx[kl] = i;
 }
 __global__ __launch_bounds__(256) void k_slab_migrate_match(uint32_t n, const float4* __restrict__ pos, float z0, float z1, SlabCounts* __restrict__ counts,
-                                                            const uint32_t* __restrict__ leave_idx, uint32_t* __restrict__ hole_idx, uint32_t* __restrict__ fill_idx) {
+                                                            const uint32_t* __restrict__ leave_idx, uint32_t* __restrict__ hole_idx, uint32_t* __restrict__ fill_idx,
+                                                            const uint32_t* __restrict__ n_dev) {
+    n = particle_count(n, n_dev, 1u);
     const uint32_t L = counts->n_leave;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x * 256u >= L && !(blockIdx.x == 0)) return;      // whole block beyond the leave list (block 0 still publishes n_stay)
@@ -110,7 +116,9 @@ __global__ __launch_bounds__(256) void k_slab_migrate_fill(const SlabCounts* __r
 // Ghost particles for the density projection: mark their cells FLUID and hang them into the density linked list
 // (what advect_particles.comp:176-181 does for the own particles).
 __global__ __launch_bounds__(256) void k_slab_insert_density_ghosts(Grid g, uint32_t first, uint32_t count, float4* __restrict__ pos, int8_t* __restrict__ marker,
-                                                                    uint32_t* __restrict__ heads) {
+                                                                    uint32_t* __restrict__ heads, const uint32_t* __restrict__ n_dev) {
+    count = particle_count(count, n_dev, 3u);
+    if (blockIdx.x * 256u >= count) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const bool live = k < count;            // no early return: the wave-level list insertion needs every lane
     const uint32_t i = first + k;
@@ -123,6 +131,63 @@ __global__ __launch_bounds__(256) void k_slab_insert_density_ghosts(Grid g, uint
     const int dx = (int)(p.x - 0.5f), dy = (int)(p.y - 0.5f), dz = (int)(p.z - 0.5f);
     const uint32_t nxt = wave_list_insert(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, i);
     if (live) reinterpret_cast<uint32_t*>(pos)[4 * (size_t)i + 3] = nxt;
+}
+
+// ---- particle exchange without the host (round 3) ---------------------------------------------------------------------------------
+// Message sizes are host arguments of the transport, particle counts are only known on the device.  So a message has a FIXED capacity the
+// two ends derive from the number that travelled over the same link in the same exchange of the PREVIOUS step (both know it: the sender
+// from its own counters, the receiver from the header it got; it reaches the host through a pinned, sequence-tagged record, never through
+// a stream synchronisation) and carries the actual count in a 16-byte header in front of the position payload.  The receiver appends what
+// arrived behind its own particles with a kernel that reads both counts on the device.  A count beyond the capacity is flagged (the next
+// exchange returns an error): the capacity is 1.5 x the previous count + 2048.
+struct SlabXferRecord { uint32_t seq, n_up, n_down, from_below, from_above, overflow, n_own, n_ghost; };   // pinned host ring entry
+// after the select / migrate kernels: headers of the two outgoing messages, the new own count of a migration, overflow of the send buffers
+__global__ void k_slab_finish_send(const SlabCounts* __restrict__ counts, float4* __restrict__ hdr_up, float4* __restrict__ hdr_dn, uint32_t cap_up, uint32_t cap_dn,
+                                   uint32_t* __restrict__ n_dev, int migrate) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t nu = counts->n_up, nd = counts->n_down;
+    if (hdr_up) *hdr_up = make_float4(__uint_as_float(nu), 0.f, 0.f, 0.f);
+    if (hdr_dn) *hdr_dn = make_float4(__uint_as_float(nd), 0.f, 0.f, 0.f);
+    if (nu > cap_up || nd > cap_dn) n_dev[2] = 1u;
+    if (migrate) { n_dev[0] = counts->n_stay; n_dev[1] = 0u; }
+}
+// after the transport: append the arrivals (headers + payloads in the staging buffers) behind the own particles, publish counts + record
+struct SlabAppendArgs { const float4* below[4]; const float4* above[4]; float4* dst[4]; };    // [0] = positions (header in front), [1..3] = velocity rows
+__global__ __launch_bounds__(256) void k_slab_append(SlabAppendArgs a, int narr, uint32_t cap_below, uint32_t cap_above, uint32_t capacity, uint32_t* __restrict__ n_dev, int migrate,
+                                                     const SlabCounts* __restrict__ counts, SlabXferRecord* __restrict__ record, uint32_t seq, uint32_t* __restrict__ done_blocks) {
+    uint32_t cb = a.below[0] ? __float_as_uint(a.below[0][0].x) : 0u, ca = a.above[0] ? __float_as_uint(a.above[0][0].x) : 0u;
+    const uint32_t own = n_dev[0];
+    bool over = cb > cap_below || ca > cap_above || (uint64_t)own + cb + ca > capacity;
+    if (over) { cb = min(cb, cap_below); ca = min(ca, cap_above); if ((uint64_t)own + cb + ca > capacity) { cb = 0; ca = 0; } }
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < cb) {
+        for (int q = 0; q < narr; ++q) a.dst[q][own + k] = a.below[q][k + (q == 0 ? 1u : 0u)];
+    } else if (k - cb < ca) {
+        for (int q = 0; q < narr; ++q) a.dst[q][own + k] = a.above[q][k - cb + (q == 0 ? 1u : 0u)];
+    }
+    // the last block to finish publishes the counts (every append of this launch is done by then for the kernels that follow on the stream;
+    // the host only reads the record)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t t = atomicAdd(done_blocks, 1u);
+        if (t == gridDim.x - 1) {
+            *done_blocks = 0u;
+            if (over) n_dev[2] = 1u;
+            if (migrate) { n_dev[0] = own + cb + ca; n_dev[1] = 0u; } else n_dev[1] = cb + ca;
+            record->n_up = counts->n_up; record->n_down = counts->n_down; record->from_below = cb; record->from_above = ca;
+            record->overflow = n_dev[2]; record->n_own = n_dev[0]; record->n_ghost = n_dev[1];
+            __threadfence_system();
+            record->seq = seq;
+        }
+    }
+}
+// the gathered fluid-brick counts of a step (PCG grid of the NEXT step's slab solves) to the host, tagged
+__global__ void k_slab_publish_cnt(const float* __restrict__ gat_cnt, int nranks, float* __restrict__ host_values, uint32_t* __restrict__ host_seq, uint32_t seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < nranks; ++k) host_values[k] = gat_cnt[k];
+    __threadfence_system();
+    *host_seq = seq;
 }
 
 // loopback transport: all plane copies of one halo exchange in ONE launch (a hipMemcpyAsync per plane costs ~4 us of queue time each,

@@ -24,6 +24,9 @@ struct blub_slab_group {
     struct Extra {
         uint32_t *leave_idx = nullptr, *hole_idx = nullptr, *fill_idx = nullptr;   // in-place migration (blub_slab.hip.h: k_slab_migrate_*)
         float4 *up[4] = {nullptr, nullptr, nullptr, nullptr}, *dn[4] = {nullptr, nullptr, nullptr, nullptr};   // send buffers: pos, vx, vy, vz
+        float4 *up_msg = nullptr, *dn_msg = nullptr;   // allocations behind up[0] / dn[0]: one float4 of header in front of the position payload
+        float4 *rb_msg = nullptr, *ra_msg = nullptr, *rb[4] = {nullptr, nullptr, nullptr, nullptr}, *ra[4] = {nullptr, nullptr, nullptr, nullptr};   // staging of what arrives from below / above
+        uint32_t* append_done = nullptr;         // device: block counter of k_slab_append
         blubk::SlabCounts* counts = nullptr;     // device
         uint32_t* recv_counts = nullptr;         // device: {from below, from above}
         float* gat_dir = nullptr;                // device: nranks x SLAB_NP partials of s.As (own segment written by the direction kernel)
@@ -40,6 +43,17 @@ struct blub_slab_group {
     float* cnt_host = nullptr;                   // pinned: [0, nranks) gathered fluid-brick counts, [nranks, nranks + nlocal) staging of the own ones
     int np_cur = blubk::SLAB_NP_DEFAULT;         // PCG grid of this step's slab solves
     blubk::SlabCopyList copies{};                // loopback transport: plane copies collected for one batched launch
+    // host-synchronisation-free particle exchange (slab_exchange_particles_async): per local slab and exchange kind what travelled last time
+    struct Hist { bool valid = false, pending = false; uint32_t seq = 0, n_up = 0, n_down = 0, from_below = 0, from_above = 0; };
+    std::vector<Hist> hist;                      // [local slab][XFER_KINDS]
+    blubk::SlabXferRecord* rec_host = nullptr;   // pinned: [local slab][XFER_KINDS][XFER_RING] records written by k_slab_append
+    blubk::SlabXferRecord* rec_dev = nullptr;    // the same ring as the device sees it
+    uint32_t xfer_seq = 0;                       // exchanges issued so far
+    bool async_exchange = true;                  // blub_slab_group_set_async_exchange
+    float* cntrec_host = nullptr; float* cntrec_dev = nullptr;       // pinned: [2][nranks] gathered fluid-brick counts, double buffered by step parity
+    uint32_t* cntseq_host = nullptr; uint32_t* cntseq_dev = nullptr; // pinned: [2] tags
+    uint32_t cnt_seq = 0; bool cnt_pending = false;
+    uint64_t host_syncs = 0, done_polls = 0;     // stream synchronisations issued by blub_slab_group_step so far: particle exchanges / looks at a solve's `done` (diagnostics)
     int gather_mode = 0;                         // RCCL only: 0 = partials as p2p inside the halo's group, 1 = ncclAllGather (calibrated at creation)
     char transport[192] = "loopback";
 };
@@ -52,7 +66,7 @@ namespace blub {
         if (_r != ncclSuccess) { char _b[256]; snprintf(_b, sizeof _b, "%s failed: %s", #expr, ncclGetErrorString(_r)); return set_error(BLUB_ERR_COMM, _b); } \
     } while (0)
 
-enum { XFER_GHOST_FULL = 0, XFER_GHOST_POS = 1, XFER_MIGRATE = 2 };
+enum { XFER_GHOST_FULL = 0, XFER_GHOST_POS = 1, XFER_MIGRATE = 2, XFER_MIGRATE_B = 3, XFER_KINDS = 4, XFER_RING = 4 };   // (MIGRATE_B: the second migration of a step; same protocol, its own history)
 
 // loopback transport: device-to-device plane copies are collected and issued as ONE kernel per exchange
 static int slab_copy_flush(blub_slab_group* G) {
@@ -161,8 +175,20 @@ static int slab_fused(blub_slab_group* G, const std::function<int()>& halos, con
 }
 
 // Ghost copies / migration of particles between z-neighbours.
-static int slab_exchange_particles(blub_slab_group* G, int mode) {
+// device copy of the (exact) host-side particle counts of a slab: {own, ghost, overflow flag}
+static int slab_upload_counts(blub_slab_group* G, int i) {
+    blub_fluid* h = G->slabs[i];
+    const uint32_t v[2] = {h->num_particles, h->num_ghost};
+    // (pageable source: the runtime stages it before returning, so the stack array may go out of scope)
+    HIP_TRY(hipMemcpyAsync(h->n_dev, v, sizeof v, hipMemcpyHostToDevice, G->stream));
+    return BLUB_OK;
+}
+
+// Synchronous variant: the counts travel first and the host waits for them (one stream synchronisation per exchange).  Used for the first
+// step after the particles were set from outside (no history to size messages from) and when the asynchronous exchange is switched off.
+static int slab_exchange_particles(blub_slab_group* G, int kind) {
     const int S = (int)G->slabs.size();
+    const int mode = kind == XFER_MIGRATE_B ? XFER_MIGRATE : kind;
     const bool with_rows = mode != XFER_GHOST_POS;
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
@@ -172,21 +198,22 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
         if (!n) continue;
         if (mode == XFER_MIGRATE) {
             hipLaunchKernelGGL(blubk::k_slab_migrate_mark, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
-                               (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.up[0], e.up[1], e.up[2], e.up[3], e.dn[0], e.dn[1], e.dn[2], e.dn[3], e.leave_idx);
+                               (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.up[0], e.up[1], e.up[2], e.up[3], e.dn[0], e.dn[1], e.dn[2], e.dn[3], e.leave_idx,
+                               (const uint32_t*)nullptr);
             // (grids cover the worst case -- every particle leaves --; blocks beyond the device-side counts exit at once)
             hipLaunchKernelGGL(blubk::k_slab_migrate_match, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (float)h->slab_z0, (float)h->slab_z1, e.counts,
-                               (const uint32_t*)e.leave_idx, e.hole_idx, e.fill_idx);
+                               (const uint32_t*)e.leave_idx, e.hole_idx, e.fill_idx, (const uint32_t*)nullptr);
             hipLaunchKernelGGL(blubk::k_slab_migrate_fill, dim3(particle_blocks(n)), dim3(256), 0, G->stream, (const blubk::SlabCounts*)e.counts, (const uint32_t*)e.hole_idx,
                                (const uint32_t*)e.fill_idx, h->pos, h->pvel[0], h->pvel[1], h->pvel[2]);
         } else {
             if (has_up(G, i))
                 hipLaunchKernelGGL(blubk::k_slab_select, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
                                    (const float4*)h->pvel[2], (float)h->slab_z1 - blubk::GHOST_MARGIN, (float)h->slab_z1, G->capacity, &e.counts->n_up, e.up[0],
-                                   with_rows ? e.up[1] : nullptr, e.up[2], e.up[3]);
+                                   with_rows ? e.up[1] : nullptr, e.up[2], e.up[3], (const uint32_t*)nullptr);
             if (has_down(G, i))
                 hipLaunchKernelGGL(blubk::k_slab_select, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
                                    (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z0 + blubk::GHOST_MARGIN, G->capacity, &e.counts->n_down, e.dn[0],
-                                   with_rows ? e.dn[1] : nullptr, e.dn[2], e.dn[3]);
+                                   with_rows ? e.dn[1] : nullptr, e.dn[2], e.dn[3], (const uint32_t*)nullptr);
         }
     }
     // counts to the host (the payload sizes of the transfers below are host-side arguments)
@@ -203,6 +230,7 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
         for (int i = 0; i < S; ++i) HIP_TRY(hipMemcpyAsync(&G->recv_host[2 * i], G->ex[i].recv_counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, G->stream));
     }
     HIP_TRY(hipStreamSynchronize(G->stream));
+    G->host_syncs += 1;
     for (int i = 0; i < S; ++i)
         if (G->counts_host[i].n_up > G->capacity || G->counts_host[i].n_down > G->capacity) return set_error(BLUB_ERR_OUT_OF_MEMORY, "slab transfer buffer overflow");
     if (mode == XFER_MIGRATE)
@@ -247,6 +275,120 @@ static int slab_exchange_particles(blub_slab_group* G, int mode) {
         blub_fluid* h = G->slabs[i];
         if (mode == XFER_MIGRATE) { h->num_particles += from_below[i] + from_above[i]; h->num_ghost = 0; }
         else h->num_ghost = from_below[i] + from_above[i];
+        int rc = slab_upload_counts(G, i);
+        if (rc != BLUB_OK) return rc;
+        // what travelled: the next exchange of this kind sizes its messages from it (slab_exchange_particles_async)
+        blub_slab_group::Hist& H = G->hist[(size_t)i * XFER_KINDS + kind];
+        H.valid = true; H.pending = false; H.n_up = G->counts_host[i].n_up; H.n_down = G->counts_host[i].n_down; H.from_below = from_below[i]; H.from_above = from_above[i];
+    }
+    return BLUB_OK;
+}
+
+// Message capacity (particles) derived from the count that travelled over the same link in the same exchange of the previous step
+static uint32_t slab_capx(const blub_slab_group* G, uint32_t prev) { return (uint32_t)std::min<uint64_t>(G->capacity, (((uint64_t)prev + prev / 2 + 2048u) + 255u) & ~255ull); }
+
+// The exchange without host synchronisation (see blub_slab.hip.h): fixed-capacity messages with a count header, appended by a kernel.
+static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
+    const int S = (int)G->slabs.size();
+    const int mode = kind == XFER_MIGRATE_B ? XFER_MIGRATE : kind;
+    const bool with_rows = mode != XFER_GHOST_POS, migrate = mode == XFER_MIGRATE;
+    const int narr = with_rows ? 4 : 1;
+    std::vector<uint32_t> cap_up(S, 0), cap_dn(S, 0), cap_below(S, 0), cap_above(S, 0);
+    for (int i = 0; i < S; ++i) {      // what travelled last time: from the host (after a synchronous exchange) or from the pinned record the last append kernel wrote
+        blub_slab_group::Hist& H = G->hist[(size_t)i * XFER_KINDS + kind];
+        if (H.pending) {
+            const volatile blubk::SlabXferRecord* r = &G->rec_host[((size_t)i * XFER_KINDS + kind) * XFER_RING + H.seq % XFER_RING];
+            unsigned spins = 0;
+            while (r->seq != H.seq) {      // (normally long since there: the record is a whole step old)
+                if (++spins > 2000) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+                if (spins > 50000000u) return set_error(BLUB_ERR_DEVICE, "timed out waiting for the record of the previous particle exchange");
+            }
+            if (r->overflow) return set_error(BLUB_ERR_OUT_OF_MEMORY, "a slab particle exchange exceeded its message capacity or the particle capacity of a slab (the counts grew by more than 1.5x + 2048 within one step)");
+            H.n_up = r->n_up; H.n_down = r->n_down; H.from_below = r->from_below; H.from_above = r->from_above; H.pending = false;
+        }
+        cap_up[i] = has_up(G, i) ? slab_capx(G, H.n_up) : 0u; cap_dn[i] = has_down(G, i) ? slab_capx(G, H.n_down) : 0u;
+        cap_below[i] = has_down(G, i) ? slab_capx(G, H.from_below) : 0u; cap_above[i] = has_up(G, i) ? slab_capx(G, H.from_above) : 0u;
+    }
+    G->xfer_seq += 1;
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        auto& e = G->ex[i];
+        h->num_particles = G->capacity;      // from here on: bounds (the counts live in n_dev)
+        HIP_TRY(hipMemsetAsync(e.counts, 0, sizeof(blubk::SlabCounts), G->stream));
+        const uint32_t n = h->num_particles;
+        const uint32_t* nd = h->n_dev;
+        if (migrate) {
+            hipLaunchKernelGGL(blubk::k_slab_migrate_mark, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                               (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.up[0], e.up[1], e.up[2], e.up[3],
+                               e.dn[0], e.dn[1], e.dn[2], e.dn[3], e.leave_idx, nd);
+            hipLaunchKernelGGL(blubk::k_slab_migrate_match, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (float)h->slab_z0, (float)h->slab_z1, e.counts,
+                               (const uint32_t*)e.leave_idx, e.hole_idx, e.fill_idx, nd);
+            hipLaunchKernelGGL(blubk::k_slab_migrate_fill, dim3(particle_blocks(n)), dim3(256), 0, G->stream, (const blubk::SlabCounts*)e.counts, (const uint32_t*)e.hole_idx,
+                               (const uint32_t*)e.fill_idx, h->pos, h->pvel[0], h->pvel[1], h->pvel[2]);
+        } else {
+            if (has_up(G, i))
+                hipLaunchKernelGGL(blubk::k_slab_select, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                                   (const float4*)h->pvel[2], (float)h->slab_z1 - blubk::GHOST_MARGIN, (float)h->slab_z1, G->capacity, &e.counts->n_up, e.up[0],
+                                   with_rows ? e.up[1] : nullptr, e.up[2], e.up[3], nd);
+            if (has_down(G, i))
+                hipLaunchKernelGGL(blubk::k_slab_select, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                                   (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z0 + blubk::GHOST_MARGIN, G->capacity, &e.counts->n_down, e.dn[0],
+                                   with_rows ? e.dn[1] : nullptr, e.dn[2], e.dn[3], nd);
+        }
+        hipLaunchKernelGGL(blubk::k_slab_finish_send, dim3(1), dim3(1), 0, G->stream, (const blubk::SlabCounts*)e.counts, has_up(G, i) ? e.up_msg : (float4*)nullptr,
+                           has_down(G, i) ? e.dn_msg : (float4*)nullptr, cap_up[i], cap_dn[i], h->n_dev, (int)migrate);
+    }
+    // transport: ONE grouped operation (round 2: counts, a host synchronisation, then the payload)
+    G->comm_ops += 1;
+    if (G->rccl) NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < S; ++i) {
+        auto& e = G->ex[i];
+        for (int k = 0; k < narr; ++k) {
+            const size_t hdr = k == 0 ? 1 : 0;      // the position message carries the header
+            const float4* up_src = k == 0 ? e.up_msg : e.up[k]; const float4* dn_src = k == 0 ? e.dn_msg : e.dn[k];
+            float4* ra_dst = k == 0 ? e.ra_msg : e.ra[k]; float4* rb_dst = k == 0 ? e.rb_msg : e.rb[k];
+            if (has_up(G, i)) {
+                if (up_local(G, i)) {      // my up message is the next slab's "from below", its down message my "from above"
+                    auto& en = G->ex[i + 1];
+                    { int rc = slab_copy(G, k == 0 ? en.rb_msg : en.rb[k], up_src, (hdr + cap_up[i]) * 16); if (rc != BLUB_OK) return rc; }
+                    { int rc = slab_copy(G, ra_dst, k == 0 ? en.dn_msg : en.dn[k], (hdr + cap_above[i]) * 16); if (rc != BLUB_OK) return rc; }
+                } else {
+                    NCCL_TRY(ncclSend(up_src, (hdr + cap_up[i]) * 16, ncclChar, G->first + i + 1, G->comm, G->stream));
+                    NCCL_TRY(ncclRecv(ra_dst, (hdr + cap_above[i]) * 16, ncclChar, G->first + i + 1, G->comm, G->stream));
+                }
+            }
+            if (has_down(G, i) && !down_local(G, i)) {
+                NCCL_TRY(ncclSend(dn_src, (hdr + cap_dn[i]) * 16, ncclChar, G->first + i - 1, G->comm, G->stream));
+                NCCL_TRY(ncclRecv(rb_dst, (hdr + cap_below[i]) * 16, ncclChar, G->first + i - 1, G->comm, G->stream));
+            }
+        }
+    }
+    if (G->rccl) NCCL_TRY(ncclGroupEnd());
+    { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        auto& e = G->ex[i];
+        blubk::SlabAppendArgs a{};
+        for (int k = 0; k < 4; ++k) { a.below[k] = has_down(G, i) ? (k == 0 ? e.rb_msg : e.rb[k]) : nullptr; a.above[k] = has_up(G, i) ? (k == 0 ? e.ra_msg : e.ra[k]) : nullptr; }
+        a.dst[0] = h->pos; a.dst[1] = h->pvel[0]; a.dst[2] = h->pvel[1]; a.dst[3] = h->pvel[2];
+        blubk::SlabXferRecord* rec = G->rec_dev + ((size_t)i * XFER_KINDS + kind) * XFER_RING + G->xfer_seq % XFER_RING;
+        hipLaunchKernelGGL(blubk::k_slab_append, dim3(std::max(1u, particle_blocks(cap_below[i] + cap_above[i]))), dim3(256), 0, G->stream, a, narr, cap_below[i], cap_above[i], G->capacity,
+                           h->n_dev, (int)migrate, (const blubk::SlabCounts*)e.counts, rec, G->xfer_seq, e.append_done);
+        blub_slab_group::Hist& H = G->hist[(size_t)i * XFER_KINDS + kind];
+        H.pending = true; H.seq = G->xfer_seq;
+        h->num_ghost = migrate ? 0u : cap_below[i] + cap_above[i];      // (bound)
+    }
+    return BLUB_OK;
+}
+
+// exact particle counts of every local slab back on the host (blocks): for the entry points that hand particles out
+static int slab_refresh_counts(blub_slab_group* G) {
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    for (size_t i = 0; i < G->slabs.size(); ++i) {
+        uint32_t v[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpy(v, G->slabs[i]->n_dev, sizeof v, hipMemcpyDeviceToHost));
+        if (v[2]) return set_error(BLUB_ERR_OUT_OF_MEMORY, "a slab particle exchange exceeded its message capacity or the particle capacity of a slab");
+        G->slabs[i]->num_particles = v[0]; G->slabs[i]->num_ghost = v[1];
     }
     return BLUB_OK;
 }
@@ -321,6 +463,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
         if (target > maxit) break;
         HIP_TRY(hipMemcpyAsync(&G->ctrl_host[which], h0->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, G->stream));
         HIP_TRY(hipStreamSynchronize(G->stream));
+        G->done_polls += 1;
         done = G->ctrl_host[which].done != 0;
         if (done) break;
         target = std::min(maxit + 1, target + freq);
@@ -429,6 +572,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
         if (target > maxit) break;
         HIP_TRY(hipMemcpyAsync(&G->ctrl_host[which], h0->ctrl[which], sizeof(PcgCtrl), hipMemcpyDeviceToHost, G->stream));
         HIP_TRY(hipStreamSynchronize(G->stream));
+        G->done_polls += 1;
         if (G->ctrl_host[which].done != 0) break;
         target = std::min(maxit + 1, target + freq);
     }
@@ -445,12 +589,31 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
 }
 
 // HybridFluid::step (hybrid_fluid.rs:770-977) over all slabs in lock step
+// ghosts are dropped: on the host (bound) and on the device (count)
+static int slab_drop_ghosts(blub_slab_group* G) {
+    for (auto h : G->slabs) { h->num_ghost = 0; HIP_TRY(hipMemsetAsync(h->n_dev + 1, 0, sizeof(uint32_t), G->stream)); }
+    return BLUB_OK;
+}
+
+// HybridFluid::step (hybrid_fluid.rs:770-977) over all slabs in lock step
 static int slab_step(blub_slab_group* G, float dt) {
     int rc;
     const int S = (int)G->slabs.size();
 #define FOR_SLABS(call) for (int i = 0; i < S; ++i) { blub_fluid* h = G->slabs[i]; (void)h; if ((rc = (call)) != BLUB_OK) return rc; }
+    // The particle exchanges run without host synchronisation once every exchange kind has a history to size its messages from (i.e. from
+    // the second step after the particles were set); all ranks take the same decision (they step in lock step).
+    bool async = G->async_exchange;
+    for (auto& H : G->hist) async = async && H.valid;
+    auto exchange = [&](int kind) { return async ? slab_exchange_particles_async(G, kind) : slab_exchange_particles(G, kind); };
     {   // size of this step's PCG grids: every slab contributes the newest fluid-brick count it has (a lagged, non-blocking snapshot) and
-        // all of them use the same grid, from the largest count (one 4-byte gather per step; read after the sync of the exchange below)
+        // all of them use the same grid, from the largest count (one 4-byte gather per step).  The gathered values reach the host through a
+        // pinned, tagged record and are used by the NEXT step (asynchronous path) / after the sync of the exchange below (synchronous path)
+        if (async && G->cnt_pending) {
+            const volatile uint32_t* tag = &G->cntseq_host[G->cnt_seq & 1];
+            unsigned spins = 0;
+            while (*tag != G->cnt_seq) { if (++spins > 2000) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); } if (spins > 50000000u) return set_error(BLUB_ERR_DEVICE, "timed out waiting for the gathered brick counts"); }
+            for (int k = 0; k < G->nranks; ++k) G->cnt_host[k] = G->cntrec_host[(size_t)(G->cnt_seq & 1) * G->nranks + k];
+        }
         for (int i = 0; i < S; ++i) {
             BrickCounts bc{}; bool have = false;
             if ((rc = latest_counts(G->slabs[i], false, &bc, &have)) != BLUB_OK) return rc;
@@ -458,9 +621,16 @@ static int slab_step(blub_slab_group* G, float dt) {
             HIP_TRY(hipMemcpyAsync(G->ex[i].gat_cnt + (G->first + i), &G->cnt_host[G->nranks + i], sizeof(float), hipMemcpyHostToDevice, G->stream));
         }
         if ((rc = slab_gather(G, [G](int i) { return G->ex[i].gat_cnt; }, 1)) != BLUB_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(G->cnt_host, G->ex[0].gat_cnt, (size_t)G->nranks * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+        if (async) {
+            G->cnt_seq += 1; G->cnt_pending = true;
+            hipLaunchKernelGGL(k_slab_publish_cnt, dim3(1), dim3(1), 0, G->stream, (const float*)G->ex[0].gat_cnt, G->nranks, G->cntrec_dev + (size_t)(G->cnt_seq & 1) * G->nranks,
+                               G->cntseq_dev + (G->cnt_seq & 1), G->cnt_seq);
+        } else {
+            G->cnt_pending = false;
+            HIP_TRY(hipMemcpyAsync(G->cnt_host, G->ex[0].gat_cnt, (size_t)G->nranks * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+        }
     }
-    if ((rc = slab_exchange_particles(G, XFER_GHOST_FULL)) != BLUB_OK) return rc;
+    if ((rc = exchange(XFER_GHOST_FULL)) != BLUB_OK) return rc;
     {
         float mx = 0.0f; bool all_known = true;
         for (int k = 0; k < G->nranks; ++k) { mx = std::max(mx, G->cnt_host[k]); all_known = all_known && G->cnt_host[k] > 0.0f; }
@@ -469,7 +639,7 @@ static int slab_step(blub_slab_group* G, float dt) {
         G->np_cur = std::max(128, std::min(SLAB_NP_MAX, (np + 7) & ~7));
     }
     FOR_SLABS(stage_transfer(h, dt))
-    for (int i = 0; i < S; ++i) G->slabs[i]->num_ghost = 0;   // the velocity ghosts are only needed by the P2G gather
+    if ((rc = slab_drop_ghosts(G)) != BLUB_OK) return rc;   // the velocity ghosts are only needed by the P2G gather
     if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
     FOR_SLABS(stage_divergence(h))
     if ((rc = slab_solve(G, 0, dt)) != BLUB_OK) return rc;
@@ -484,16 +654,16 @@ static int slab_step(blub_slab_group* G, float dt) {
     FOR_SLABS(stage_extrapolate(h))
     if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
     FOR_SLABS(stage_advect_particles(h, dt, false))
-    if ((rc = slab_exchange_particles(G, XFER_MIGRATE)) != BLUB_OK) return rc;
-    if ((rc = slab_exchange_particles(G, XFER_GHOST_POS)) != BLUB_OK) return rc;
+    if ((rc = exchange(XFER_MIGRATE)) != BLUB_OK) return rc;
+    if ((rc = exchange(XFER_GHOST_POS)) != BLUB_OK) return rc;
     for (int i = 0; i < S; ++i) {   // marker + density list for own and ghost particles (advect_particles.comp:176-181)
         blub_fluid* h = G->slabs[i];
         const uint32_t n = h->num_particles + h->num_ghost;
-        if (n) hipLaunchKernelGGL(k_slab_insert_density_ghosts, dim3(particle_blocks(n)), dim3(256), 0, G->stream, h->g, 0u, n, h->pos, h->marker, h->ll[0]);
+        if (n) hipLaunchKernelGGL(k_slab_insert_density_ghosts, dim3(particle_blocks(n)), dim3(256), 0, G->stream, h->g, 0u, n, h->pos, h->marker, h->ll[0], (const uint32_t*)h->n_dev);
     }
     FOR_SLABS(build_lists_from_particles(h, COMPACT_STEP_B))
     FOR_SLABS(stage_density_gather(h, dt))
-    for (int i = 0; i < S; ++i) G->slabs[i]->num_ghost = 0;
+    if ((rc = slab_drop_ghosts(G)) != BLUB_OK) return rc;
     if ((rc = slab_solve(G, 1, dt)) != BLUB_OK) return rc;
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
@@ -504,7 +674,7 @@ static int slab_step(blub_slab_group* G, float dt) {
     FOR_SLABS(stage_extrapolate(h))
     if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
     FOR_SLABS(stage_correct(h))
-    if ((rc = slab_exchange_particles(G, XFER_MIGRATE)) != BLUB_OK) return rc;
+    if ((rc = exchange(XFER_MIGRATE_B)) != BLUB_OK) return rc;
     for (int i = 0; i < S; ++i) { G->slabs[i]->step_counter += 1; (void)poll_stats(G->slabs[i], false); }
 #undef FOR_SLABS
     return check_launch(h0);
@@ -516,10 +686,14 @@ static void slab_group_destroy(blub_slab_group* G) {
     if (G->stream) (void)hipStreamSynchronize(G->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     for (auto& e : G->ex) {
-        F(e.leave_idx); F(e.hole_idx); F(e.fill_idx); for (auto p : e.up) F(p); for (auto p : e.dn) F(p);
+        F(e.leave_idx); F(e.hole_idx); F(e.fill_idx); F(e.up_msg); F(e.dn_msg); for (int k = 1; k < 4; ++k) { F(e.up[k]); F(e.dn[k]); }
         F(e.counts); F(e.recv_counts); F(e.gat_dir); F(e.gat_upd); F(e.gat4[0]); F(e.gat4[1]); F(e.gat_cnt);
+        F(e.rb_msg); F(e.ra_msg); for (int k = 1; k < 4; ++k) { F(e.rb[k]); F(e.ra[k]); } F(e.append_done);
     }
-    for (auto h : G->slabs) destroy(h);
+    for (auto h : G->slabs) { F(h->n_dev); h->n_dev = nullptr; destroy(h); }
+    if (G->rec_host) (void)hipHostFree(G->rec_host);
+    if (G->cntrec_host) (void)hipHostFree(G->cntrec_host);
+    if (G->cntseq_host) (void)hipHostFree(G->cntseq_host);
     if (G->counts_host) (void)hipHostFree(G->counts_host);
     if (G->recv_host) (void)hipHostFree(G->recv_host);
     if (G->ctrl_host) (void)hipHostFree(G->ctrl_host);
@@ -615,7 +789,12 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
         const size_t P = G->capacity;
         A(dev_alloc_zero(G->stream, &e.leave_idx, P)); A(dev_alloc_zero(G->stream, &e.hole_idx, P)); A(dev_alloc_zero(G->stream, &e.fill_idx, P));
-        for (int k = 0; k < 4; ++k) { A(dev_alloc_zero(G->stream, &e.up[k], P)); A(dev_alloc_zero(G->stream, &e.dn[k], P)); }
+        // send buffers (position messages carry one float4 of header in front) and the staging of what arrives
+        A(dev_alloc_zero(G->stream, &e.up_msg, P + 1)); A(dev_alloc_zero(G->stream, &e.dn_msg, P + 1)); A(dev_alloc_zero(G->stream, &e.rb_msg, P + 1)); A(dev_alloc_zero(G->stream, &e.ra_msg, P + 1));
+        if (rc == BLUB_OK) { e.up[0] = e.up_msg + 1; e.dn[0] = e.dn_msg + 1; e.rb[0] = e.rb_msg + 1; e.ra[0] = e.ra_msg + 1; }
+        for (int k = 1; k < 4; ++k) { A(dev_alloc_zero(G->stream, &e.up[k], P)); A(dev_alloc_zero(G->stream, &e.dn[k], P)); A(dev_alloc_zero(G->stream, &e.rb[k], P)); A(dev_alloc_zero(G->stream, &e.ra[k], P)); }
+        A(dev_alloc_zero(G->stream, &e.append_done, 1));
+        A(dev_alloc_zero(G->stream, &h->n_dev, 4));
         A(dev_alloc_zero(G->stream, &e.counts, 1)); A(dev_alloc_zero(G->stream, &e.recv_counts, 2));
         A(dev_alloc_zero(G->stream, &e.gat_dir, (size_t)nranks * blubk::SLAB_NP_MAX)); A(dev_alloc_zero(G->stream, &e.gat_upd, (size_t)nranks * blubk::SLAB_NP_MAX));
         A(dev_alloc_zero(G->stream, &e.gat_cnt, (size_t)nranks));
@@ -627,6 +806,16 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->ctrl_host, 2 * sizeof(blubk::PcgCtrl)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->cnt_host, (size_t)(nranks + nlocal) * sizeof(float)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     if (rc == BLUB_OK) memset(G->cnt_host, 0, (size_t)(nranks + nlocal) * sizeof(float));
+    G->hist.assign((size_t)nlocal * XFER_KINDS, blub_slab_group::Hist());
+    const size_t nrec = (size_t)nlocal * XFER_KINDS * XFER_RING;
+    if (rc == BLUB_OK && (hipHostMalloc((void**)&G->rec_host, nrec * sizeof(blubk::SlabXferRecord), hipHostMallocMapped) != hipSuccess ||
+                          hipHostGetDevicePointer((void**)&G->rec_dev, G->rec_host, 0) != hipSuccess)) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK) memset(G->rec_host, 0, nrec * sizeof(blubk::SlabXferRecord));
+    if (rc == BLUB_OK && (hipHostMalloc((void**)&G->cntrec_host, 2 * (size_t)nranks * sizeof(float), hipHostMallocMapped) != hipSuccess ||
+                          hipHostGetDevicePointer((void**)&G->cntrec_dev, G->cntrec_host, 0) != hipSuccess)) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK && (hipHostMalloc((void**)&G->cntseq_host, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+                          hipHostGetDevicePointer((void**)&G->cntseq_dev, G->cntseq_host, 0) != hipSuccess)) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (rc == BLUB_OK) { memset(G->cntrec_host, 0, 2 * (size_t)nranks * sizeof(float)); memset(G->cntseq_host, 0, 2 * sizeof(uint32_t)); }
     if (rc == BLUB_OK) { memset(G->counts_host, 0, nlocal * sizeof(blubk::SlabCounts)); memset(G->recv_host, 0, 2 * nlocal * sizeof(uint32_t)); memset(G->ctrl_host, 0, 2 * sizeof(blubk::PcgCtrl)); }
     if (rc == BLUB_OK && G->rccl) {
         if (nlocal != 1) rc = set_error(BLUB_ERR_INVALID_ARGUMENT, "RCCL slab groups hold exactly one slab per process");
@@ -694,13 +883,23 @@ int blub_slab_group_set_particles(blub_slab_group* g, uint32_t n, const float* p
         int rc = blub_fluid_set_particles(h, (uint32_t)(p.size() / 4), p.data(), vx ? a.data() : nullptr, vy ? b.data() : nullptr, vz ? c.data() : nullptr);
         if (rc != BLUB_OK) return rc;
         h->num_ghost = 0;
+        if ((rc = blub::slab_upload_counts(g, (int)s)) != BLUB_OK) return rc;
+        HIP_TRY(hipMemsetAsync(h->n_dev + 2, 0, sizeof(uint32_t), g->stream));      // (overflow flag)
     }
+    for (auto& H : g->hist) H = blub_slab_group::Hist();      // the next step sizes nothing from the past: synchronous exchanges
+    g->cnt_pending = false;
     return BLUB_OK;
 }
-uint32_t blub_slab_group_num_particles(const blub_slab_group* g) { uint32_t n = 0; if (g) for (auto h : g->slabs) n += h->num_particles; return n; }
+uint32_t blub_slab_group_num_particles(blub_slab_group* g) {      // blocks (the counts live on the device)
+    uint32_t n = 0;
+    if (g && hipSetDevice(g->device) == hipSuccess && blub::slab_refresh_counts(g) == BLUB_OK) for (auto h : g->slabs) n += h->num_particles;
+    return n;
+}
 // Own particles of all LOCAL slabs, concatenated in slab order (any pointer may be NULL); blocks.
 int blub_slab_group_get_particles(blub_slab_group* g, float* pos_ll, float* vx, float* vy, float* vz) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    { int rc = blub::slab_refresh_counts(g); if (rc != BLUB_OK) return rc; }
     size_t off = 0;
     for (auto h : g->slabs) {
         int rc = blub_fluid_get_particles(h, pos_ll ? pos_ll + off : nullptr, vx ? vx + off : nullptr, vy ? vy + off : nullptr, vz ? vz + off : nullptr);
@@ -754,11 +953,21 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     return rc;
 }
 uint64_t blub_slab_group_transport_ops(const blub_slab_group* g) { return g ? g->comm_ops : 0; }
+int blub_slab_group_set_async_exchange(blub_slab_group* g, int enabled) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    g->async_exchange = enabled != 0;
+    return BLUB_OK;
+}
+int blub_slab_group_host_syncs(const blub_slab_group* g, uint64_t* particle_exchanges, uint64_t* done_polls) {
+    if (!g || !particle_exchanges || !done_polls) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    *particle_exchanges = g->host_syncs; *done_polls = g->done_polls;
+    return BLUB_OK;
+}
 const char* blub_slab_group_transport_description(const blub_slab_group* g) { return g ? g->transport : ""; }
 int blub_slab_group_synchronize(blub_slab_group* g) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
     for (auto h : g->slabs) { int rc = blub_fluid_synchronize(h); if (rc != BLUB_OK) return rc; }
-    return BLUB_OK;
+    return blub::slab_refresh_counts(g);
 }
 }  // extern "C"

@@ -625,6 +625,8 @@ class SlabGroup:
                 ("blub_slab_group_set_solver_config", C.c_int, [vp, C.c_int, C.POINTER(_SolverConfig)]),
                 ("blub_slab_group_set_rebinning_frequency", C.c_int, [vp, C.c_uint32]),
                 ("blub_slab_group_set_pcg_schedule", C.c_int, [vp, C.c_int]), ("blub_slab_group_set_gather_mode", C.c_int, [vp, C.c_int]),
+                ("blub_slab_group_set_async_exchange", C.c_int, [vp, C.c_int]),
+                ("blub_slab_group_host_syncs", C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
                 ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
                 ("blub_slab_group_transport_ops", C.c_uint64, [vp]), ("blub_slab_group_transport_description", C.c_char_p, [vp]),
                 ("blub_slab_group_set_meshes", C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
@@ -726,6 +728,16 @@ class SlabGroup:
     def set_pcg_schedule(self, mode):
         """"reference" | "single_reduction" on every local slab (all ranks must pass the same mode)"""
         _check(self._L, self._L.blub_slab_group_set_pcg_schedule(self._g, {"reference": 0, "single_reduction": 1}[mode]))
+
+    def set_async_exchange(self, enabled):
+        """Particle exchanges without host synchronisation (default on), see include/blubhip.h; all ranks must agree."""
+        _check(self._L, self._L.blub_slab_group_set_async_exchange(self._g, 1 if enabled else 0))
+
+    def host_syncs(self):
+        """(stream synchronisations by particle exchanges, by looks at a solve's `done`) issued inside step() so far."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self._L, self._L.blub_slab_group_host_syncs(self._g, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def set_gather_mode(self, mode):
         """RCCL transport of the PCG partials: "p2p" (grouped send/recv fused with the halo) | "allgather"; all ranks must agree."""

@@ -346,7 +346,7 @@ blub_fluid* blub_slab_group_local_fluid(blub_slab_group* g, int local_index);   
 int blub_slab_group_local_range(const blub_slab_group* g, int local_index, int32_t* z0, int32_t* z1);
 /* every rank passes the same global arrays; each slab keeps the particles of its z-range */
 int blub_slab_group_set_particles(blub_slab_group* g, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz);
-uint32_t blub_slab_group_num_particles(const blub_slab_group* g);   /* own particles of the local slabs */
+uint32_t blub_slab_group_num_particles(blub_slab_group* g);   /* blocks: the counts live on the device between steps */   /* own particles of the local slabs */
 int blub_slab_group_get_particles(blub_slab_group* g, float* pos_ll, float* vx, float* vy, float* vz);
 int blub_slab_group_set_gravity_grid(blub_slab_group* g, const float gravity_grid[3]);
 int blub_slab_group_set_solver_config(blub_slab_group* g, int which, const blub_solver_config* cfg);
@@ -358,6 +358,13 @@ int blub_slab_group_set_gather_mode(blub_slab_group* g, int mode);
 /* static objects (see blub_fluid_set_meshes / blub_fluid_voxelize): every local slab voxelises the meshes in global grid coordinates */
 int blub_slab_group_set_meshes(blub_slab_group* g, uint32_t num_vertices, const float* positions_xyz, uint32_t num_indices, const uint32_t* indices);
 int blub_slab_group_voxelize(blub_slab_group* g, uint32_t num_meshes, const blub_mesh_desc* meshes);
+/* Particle exchanges without host synchronisation (default on): from the second step after the particles were set, ghost copies and
+ * migrating particles travel in fixed-capacity messages with a count header (capacity = 1.5 x the count of the same exchange one step
+ * earlier + 2048; an overflow makes the NEXT step return BLUB_ERR_OUT_OF_MEMORY) and the particle counts stay on the device.  0: the
+ * synchronous protocol of rounds 1-2 (counts first, one stream synchronisation per exchange).  All ranks must pass the same value. */
+int blub_slab_group_set_async_exchange(blub_slab_group* g, int enabled);
+/* diagnostics: stream synchronisations issued inside blub_slab_group_step so far -- by particle exchanges / by looks at a solve's `done` */
+int blub_slab_group_host_syncs(const blub_slab_group* g, uint64_t* particle_exchanges, uint64_t* done_polls);
 int blub_slab_group_step(blub_slab_group* g, float simulation_delta_seconds);
 int blub_slab_group_synchronize(blub_slab_group* g);
 /* diagnostics: grouped transport operations (halo / partial / particle exchanges) issued by this process so far */

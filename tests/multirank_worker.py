@@ -69,6 +69,7 @@ def main():
             out["pos%d" % step] = group.get_particles()[0][:, :3]
             out["ops%d" % step] = group.transport_ops() - ops0
         out["stats"] = np.array([fluid.solver_stats(0), fluid.solver_stats(1)], np.float64)
+        out["host_syncs"] = np.array(group.host_syncs())
         out["marker"] = fluid.read_volume("marker")
         out["status"] = "ok"
     except blub_amd.hybrid_fluid.BlubError as e:

@@ -88,6 +88,8 @@ def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedu
             ops = [int(d["ops%d" % step]) for d in ranks]
             assert all(o == ops[0] for o in ops) and ops[0] > 0, ops      # every rank issued the same sequence of transport operations
         assert [d["pos2"].shape[0] for d in ranks] != counts0, "no particle migrated between the processes"
+        # particle exchanges synchronise the host only in the first step (no history to size the messages from): 4 of them, then none
+        assert all(int(d["host_syncs"][0]) == 4 for d in ranks), [d["host_syncs"] for d in ranks]
         st = [d["stats"] for d in ranks]
         assert all(np.array_equal(x, st[0]) for x in st)                  # identical solver statistics on every rank (gathered partials, fixed order)
         m_single = single.read_volume("marker")

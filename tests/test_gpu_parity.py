@@ -438,8 +438,8 @@ def _match_particles(a, b):
     return d
 
 
-@pytest.mark.parametrize("slabs", [2, 3])
-def test_z_slab_decomposition_matches_single_domain(slabs):
+@pytest.mark.parametrize("slabs,async_exchange", [(2, True), (3, True), (3, False)])
+def test_z_slab_decomposition_matches_single_domain(slabs, async_exchange):
     """the z-slab protocol (ghost particles, halo planes, all-reduced PCG scalars, migration) run as `slabs`
     slabs on ONE GPU (loopback transport) reproduces the single-domain engine.  The blob straddles the slab interfaces
     and shears across them, so every exchange carries data.
@@ -464,6 +464,7 @@ def test_z_slab_decomposition_matches_single_domain(slabs):
     single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     rerun = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     group = blub_amd.SlabGroup(dim, pos.shape[0], local=slabs, binning="off")
+    group.set_async_exchange(async_exchange)
     try:
         for f in (single, rerun, group):
             f.set_gravity_grid((0.0, -981.0, 0.0))
@@ -491,6 +492,9 @@ def test_z_slab_decomposition_matches_single_domain(slabs):
         counts1 = [group.local_fluid(i).num_particles() for i in range(slabs)]
         assert sum(counts1) == pos.shape[0]
         assert counts1 != counts0, "no particle migrated: the test does not exercise the exchange"
+        # host synchronisations by particle exchanges: four in the first step (no history to size the messages from), none afterwards --
+        # or four per step with the round-2 protocol
+        assert group.host_syncs()[0] == (4 if async_exchange else 12), group.host_syncs()
         # every slab only holds particles of its own z-range
         pgl = group.get_particles()[0]
         off = 0
@@ -547,7 +551,7 @@ def test_z_slab_solve_follows_convergence(schedule):
         slab_fluids = [group.local_fluid(i) for i in range(3)]
         for f in slab_fluids:
             f.update_statistics()
-        full = 1 + 4 * 2 + 5 + 2 * solve_ops(33)      # brick-count gather, particle exchanges, velocity halos, 2 solves of 33 iterations
+        full = 1 + 4 * 2 + 5 + 2 * solve_ops(33)      # brick-count gather, particle exchanges (counts + payload), velocity halos, 2 solves of 33 iterations
         assert ops[0] == full, (ops, full)           # first step: no previous iteration count
         hist = lambda f, w: [x.iteration_count for x in (f.pressure_solver_stats_velocity() if w == 0 else f.pressure_solver_stats_density())]
         its = []
@@ -561,7 +565,8 @@ def test_z_slab_solve_follows_convergence(schedule):
             assert len(it_g) == 6 and len(it_s) == 6 and all(abs(a - b) <= 4 for a, b in zip(it_s, it_g)), (it_s, it_g)
             assert all(0 < x <= 32 for x in it_g)
         for step in range(1, 6):   # launched per solve = iterations through the later of {previous, this} deciding check + its detection
-            need = 1 + 4 * 2 + 5 + sum(solve_ops(min(33, max(its[w][step], its[w][step - 1]) + 2)) for w in (0, 1))
+            # (from the second step on a particle exchange is ONE grouped operation: fixed-capacity messages with a count header)
+            need = 1 + 4 * 1 + 5 + sum(solve_ops(min(33, max(its[w][step], its[w][step - 1]) + 2)) for w in (0, 1))
             assert ops[step] == need, (step, ops, need, its)
         d = _match_particles(group.get_particles()[0][:, :3].astype(np.float64), single.get_particles()[0][:, :3].astype(np.float64))
         assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 2e-2, (np.median(d), np.quantile(d, 0.99), d.max())
