@@ -7,6 +7,7 @@
 // No device code, no HIP calls: stepping goes through callbacks (default: blub_fluid_step / blub_fluid_synchronize).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <new>
 
@@ -20,12 +21,33 @@ constexpr uint64_t MAX_STEP_COMPUTATION_PER_FRAME_NS = NS / 50;    // simulation
 constexpr uint64_t NO_LIMIT = ~0ull;                              // Duration::from_secs(u64::MAX), :191
 constexpr int MAX_FAST_FORWARD_SIMULATION_BATCH_SIZE = 16;         // :112
 
+// Duration::from_secs_f32 (core::time, try_from_secs_f32): the f32 is converted EXACTLY -- v = m 2^e with a 24-bit m -- and the nanoseconds are
+// rounded to nearest, ties to even (round 2 truncated: 1 ns off the reference for about half of all inputs).  Negative / NaN input and values
+// beyond u64 seconds make the reference panic; they saturate here (0 / "no limit").
+uint64_t duration_from_secs_f32(float v) {
+    if (!(v > 0.0f)) return 0;
+    if (!(v < 1.8446744e19f)) return ~0ull;
+    int e = 0;
+    const float fr = std::frexp(v, &e);                        // v = fr 2^e, 0.5 <= fr < 1
+    const uint64_t m = (uint64_t)std::ldexp(fr, 24);            // exact: 24-bit significand
+    e -= 24;                                                    // v = m 2^e
+    const unsigned __int128 num = (unsigned __int128)m * (unsigned __int128)NS;   // < 2^24 x 2^30
+    unsigned __int128 ns128;
+    if (e >= 0) {
+        if (e > 64) return ~0ull;
+        ns128 = num << e;
+    } else {
+        const int sh = -e;
+        if (sh >= 100) return 0;
+        const unsigned __int128 q = num >> sh, rem = num - (q << sh), half = (unsigned __int128)1 << (sh - 1);
+        ns128 = q + ((rem > half || (rem == half && (q & 1))) ? 1 : 0);
+    }
+    return ns128 > (unsigned __int128)~0ull ? ~0ull : (uint64_t)ns128;
+}
 // Duration::mul_f32: from_secs_f32(rhs * self.as_secs_f32())
 uint64_t mul_f32(uint64_t ns, float rhs) {
     const float secs = (float)(ns / NS) + (float)(ns % NS) / 1e9f;
-    const float v = rhs * secs;
-    if (!(v > 0.0f)) return 0;
-    return (uint64_t)((double)v * 1e9);
+    return duration_from_secs_f32(rhs * secs);
 }
 
 enum StepResult { PERFORM_STEP_AND_CALL_AGAIN, CAUGHT_UP_WITH_RENDER_TIME, DROPPING_SIMULATION_STEPS };   // timer.rs:37-43
@@ -106,6 +128,9 @@ bool single_step(blub_controller* c, const blub_step_callbacks* cb, int* rc) {
         const uint64_t d = c->timer.simulation_delta;
         const float dt = (float)(d / NS) + (float)(d % NS) / 1e9f;
         *rc = cb->step(cb->user, dt, c->timer.total_simulated_time);
+        if (*rc != BLUB_OK) {      // the step did not happen: take it off the clocks again (round-2 ADVICE)
+            c->timer.num_simulation_steps_this_frame -= 1; c->timer.num_simulation_steps -= 1; c->timer.total_simulated_time -= d;
+        }
         return *rc == BLUB_OK;
     }
     return false;

@@ -121,3 +121,50 @@ def test_step_errors_end_the_jump_and_are_reported():
     with pytest.raises(RuntimeError):
         c.fast_forward_steps(s, NS)
     assert len(s.steps) == 5 and c.status == SimulationController.PAUSED
+
+
+def _rust_mul_f32(ns, scale):
+    """Duration::mul_f32 = from_secs_f32(rhs * self.as_secs_f32()): f32 arithmetic, then the exact value of the f32 rounded to the nearest
+    nanosecond, ties to even (core::time::Duration::try_from_secs_f32)."""
+    from fractions import Fraction
+    secs = np.float32(ns // NS) + np.float32(ns % NS) / np.float32(1e9)
+    v = np.float32(scale) * secs
+    exact = Fraction(float(v)) * NS
+    q, r = divmod(exact.numerator, exact.denominator)
+    twice = 2 * r
+    if twice > exact.denominator or (twice == exact.denominator and q % 2 == 1):
+        q += 1
+    return q
+
+
+def test_frame_deltas_round_like_duration_from_secs_f32():
+    """Round-2 ADVICE: the frame delta (and the accepted lag) used to be TRUNCATED to nanoseconds where the reference rounds to nearest; one
+    nanosecond off for about half of all inputs."""
+    rng = np.random.default_rng(12)
+    durations = [1, 999, 4166666, 8333333, 16666667, NS // 3, NS - 1, NS + 1, 7 * NS + 123456789] + [int(v) for v in rng.integers(1, 3 * NS, 40)]
+    off_by_truncation = 0
+    for scale in (1.0, 0.5, 0.9, 1.7):
+        for d in durations:
+            c = SimulationController()
+            c.set_time_scale(scale)
+            c.on_frame_submitted(d)
+            want = _rust_mul_f32(d, scale)
+            assert c.total_render_time_ns == want, (d, scale, c.total_render_time_ns, want)
+            secs = np.float32(d // NS) + np.float32(d % NS) / np.float32(1e9)
+            off_by_truncation += int(int(float(np.float32(scale) * secs) * 1e9) != want)
+            c.close()
+    assert off_by_truncation > 20       # the inputs do distinguish rounding from truncation
+
+
+def test_a_failing_step_is_not_counted():
+    """A step callback that fails ends the frame; the step it stood for did not happen and must not stay on the clocks."""
+    class Failing(FakeScene):
+        def step(self, dt):
+            if len(self.steps) == 1:
+                raise RuntimeError("device lost")
+            super().step(dt)
+    c, s = SimulationController(), Failing()
+    c.on_frame_submitted(NS // 30 + 1000)            # four 120 Hz steps wanted
+    with pytest.raises(RuntimeError):
+        c.frame_steps(s)
+    assert len(s.steps) == 1 and c.num_simulation_steps_performed == 1 and c.total_simulated_time_ns == DELTA
