@@ -346,10 +346,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-pcg", action="store_true")
     ap.add_argument("--no-dense-512", action="store_true", help="skip the 512^3 repetition of the dense PCG micro-benchmark (roofline_512)")
+    ap.add_argument("--no-other-schedule", action="store_true", help="skip the second window with the other PCG schedule (kernel traces of ONE schedule: tools/kstats.sh)")
     ap.add_argument("--tune", action="append", default=[], help="name=value for blub_fluid_set_tuning on every scene of the run (A/B measurements)")
     ap.add_argument("--pcg-schedule", default="single_reduction", choices=["single_reduction", "reference"], help="schedule of the headline window (the other one is timed beside it)")
     ap.add_argument("--no-fast-forward", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--profile-steps", type=int, default=1000000, help="steps of the instrumented pass (a fresh scene, same warm-up; default: the whole timed window; 0: skip)")
     ap.add_argument("--dense-only", action="store_true", help="only run the dense PCG micro-benchmark (tuning)")
     ap.add_argument("--dense-size", type=int, default=256)
     ap.add_argument("--dense-tile-quads", type=int, default=0, help="--dense-only: tile width of the dense PCG kernels (256 | 512 | 1024 quads; tuning)")
@@ -481,9 +482,10 @@ def main():
 
     # ---- the same window with the OTHER schedule (round-2 review: the cost of the literal order of operations must be visible)
     other = "reference" if args.pcg_schedule == "single_reduction" else "single_reduction"
-    el_o, it_o = timed_window(other)
+    el_o, it_o = timed_window(other) if not args.no_other_schedule else (float("nan"), 0)
     by_schedule = {args.pcg_schedule: {"steps_per_s": round(args.steps / elapsed, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2)},
-                   other: {"steps_per_s": round(args.steps / el_o, 3), "ms_per_step": round(el_o / args.steps * 1e3, 4), "pcg_iters_per_step": round(it_o / args.steps, 2)}}
+                   other: ({"steps_per_s": round(args.steps / el_o, 3), "ms_per_step": round(el_o / args.steps * 1e3, 4), "pcg_iters_per_step": round(it_o / args.steps, 2)}
+                           if not args.no_other_schedule else {"steps_per_s": None, "ms_per_step": None, "pcg_iters_per_step": None})}
 
     # ---- fast-forward through the native scheduler (simulation_controller.rs:96-157): the reference's own way of timing steps.
     # Same window as the timed region above (a fresh scene, the same warm-up), no Python in the stepping loop, a wait every 16 steps.
@@ -516,15 +518,25 @@ def main():
     # the per-kernel table of record is the rocprofv3 trace under profiles/.
     roofline_workload, breakdown, pcg_ms = None, None, 0.0
     if args.profile_steps > 0:
-        fluid.profile_enable(True)
-        fluid.profile_reset()
-        for _ in range(args.profile_steps):
-            step()
-        fluid.synchronize()
-        prof = fluid.profile_read()
-        fluid.profile_enable(False)
-        F = int((fluid.read_volume("marker") == 1).sum())
-        bc = fluid.brick_counts()
+        # a fresh scene over the SAME window as the timed region (warm-up, then profile_steps steps -- by default all of them), so that the
+        # classes can be held against that pass's own wall clock: sum of the kernels' durations <= its ms per step
+        n_prof = args.steps if args.profile_steps >= args.steps else args.profile_steps
+        scene_p, fluid_p = new_scene(args.pcg_schedule)
+        for _ in range(args.warmup):
+            scene_p.step(dt)
+        fluid_p.synchronize()
+        fluid_p.profile_enable(True)
+        fluid_p.profile_reset()
+        t0p = time.perf_counter()
+        for _ in range(n_prof):
+            scene_p.step(dt)
+        fluid_p.synchronize()
+        wall_p = time.perf_counter() - t0p
+        prof = fluid_p.profile_read()
+        fluid_p.profile_enable(False)
+        F = int((fluid_p.read_volume("marker") == 1).sum())
+        bc = fluid_p.brick_counts()
+        fluid_p.close()
         A, Fb = bc["active"] * bc["cells_per_brick"], bc["fluid"] * bc["cells_per_brick"]
         total_ms = sum(v["total_ms"] for v in prof.values())
         dominant = max(prof, key=lambda k: prof[k]["total_ms"])
@@ -532,12 +544,15 @@ def main():
         ach = algorithmic_bytes(dominant, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
         roofline_workload = {"bound": "fabric latency / launch count (see DESIGN.md 6): a few MB per launch", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
-                             "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells": F, "active_brick_cells": A, "fluid_brick_cells": Fb,
-                             "launches_per_step": round(prof[dominant]["launches"] / args.profile_steps, 1)}
+                             "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells_at_end": F, "active_brick_cells_at_end": A, "fluid_brick_cells_at_end": Fb,
+                             "launches_per_step": round(prof[dominant]["launches"] / n_prof, 1)}
         pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
-        breakdown = {"us_per_step": {k: round(v["total_ms"] / args.profile_steps * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
-                     "sum_us_per_step": round(total_ms / args.profile_steps * 1e3, 1), "launches_per_step": round(sum(v["launches"] for v in prof.values()) / args.profile_steps, 1),
-                     "window": "the %d steps after the timed window (steps %d..%d of the scene): later, i.e. costlier, steps than the timed ones" % (args.profile_steps, args.warmup + args.steps, args.warmup + args.steps + args.profile_steps)}
+        breakdown = {"us_per_step": {k: round(v["total_ms"] / n_prof * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
+                     "sum_us_per_step": round(total_ms / n_prof * 1e3, 1), "launches_per_step": round(sum(v["launches"] for v in prof.values()) / n_prof, 1),
+                     "profiled_pass_ms_per_step": round(wall_p / n_prof * 1e3, 4),
+                     "window": "steps %d..%d of a fresh scene (the timed window) with profiling on: kernel durations from events inside the dispatches; the difference to the "
+                               "pass's own ms per step is idle time between dependent launches" % (args.warmup, args.warmup + n_prof)}
+        pcg_iters_prof = None
 
     result = {
         "metric": METRIC, "value": round(args.steps / elapsed, 3), "unit": "steps/s",
@@ -553,7 +568,7 @@ def main():
         "by_schedule": by_schedule,
         "pcg_iters_per_sec": round((it1 - it0) / elapsed, 1),
         "pcg_iters_per_step": round((it1 - it0) / args.steps, 2),
-        "pcg_iters_per_sec_in_solver": round((it1 - it0) / args.steps * args.profile_steps / (pcg_ms * 1e-3), 1) if pcg_ms > 0 else None,
+        "pcg_iters_per_sec_in_solver": round((it1 - it0) / args.steps * (args.steps if args.profile_steps >= args.steps else args.profile_steps) / (pcg_ms * 1e-3), 1) if pcg_ms > 0 else None,
         "fast_forward": fast_forward,
         "rebinning_tuned": rebinning_tuned,
         "roofline": None,
