@@ -202,6 +202,7 @@ __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, 
     __shared__ uint32_t sm[17];
     __shared__ uint32_t base[4], total[4];
     __shared__ uint32_t wtot[16];
+    __shared__ int timed_out;
     const int b = blockIdx.x * 1024 + threadIdx.x;
     const int nblocks = gridDim.x;
     uint32_t fl = 0;
@@ -250,10 +251,14 @@ __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(block_ready + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (threadIdx.x == 0) timed_out = 0;
     if (threadIdx.x < 64) {   // one wave waits for all blocks and sums their counts: lanes stride over the blocks in order
         uint32_t before[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};
         for (int k = threadIdx.x; k < nblocks; k += 64) {
-            while (__hip_atomic_load(block_ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
+            // (bounded: if the blocks were NOT co-resident after all -- a masked or partitioned device -- the build ends with a wrong list and the
+            //  counts carry an error mark instead of hanging the GPU; the host then reports BLUB_ERR_DEVICE and falls back to the two-kernel build)
+            unsigned spins = 0;
+            while (__hip_atomic_load(block_ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) { timed_out = 1; break; } }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             uint32_t c[4];
 #pragma unroll
@@ -278,10 +283,11 @@ __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, 
     if (fl & BF_ACTIVE) list_active[base[1] + oa] = (uint32_t)b;
     if (fl & BF_RESET) list_reset[base[2] + orr] = (uint32_t)b | ((fl & BF_STALE) ? STALE_BIT : 0u);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        BrickCounts c; c.n_fluid = total[0]; c.n_active = total[1]; c.n_reset = total[2]; c.n_stale = total[3]; c.seq = seq; c.pad0 = 0; c.pad1 = 0; c.seq_check = seq;
+        BrickCounts c; c.n_fluid = total[0]; c.n_active = total[1]; c.n_reset = total[2]; c.n_stale = total[3]; c.seq = seq; c.pad0 = (uint32_t)timed_out; c.pad1 = 0; c.seq_check = seq;
         *counts = c;
         if (host_snapshot) {   // pinned host ring slot (path selection only): payload first, tags last
             host_snapshot->n_fluid = c.n_fluid; host_snapshot->n_active = c.n_active; host_snapshot->n_reset = c.n_reset; host_snapshot->n_stale = c.n_stale;
+            host_snapshot->pad0 = c.pad0;
             __threadfence_system();
             host_snapshot->seq = seq; host_snapshot->seq_check = seq;
         }

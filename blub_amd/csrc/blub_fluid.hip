@@ -300,8 +300,14 @@ static int latest_counts(blub_fluid* h, bool block, BrickCounts* out, bool* have
         const uint32_t seq = h->counts_seq - k;
         const volatile BrickCounts* c = &h->counts_host[seq % COUNTS_RING];
         BrickCounts snap;
-        snap.n_fluid = c->n_fluid; snap.n_active = c->n_active; snap.n_reset = c->n_reset; snap.n_stale = c->n_stale; snap.seq = c->seq; snap.seq_check = c->seq_check;
-        if (snap.seq == seq && snap.seq_check == seq) { *out = snap; *have = true; return BLUB_OK; }
+        snap.n_fluid = c->n_fluid; snap.n_active = c->n_active; snap.n_reset = c->n_reset; snap.n_stale = c->n_stale; snap.seq = c->seq; snap.seq_check = c->seq_check; snap.pad0 = c->pad0;
+        if (snap.seq == seq && snap.seq_check == seq) {
+            if (snap.pad0) {      // k_bricks_build gave up waiting for its own blocks: not co-resident on this device
+                h->num_cus = 0;   // (two-kernel build from now on)
+                return set_error(BLUB_ERR_DEVICE, "a brick list build timed out waiting for its workgroups (device shared or partitioned?): the step that contained it is invalid; later steps use the two-kernel build");
+            }
+            *out = snap; *have = true; return BLUB_OK;
+        }
     }
     return BLUB_OK;
 }
@@ -471,8 +477,17 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
             return enqueue_stats_readback(h, which, dt, true);
         }
-        // the reference's two-reduction schedule: two kernels per iteration (a finished solve's launches return after one load)
-        for (int i = 0; i <= maxit; ++i) {
+        // the reference's two-reduction schedule: two kernels per iteration.  As for the single-reduction schedule the host launches the pairs the
+        // last few solves needed (+ `tail_margin_checks` check intervals) and ONE persistent kernel for the rest (k_pcg_tail_s): it normally finds
+        // the solve finished and only publishes the statistics; without it a finished solve still cost 2 x (max - needed) no-op launches.
+        int launched = maxit + 1;
+        if (h->use_tail && (!have || bc.n_fluid <= 2048u) && freq > 0 && !h->stats_history[which].empty()) {
+            int recent = 0, k = 0;
+            for (auto it2 = h->stats_history[which].rbegin(); it2 != h->stats_history[which].rend() && k < 4; ++it2, ++k) recent = std::max(recent, (int)it2->iteration_count);
+            if (recent >= 0 && recent < maxit) launched = std::min(maxit + 1, (recent / freq + h->tail_margin_checks) * freq + 1);   // KD(c + 1) forms the verdict of check c
+        }
+        if (h->use_tail && h->tail_first_forced >= 0) launched = std::min(maxit + 1, std::max(1, h->tail_first_forced));   // (test hook; iteration 0 is always launched)
+        for (int i = 0; i < launched; ++i) {
             if (i == 0)
                 LAUNCH(h, KC_PCG_DIR, k_pcg_dir_s<true>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],
                        (const float2*)part_upd, part_dir, 0, ctrl, tol, i, 0, -1, -1);
@@ -482,7 +497,12 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             LAUNCH(h, KC_PCG_UPDATE, k_pcg_update_s, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,
                    (const float*)part_dir, part_upd, 0, (const PcgCtrl*)ctrl, i);
         }
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, 0, nfl, maxit, h->solve_seq[which], stat_slot);
+        if (launched <= maxit) {
+            const dim3 tgrid((unsigned)std::min(np, h->tail_grid));
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_tail_s, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, h->residual, sbuf[0], sbuf[1], p, part_upd, part_dir, ctrl, tol,
+                   launched, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
+        } else
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, 0, nfl, maxit, h->solve_seq[which], stat_slot);
     } else {
         const int np = h->pcg_grid_z;
         const dim3 grid(np);
@@ -721,9 +741,11 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
         // (round-2 ADVICE: the bound used to come from another kernel with a smaller footprint).  tail_grid_max = every co-resident block, but
         // the default stays at one block per CU: with ~1000 blocks on the one barrier counter an iteration inside the tail costs 3x as much
         // (measured, round 3: 483-510 steps/s against 929-953 with the tail forced in after 6 iterations)
-        int per_cu = 0, cus = 0;
+        int per_cu = 0, per_cu0 = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg1_tail_s<true>, PCG_B_THREADS, 0) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu0, k_pcg_tail_s, PCG_B_THREADS, 0) == hipSuccess && per_cu0 > 0 &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus >= 8) {
+            per_cu = std::min(per_cu, per_cu0);
             h->tail_grid_max = ((per_cu * cus) / 8) * 8;
             h->tail_grid = std::min(h->tail_grid_max, (std::min(256, cus) / 8) * 8);
         } else h->use_tail = false;

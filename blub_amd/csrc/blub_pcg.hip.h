@@ -400,16 +400,16 @@ __device__ __forceinline__ void st_fill(StagedTile& T, const BrickGeom& bg, uint
 // KD on the brick lists.  HALO (z-slab groups): the block also stores the s it computed for the ghost plane below `halo_lo` / above
 // `halo_hi` (own planes of the slab, -1 = none), so the search direction needs no halo exchange of its own.
 // num_part_in > 0: that many partials are reduced (z-slab groups: the gathered segments of all slabs); 0: the solve's own V.
-template <bool FIRST, bool HALO = false>
-__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
-                                                             const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
-                                                             const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part_in,
-                                                             PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev, int halo_lo = -1, int halo_hi = -1) {
-    __shared__ float sm[8];
-    __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
-    __shared__ DivConst sDiv[8];
-    __shared__ StagedTile tiles[PCG_BPB];
-    pcg_fill_div_lut(sDiv);   // (published by the barriers of the prologue's reduction)
+// (the body as a device function: k_pcg_dir_s runs it once per launch, k_pcg_tail_s in a loop with grid barriers.  Returns false when the solve is
+//  finished -- `done` was set, or this iteration's convergence test succeeded -- and nothing was computed.  SURPLUS_EXITS: launched workgroups
+//  beyond the virtual ones return at once; the tail kernel's must stay, they take part in its grid barriers)
+struct PcgBrickShared { float sm[8]; float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4]; DivConst sDiv[8]; StagedTile tiles[PCG_BPB]; };
+template <bool FIRST, bool HALO, bool SURPLUS_EXITS>
+__device__ __forceinline__ bool pcg_dir_iteration(PcgBrickShared& S, BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
+                                                  const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
+                                                  const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part_in,
+                                                  PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev, int halo_lo, int halo_hi) {
+    float* const sm = S.sm; float2* const sm2 = S.sm2; DivConst* const sDiv = S.sDiv; StagedTile* const tiles = S.tiles;
     // one round trip: list length, `done`, sigma_{i-1} and this thread's share of the partials (spec_partials_load)
     const uint32_t n = *count;
     const int done = ctrl->done;
@@ -418,12 +418,12 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_s(BrickGeom bg, const
     SpecPartials<float2> SP;
     spec_partials_load(part_upd, spec, SP);
     const int V = pcg_vblocks(n, vb_force);
-    if ((int)blockIdx.x >= V || done) return;
+    if ((SURPLUS_EXITS && (int)blockIdx.x >= V) || done) return false;
     const int num_part = num_part_in > 0 ? num_part_in : V;
     spec_partials_fix(part_upd, spec, num_part, SP);
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     float beta;
-    if (!pcg_dir_decide(ctrl, reduce_spec2(SP, part_upd, num_part, sm2), sigma_prev, tolerance, iteration, check_prev, beta)) return;
+    if (!pcg_dir_decide(ctrl, reduce_spec2(SP, part_upd, num_part, sm2), sigma_prev, tolerance, iteration, check_prev, beta)) return false;
     StagedTile& T = tiles[half];
     for (int vb = blockIdx.x; vb < V; vb += gridDim.x) {
         float acc = 0.0f;
@@ -473,16 +473,24 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_s(BrickGeom bg, const
         const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
         if (threadIdx.x == 0) part_dir[vb] = tot;
     }
+    return true;
+}
+template <bool FIRST, bool HALO = false>
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_dir_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
+                                                             const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in, float* __restrict__ s_out,
+                                                             const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part_in,
+                                                             PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev, int halo_lo = -1, int halo_hi = -1) {
+    __shared__ PcgBrickShared S;
+    pcg_fill_div_lut(S.sDiv);   // (published by the barriers of the prologue's reduction)
+    (void)pcg_dir_iteration<FIRST, HALO, true>(S, bg, list, count, vb_force, dvol, r, s_in, s_out, part_upd, part_dir, num_part_in, ctrl, tolerance, iteration, check_prev, halo_lo, halo_hi);
 }
 
-__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
-                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
-                                                                float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part_in,
-                                                                const PcgCtrl* __restrict__ ctrl, int iteration) {
-    __shared__ float sm[8];
-    __shared__ DivConst sDiv[8];
-    __shared__ StagedTile tiles[PCG_BPB];
-    pcg_fill_div_lut(sDiv);   // (published by the barriers of the prologue's reduction)
+template <bool SURPLUS_EXITS>
+__device__ __forceinline__ bool pcg_update_iteration(PcgBrickShared& S, BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
+                                                     const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+                                                     float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part_in,
+                                                     const PcgCtrl* __restrict__ ctrl, int iteration) {
+    float* const sm = S.sm; DivConst* const sDiv = S.sDiv; StagedTile* const tiles = S.tiles;
     const uint32_t n = *count;       // one round trip: see k_pcg_dir_s
     const int done = ctrl->done;
     const float sigma = ctrl->sigma[iteration & 1];
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_s(BrickGeom bg, co
     SpecPartials<float> SP;
     spec_partials_load(part_dir, spec, SP);
     const int V = pcg_vblocks(n, vb_force);
-    if ((int)blockIdx.x >= V || done) return;
+    if ((SURPLUS_EXITS && (int)blockIdx.x >= V) || done) return false;
     const int num_part = num_part_in > 0 ? num_part_in : V;
     spec_partials_fix(part_dir, spec, num_part, SP);
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
@@ -524,6 +532,15 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_s(BrickGeom bg, co
         const float mx = block_reduce<PCG_B_THREADS, true>(emax, sm);
         if (threadIdx.x == 0) part_upd[vb] = make_float2(tot, mx);
     }
+    return true;
+}
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_update_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
+                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ s, float* __restrict__ p,
+                                                                float* __restrict__ r, const float* __restrict__ part_dir, float2* __restrict__ part_upd, int num_part_in,
+                                                                const PcgCtrl* __restrict__ ctrl, int iteration) {
+    __shared__ PcgBrickShared S;
+    pcg_fill_div_lut(S.sDiv);   // (published by the barriers of the prologue's reduction)
+    (void)pcg_update_iteration<true>(S, bg, list, count, vb_force, dvol, s, p, r, part_dir, part_upd, num_part_in, ctrl, iteration);
 }
 
 // ---- grid barrier of the persistent tail kernel (blub_pcg1.hip.h) -----------------------------------------------------
@@ -549,6 +566,44 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target,
     }
     __syncthreads();
     return s_ok != 0;
+}
+
+// Persistent tail of a solve in the reference's two-reduction order: the host launches the iteration pairs the last few solves needed (+ one
+// check interval) and this ONE kernel for the rest.  Normally KD(first) finds the solve converged (or `done` already set), publishes the
+// statistics -- k_pcg_finalize's job -- and the kernel is a single short launch instead of 2 x (max - first) of them; otherwise it runs the
+// remaining iterations itself: the same bodies, the same virtual workgroups (bit-identical to the launched solve), two bounded grid barriers per
+// iteration (one workgroup per CU, all co-resident).  Round 2 had this for the plain brick kernels; round 3 dropped it with them and a
+// finished solve of the library's DEFAULT schedule then cost ~24 pairs of no-op launches (134 us per step on the headline scene).
+__global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_tail_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint8_t* __restrict__ dvol,
+                                                              float* r, float* s_even, float* s_odd, float* p, float2* part_upd, float* part_dir, PcgCtrl* ctrl, float tolerance,
+                                                              int first_iteration, int max_iterations, int check_frequency, PcgTailSync* sync, uint32_t seq, PcgCtrl* host_snapshot) {
+    __shared__ PcgBrickShared S;
+    __shared__ float2 smf[4];
+    pcg_fill_div_lut(S.sDiv);
+    __syncthreads();
+    const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+    auto publish = [&]() {   // what k_pcg_finalize does
+        ctrl->seq = seq;
+        if (host_snapshot) { host_snapshot->max_err = ctrl->max_err; host_snapshot->num_iter = ctrl->num_iter; __threadfence_system(); host_snapshot->seq = seq; }
+    };
+    if (ctrl->done) { if (leader) publish(); return; }      // uniform
+    uint32_t barrier_no = 0;
+    for (int it = first_iteration; it <= max_iterations; ++it) {
+        const int prev = it - 1;
+        const int check_prev = prev > 0 && check_frequency > 0 && prev % check_frequency == 0;
+        const float* s_in = ((it - 1) & 1) ? s_odd : s_even;
+        float* s_out = (it & 1) ? s_odd : s_even;
+        const bool ran = pcg_dir_iteration<false, false, false>(S, bg, list, count, 0, dvol, r, s_in, s_out, part_upd, part_dir, 0, ctrl, tolerance, it, check_prev, -1, -1);
+        if (!ran) { if (leader) publish(); return; }        // converged at the check of iteration it - 1 (the leader wrote the statistics itself)
+        if (!grid_barrier(&sync->arrivals, gridDim.x * ++barrier_no, &sync->timed_out)) { if (leader) { ctrl->num_iter = -1.0f; ctrl->done = 1; publish(); } return; }
+        (void)pcg_update_iteration<false>(S, bg, list, count, 0, dvol, s_out, p, r, part_dir, part_upd, 0, ctrl, it);
+        if (!grid_barrier(&sync->arrivals, gridDim.x * ++barrier_no, &sync->timed_out)) { if (leader) { ctrl->num_iter = -1.0f; ctrl->done = 1; publish(); } return; }
+    }
+    // i == max_num_iterations reached without convergence (pressure_reduce.comp:84)
+    if (blockIdx.x == 0) {
+        const float2 fin = reduce_partials2<PCG_B_THREADS>(part_upd, pcg_vblocks(*count, 0), smf);
+        if (threadIdx.x == 0) { ctrl->max_err = fin.y; ctrl->num_iter = (float)max_iterations; ctrl->done = 1; publish(); }
+    }
 }
 
 // After the last update (i == max_num_iterations): statistics are written unconditionally if nothing converged before

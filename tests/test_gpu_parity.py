@@ -617,19 +617,21 @@ def test_empty_fluid_steps_are_harmless():
         h.close()
 
 
+@pytest.mark.parametrize("schedule", ["reference", "single_reduction"])
 @pytest.mark.parametrize("first", [1, 3, 9])
-def test_pcg_persistent_tail_kernel(first):
-    """Single-reduction solves hand the iterations the host did not launch to ONE persistent kernel (k_pcg1_tail_s: the same iteration
-    body, grid barriers in between).  Forced hand-over after `first` launched iterations: same iteration counts as the oracle, and
-    BIT-IDENTICAL to the fully launched solve (tail and launched kernels share the virtual-workgroup grouping of the dot products:
-    fixed 14 iterations, and a converging run that stops inside the tail)."""
+def test_pcg_persistent_tail_kernel(first, schedule):
+    """Brick-mapped solves hand the iterations the host did not launch to ONE persistent kernel (k_pcg_tail_s for the reference's
+    two-reduction order, k_pcg1_tail_s for the single-reduction one: the same iteration bodies, grid barriers in between).  Forced
+    hand-over after `first` launched iterations: same iteration counts as the oracle, and BIT-IDENTICAL to the fully launched solve (tail
+    and launched kernels share the virtual-workgroup grouping of the dot products: fixed 14 iterations, and a converging run that stops
+    inside the tail)."""
     pos, vel, maxp = util.make_dam(*GRID)
     _, full = util.new_pair(*GRID, maxp)
     o, h = util.new_pair(*GRID, maxp)
     try:
         for f in (full, h):
             f.set_pcg_work_mapping("bricks")
-            f.set_pcg_schedule("single_reduction")
+            f.set_pcg_schedule(schedule)
         full.set_tuning("pcg_tail", 0)
         h.set_tuning("pcg_tail_first", first)
         o.set_particles(pos, *vel)
@@ -654,7 +656,7 @@ def test_pcg_persistent_tail_kernel(first):
             eh, ih = h.solver_stats(0)
             ef, i_f = full.solver_stats(0)
             assert ih == io and ih >= 0, (cfg, (eh, ih), (eo, io))
-            assert abs(eh - eo) <= 2e-2 * eo          # a different rounding of the recurrence than the oracle's (tests/test_gpu_pcg_schedule.py)
+            assert abs(eh - eo) <= (2e-2 if schedule == "single_reduction" else 2e-3) * eo      # (single reduction: a different rounding of the recurrence, tests/test_gpu_pcg_schedule.py)
             assert (ef, i_f) == (eh, ih), ((ef, i_f), (eh, ih))
             for name in ("pressure_velocity", "residual", "search"):
                 a, b = h.read_volume(name), full.read_volume(name)
