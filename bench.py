@@ -369,6 +369,8 @@ def main():
         tuning = {k_: v_ for k_, v_ in (("dense_tile_quads", args.dense_tile_quads), ("dense_tile_planes", args.dense_tile_planes), ("dense_grid", args.dense_grid)) if v_}
         if args.volume_shift_kib:
             tuning["volume_shift_kib"] = args.volume_shift_kib
+        for kv in args.tune:
+            tuning[kv.split("=")[0]] = int(kv.split("=")[1])
         res = dense_pcg_benchmark(args.dense_size, 32, tuning, repeats=args.dense_repeats)
         res["tuning"] = tuning
         print(json.dumps(res))

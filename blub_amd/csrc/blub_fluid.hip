@@ -114,6 +114,7 @@ struct blub_fluid {
     uint32_t max_steps_in_flight = 4;
     bool all_touched = false;
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, >= 1 brick lists
+    int dense_kd_nt = -1;                     // non-temporal s_out stores of the dense direction kernel: -1 = by grid size, 0 / 1 = forced (tuning knob)
     int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
     uint8_t* dvol = nullptr;
@@ -523,7 +524,10 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             }                                                                                                                                                   \
         }
         // p / r of KU are touched exactly once per kernel: non-temporal (66.8 -> 62.5 us at 256^3); s_out of KD is re-read as a halo: default policy
-        if (h->gz.T == 256) BLUB_LAUNCH_Z(256, true, false)
+        // s_out of KD: default cache policy while the iteration's working set fits the 256 MiB Infinity Cache (KU re-reads it: 256^3 KU 55.4 vs 58.0 us),
+        // non-temporal beyond (512^3: KD 316 vs 324 us, KU 524 vs 538 us)
+        if (h->dense_kd_nt > 0 || (h->dense_kd_nt < 0 && h->N >= ((size_t)1 << 26))) { if (h->gz.T == 256) BLUB_LAUNCH_Z(256, true, true) else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024, true, true) else BLUB_LAUNCH_Z(512, true, true) }
+        else if (h->gz.T == 256) BLUB_LAUNCH_Z(256, true, false)
         else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024, true, false)
         else BLUB_LAUNCH_Z(512, true, false)
 #undef BLUB_LAUNCH_Z
@@ -1091,6 +1095,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_tail_first") h->tail_first_forced = value;
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
+    else if (k == "dense_kd_nt") h->dense_kd_nt = value;
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);
     else if (k == "dense_tile_quads" || k == "dense_tile_planes" || k == "dense_grid") {
         HIP_TRY(hipStreamSynchronize(h->stream));

@@ -276,7 +276,8 @@ int blub_fluid_get_pcg_schedule(const blub_fluid* h);
  * "pcg1_max_iterations" n (default 64): solves configured with more iterations run schedule 0 even when schedule 1 is selected;
  * "pcg_launch_grid" n: launch grid of the brick-mapped PCG kernels (0: estimated from the last landed brick count) -- results do not depend on it;
  * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
- * (0 = default for the grid).  Unknown names: BLUB_ERR_INVALID_ARGUMENT. */
+ * (0 = default for the grid); "dense_kd_nt" -1|0|1: non-temporal stores of the dense direction kernel's output (-1: by grid size).
+ * Unknown names: BLUB_ERR_INVALID_ARGUMENT. */
 int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value);
 /* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks
  * (polling pinned memory) until step n - max has finished. */
