@@ -508,16 +508,16 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         const int np = h->pcg_grid_z;
         const dim3 grid(np);
         const size_t lds_dir = dense_dir_lds_bytes(h->gz.T, h->gz.qpr);
-#define BLUB_LAUNCH_Z(TT, NTU, NTD)                                                                                                                             \
+#define BLUB_LAUNCH_Z(TT, NTU, NTD, DD)                                                                                                                           \
         {                                                                                                                                                       \
             const dim3 block(TT);                                                                                                                               \
             LAUNCH(h, KC_PCG_INIT, k_pcg_init_z<TT>, grid, block, h->gz, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags, ctrl);   \
             for (int i = 0; i <= maxit; ++i) {                                                                                                                  \
                 if (i == 0)                                                                                                                                     \
-                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true, NTD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
+                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true, NTD, DD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);                                              \
                 else                                                                                                                                            \
-                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
+                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD, DD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));                           \
                 LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,     \
                        (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
@@ -526,10 +526,12 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
         // p / r of KU are touched exactly once per kernel: non-temporal (66.8 -> 62.5 us at 256^3); s_out of KD is re-read as a halo: default policy
         // s_out of KD: default cache policy while the iteration's working set fits the 256 MiB Infinity Cache (KU re-reads it: 256^3 KU 55.4 vs 58.0 us),
         // non-temporal beyond (512^3: KD 316 vs 324 us, KU 524 vs 538 us)
-        if (h->dense_kd_nt > 0 || (h->dense_kd_nt < 0 && h->N >= ((size_t)1 << 26))) { if (h->gz.T == 256) BLUB_LAUNCH_Z(256, true, true) else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024, true, true) else BLUB_LAUNCH_Z(512, true, true) }
-        else if (h->gz.T == 256) BLUB_LAUNCH_Z(256, true, false)
-        else if (h->gz.T == 1024) BLUB_LAUNCH_Z(1024, true, false)
-        else BLUB_LAUNCH_Z(512, true, false)
+        const bool kd_nt = h->dense_kd_nt > 0 || (h->dense_kd_nt < 0 && h->N >= ((size_t)1 << 26));
+        // (raw planes in flight per quad of the direction kernel: 2.  Measured with 3 and 4 -- 139 / 159 VGPRs, one wave of occupancy less each --:
+        //  46.1 / 46.6 us against 39.0 us at 256^3, 345 against 316 us at 512^3, also with 32- and 64-plane tiles)
+        if (h->gz.T == 256) { if (kd_nt) BLUB_LAUNCH_Z(256, true, true, 2) else BLUB_LAUNCH_Z(256, true, false, 2) }
+        else if (h->gz.T == 1024) { if (kd_nt) BLUB_LAUNCH_Z(1024, true, true, 2) else BLUB_LAUNCH_Z(1024, true, false, 2) }
+        else { if (kd_nt) BLUB_LAUNCH_Z(512, true, true, 2) else BLUB_LAUNCH_Z(512, true, false, 2) }
 #undef BLUB_LAUNCH_Z
         LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, np, (const uint32_t*)nullptr, maxit, h->solve_seq[which], stat_slot);
     }

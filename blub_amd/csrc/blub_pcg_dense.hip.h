@@ -207,10 +207,12 @@ struct DirTile {      // per-thread constants of a tile
     int halo_slot, z_begin, z_end;
     bool valid, halo_thread;
 };
-// the plane march of one tile; HALO: this wave owns halo quads
-template <int T, bool FIRST, bool NT, bool HALO>
+// the plane march of one tile; HALO: this wave owns halo quads; D: raw planes in flight per quad (own plane p and halo plane p live in
+// register set (p - z_begin) % D; the plane loop is unrolled by D so that the set indices are compile-time constants)
+template <int T, bool FIRST, bool NT, bool HALO, int D>
 __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, float4* __restrict__ ext, const uint8_t* __restrict__ dvol, const float* __restrict__ r,
                                           const float* __restrict__ s_in, float* __restrict__ s_out, float beta, const DivConst* lut, float& acc) {
+    static_assert(D >= 2 && D <= 4, "pipeline depth");
     const Grid g = gz.g;
     const int t = threadIdx.x, qpr = gz.qpr, ext_n = T + 2 * qpr;
     const size_t plane = (size_t)g.nx * (size_t)g.ny;
@@ -219,8 +221,9 @@ __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, 
     auto plane_of = [&](int zz, bool wanted, uint32_t& pm) -> size_t { const bool ok = wanted && zz >= 0 && zz < g.nz; pm = ok ? 0xFFFFFFFFu : 0u; return (size_t)(ok ? zz : zb) * plane; };
     float4 n_m, n_c, n_p, h_c = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t d_c, d_p;
-    DirRaw A, B, HA, HB;                       // own planes z + 2 / z + 3 and halo planes z + 1 / z + 2, alternating roles
-    HA.dq = 0; HB.dq = 0; HA.s = HA.r = HB.s = HB.r = make_float4(0.f, 0.f, 0.f, 0.f);
+    DirRaw own[D], hal[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { hal[k].dq = 0; hal[k].s = hal[k].r = make_float4(0.f, 0.f, 0.f, 0.f); own[k].dq = 0; own[k].s = own[k].r = make_float4(0.f, 0.f, 0.f, 0.f); }
     {   // ---- planes zb - 1, zb, zb + 1 of the own quad and plane zb of the halo quad: loaded and converted at once
         uint32_t pm_m, pm_c, pm_p;
         const size_t b_m = plane_of(zb - 1, true, pm_m), b_c = plane_of(zb, true, pm_c), b_p = plane_of(zb + 1, true, pm_p);
@@ -229,11 +232,14 @@ __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, 
         dir_raw_load<FIRST>(M, dvol + b_m, s_in + b_m, r + b_m, K.goff, K.vmask & pm_m);
         dir_raw_load<FIRST>(C, dvol + b_c, s_in + b_c, r + b_c, K.goff, K.vmask & pm_c);
         dir_raw_load<FIRST>(P, dvol + b_p, s_in + b_p, r + b_p, K.goff, K.vmask & pm_p);
-        // ... and the first set of the pipeline: own plane zb + 2, halo plane zb + 1
-        uint32_t pm_a, pm_ha;
-        const size_t b_a = plane_of(zb + 2, zb + 1 < ze, pm_a), b_ha = plane_of(zb + 1, zb + 1 < ze, pm_ha);
-        if (HALO) dir_raw_load<FIRST>(HA, dvol + b_ha, s_in + b_ha, r + b_ha, K.hoff, K.hmask & pm_ha);
-        dir_raw_load<FIRST>(A, dvol + b_a, s_in + b_a, r + b_a, K.goff, K.vmask & pm_a);
+        // ... and the first sets of the pipeline: halo planes zb + 1 .. zb + D - 1, own planes zb + 2 .. zb + D (in the order the loop consumes them)
+#pragma unroll
+        for (int j = 1; j < D; ++j) {
+            uint32_t pm_h, pm_o;
+            const size_t b_h = plane_of(zb + j, zb + j < ze, pm_h), b_o = plane_of(zb + j + 1, zb + j < ze, pm_o);
+            if (HALO) dir_raw_load<FIRST>(hal[j % D], dvol + b_h, s_in + b_h, r + b_h, K.hoff, K.hmask & pm_h);
+            dir_raw_load<FIRST>(own[(j + 1) % D], dvol + b_o, s_in + b_o, r + b_o, K.goff, K.vmask & pm_o);
+        }
         n_m = dir_snew<FIRST>(M, beta, lut);                                      // z-halo plane: not written
         n_c = dir_snew<FIRST>(C, beta, lut);
         n_p = dir_snew<FIRST>(P, beta, lut);
@@ -244,10 +250,10 @@ __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, 
             if (zb + 1 < ze) st4so<NT>(s_out + (size_t)(zb + 1) * plane, K.goff, n_p);
         }
     }
-    // one plane: request `issue` / `hissue` (own plane z + 3, halo plane z + 2), stencil of plane z, then `use` / `huse` (own plane z + 2, halo plane z + 1) enter
+    // one plane: request `issue` / `hissue` (own plane z + D + 1, halo plane z + D), stencil of plane z, then `use` / `huse` (own plane z + 2, halo plane z + 1) enter
     auto body = [&](int z, DirRaw& issue, DirRaw& hissue, DirRaw& use, DirRaw& huse) {
         uint32_t pm_o, pm_h;
-        const size_t b_o = plane_of(z + 3, z + 2 < ze, pm_o), b_h = plane_of(z + 2, z + 2 < ze, pm_h);
+        const size_t b_o = plane_of(z + D + 1, z + D < ze, pm_o), b_h = plane_of(z + D, z + D < ze, pm_h);
         if (HALO) dir_raw_load<FIRST>(hissue, dvol + b_h, s_in + b_h, r + b_h, K.hoff, K.hmask & pm_h);
         dir_raw_load<FIRST>(issue, dvol + b_o, s_in + b_o, r + b_o, K.goff, K.vmask & pm_o);
         // exchange of plane z (double buffered by plane parity: one LDS-only barrier per plane, see k_pcg_update_z)
@@ -268,13 +274,16 @@ __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, 
         if (!FIRST && z + 2 < ze && K.valid) st4so<NT>(s_out + (size_t)(z + 2) * plane, K.goff, n_n);
         n_m = n_c; n_c = n_p; n_p = n_n; d_c = d_p; d_p = use.dq;
     };
-    for (int z = zb; z < ze; z += 2) {
-        body(z, B, HB, A, HA);
-        if (z + 1 < ze) body(z + 1, A, HA, B, HB);
+    // at plane z = zb + m D + k: own plane z + D + 1 goes into set (k + 1) % D, own plane z + 2 comes out of set (k + 2) % D; halo plane z + D into set k,
+    // halo plane z + 1 out of set (k + 1) % D
+    for (int z = zb; z < ze; z += D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (z + k < ze) body(z + k, own[(k + 1) % D], hal[k % D], own[(k + 2) % D], hal[(k + 1) % D]);
     }
 }
 
-template <int T, bool FIRST, bool NT = false>
+template <int T, bool FIRST, bool NT = false, int D = 2>
 __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __restrict__ dvol, const float* __restrict__ r, const float* __restrict__ s_in,
                                                  float* __restrict__ s_out, const float2* __restrict__ part_upd, float* __restrict__ part_dir, int num_part,
                                                  const uint8_t* __restrict__ tile_flags, PcgCtrl* __restrict__ ctrl, float tolerance, int iteration, int check_prev) {
@@ -309,8 +318,8 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
         K.hoff = halo_valid ? (uint32_t)hq * 16u : 0u;
         K.hmask = halo_valid ? 0xFFFFFFFFu : 0u;
         K.halo_slot = t < qpr ? t : T + t;                                        // upper halo: T + qpr + (t - qpr)
-        if (halo_wave) dir_march<T, FIRST, NT, true>(gz, K, ext, dvol, r, s_in, s_out, beta, div_lut, acc);
-        else dir_march<T, FIRST, NT, false>(gz, K, ext, dvol, r, s_in, s_out, beta, div_lut, acc);
+        if (halo_wave) dir_march<T, FIRST, NT, true, D>(gz, K, ext, dvol, r, s_in, s_out, beta, div_lut, acc);
+        else dir_march<T, FIRST, NT, false, D>(gz, K, ext, dvol, r, s_in, s_out, beta, div_lut, acc);
         __syncthreads();   // the LDS buffers are reused by the next tile
     }
     const float tot = block_reduce<T, false>(acc, sm);

@@ -107,7 +107,8 @@ def default_simulation_delta(steps_per_second=120):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libblubhip.so")
+    """The in-tree library; BLUBHIP_LIB (development: A/B builds with other compile-time constants) names another build of it."""
+    return os.environ.get("BLUBHIP_LIB") or os.path.join(_HERE, "libblubhip.so")
 
 
 _lib = None
