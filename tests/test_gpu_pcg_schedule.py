@@ -258,3 +258,39 @@ def test_long_solve_true_residual(mapping):
         assert rel < 3e-6, rel
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("mapping", ["bricks", "bricks_single", "rows"])
+def test_work_volumes_may_hold_anything_outside_the_fluid(mapping):
+    """Round-2 ADVICE: AUX_TEMP doubles as the u32 counter / prefix-sum scratch of the binning pass and as a PCG work volume, SEARCH / AUX /
+    RESIDUAL are only ever written on FLUID cells -- so outside the fluid they may hold integer garbage reinterpreted as f32, NaN patterns
+    included.  Every reader gates on the FLUID bit of the stencil descriptor: a solve on volumes poisoned with NaN outside the fluid (AUX and
+    AUX_TEMP everywhere) gives the SAME BITS on the fluid as the solve on clean volumes."""
+    pos, vel, maxp = util.make_dam(*GRID)
+    o, h = util.new_pair(*GRID, maxp)
+    try:
+        util.set_mapping(h, mapping)
+        o.set_particles(pos, *vel)
+        run_until(o, "solve_velocity")
+        util.copy_state(o, h)
+        fluid = o.read_volume("marker") == 1
+        state = {v: o.read_volume(v) for v in ("residual", "pressure_velocity", "search")}
+        h.set_solver_config(0, error_tolerance=0.0, max_num_iterations=13, error_check_frequency=4)
+        results = []
+        for poison in (False, True):
+            for v, a in state.items():
+                a = a.copy()
+                if poison and v != "pressure_velocity":      # (the pressure field IS defined everywhere: pressure_init.comp:45-48 zeroes it outside the fluid)
+                    a[~fluid] = np.float32(np.nan)
+                h.write_volume(v, a)
+            junk = np.full(fluid.shape, np.nan, np.float32) if poison else np.zeros(fluid.shape, np.float32)
+            h.write_volume("aux", junk)
+            h.write_volume("aux_temp", junk.view(np.uint32).astype(np.uint32).view(np.float32) if not poison else np.full(fluid.shape, 0x7FC00001, np.uint32).view(np.float32))
+            h.mark_pressure_initialised(0, False)
+            h.run_stage("solve_velocity", util.DT)
+            results.append((h.solver_stats(0), h.read_volume("pressure_velocity").copy(), h.read_volume("residual")[fluid].copy()))
+        (sa, pa, ra), (sb, pb, rb) = results
+        assert sa == sb and sa[1] == 13 and np.isfinite(sa[0])
+        assert np.array_equal(pa[fluid], pb[fluid]) and np.array_equal(ra, rb) and np.all(pb[~fluid] == 0)
+    finally:
+        h.close()
