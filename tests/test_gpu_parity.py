@@ -117,7 +117,9 @@ def test_pcg_default_config(pair, which, stage, mapping):
     eh, ih = h.solver_stats(which)
     # (max|r| of the unconverged DENSITY solve is carried by single cells: the oracle against itself spreads by ~3x when only the
     #  rounding of its inputs changes, tests/test_gpu_baseline_parity.py::_compare_solve; the pressure field above is the robust measure)
-    lo, hi = (0.5, 2.0) if which == 0 else (0.25, 4.0)
+    # (round-2 ADVICE: the reference-order mappings keep the tight bound; only the single-reduction opt-in gets the wide one for the density solve)
+    lo, hi = (0.25, 4.0) if (which == 1 and mapping == "bricks_single") else (0.5, 2.0)
+    print("%s solver %d: max|r| dt engine %.4g oracle %.4g, pressure rel. L2 %.3g" % (mapping, which, eh, eo, rel_l2))
     assert ih == io == 32 and lo < eh / eo < hi, ((eh, ih), (eo, io))
     # self-consistency of the HIP state: r = b - A p (pressure.glsl:34-75), A from the marker
     mpad = np.pad(marker, 1, constant_values=0)
