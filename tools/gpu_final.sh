@@ -4,11 +4,15 @@ tag=${1:-r03}; ver=${2:-v2}
 root=${GRAFT_REPO_ROOT:-$(pwd)}; cd $root; mkdir -p gpurun_out
 o=gpurun_out/${tag}
 timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 -s > ${o}_gpu_tests_${ver}.log 2>&1; tail -3 ${o}_gpu_tests_${ver}.log
+python -c "import __graft_entry__ as g; g.smoke()" > ${o}_smoke_${ver}.log 2>&1; tail -1 ${o}_smoke_${ver}.log
 timeout 600 python bench.py > ${o}_bench_${ver}.log 2>&1; grep '^{' ${o}_bench_${ver}.log | tail -1 > ${o}_bench_${ver}.json
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > ${o}_bench_${ver}_driver_window.log 2>&1; grep '^{' ${o}_bench_${ver}_driver_window.log | tail -1 > ${o}_bench_${ver}_driver_window.json
 bash tools/kstats.sh ${o}_kernel_stats_${ver}_sparse_bench.csv
 bash tools/dense_pmc.sh 256 ${o}_${ver}_dense_pcg_256 > /dev/null 2>&1
 bash tools/dense_pmc.sh 512 ${o}_${ver}_dense_pcg_512 > /dev/null 2>&1
+# the bench line again, now that the PMC captures of THIS code state exist (bench.py reads them from profiles/)
+mkdir -p profiles; for n in 256 512; do cp ${o}_${ver}_dense_pcg_${n}_pmc.json profiles/r03_pmc_dense_pcg_${n}.json; done
+timeout 600 python bench.py > ${o}_bench_${ver}.log 2>&1; grep '^{' ${o}_bench_${ver}.log | tail -1 > ${o}_bench_${ver}.json
 ( cd /tmp && export TMPDIR=/tmp && rm -rf $root/gpurun_out/_sq && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $root/gpurun_out/_sq -o p -- python $root/bench.py --dense-only --dense-size 256 > $root/gpurun_out/_sq.log 2>&1 )
 python tools/pmc_summary.py gpurun_out/_sq > ${o}_${ver}_pmc_sq_dense_pcg_256.csv; rm -rf gpurun_out/_sq
 for n in 2 4; do python tools/slab_loopback_bench.py corner_dams_256 $n 60 5 single_reduction 1; python tools/slab_loopback_bench.py corner_dams_256 $n 60 5 single_reduction 0; done > ${o}_${ver}_slab_loopback.jsonl 2>${o}_slab.err
