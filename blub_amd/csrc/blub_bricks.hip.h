@@ -350,7 +350,7 @@ constexpr int GT_X = BX + 1, GT_Y = BY + 1, GT_Z = BZ + 1, GT_N = GT_X * GT_Y * 
 // stay in flight across the exchange (a __syncthreads() would drain vmcnt first).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct GatherArgs3 { const uint32_t* heads[3]; const uint32_t* next[3]; const float4* rows[3]; float* out[3]; float gravity_dt[3]; };
+struct GatherArgs3 { const uint32_t* heads[3]; float* out[3]; float gravity_dt[3]; };
 
 // "Partial sum" formulation.  (Round 1 moved PARTICLES to faces -- per round every thread published one particle through LDS and read
 // seven, with a 12-wave barrier per round: measured LDS-issue / barrier bound; removed.)  Every
@@ -366,10 +366,42 @@ struct GatherPartialsV { float2 part[8][GP_STRIDE]; };     // [corner][list cell
 struct GatherPartialsD { float part[8][GP_STRIDE]; };      // [corner][list cell] sum w: 24 KiB
 
 template <int COMP>
+__device__ __forceinline__ void gather_walk(const GatherNode* __restrict__ nodes, uint32_t cur, int gx, int gy, int gz, float (&v)[8], float (&ws)[8]) {
+    // the two sample coordinates per axis this list reaches: faces d and d + 1 (:20, sample = face + 0.5 (+ 0.5 along COMP))
+    const float sx0 = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f), sx1 = (float)(gx + 1) + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
+    const float sy0 = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f), sy1 = (float)(gy + 1) + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
+    const float sz0 = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f), sz1 = (float)(gz + 1) + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
+    // one hop = the two halves of ONE 32-byte node (k_build_lists): {position, link}, {row}
+    const float4* nd = reinterpret_cast<const float4*>(nodes) + COMP * 2;
+    float4 p = nd[6 * (size_t)cur], r = nd[6 * (size_t)cur + 1];
+    uint32_t nxt = __float_as_uint(p.w);
+    for (int round = 0; round < GATHER_CAP_V; ++round) {                                           // :61
+        const bool has_n = nxt != INVALID_LL && round + 1 < GATHER_CAP_V;
+        float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
+        if (has_n) { pn = nd[6 * (size_t)nxt]; rn = nd[6 * (size_t)nxt + 1]; nn = __float_as_uint(pn.w); }   // next node in flight during the arithmetic
+        const float tx[2] = {sx0 - p.x, sx1 - p.x}, ty[2] = {sy0 - p.y, sy1 - p.y}, tz[2] = {sz0 - p.z, sz1 - p.z};   // :20
+        const float ox[2] = {satf(1.0f - fabsf(tx[0])), satf(1.0f - fabsf(tx[1]))};
+        const float oy[2] = {satf(1.0f - fabsf(ty[0])), satf(1.0f - fabsf(ty[1]))};
+        const float oz[2] = {satf(1.0f - fabsf(tz[0])), satf(1.0f - fabsf(tz[1]))};
+        const float ax[2] = {r.x * tx[0], r.x * tx[1]}, ay[2] = {r.y * ty[0], r.y * ty[1]}, az[2] = {r.z * tz[0], r.z * tz[1]};
+        const float rw = r.w * 1.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
+            const float w = ox[kx] * oy[ky] * oz[kz];                                    // :22
+            const float d = ((ax[kx] + ay[ky]) + az[kz]) + rw;                           // :24
+            v[k] += w * d;
+            ws[k] += w;
+        }
+        if (!has_n) break;
+        p = pn; r = rn; nxt = nn;
+    }
+}
+
+template <int COMP>
 __device__ __forceinline__ void gather_velocity_partial_body(GatherPartialsV& sh, uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ count, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
-                                                             const float4* __restrict__ pos, const uint32_t* __restrict__ next,
-                                                             const float4* __restrict__ rows, float* __restrict__ out, float gravity_dt) {
+                                                             const GatherNode* __restrict__ nodes, float* __restrict__ out, float gravity_dt) {
     const Grid g = bg.g;
     const int tid = threadIdx.x;
     const bool live = tid < GT_N;
@@ -387,35 +419,7 @@ __device__ __forceinline__ void gather_velocity_partial_body(GatherPartialsV& sh
         float v[8], ws[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { v[k] = 0.0f; ws[k] = 0.0f; }
-        if (has) {
-            // the two sample coordinates per axis this list reaches: faces d and d + 1 (:20, sample = face + 0.5 (+ 0.5 along COMP))
-            const float sx0 = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f), sx1 = (float)(gx + 1) + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
-            const float sy0 = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f), sy1 = (float)(gy + 1) + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
-            const float sz0 = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f), sz1 = (float)(gz + 1) + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
-            float4 p = pos[cur], r = rows[cur];
-            uint32_t nxt = next ? next[cur] : __float_as_uint(p.w);
-            for (int round = 0; round < GATHER_CAP_V; ++round) {                                           // :61
-                const bool has_n = nxt != INVALID_LL && round + 1 < GATHER_CAP_V;
-                float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
-                if (has_n) { pn = pos[nxt]; rn = rows[nxt]; nn = next ? next[nxt] : __float_as_uint(pn.w); }   // next node in flight during the arithmetic
-                const float tx[2] = {sx0 - p.x, sx1 - p.x}, ty[2] = {sy0 - p.y, sy1 - p.y}, tz[2] = {sz0 - p.z, sz1 - p.z};   // :20
-                const float ox[2] = {satf(1.0f - fabsf(tx[0])), satf(1.0f - fabsf(tx[1]))};
-                const float oy[2] = {satf(1.0f - fabsf(ty[0])), satf(1.0f - fabsf(ty[1]))};
-                const float oz[2] = {satf(1.0f - fabsf(tz[0])), satf(1.0f - fabsf(tz[1]))};
-                const float ax[2] = {r.x * tx[0], r.x * tx[1]}, ay[2] = {r.y * ty[0], r.y * ty[1]}, az[2] = {r.z * tz[0], r.z * tz[1]};
-                const float rw = r.w * 1.0f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
-                    const float w = ox[kx] * oy[ky] * oz[kz];                                    // :22
-                    const float d = ((ax[kx] + ay[ky]) + az[kz]) + rw;                           // :24
-                    v[k] += w * d;
-                    ws[k] += w;
-                }
-                if (!has_n) break;
-                p = pn; r = rn; nxt = nn;
-            }
-        }
+        if (has) gather_walk<COMP>(nodes, cur, gx, gy, gz, v, ws);
         if (live) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) sh.part[k][tid] = make_float2(v[k], ws[k]);
@@ -454,13 +458,127 @@ __device__ __forceinline__ void gather3_block_role(uint32_t& slot, uint32_t& slo
     slots = gridDim.x / 3u;
 }
 __global__ __launch_bounds__(768) void k_gather_velocity3_p(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                            const int8_t* __restrict__ marker, const float4* __restrict__ pos, GatherArgs3 a) {
+                                                            const int8_t* __restrict__ marker, const GatherNode* __restrict__ nodes, GatherArgs3 a) {
     __shared__ GatherPartialsV sh;
     uint32_t slot, slots; int comp;
     gather3_block_role(slot, slots, comp);
-    if (comp == 0) gather_velocity_partial_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], pos, a.next[0], a.rows[0], a.out[0], a.gravity_dt[0]);
-    else if (comp == 1) gather_velocity_partial_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], pos, a.next[1], a.rows[1], a.out[1], a.gravity_dt[1]);
-    else gather_velocity_partial_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], pos, a.next[2], a.rows[2], a.out[2], a.gravity_dt[2]);
+    if (comp == 0) gather_velocity_partial_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes, a.out[0], a.gravity_dt[0]);
+    else if (comp == 1) gather_velocity_partial_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes, a.out[1], a.gravity_dt[1]);
+    else gather_velocity_partial_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes, a.out[2], a.gravity_dt[2]);
+}
+
+// ---- the same gather with the tile's NON-EMPTY lists compacted -------------------------------------------------------------------
+// The kernel above gives every list cell of the tile a lane; a brick of the headline scene holds particles in a fifth of its cells, so
+// four lanes of five only wait at the exchange barrier, and with 12 waves per workgroup two workgroups fill a CU.  Here 256 threads load
+// the 765 heads, compact the non-empty lists IN CELL ORDER (ballots + a 12-entry scan), and thread t walks the list in slot t: every
+// lane of the walk phase is busy and 6-8 workgroups fit a CU.  Tiles with more than 256 lists take several passes, last slots first:
+// a face's eight lists d - {0,1}^3 come in DESCENDING cell order for k = 0..7, so a running sum over (pass descending, k ascending)
+// adds the eight partial sums in exactly the reference's list order (:87-93) -- bit-identical to k_gather_velocity3_p.
+constexpr int GS_THREADS = 256;
+constexpr int GS_CHUNKS = 3 * (GS_THREADS / 64);      // (pass over the tile, wave): 64 consecutive tile cells each
+constexpr uint32_t GS_EMPTY = 0xFFFFu;
+struct GatherSparseShared {
+    float2 part[8][GS_THREADS];      // [corner][slot of this pass] {sum w*d, sum w}: 16 KiB
+    uint16_t cell_of[GT_N + 3];      // slot -> tile cell
+    uint16_t slot_of[GT_N + 3];      // tile cell -> slot (GS_EMPTY: no list)
+    uint32_t chunk[2][GS_CHUNKS];    // non-empty lists per chunk; double buffered by brick parity
+};
+
+template <int COMP>
+__device__ __forceinline__ void gather_velocity_sparse_body(GatherSparseShared& sh, uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg,
+                                                            const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const int8_t* __restrict__ marker,
+                                                            const uint32_t* __restrict__ heads, const GatherNode* __restrict__ nodes, float* __restrict__ out, float gravity_dt) {
+    const Grid g = bg.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = *count;
+    int parity = 0;
+    for (uint32_t i = first_brick; i < n; i += brick_stride, parity ^= 1) {
+        const uint32_t b = list[i];
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
+        const int ox0 = bx * BX - 1, oy0 = by * BY - 1, oz0 = bz * BZ - 1;                   // grid coordinates of tile cell 0 (:41)
+        // ---- compact the tile's non-empty lists, in cell order ----
+        unsigned long long mask[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = tid + GS_THREADS * j;
+            const int gx = ox0 + c % GT_X, gy = oy0 + (c / GT_X) % GT_Y, gz = oz0 + c / (GT_X * GT_Y);
+            mask[j] = __ballot(c < GT_N && inb(g, gx, gy, gz) && heads[cidx(g, gx, gy, gz)] != 0u);
+            if (lane == 0) sh.chunk[parity][j * (GS_THREADS / 64) + wave] = (uint32_t)__popcll(mask[j]);
+        }
+        __syncthreads();                // (the chunk counts of the brick before the last were read before this barrier: the other buffer is free)
+        uint32_t nl = 0, before[3] = {0, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < GS_CHUNKS; ++ch) {
+            const uint32_t v = sh.chunk[parity][ch];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (ch < j * (GS_THREADS / 64) + wave) before[j] += v;
+            nl += v;
+        }
+        if (nl == 0) continue;          // no particle anywhere in the tile: no face of this brick touches a FLUID cell, nothing is written
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = tid + GS_THREADS * j;
+            const bool has = (mask[j] >> lane) & 1ull;
+            const uint32_t slot = before[j] + (uint32_t)__popcll(mask[j] & ((1ull << lane) - 1ull));
+            if (has) sh.cell_of[slot] = (uint16_t)c;
+            if (c < GT_N) sh.slot_of[c] = has ? (uint16_t)slot : (uint16_t)GS_EMPTY;
+        }
+        __syncthreads();
+        // ---- walk: thread t takes the list in slot pass * 256 + t; the faces add up what they reach ----
+        float val[2] = {0.0f, 0.0f}, wsum[2] = {0.0f, 0.0f};
+        for (int pass = (int)((nl - 1u) / GS_THREADS); pass >= 0; --pass) {
+            const uint32_t s = (uint32_t)pass * GS_THREADS + tid;
+            if (s < nl) {
+                const int c = sh.cell_of[s];
+                const int gx = ox0 + c % GT_X, gy = oy0 + (c / GT_X) % GT_Y, gz = oz0 + c / (GT_X * GT_Y);
+                float v[8], ws[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v[k] = 0.0f; ws[k] = 0.0f; }
+                gather_walk<COMP>(nodes, heads[cidx(g, gx, gy, gz)] - 1u, gx, gy, gz, v, ws);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sh.part[k][tid] = make_float2(v[k], ws[k]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int fc = tid + GS_THREADS * f;                                        // face (fc % 16, fc / 16 % 8, fc / 128) of the brick
+                const int tc = ((fc & 15) + 1) + (((fc >> 4) & 7) + 1) * GT_X + ((fc >> 7) + 1) * GT_X * GT_Y;
+                // the face's eight lists in the reference's order (:87-93): own cell, then the seven negative neighbours
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t sl = sh.slot_of[tc - (k & 1) - ((k >> 1) & 1) * GT_X - (k >> 2) * GT_X * GT_Y];
+                    if (sl != GS_EMPTY && (int)(sl / GS_THREADS) == pass) { const float2 q = sh.part[k][sl % GS_THREADS]; val[f] += q.x; wsum[f] += q.y; }
+                }
+            }
+            __syncthreads();            // (also: the next brick's compaction overwrites slot_of / cell_of)
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int fc = tid + GS_THREADS * f;
+            const int gx = bx * BX + (fc & 15), gy = by * BY + ((fc >> 4) & 7), gz = bz * BZ + (fc >> 7);
+            if (!inb(g, gx, gy, gz)) continue;
+            const int mA = (int)marker[cidx(g, gx, gy, gz)];
+            const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
+            if (mA == CELL_FLUID || mB == CELL_FLUID) {                                          // :50
+                float o = 0.0f;
+                if (mA != CELL_SOLID && mB != CELL_SOLID) {                                      // :51
+                    o = val[f];
+                    if (wsum[f] > 0.0f) o /= wsum[f];                                            // :117-119
+                    o += gravity_dt;                                                             // :120
+                }
+                out[cidx(g, gx, gy, gz)] = o;                                                    // (:121-124: 0 with exactly one solid side)
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(GS_THREADS) void k_gather_velocity3_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                   const int8_t* __restrict__ marker, const GatherNode* __restrict__ nodes, GatherArgs3 a) {
+    __shared__ GatherSparseShared sh;
+    uint32_t slot, slots; int comp;
+    gather3_block_role(slot, slots, comp);
+    if (comp == 0) gather_velocity_sparse_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes, a.out[0], a.gravity_dt[0]);
+    else if (comp == 1) gather_velocity_sparse_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes, a.out[1], a.gravity_dt[1]);
+    else gather_velocity_sparse_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes, a.out[2], a.gravity_dt[2]);
 }
 
 // R1 in the same formulation (density_projection_gather_error.comp:41-198): samples are cell centres, the list cap is 32

@@ -83,7 +83,7 @@ struct blub_fluid {
     uint32_t step_counter = 0;
     // particles (hybrid_fluid.rs:114-122)
     float4 *pos = nullptr, *pos_tmp = nullptr, *pvel[3] = {nullptr, nullptr, nullptr};
-    uint32_t *next1 = nullptr, *next2 = nullptr;
+    blubk::GatherNode* nodes = nullptr;       // 3 x 32 bytes per particle: what the P2G list walks read (written by k_build_lists)
     // volumes (hybrid_fluid.rs:142-154; pressure_solver.rs:104-108, 332-351)
     int8_t* marker = nullptr;
     uint32_t* ll[3] = {nullptr, nullptr, nullptr};
@@ -115,6 +115,8 @@ struct blub_fluid {
     bool all_touched = false;
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, >= 1 brick lists
     int dense_kd_nt = -1;                     // non-temporal s_out stores of the dense direction kernel: -1 = by grid size, 0 / 1 = forced (tuning knob)
+    int p2g_compact = -1;                     // P2G gather: 1 = the tile's non-empty lists compacted (k_gather_velocity3_s), 0 = one lane per list cell, -1 = by fill (stage_transfer)
+    bool two_kernel_build = false;            // test hook ("bricks_two_kernel_build"): the list build of grids with more brick blocks than CUs
     int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
     uint8_t* dvol = nullptr;
@@ -269,7 +271,7 @@ static int build_lists(blub_fluid* h, int phase) {
     const int nblk = (h->bg.nb + 1023) / 1024;
     const int all_touched = (phase == COMPACT_ALL_ACTIVE) ? 1 : (int)h->all_touched;
     h->counts_seq += 1;
-    if (nblk <= h->num_cus) {      // every block co-resident: classification and scatter in ONE launch (k_bricks_build)
+    if (nblk <= h->num_cus && !h->two_kernel_build) {      // every block co-resident: classification and scatter in ONE launch (k_bricks_build)
         hipLaunchKernelGGL(k_bricks_build, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, h->brick_fluid, h->brick_active,
                            h->brick_touched, reinterpret_cast<uint32_t*>(h->brick_block_counts), h->brick_block_ready, h->list_fluid, h->list_active, h->list_reset, h->counts,
                            h->counts_seq, h->counts_host_dev + (h->counts_seq % COUNTS_RING));
@@ -325,12 +327,22 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     const uint32_t np_all = h->num_particles + h->num_ghost;
     if (np_all)
         LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, h->marker,
-               h->ll[0], h->ll[1], h->ll[2], h->next1, h->next2, (int)(h->solid == nullptr), (const uint32_t*)h->n_dev, N_ALL);
+               h->ll[0], h->ll[1], h->ll[2], (const float4*)h->pvel[0], (const float4*)h->pvel[1], (const float4*)h->pvel[2], h->nodes, (int)(h->solid == nullptr), (const uint32_t*)h->n_dev, N_ALL);
     {
         GatherArgs3 a;
-        const uint32_t* nexts[3] = {nullptr, h->next1, h->next2};
-        for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.next[c] = nexts[c]; a.rows[c] = h->pvel[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
-        LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, dim3(3 * ((h->brick_grid + 7) / 8) * 8), dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const float4*)h->pos, a);
+        for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
+        const dim3 ggrid(3 * ((h->brick_grid + 7) / 8) * 8);
+        // Which of the two (bit-identical) gathers: the compacting one wins while a FLUID brick holds particles in a minority of its cells (headline scene: ~750
+        // particles per FLUID brick, 69 against 76 us), one lane per list cell when the bricks are full (M4: ~4000 per brick, 3.7 against 4.1 ms).
+        // Decided from the newest brick counts that have landed -- a speed choice only.
+        bool compact = h->p2g_compact == 1;
+        if (h->p2g_compact < 0) {
+            BrickCounts bc; bool have = false;
+            if ((rc = latest_counts(h, false, &bc, &have)) != BLUB_OK) return rc;
+            compact = have && (uint64_t)np_all < 1536ull * bc.n_fluid;
+        }
+        if (compact) LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_s, ggrid, dim3(GS_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker, (const blubk::GatherNode*)h->nodes, a);
+        else LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, ggrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const blubk::GatherNode*)h->nodes, a);
     }
     return BLUB_OK;
 }
@@ -652,7 +664,7 @@ static void destroy(blub_fluid* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     auto F = [h](void* p) { if (p && !(h->slab && (char*)p >= h->slab && (char*)p < h->slab + h->slab_bytes)) (void)hipFree(p); };
-    F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->next1); F(h->next2); F(h->marker); for (auto p : h->ll) F(p);
+    F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->marker); for (auto p : h->ll) F(p);
     for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_block_ready); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
@@ -717,7 +729,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     A(dev_alloc_zero(h->stream, &h->pos, P)); A(dev_alloc_zero(h->stream, &h->pos_tmp, P));
     for (int c = 0; c < 3; ++c) A(dev_alloc_zero(h->stream, &h->pvel[c], P));
-    A(dev_alloc_zero(h->stream, &h->next1, P)); A(dev_alloc_zero(h->stream, &h->next2, P));
+    A(dev_alloc_zero(h->stream, &h->nodes, 3 * P));
     if (d->volume_shift_kib != 0xFFFFFFFFu) {      // (0xFFFFFFFF: one allocation per volume)
         h->slab_shift = (size_t)(d->volume_shift_kib ? d->volume_shift_kib : 64u) * 1024u;
         const size_t per = ((h->N * 4 + 0x1FFFFFull) & ~0x1FFFFFull) + 0x400000ull;      // 2 MiB alignment + up to 2 MiB of shift
@@ -1098,6 +1110,8 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
     else if (k == "dense_kd_nt") h->dense_kd_nt = value;
+    else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);
+    else if (k == "bricks_two_kernel_build") h->two_kernel_build = value != 0;
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);
     else if (k == "dense_tile_quads" || k == "dense_tile_planes" || k == "dense_grid") {
         HIP_TRY(hipStreamSynchronize(h->stream));

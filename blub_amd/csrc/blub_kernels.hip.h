@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ head
     const int lane = threadIdx.x & 63;
     unsigned long long remaining = ~0ull, mine = 0ull;
     while (remaining) {
-        const int k = __shfl(key, __builtin_ctzll(remaining), 64);     // (uniform source lane: a v_readlane)
+        const int k = __builtin_amdgcn_readlane(key, __builtin_ctzll(remaining));     // uniform source lane: v_readlane (__shfl would be a ds_bpermute + wait per round)
         const unsigned long long m = __ballot(key == k);
         if (key == k) mine = m;
         remaining &= ~m;
@@ -119,17 +119,26 @@ __device__ __forceinline__ uint32_t wave_list_insert_runs(uint32_t* __restrict__
     return is_start ? old_of_run - 1u : prev_particle;
 }
 
+// Gather nodes: what one hop of a P2G list walk reads, in ONE 32-byte piece -- {position, link of component c's list, velocity row c}.  Particle i
+// owns 96 consecutive bytes (three nodes), so a node never straddles a 64-byte sector and the list build writes them as one coalesced stream.
+// (The walk used to read position, row and link from three arrays: three sectors per hop, 36 useful bytes of 192.)
+struct alignas(16) GatherNode { float px, py, pz; uint32_t next; float4 row; };
+static_assert(sizeof(GatherNode) == 32, "GatherNode");
+
 __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_particles, float4* __restrict__ pos, int8_t* __restrict__ marker,
                                                      uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
-                                                     uint32_t* __restrict__ next1, uint32_t* __restrict__ next2, int no_solid_voxels,
+                                                     const float4* __restrict__ pvx, const float4* __restrict__ pvy, const float4* __restrict__ pvz,
+                                                     GatherNode* __restrict__ nodes, int no_solid_voxels,
                                                      const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
     num_particles = particle_count(num_particles, n_dev, n_sel);
     if (blockIdx.x * 256u >= num_particles) return;      // (uniform)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < num_particles;          // no early return: the wave-level insertion needs every lane
     float4 p = make_float4(-8.f, -8.f, -8.f, 0.f);
+    float4 rows[3] = {p, p, p};
     if (live) {
         p = pos[i];
+        rows[0] = pvx[i]; rows[1] = pvy[i]; rows[2] = pvz[i];
         const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
         if (inb(g, x, y, z)) {
             const int c = cidx(g, x, y, z);
@@ -147,9 +156,13 @@ __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_partic
         nxt[c] = wave_list_insert(heads[c], key, i);
     }
     if (!live) return;
-    reinterpret_cast<uint32_t*>(pos)[4 * (size_t)i + 3] = nxt[0];
-    next1[i] = nxt[1];
-    next2[i] = nxt[2];
+    pos[i] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[0]));      // particles_position_ll keeps the x list's links, as in the reference (the whole record: a 4-byte store is a partial sector write)
+    float4* out = reinterpret_cast<float4*>(nodes + 3 * (size_t)i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out[2 * c] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[c]));
+        out[2 * c + 1] = rows[c];
+    }
 }
 
 // ---- shared by the P2G gather (blub_bricks.hip.h): transfer_gather_velocity.comp:18-26 ----

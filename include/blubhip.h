@@ -277,6 +277,9 @@ int blub_fluid_get_pcg_schedule(const blub_fluid* h);
  * "pcg_launch_grid" n: launch grid of the brick-mapped PCG kernels (0: estimated from the last landed brick count) -- results do not depend on it;
  * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
  * (0 = default for the grid); "dense_kd_nt" -1|0|1: non-temporal stores of the dense direction kernel's output (-1: by grid size).
+ * "p2g_compact" -1|0|1 (default -1): 1 = the P2G gather compacts each tile's non-empty lists, 0 = one lane per list cell (same results bit for
+ *   bit), -1 = chosen per step from the particles per FLUID brick.
+ * "bricks_two_kernel_build" 0|1: build the brick lists with the two-kernel scan that grids with more 1024-brick blocks than CUs use.
  * Unknown names: BLUB_ERR_INVALID_ARGUMENT. */
 int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value);
 /* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks

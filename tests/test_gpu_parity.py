@@ -577,6 +577,34 @@ def test_z_slab_solve_follows_convergence(schedule):
         group.close()
 
 
+def test_one_launch_and_two_kernel_list_builds_agree():
+    """k_bricks_build (classification + scatter in one launch, the blocks waiting for each other's counts) against the two-kernel scan it
+    replaces on grids with at most one brick block per CU: identical brick counts after every build of three steps and -- with the
+    solves converged, so that nothing amplifies the order of the atomics -- the same particles to 1e-4 cells."""
+    import blub_amd
+    pos, vel, maxp = util.make_dam(*GRID, seed=3)
+    out = []
+    for two_kernel in (0, 1):
+        h = blub_amd.HybridFluid(GRID, maxp, binning="off")
+        try:
+            h.set_tuning("bricks_two_kernel_build", two_kernel)
+            h.set_gravity_grid((0.0, -981.0, 0.0))
+            h.set_particles(pos, *vel)
+            for w in (0, 1):
+                h.set_solver_config(w, error_tolerance=2e-6, max_num_iterations=400, error_check_frequency=8)
+            counts = []
+            for _ in range(3):
+                h.step(util.DT)
+                counts.append(h.brick_counts())
+            out.append((counts, h.get_particles()[0][:, :3].astype(np.float64), h.read_volume("marker")))
+        finally:
+            h.close()
+    assert out[0][0] == out[1][0] and out[0][0][-1]["fluid"] > 0
+    assert np.array_equal(out[0][2], out[1][2])
+    d = np.abs(out[0][1] - out[1][1]).max(axis=1)
+    assert (d > 1e-4).mean() < 1e-3, d.max()
+
+
 def test_partial_bricks_odd_grid_full_step():
     """Grid dimensions that are not multiples of the 16x8x4 brick (only x % 4 == 0 is required): partial bricks at the
     upper domain faces, full step against the oracle with converged solves."""
@@ -737,6 +765,56 @@ def test_extrapolation_with_every_neighbour_count():
             inner = np.zeros_like(fl); inner[2:-2, 2:-2, 2:-2] = True
             counts |= set(np.unique(n[inner & ~valid]).tolist())
         assert set(range(1, 9)) <= counts, counts
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("kind", ["single_full", "single_sparse", "dam", "dam_sparse"])
+def test_transfer_gather_kernels(kind):
+    """The P2G gather exists twice: one lane per list cell of the tile (k_gather_velocity3_p) and with the tile's non-empty lists compacted
+    (k_gather_velocity3_s; tiles with more than 256 lists take several passes, last slots first).  Both add a face's eight partial sums in
+    the reference's list order.  "single_*": one particle per cell with fractional offsets in (0.5, 1) puts exactly one particle on every
+    list of all three staggerings, so the lists do not depend on the order of the atomics and the velocity volumes of the two kernels must
+    agree BIT FOR BIT (every tile cell occupied: three passes; a tenth of them: one pass).  "dam*": 8 particles per cell in random memory
+    order -- the node order of a list is a race, so both kernels are held to the oracle at 1e-5 instead."""
+    rng = np.random.default_rng(31)
+    if kind.startswith("single"):
+        nx, ny, nz = GRID
+        cells = np.stack(np.meshgrid(np.arange(1, nx - 2), np.arange(1, int(ny * 0.7)), np.arange(1, nz - 2), indexing="ij"), -1).reshape(-1, 3)
+        if kind == "single_sparse":
+            cells = cells[rng.random(len(cells)) < 0.1]
+        pos = (cells + 0.5 + 0.49 * rng.random(cells.shape)).astype(np.float32)
+        vel = []
+        for c in range(3):
+            rows = (rng.standard_normal((len(pos), 4)) * 0.3).astype(np.float32)
+            rows[:, 3] = (3.0 * np.sin(pos[:, (c + 1) % 3] * 0.3 + c)).astype(np.float32)
+            vel.append(rows)
+        vel = tuple(vel)
+        maxp = len(pos) + 64
+    else:
+        pos, vel, maxp = util.make_dam(*GRID, seed=5)
+        if kind == "dam_sparse":
+            keep = (rng.random(len(pos)) < 0.04) & (pos[:, 1] < 0.35 * GRID[1])
+            pos, vel = pos[keep], tuple(v[keep] for v in vel)
+    perm = rng.permutation(len(pos))
+    pos, vel = pos[perm], tuple(v[perm] for v in vel)
+    o, h = util.new_pair(*GRID, maxp)
+    out = {}
+    try:
+        o.set_particles(pos, *vel)
+        o.run_stage("transfer", util.DT)
+        for compact in (0, 1):
+            h.set_tuning("p2g_compact", compact)
+            h.set_particles(pos, *vel)
+            h.run_stage("transfer", util.DT)
+            out[compact] = [h.read_volume(v) for v in ("vel_x", "vel_y", "vel_z")]
+            assert np.array_equal(h.read_volume("marker"), o.read_volume("marker"))
+            for a, name in zip(out[compact], ("vel_x", "vel_y", "vel_z")):
+                util.assert_close(name, a, o.read_volume(name), rel=1e-5)
+                assert np.abs(a).max() > 0.5
+        if kind.startswith("single"):
+            for a, b, name in zip(out[0], out[1], "xyz"):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "vel_%s differs in %d cells" % (name, (a != b).sum())
     finally:
         h.close()
 
