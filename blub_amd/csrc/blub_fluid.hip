@@ -117,6 +117,7 @@ struct blub_fluid {
     int dense_kd_nt = -1;                     // non-temporal s_out stores of the dense direction kernel: -1 = by grid size, 0 / 1 = forced (tuning knob)
     int p2g_compact = -1;                     // P2G gather: 1 = the tile's non-empty lists compacted (k_gather_velocity3_s), 0 = one lane per list cell, -1 = by fill (stage_transfer)
     bool two_kernel_build = false;            // test hook ("bricks_two_kernel_build"): the list build of grids with more brick blocks than CUs
+    int list_grid_forced = 0;                 // test hook ("list_launch_grid"): launch grid of the brick-list kernels
     int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
     uint8_t* dvol = nullptr;
@@ -317,12 +318,28 @@ static int latest_counts(blub_fluid* h, bool block, BrickCounts* out, bool* have
 
 #define LIST(h, which) (const uint32_t*)(h)->list_##which, (const uint32_t*)&(h)->counts->n_##which
 
+// Launch grids of the kernels that loop over a brick list: the list lengths live on the device, so the grid is an ESTIMATE from the newest
+// counts that have landed (+12 %), like pcg_brick_grid -- any grid is correct (grid-stride loops), it only costs speed.  One workgroup per
+// brick matters: these kernels are one dependent load chain per brick (~4-8 us), and with the fixed grid of 2048 the 2600 active bricks of
+// the headline scene made a quarter of the workgroups run two chains back to back (k_extrapolate_b: 16.7 us per launch against 8.7 us while
+// the list still fitted).
+struct ListGrids { int fluid, active, reset; };
+static ListGrids list_grids(blub_fluid* h) {
+    ListGrids lg{h->brick_grid, h->brick_grid, h->brick_grid};
+    if (h->list_grid_forced > 0) { lg.fluid = lg.active = lg.reset = std::min(h->list_grid_forced, h->bg.nb); return lg; }
+    BrickCounts bc; bool have = false;
+    if (latest_counts(h, false, &bc, &have) != BLUB_OK || !have) return lg;      // (an error is reported by the solve stage, which asks too)
+    auto sz = [&](uint32_t n) { return (int)std::min<uint32_t>((uint32_t)h->bg.nb, std::max<uint32_t>(256u, n + n / 8u + 16u)); };
+    lg.fluid = sz(bc.n_fluid); lg.active = sz(bc.n_active); lg.reset = sz(bc.n_reset);
+    return lg;
+}
+
 // ---- stages ------------------------------------------------------------------------------------------------------
 static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-833
     int rc = build_lists_from_particles(h, COMPACT_STEP_A);
     if (rc != BLUB_OK) return rc;
-    const dim3 bgrid(h->brick_grid);
-    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, bgrid, dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0], h->ll[1], h->ll[2],
+    const ListGrids lg = list_grids(h);
+    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(lg.reset), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0], h->ll[1], h->ll[2],
            h->vel[0], h->vel[1], h->vel[2], h->pressure[0], h->pressure[1]);
     const uint32_t np_all = h->num_particles + h->num_ghost;
     if (np_all)
@@ -331,7 +348,7 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     {
         GatherArgs3 a;
         for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
-        const dim3 ggrid(3 * ((h->brick_grid + 7) / 8) * 8);
+        const dim3 ggrid(3 * ((lg.active + 7) / 8) * 8);
         // Which of the two (bit-identical) gathers: the compacting one wins while a FLUID brick holds particles in a minority of its cells (headline scene: ~750
         // particles per FLUID brick, 69 against 76 us), one lane per list cell when the bricks are full (M4: ~4000 per brick, 3.7 against 4.1 ms).
         // Decided from the newest brick counts that have landed -- a speed choice only.
@@ -347,7 +364,7 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     return BLUB_OK;
 }
 static int stage_divergence(blub_fluid* h) {   // :836-840
-    LAUNCH(h, KC_DIVERGENCE, k_divergence_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const float*)h->vel[0],
+    LAUNCH(h, KC_DIVERGENCE, k_divergence_b, dim3(list_grids(h).fluid), dim3(BRICK_THREADS), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const float*)h->vel[0],
            (const float*)h->vel[1], (const float*)h->vel[2], (const float4*)h->solid, h->residual);
     return BLUB_OK;
 }
@@ -578,18 +595,18 @@ static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
     return BLUB_OK;
 }
 static int stage_extrapolate(blub_fluid* h) {
-    LAUNCH(h, KC_EXTRAPOLATE, k_extrapolate_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker, h->vel[0], h->vel[1], h->vel[2]);
+    LAUNCH(h, KC_EXTRAPOLATE, k_extrapolate_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker, h->vel[0], h->vel[1], h->vel[2]);
     return BLUB_OK;
 }
 static int stage_project(blub_fluid* h) {   // :906-914
-    LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+    LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
            (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
     return stage_extrapolate(h);
 }
 static int stage_advect_particles(blub_fluid* h, float dt, bool insert_lists, bool mark_bricks = false) {   // :916-926
     // mark_bricks: the list build that follows takes its FLUID bricks from this kernel's marks (brick_fluid is all zero here, see build_lists)
     // the reset list (active + stale bricks of this step, own AND ghost bricks) is a superset of the active list
-    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0],
+    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(list_grids(h).reset), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0],
            (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     if (h->num_particles)
         LAUNCH(h, KC_ADVECT, k_advect, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
@@ -603,12 +620,12 @@ static int stage_advect(blub_fluid* h, float dt) {   // :916-932
     return rc != BLUB_OK ? rc : build_lists_from_particles(h, COMPACT_STEP_B);
 }
 static int stage_density_gather(blub_fluid* h, float dt) {   // :933-937
-    LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_p, dim3(h->brick_grid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
+    LAUNCH(h, KC_DENSITY_GATHER, k_density_gather_p, dim3(list_grids(h).fluid), dim3(768), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const uint32_t*)h->ll[0],
            (const float4*)h->pos, h->residual, dt);
     return BLUB_OK;
 }
 static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
-    LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+    LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
            (const float*)h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
     return stage_extrapolate(h);
 }
@@ -1110,6 +1127,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
     else if (k == "dense_kd_nt") h->dense_kd_nt = value;
+    else if (k == "list_launch_grid") h->list_grid_forced = value;
     else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);
     else if (k == "bricks_two_kernel_build") h->two_kernel_build = value != 0;
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);

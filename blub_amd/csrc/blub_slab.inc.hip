@@ -647,7 +647,7 @@ static int slab_step(blub_slab_group* G, float dt) {
     if (h0->rebin_freq != 0 && h0->step_counter % h0->rebin_freq == 0) FOR_SLABS(stage_binning(h))
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+        LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
                (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
     }
     if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
@@ -667,7 +667,7 @@ static int slab_step(blub_slab_group* G, float dt) {
     if ((rc = slab_solve(G, 1, dt)) != BLUB_OK) return rc;
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(h->brick_grid), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+        LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
                (const float*)h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
     }
     if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;

@@ -136,6 +136,26 @@ def test_pcg_default_config(pair, which, stage, mapping):
     assert abs(np.abs(r_hip).max() * util.DT - eh) <= 1e-5 * eh + 1e-9   # reported error = max|r| * dt (pressure_solver.rs:162)
 
 
+@pytest.mark.parametrize("grid", [8, 100000])
+def test_brick_list_kernels_do_not_depend_on_their_launch_grid(pair, grid):
+    """The kernels that loop over a brick list are launched with an ESTIMATED grid (the list lengths live on the device): far fewer workgroups
+    than bricks (every workgroup loops) and far more (clamped to the brick count; the surplus exits) must give the same bits."""
+    o, h = pair
+    h.set_tuning("list_launch_grid", grid)
+    o.run_stage("transfer", util.DT)
+    h.run_stage("transfer", util.DT)
+    for v in ("vel_x", "vel_y", "vel_z"):
+        util.assert_close(v, h.read_volume(v), o.read_volume(v), rel=1e-5)
+    for stage, outputs in (("divergence", ["residual"]), ("project", ["vel_x", "vel_y", "vel_z"]), ("position_change", ["vel_x", "vel_y", "vel_z"])):
+        run_until(o, stage)
+        util.copy_state(o, h)
+        o.run_stage(stage, util.DT)
+        h.run_stage(stage, util.DT)
+        for v in outputs:
+            a, b = h.read_volume(v), o.read_volume(v)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "%s / %s differs in %d cells" % (stage, v, (a != b).sum())
+
+
 def test_advect_bit_exact(pair):
     o, h = pair
     run_until(o, "advect")
