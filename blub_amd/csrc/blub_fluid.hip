@@ -53,7 +53,7 @@ constexpr int PCG_GRID_DENSE = 2048; // dense rows: 8 blocks of 256 threads per 
 constexpr int BRICK_GRID_MAX = 2048; // persistent blocks of the brick-list kernels
 constexpr int STATS_RING = 32;       // pressure_solver.rs:49 NUM_PRESSURE_ERROR_BUFFER
 constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
-constexpr int COUNTS_RING = 8;
+constexpr int COUNTS_RING = 32;
 constexpr float SPARSE_PCG_MAX_FILL = 0.30f;   // fluid bricks / bricks below which the brick-list PCG kernels are used
 
 struct PendingStat { uint32_t seq; int slot; };
@@ -104,6 +104,7 @@ struct blub_fluid {
     uint32_t* brick_block_ready = nullptr;    // per block of k_bricks_build: sequence number of the last build it has classified
     int num_cus = 0;
     BrickCounts* counts = nullptr;            // device
+    BrickCounts last_counts{}; bool have_last_counts = false;      // newest snapshot latest_counts() has seen land
     BrickCounts* counts_host = nullptr;       // pinned ring of COUNTS_RING snapshots (path selection only), tagged by seq
     BrickCounts* counts_host_dev = nullptr;   // the same ring as the device sees it (kernels write the snapshots directly)
     uint32_t counts_seq = 0;                  // number of list builds enqueued so far
@@ -310,9 +311,12 @@ static int latest_counts(blub_fluid* h, bool block, BrickCounts* out, bool* have
                 h->num_cus = 0;   // (two-kernel build from now on)
                 return set_error(BLUB_ERR_DEVICE, "a brick list build timed out waiting for its workgroups (device shared or partitioned?): the step that contained it is invalid; later steps use the two-kernel build");
             }
+            h->last_counts = snap; h->have_last_counts = true;
             *out = snap; *have = true; return BLUB_OK;
         }
     }
+    // the host is a whole ring of list builds ahead of the device (short steps, several in flight): the last snapshot seen is still the best estimate
+    if (h->have_last_counts) { *out = h->last_counts; *have = true; }
     return BLUB_OK;
 }
 
@@ -452,10 +456,11 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
     if (h->force_pcg_path >= 0) sparse = h->force_pcg_path >= 1;
     else {
-        // small grids stay launch/latency-bound even when fairly full: the brick mapping wins up to ~70 % fill there
-        // (dam_halfhalf, 128x64x64 at 40 %: 997 vs 925 steps/s); large ones are byte-bound and want the 2.5-D dense mapping early
-        const float max_fill = h->N <= (size_t)1 << 20 ? 0.70f : SPARSE_PCG_MAX_FILL;
-        sparse = (have && (float)bc.n_fluid < max_fill * (float)h->bg.nb) || h->gz.tiles < 256;   // tiny grids: too few dense tiles to fill the chip
+        // small grids stay launch/latency-bound however full they are: the brick mapping always wins there (dam_halfhalf, 128x64x64, 40-75 % of
+        // the bricks FLUID while it sloshes: 1647 steps/s on the brick mapping, 1115 on the dense one, and 1480-1650 from run to run while a
+        // 70 % threshold sat inside that range); large ones are byte-bound and want the 2.5-D dense mapping early
+        const float max_fill = h->N <= (size_t)1 << 20 ? 2.0f : SPARSE_PCG_MAX_FILL;
+        sparse = (have && (float)bc.n_fluid < max_fill * (float)h->bg.nb) || h->N <= (size_t)1 << 20 || h->gz.tiles < 256;   // (tiny grids: too few dense tiles to fill the chip)
     }
     if (2 * h->gz.qpr > h->gz.T) sparse = true;   // rows wider than 2048 cells: the dense tiles cannot hold their halo rows (k_pcg_dir_z)
     const int maxit = c.max_num_iterations;
@@ -1047,7 +1052,7 @@ int blub_fluid_set_particles(blub_fluid* h, uint32_t n, const float* pos_ll, con
     if (n > h->max_particles) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "more particles than max_num_particles");
     { int rc0 = blub::drop_brick_marks(h); if (rc0 != BLUB_OK) return rc0; }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->num_particles = n;
+    h->num_particles = n; h->have_last_counts = false;      // (brick counts of the old particle set are no estimate for the new one)
     if (n == 0) return BLUB_OK;
     if (pos_ll) { int rc2 = blub::copy_sync(h, h->pos, pos_ll, (size_t)n * 16, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
     const float* src[3] = {vx, vy, vz};
