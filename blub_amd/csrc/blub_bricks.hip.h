@@ -656,41 +656,46 @@ __device__ __forceinline__ float solid_comp(const float4* __restrict__ solid, co
     return (solid && inb(g, x, y, z)) ? comp3(solid[cidx(g, x, y, z)], comp) : 0.0f;
 }
 
-// D1: divergence_compute.comp:28-87 (fluid bricks; FLUID cells only)
+// D1: divergence_compute.comp:28-87, one quad: the FLUID lanes of rr become the divergence, the others keep what they hold.  `m`: the quad's markers and
+// its six neighbours' (load_quad_markers).  Shared by k_divergence_b and by the init kernel of the velocity solve, which forms b = div u on the fly
+// inside a step (k_pcg_init_b<true>: one launch and one pass over the residual volume less).
+struct DivergenceSrc { const float* vx; const float* vy; const float* vz; const float4* solid; };
+__device__ __forceinline__ void divergence_quad(const Grid& g, const QuadMarkers& m, const DivergenceSrc& v, int base, int x0, int y, int z, float (&rr)[4]) {
+    const int plane = g.nx * g.ny;
+    const float4 px = ld4(v.vx + base), py = ld4(v.vy + base), pz = ld4(v.vz + base);
+    const float qx_edge = x0 > 0 ? v.vx[base - 1] : 0.0f;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 qy = y > 0 ? ld4(v.vy + base - g.nx) : zero;
+    const float4 qz = z > 0 ? ld4(v.vz + base - plane) : zero;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (mbyte(m.c, j) != CELL_FLUID) continue;
+        const int x = x0 + j;
+        const float vpx = f4(px, j), vpy = f4(py, j), vpz = f4(pz, j);
+        const float vqx = j > 0 ? f4(px, j - 1) : qx_edge, vqy = f4(qy, j), vqz = f4(qz, j);
+        float div = vpx - vqx;
+        div += vpy - vqy;
+        div += vpz - vqz;
+        const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
+        div += (mX0 == CELL_SOLID) ? vqx - solid_comp(v.solid, g, x - 1, y, z, 0) : 0.0f;       // :67-75
+        div += (mbyte(m.ym, j) == CELL_SOLID) ? vqy - solid_comp(v.solid, g, x, y - 1, z, 1) : 0.0f;
+        div += (mbyte(m.zm, j) == CELL_SOLID) ? vqz - solid_comp(v.solid, g, x, y, z - 1, 2) : 0.0f;
+        div -= (mX1 == CELL_SOLID) ? vpx - solid_comp(v.solid, g, x + 1, y, z, 0) : 0.0f;       // :76-84
+        div -= (mbyte(m.yp, j) == CELL_SOLID) ? vpy - solid_comp(v.solid, g, x, y + 1, z, 1) : 0.0f;
+        div -= (mbyte(m.zp, j) == CELL_SOLID) ? vpz - solid_comp(v.solid, g, x, y, z + 1, 2) : 0.0f;
+        rr[j] = div;
+    }
+}
 __global__ __launch_bounds__(BRICK_THREADS) void k_divergence_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                                const int8_t* __restrict__ marker, const float* __restrict__ vx, const float* __restrict__ vy,
-                                                                const float* __restrict__ vz, const float4* __restrict__ solid, float* __restrict__ residual) {
+                                                                const int8_t* __restrict__ marker, DivergenceSrc v, float* __restrict__ residual) {
     const Grid g = bg.g;
     BRICK_LOOP_BEGIN(bg, list, count)
         QuadMarkers m; m.c = *reinterpret_cast<const uint32_t*>(marker + base);
         if (!any_fluid4(m.c)) continue;
         load_quad_markers(marker, g, base, x0, y, z, m);
-        const int plane = g.nx * g.ny;
-        const float4 px = ld4(vx + base), py = ld4(vy + base), pz = ld4(vz + base);
-        const float qx_edge = x0 > 0 ? vx[base - 1] : 0.0f;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 qy = y > 0 ? ld4(vy + base - g.nx) : zero;
-        const float4 qz = z > 0 ? ld4(vz + base - plane) : zero;
-        float4 rc = ld4(residual + base);
+        const float4 rc = ld4(residual + base);
         float rr[4] = {rc.x, rc.y, rc.z, rc.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (mbyte(m.c, j) != CELL_FLUID) continue;
-            const int x = x0 + j;
-            const float vpx = f4(px, j), vpy = f4(py, j), vpz = f4(pz, j);
-            const float vqx = j > 0 ? f4(px, j - 1) : qx_edge, vqy = f4(qy, j), vqz = f4(qz, j);
-            float div = vpx - vqx;
-            div += vpy - vqy;
-            div += vpz - vqz;
-            const int mX0 = j > 0 ? mbyte(m.c, j - 1) : m.xm, mX1 = j < 3 ? mbyte(m.c, j + 1) : m.xp;
-            div += (mX0 == CELL_SOLID) ? vqx - solid_comp(solid, g, x - 1, y, z, 0) : 0.0f;       // :67-75
-            div += (mbyte(m.ym, j) == CELL_SOLID) ? vqy - solid_comp(solid, g, x, y - 1, z, 1) : 0.0f;
-            div += (mbyte(m.zm, j) == CELL_SOLID) ? vqz - solid_comp(solid, g, x, y, z - 1, 2) : 0.0f;
-            div -= (mX1 == CELL_SOLID) ? vpx - solid_comp(solid, g, x + 1, y, z, 0) : 0.0f;       // :76-84
-            div -= (mbyte(m.yp, j) == CELL_SOLID) ? vpy - solid_comp(solid, g, x, y + 1, z, 1) : 0.0f;
-            div -= (mbyte(m.zp, j) == CELL_SOLID) ? vpz - solid_comp(solid, g, x, y, z + 1, 2) : 0.0f;
-            rr[j] = div;
-        }
+        divergence_quad(g, m, v, base, x0, y, z, rr);
         *reinterpret_cast<float4*>(residual + base) = make_float4(rr[0], rr[1], rr[2], rr[3]);
     BRICK_LOOP_END
 }

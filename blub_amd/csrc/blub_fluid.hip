@@ -116,6 +116,7 @@ struct blub_fluid {
     bool all_touched = false;
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, >= 1 brick lists
     int dense_kd_nt = -1;                     // non-temporal s_out stores of the dense direction kernel: -1 = by grid size, 0 / 1 = forced (tuning knob)
+    int fuse_divergence = 1; bool divergence_deferred = false;     // ("fuse_divergence" tuning: 0 never, 1 inside blub_fluid_step, 2 also for blub_fluid_run_stage -- a test hook; see stage_divergence)
     int p2g_compact = -1;                     // P2G gather: 1 = the tile's non-empty lists compacted (k_gather_velocity3_s), 0 = one lane per list cell, -1 = by fill (stage_transfer)
     bool two_kernel_build = false;            // test hook ("bricks_two_kernel_build"): the list build of grids with more brick blocks than CUs
     int list_grid_forced = 0;                 // test hook ("list_launch_grid"): launch grid of the brick-list kernels
@@ -367,9 +368,13 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     }
     return BLUB_OK;
 }
-static int stage_divergence(blub_fluid* h) {   // :836-840
-    LAUNCH(h, KC_DIVERGENCE, k_divergence_b, dim3(list_grids(h).fluid), dim3(BRICK_THREADS), h->bg, LIST(h, fluid), (const int8_t*)h->marker, (const float*)h->vel[0],
-           (const float*)h->vel[1], (const float*)h->vel[2], (const float4*)h->solid, h->residual);
+static DivergenceSrc divergence_src(const blub_fluid* h) { return DivergenceSrc{h->vel[0], h->vel[1], h->vel[2], (const float4*)h->solid}; }
+// `defer`: inside blub_fluid_step the divergence is not launched here -- the velocity solve that follows forms it inside its init kernel when it runs on
+// the brick mapping (k_pcg_init_b<true>: one launch and one pass over the residual volume less) and launches this kernel itself otherwise
+static int stage_divergence(blub_fluid* h, bool defer = false) {   // :836-840
+    if (defer && h->fuse_divergence) { h->divergence_deferred = true; return BLUB_OK; }
+    h->divergence_deferred = false;
+    LAUNCH(h, KC_DIVERGENCE, k_divergence_b, dim3(list_grids(h).fluid), dim3(BRICK_THREADS), h->bg, LIST(h, fluid), (const int8_t*)h->marker, divergence_src(h), h->residual);
     return BLUB_OK;
 }
 
@@ -445,7 +450,9 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     PcgCtrl* ctrl = h->ctrl[which];
     h->solve_seq[which] += 1;
     int rc;
+    const bool div_pending = which == 0 && h->divergence_deferred;
     if (h->precond_mode != BLUB_PRECOND_ZERO) {
+        if (div_pending && (rc = stage_divergence(h)) != BLUB_OK) return rc;
         HIP_TRY(hipMemsetAsync(ctrl, 0, sizeof(PcgCtrl), h->stream));
         if ((rc = stage_solve_lod0(h, which, dt)) != BLUB_OK) return rc;
         return enqueue_stats_readback(h, which, dt);
@@ -472,11 +479,16 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     PcgCtrl* stat_slot = ring_free ? h->stats_host_dev[which] + (h->solve_seq[which] % STATS_RING) : (PcgCtrl*)nullptr;
     float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
     float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
+    if (div_pending && !sparse && (rc = stage_divergence(h)) != BLUB_OK) return rc;     // the dense mapping reads b from the residual volume
     if (sparse) {
         const int np = pcg_brick_grid(h, have, bc);
         const dim3 grid(np), block(PCG_B_THREADS);
         const uint32_t* nfl = &h->counts->n_fluid;
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), nfl, 0, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which]);
+        if (div_pending) {
+            h->divergence_deferred = false;
+            LAUNCH(h, KC_PCG_INIT, k_pcg_init_b<true>, grid, block, h->bg, LIST(h, active), nfl, 0, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which], divergence_src(h));
+        } else
+            LAUNCH(h, KC_PCG_INIT, k_pcg_init_b<false>, grid, block, h->bg, LIST(h, active), nfl, 0, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, ctrl, h->tail_sync[which], DivergenceSrc{});
         if (h->pcg_schedule == 1 && maxit <= h->pcg1_max_iterations) {
             // ONE kernel per iteration (blub_pcg1.hip.h): r, w = A M^-1 r and q = A d are double buffered by iteration parity,
             // the search direction d (BLUB_VOLUME_SEARCH) and p are updated in place
@@ -659,9 +671,10 @@ static int run_stage(blub_fluid* h, int stage, float dt, bool standalone) {
     if (standalone && stage != BLUB_STAGE_TRANSFER && stage != BLUB_STAGE_BINNING)
         if ((rc = build_lists_from_marker(h)) != BLUB_OK) return rc;
     h->cur_stage = stage;
+    if (h->divergence_deferred && stage != BLUB_STAGE_SOLVE_VELOCITY && (rc = stage_divergence(h)) != BLUB_OK) return rc;     // (not reached by blub_fluid_step's order)
     switch (stage) {
     case BLUB_STAGE_TRANSFER: return stage_transfer(h, dt);
-    case BLUB_STAGE_DIVERGENCE: return stage_divergence(h);
+    case BLUB_STAGE_DIVERGENCE: return stage_divergence(h, !standalone || h->fuse_divergence == 2);
     case BLUB_STAGE_SOLVE_VELOCITY: return stage_solve(h, 0, dt, standalone);
     case BLUB_STAGE_BINNING: return stage_binning(h);
     case BLUB_STAGE_PROJECT: return stage_project(h);
@@ -1133,6 +1146,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
     else if (k == "dense_kd_nt") h->dense_kd_nt = value;
     else if (k == "list_launch_grid") h->list_grid_forced = value;
+    else if (k == "fuse_divergence") h->fuse_divergence = std::max(0, std::min(2, value));
     else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);
     else if (k == "bricks_two_kernel_build") h->two_kernel_build = value != 0;
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);

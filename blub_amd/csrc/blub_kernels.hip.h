@@ -84,6 +84,8 @@ __device__ __forceinline__ float reduce_partials_256(const float* __restrict__ p
 // between two rebinnings.  key < 0: the particle is outside the grid (no insertion, next = invalid).  All 64 lanes must call this.
 __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ heads, int key, uint32_t particle) {
     const int lane = threadIdx.x & 63;
+    // (capping the number of rounds and letting the left-over lanes insert on their own was measured: 16 rounds 77 us, 32 rounds 67 us, no cap 62-65 us
+    // per step -- the device atomics are what costs, not the search)
     unsigned long long remaining = ~0ull, mine = 0ull;
     while (remaining) {
         const int k = __builtin_amdgcn_readlane(key, __builtin_ctzll(remaining));     // uniform source lane: v_readlane (__shfl would be a ds_bpermute + wait per round)

@@ -83,8 +83,10 @@ __device__ __forceinline__ float precond_div(float x, float d) { if (d > 0.0f) {
 
 // ---- per-quad bodies ---------------------------------------------------------------------------------------------
 // S0 (pressure_init.comp:19-84) + dvol + initial preconditioner/sigma (pressure_solver.rs:636-648)
+// DIV: the right-hand side is the divergence of `dv`, formed here (D1, divergence_quad) instead of read from r
+template <bool DIV = false>
 __device__ __forceinline__ bool pcg_init_quad(const Grid& g, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
-                                              float* __restrict__ r, float* __restrict__ s, int base, int x0, int y, int z, float& acc) {
+                                              float* __restrict__ r, float* __restrict__ s, int base, int x0, int y, int z, float& acc, const DivergenceSrc& dv = DivergenceSrc{}) {
     const uint32_t mc = *reinterpret_cast<const uint32_t*>(marker + base);
     float4 pc = ld4(p + base);
     uint32_t dq = 0;
@@ -95,6 +97,7 @@ __device__ __forceinline__ bool pcg_init_quad(const Grid& g, const int8_t* __res
         const float4 rc = ld4(r + base);
         float4 so = ld4(s + base);
         float rr[4] = {rc.x, rc.y, rc.z, rc.w}, ss[4] = {so.x, so.y, so.z, so.w};
+        if (DIV) divergence_quad(g, m, dv, base, x0, y, z, rr);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (mbyte(mc, j) != CELL_FLUID) continue;
@@ -319,10 +322,11 @@ __device__ __forceinline__ float reduce_spec1(const SpecPartials<float>& L, cons
     return block_reduce<PCG_B_THREADS, false>(v, sm);
 }
 
+template <bool DIV>
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint32_t* __restrict__ count_fluid,
                                                               int vb_force, const int8_t* __restrict__ marker, uint8_t* __restrict__ dvol, float* __restrict__ p,
                                                               float* __restrict__ r, float* __restrict__ s, float2* __restrict__ part_upd, PcgCtrl* __restrict__ ctrl_to_clear,
-                                                              PcgTailSync* __restrict__ sync_to_clear) {
+                                                              PcgTailSync* __restrict__ sync_to_clear, DivergenceSrc dv) {
     __shared__ float sm[8];
     if (ctrl_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { PcgCtrl z{}; *ctrl_to_clear = z; }   // nobody reads it before the next kernel
     if (sync_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { PcgTailSync z{}; *sync_to_clear = z; }
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg_init_b(BrickGeom bg, cons
         for (uint32_t i = (uint32_t)vb * PCG_BPB + half; i < n; i += (uint32_t)V * PCG_BPB) {
             int x0, y, z;
             if (!brick_quad(bg, list[i], t, x0, y, z)) continue;
-            (void)pcg_init_quad(bg.g, marker, dvol, p, r, s, cidx(bg.g, x0, y, z), x0, y, z, acc);
+            (void)pcg_init_quad<DIV>(bg.g, marker, dvol, p, r, s, cidx(bg.g, x0, y, z), x0, y, z, acc, dv);
         }
         const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
         if (threadIdx.x == 0) part_upd[vb] = make_float2(tot, 0.0f);

@@ -428,8 +428,8 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
         blub_fluid* h = G->slabs[i];
         if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
         h->solve_seq[which] += 1;
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
-               seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr);
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b<false>, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
+               seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr, DivergenceSrc{});
     }
     // descriptor, r, s planes and the initial partials: one grouped operation
     if ((rc = slab_fused(G, [&]() -> int {
@@ -507,8 +507,8 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
         if ((rc = ensure_pcg1_buffers(h)) != BLUB_OK) return rc;
         if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
         h->solve_seq[which] += 1;
-        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
-               seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr);
+        LAUNCH(h, KC_PCG_INIT, k_pcg_init_b<false>, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
+               seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr, DivergenceSrc{});
     }
     // descriptor, r_0 and u_0 = M^-1 r_0 planes and the gamma_0 partials: one grouped operation
     if ((rc = slab_fused(G, [&]() -> int {

@@ -278,6 +278,8 @@ int blub_fluid_get_pcg_schedule(const blub_fluid* h);
  * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
  * (0 = default for the grid); "dense_kd_nt" -1|0|1: non-temporal stores of the dense direction kernel's output (-1: by grid size).
  * "list_launch_grid" n: launch grid of the kernels that loop over a brick list (0 = estimated from the latest brick counts); results do not depend on it.
+ * "fuse_divergence" 0|1|2 (default 1; 2 = also across blub_fluid_run_stage calls, for tests): inside blub_fluid_step the brick-mapped velocity solve forms div u in its init kernel (same bits; 0 = the
+ *   separate divergence kernel, which blub_fluid_run_stage and the dense mapping always use).
  * "p2g_compact" -1|0|1 (default -1): 1 = the P2G gather compacts each tile's non-empty lists, 0 = one lane per list cell (same results bit for
  *   bit), -1 = chosen per step from the particles per FLUID brick.
  * "bricks_two_kernel_build" 0|1: build the brick lists with the two-kernel scan that grids with more 1024-brick blocks than CUs use.

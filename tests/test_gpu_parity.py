@@ -156,6 +156,33 @@ def test_brick_list_kernels_do_not_depend_on_their_launch_grid(pair, grid):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "%s / %s differs in %d cells" % (stage, v, (a != b).sum())
 
 
+@pytest.mark.parametrize("schedule", ["reference", "single_reduction"])
+def test_divergence_formed_inside_the_solve_is_the_same_solve(pair, schedule):
+    """Inside blub_fluid_step the brick-mapped velocity solve forms b = div u in its init kernel (k_pcg_init_b<true>) instead of reading the residual
+    volume a divergence kernel wrote.  Same function, same operands: residual, pressure, search direction and the solver statistics must agree
+    BIT FOR BIT with the two-kernel sequence ("fuse_divergence" = 2 defers the divergence across blub_fluid_run_stage calls as well; the
+    marker-derived lists of the stage hook are deterministic)."""
+    o, h = pair
+    run_until(o, "divergence")
+    fluid = o.read_volume("marker") == 1
+    h.set_pcg_work_mapping("bricks")
+    h.set_pcg_schedule(schedule)
+    out = []
+    for fuse in (0, 2):
+        h.set_tuning("fuse_divergence", fuse)
+        util.copy_state(o, h)
+        res = o.read_volume("residual").copy()
+        res[fluid] = np.nan                          # whatever the residual volume holds in FLUID cells is not an input of either sequence
+        h.write_volume("residual", res)
+        h.run_stage("divergence", util.DT)
+        h.run_stage("solve_velocity", util.DT)
+        out.append(([h.read_volume(v) for v in ("residual", "pressure_velocity", "search")], h.solver_stats(0)))
+    for a, b, name in zip(out[0][0], out[1][0], ("residual", "pressure", "search")):
+        assert np.array_equal(a[fluid].view(np.uint32), b[fluid].view(np.uint32)), "%s differs in %d FLUID cells" % (name, (a[fluid] != b[fluid]).sum())
+    assert out[0][1] == out[1][1] and out[0][1][1] > 0
+    assert np.abs(out[0][0][1]).max() > 0
+
+
 def test_advect_bit_exact(pair):
     o, h = pair
     run_until(o, "advect")
