@@ -119,6 +119,7 @@ struct blub_fluid {
     int fuse_divergence = 1; bool divergence_deferred = false;     // ("fuse_divergence" tuning: 0 never, 1 inside blub_fluid_step, 2 also for blub_fluid_run_stage -- a test hook; see stage_divergence)
     int p2g_compact = -1;                     // P2G gather: 1 = the tile's non-empty lists compacted (k_gather_velocity3_s), 0 = one lane per list cell, -1 = by fill (stage_transfer)
     bool two_kernel_build = false;            // test hook ("bricks_two_kernel_build"): the list build of grids with more brick blocks than CUs
+    int dense_alternate_march = -1;           // odd z-chunks of the dense kernels march downwards (blub_pcg_dense.hip.h: xcd_tile_pairs): bit 0 KD, bit 1 KU, -1 by grid size
     int list_grid_forced = 0;                 // test hook ("list_launch_grid"): launch grid of the brick-list kernels
     int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
@@ -729,6 +730,9 @@ static void set_dense_geometry(blub_fluid* h, int T, int zc, int grid) {
     if (zc <= 0) { zc = 32; while (zc > 2 && (size_t)gz.plane_tiles * (size_t)((h->g.nz + zc - 1) / zc) * (size_t)(T / 64) < 4096) zc >>= 1; }
     gz.zc = std::max(2, zc);
     gz.z_chunks = (h->g.nz + gz.zc - 1) / gz.zc; gz.tiles = gz.plane_tiles * gz.z_chunks;
+    // measured (profiles/r03_dense_march_direction.txt): beyond the Infinity Cache (512^3) the direction kernel gains 0.6 % from alternating and the update
+    // kernel loses 4.7 %; at 256^3 alternating the update kernel is the best of the four combinations by ~1 %
+    gz.alternate_march = h->dense_alternate_march >= 0 ? h->dense_alternate_march : (h->N >= ((size_t)1 << 26) ? 1 : 2);
     if (grid <= 0) grid = 2048;
     h->pcg_grid_z = std::min(std::min(grid, PCG_GRID_MAX), ((gz.tiles + 7) / 8) * 8);
 }
@@ -1145,6 +1149,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
     else if (k == "dense_kd_nt") h->dense_kd_nt = value;
+    else if (k == "dense_alternate_march") { h->dense_alternate_march = value < 0 ? -1 : (value & 3); set_dense_geometry(h, h->gz.T, h->gz.zc, h->pcg_grid_z); }
     else if (k == "list_launch_grid") h->list_grid_forced = value;
     else if (k == "fuse_divergence") h->fuse_divergence = std::max(0, std::min(2, value));
     else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);

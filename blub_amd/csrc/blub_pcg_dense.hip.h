@@ -22,6 +22,7 @@ struct PcgGeomZ {
     int plane_tiles;      // ceil(qpp / T)
     int zc, z_chunks;
     int tiles;
+    int alternate_march;  // odd z-chunks march downwards (xcd_tile_pairs): bit 0 in k_pcg_dir_z, bit 1 in k_pcg_update_z
 };
 
 // XCD-contiguous tile order: block b runs on XCD b % 8 (observed dispatch order, a speed hint only), so give XCD k the
@@ -30,6 +31,17 @@ __device__ __forceinline__ int xcd_tile(int i, int tiles) {
     const int per = (tiles + 7) >> 3;
     const int t = (i & 7) * per + (i >> 3);
     return t;   // may be >= tiles for the padded tail: callers skip those
+}
+
+// The same ranges per XCD, with the two z-chunks of a PAIR interleaved (tile j of chunk 2c, tile j of chunk 2c + 1, tile j + 1 of chunk 2c, ...) when
+// the XCD's range is a whole number of chunk pairs: together with the alternating march direction of k_pcg_dir_z (even chunks upwards, odd chunks
+// downwards) the two workgroups either side of a chunk interface reach it at the same time -- both at the start or both at the end of their
+// march -- and on the same XCD, so the second one finds the planes it shares with its neighbour in that XCD's L2 instead of fetching them again.
+__device__ __forceinline__ int xcd_tile_pairs(int i, const PcgGeomZ& gz) {
+    const int per = (gz.tiles + 7) >> 3, two = 2 * gz.plane_tiles;
+    if (per % two != 0 || gz.tiles % 8 != 0) return xcd_tile(i, gz.tiles);
+    const int j = i >> 3, pair = j / two, jj = j - pair * two;
+    return (i & 7) * per + pair * two + (jj & 1) * gz.plane_tiles + (jj >> 1);
 }
 
 // Streaming accesses that must not displace the halo rows other tiles are about to re-read from the L2 (p and r in KU have no
@@ -75,18 +87,24 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
     float acc = 0.0f, emax = 0.0f;
     const int padded = ((gz.tiles + 7) >> 3) << 3;
     for (int it = blockIdx.x; it < padded; it += gridDim.x) {
-        const int tile = xcd_tile(it, gz.tiles);
+        const int tile = xcd_tile_pairs(it, gz);
         if (tile >= gz.tiles || !tile_flags[tile]) continue;
         const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
         const int q = pt * T + t;
         const bool valid = q < gz.qpp;
         const int x0 = (q % qpr) << 2, y = q / qpr;
         const int z_begin = zci * gz.zc, z_end = min(z_begin + gz.zc, g.nz);
+        // planes in MARCH order u = 0 .. n - 1: physical plane z0 + dz u -- odd z-chunks march downwards (xcd_tile_pairs); the stencil keeps its
+        // physical orientation, only the order in which a thread adds its planes to the partials differs
+        const int n = z_end - z_begin;
+        const bool down = (zci & 1) != 0 && (gz.alternate_march & 2) != 0;
+        const int z0 = down ? z_end - 1 : z_begin, dz = down ? -1 : 1;
+        const int dplane = dz * plane;
         const int row_base = valid ? (y * g.nx + x0) : 0;
         const bool edge_lo = valid && (t < qpr) && y > 0, edge_hi = valid && (t >= T - qpr || q + qpr >= gz.qpp) && y + 1 < g.ny;
         const bool in_lo = t >= qpr, in_hi = (t + qpr < T) && (q + qpr < gz.qpp);
         const bool xm_glob = valid && x0 > 0 && t == 0, xp_glob = valid && x0 + 4 < g.nx && (t == T - 1);
-        // planes z_begin-1 (m), z_begin (c), z_begin+1 (p) in registers; plane z+2 and the next plane's p, r are in flight
+        // march planes u - 1 (m), u (c), u + 1 (p) in registers; plane u + 2 and the next plane's p, r are in flight
         float4 s_m = zero4, s_c = zero4, s_p = zero4, s_n = zero4, pc = zero4, rc = zero4, pn = zero4, rn = zero4;
         uint32_t d_m = 0, d_c = 0, d_p = 0, d_n = 0;
         // tile-edge values of plane z that other tiles own (two rows + the row-continuation cells): fetched ONE PLANE AHEAD like
@@ -105,27 +123,28 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
         // (only the waves at the tile edge have such values: the others skip the loads, the zero fills and the plane rotation of them)
         const bool wave_halo = __ballot((edge_lo && !in_lo) || (edge_hi && !in_hi) || xm_glob || xp_glob) != 0ull;
         Halo hc = load_halo(0, false), hn = hc;
+        auto exists = [&](int u) -> bool { const int zz = z0 + dz * u; return zz >= 0 && zz < g.nz; };
         if (valid) {
-            const int b0 = z_begin * plane + row_base;
+            const int b0 = z0 * plane + row_base;
             // s is only defined on FLUID cells (the reference never writes it elsewhere): every value is zeroed outside the fluid as it
             // arrives, so that the stencil below needs no per-neighbour tests (quad_mulA_u) -- these kernels are bound by VALU issue as
             // much as by bytes
             d_c = *reinterpret_cast<const uint32_t*>(dvol + b0); s_c = zero_outside_fluid(d_c, ld4(s + b0));
-            if (z_begin > 0) { d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - plane); s_m = zero_outside_fluid(d_m, ld4(s + b0 - plane)); }
-            if (z_begin + 1 < g.nz) { d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + plane); s_p = zero_outside_fluid(d_p, ld4(s + b0 + plane)); }
+            if (exists(-1)) { d_m = *reinterpret_cast<const uint32_t*>(dvol + b0 - dplane); s_m = zero_outside_fluid(d_m, ld4(s + b0 - dplane)); }
+            if (exists(1)) { d_p = *reinterpret_cast<const uint32_t*>(dvol + b0 + dplane); s_p = zero_outside_fluid(d_p, ld4(s + b0 + dplane)); }
             if (any_fluid_d(d_c)) { pc = ld4s<NT>(p + b0); rc = ld4s<NT>(r + b0); }
             if (wave_halo) hc = load_halo(b0, any_fluid_d(d_c));
         }
-        for (int z = z_begin; z < z_end; ++z) {
-            const int base = z * plane + row_base;
-            const int buf = z & 1;
+        for (int u = 0; u < n; ++u) {
+            const int base = (z0 + dz * u) * plane + row_base;
+            const int buf = u & 1;
             // issue the loads of the planes ahead: they are consumed after this plane's compute
-            const uint32_t ub = (uint32_t)base, up = (uint32_t)plane;
-            if (valid && z + 2 < g.nz && z + 1 < z_end) { s_n = ld4o(s, (ub + 2u * up) * 4u); d_n = ldu32o(dvol, ub + 2u * up); }
+            const uint32_t ub = (uint32_t)base;
+            if (valid && exists(u + 2) && u + 1 < n) { s_n = ld4o(s, (uint32_t)(base + 2 * dplane) * 4u); d_n = ldu32o(dvol, (uint32_t)(base + 2 * dplane)); }
             else { s_n = zero4; d_n = 0; }      // (s_n is zeroed outside the fluid when it rotates in, below)
-            const bool work_next = valid && z + 1 < z_end && any_fluid_d(d_p);
-            if (work_next) { pn = ld4so<NT>(p, (ub + up) * 4u); rn = ld4so<NT>(r, (ub + up) * 4u); }
-            if (wave_halo) hn = load_halo(base + plane, work_next);
+            const bool work_next = valid && u + 1 < n && any_fluid_d(d_p);
+            if (work_next) { pn = ld4so<NT>(p, (uint32_t)(base + dplane) * 4u); rn = ld4so<NT>(r, (uint32_t)(base + dplane) * 4u); }
+            if (wave_halo) hn = load_halo(base + dplane, work_next);
             const bool work = valid && any_fluid_d(d_c);
             ls[buf][t] = s_c;
             // LDS-only barrier: a __syncthreads() would first drain vmcnt, i.e. wait for the planes just requested (the whole point of
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(T) void k_pcg_update_z(PcgGeomZ gz, const uint8_t* 
             lds_barrier();
             if (work) {
                 QuadValues sv;
-                sv.c = s_c; sv.zm = s_m; sv.zp = s_p;
+                sv.c = s_c; sv.zm = down ? s_p : s_m; sv.zp = down ? s_m : s_p;      // physical z - 1 / z + 1
                 if (y > 0) { if (in_lo) sv.ym = ls[buf][t - qpr]; else sv.ym = zero_outside_fluid(hc.dlo, hc.lo); } else sv.ym = zero4;
                 if (y + 1 < g.ny) { if (in_hi) sv.yp = ls[buf][t + qpr]; else sv.yp = zero_outside_fluid(hc.dhi, hc.hi); } else sv.yp = zero4;
                 if (x0 > 0) { if (t > 0) sv.xm = ls[buf][t - 1].w; else sv.xm = and_mask(hc.xm, fluid_mask((uint32_t)hc.dxm, 0)); } else sv.xm = 0.f;
@@ -206,9 +225,13 @@ struct DirTile {      // per-thread constants of a tile
     uint32_t goff, vmask, mxm, mxp, hoff, hmask;
     int halo_slot, z_begin, z_end;
     bool valid, halo_thread;
+    bool down;            // march from z_end - 1 to z_begin (odd z-chunks, see xcd_tile_pairs)
 };
 // the plane march of one tile; HALO: this wave owns halo quads; D: raw planes in flight per quad (own plane p and halo plane p live in
-// register set (p - z_begin) % D; the plane loop is unrolled by D so that the set indices are compile-time constants)
+// register set p % D; the plane loop is unrolled by D so that the set indices are compile-time constants).  Planes are counted in MARCH
+// order, u = 0 .. n - 1 (u = -1 and n: the z-halo planes): physical plane z0 + dz u, upwards for even z-chunks, downwards for odd ones.
+// The stencil keeps its physical orientation (sv.zm is plane z - 1 whichever way the march runs), so A s of a cell does not depend on the
+// direction; only the order in which a thread adds its planes to the s.As partial does.
 template <int T, bool FIRST, bool NT, bool HALO, int D>
 __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, float4* __restrict__ ext, const uint8_t* __restrict__ dvol, const float* __restrict__ r,
                                           const float* __restrict__ s_in, float* __restrict__ s_out, float beta, const DivConst* lut, float& acc) {
@@ -216,27 +239,29 @@ __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, 
     const Grid g = gz.g;
     const int t = threadIdx.x, qpr = gz.qpr, ext_n = T + 2 * qpr;
     const size_t plane = (size_t)g.nx * (size_t)g.ny;
-    const int zb = K.z_begin, ze = K.z_end;
-    // (uniform) base of plane `zz` if it exists and is wanted, else of the tile's first plane with a zero descriptor mask
-    auto plane_of = [&](int zz, bool wanted, uint32_t& pm) -> size_t { const bool ok = wanted && zz >= 0 && zz < g.nz; pm = ok ? 0xFFFFFFFFu : 0u; return (size_t)(ok ? zz : zb) * plane; };
+    const int n = K.z_end - K.z_begin;
+    const bool down = K.down;
+    const int z0 = down ? K.z_end - 1 : K.z_begin, dz = down ? -1 : 1;
+    // (uniform) base of march plane `u` if it exists and is wanted, else of the tile's first plane with a zero descriptor mask
+    auto plane_of = [&](int u, bool wanted, uint32_t& pm) -> size_t { const int zz = z0 + dz * u; const bool ok = wanted && zz >= 0 && zz < g.nz; pm = ok ? 0xFFFFFFFFu : 0u; return (size_t)(ok ? zz : z0) * plane; };
     float4 n_m, n_c, n_p, h_c = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t d_c, d_p;
     DirRaw own[D], hal[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) { hal[k].dq = 0; hal[k].s = hal[k].r = make_float4(0.f, 0.f, 0.f, 0.f); own[k].dq = 0; own[k].s = own[k].r = make_float4(0.f, 0.f, 0.f, 0.f); }
-    {   // ---- planes zb - 1, zb, zb + 1 of the own quad and plane zb of the halo quad: loaded and converted at once
+    {   // ---- planes -1, 0, 1 of the own quad and plane 0 of the halo quad: loaded and converted at once
         uint32_t pm_m, pm_c, pm_p;
-        const size_t b_m = plane_of(zb - 1, true, pm_m), b_c = plane_of(zb, true, pm_c), b_p = plane_of(zb + 1, true, pm_p);
+        const size_t b_m = plane_of(-1, true, pm_m), b_c = plane_of(0, true, pm_c), b_p = plane_of(1, true, pm_p);
         DirRaw M, C, P, H;
         if (HALO) dir_raw_load<FIRST>(H, dvol + b_c, s_in + b_c, r + b_c, K.hoff, K.hmask);
         dir_raw_load<FIRST>(M, dvol + b_m, s_in + b_m, r + b_m, K.goff, K.vmask & pm_m);
         dir_raw_load<FIRST>(C, dvol + b_c, s_in + b_c, r + b_c, K.goff, K.vmask & pm_c);
         dir_raw_load<FIRST>(P, dvol + b_p, s_in + b_p, r + b_p, K.goff, K.vmask & pm_p);
-        // ... and the first sets of the pipeline: halo planes zb + 1 .. zb + D - 1, own planes zb + 2 .. zb + D (in the order the loop consumes them)
+        // ... and the first sets of the pipeline: halo planes 1 .. D - 1, own planes 2 .. D (in the order the loop consumes them)
 #pragma unroll
         for (int j = 1; j < D; ++j) {
             uint32_t pm_h, pm_o;
-            const size_t b_h = plane_of(zb + j, zb + j < ze, pm_h), b_o = plane_of(zb + j + 1, zb + j < ze, pm_o);
+            const size_t b_h = plane_of(j, j < n, pm_h), b_o = plane_of(j + 1, j < n, pm_o);
             if (HALO) dir_raw_load<FIRST>(hal[j % D], dvol + b_h, s_in + b_h, r + b_h, K.hoff, K.hmask & pm_h);
             dir_raw_load<FIRST>(own[(j + 1) % D], dvol + b_o, s_in + b_o, r + b_o, K.goff, K.vmask & pm_o);
         }
@@ -247,23 +272,24 @@ __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, 
         d_c = C.dq; d_p = P.dq;
         if (!FIRST && K.valid) {
             st4so<NT>(s_out + b_c, K.goff, n_c);
-            if (zb + 1 < ze) st4so<NT>(s_out + (size_t)(zb + 1) * plane, K.goff, n_p);
+            if (1 < n) st4so<NT>(s_out + (size_t)(z0 + dz) * plane, K.goff, n_p);
         }
     }
-    // one plane: request `issue` / `hissue` (own plane z + D + 1, halo plane z + D), stencil of plane z, then `use` / `huse` (own plane z + 2, halo plane z + 1) enter
-    auto body = [&](int z, DirRaw& issue, DirRaw& hissue, DirRaw& use, DirRaw& huse) {
+    // one plane: request `issue` / `hissue` (own plane u + D + 1, halo plane u + D), stencil of plane u, then `use` / `huse` (own plane u + 2, halo plane u + 1) enter
+    auto body = [&](int u, DirRaw& issue, DirRaw& hissue, DirRaw& use, DirRaw& huse) {
         uint32_t pm_o, pm_h;
-        const size_t b_o = plane_of(z + D + 1, z + D < ze, pm_o), b_h = plane_of(z + D, z + D < ze, pm_h);
+        const size_t b_o = plane_of(u + D + 1, u + D < n, pm_o), b_h = plane_of(u + D, u + D < n, pm_h);
         if (HALO) dir_raw_load<FIRST>(hissue, dvol + b_h, s_in + b_h, r + b_h, K.hoff, K.hmask & pm_h);
         dir_raw_load<FIRST>(issue, dvol + b_o, s_in + b_o, r + b_o, K.goff, K.vmask & pm_o);
-        // exchange of plane z (double buffered by plane parity: one LDS-only barrier per plane, see k_pcg_update_z)
-        float4* const eb = ext + ((z - zb) & 1) * ext_n;
+        // exchange of plane u (double buffered by plane parity: one LDS-only barrier per plane, see k_pcg_update_z)
+        float4* const eb = ext + (u & 1) * ext_n;
         eb[t + qpr] = n_c;
         if (HALO) { if (K.halo_thread) eb[K.halo_slot] = h_c; }
         lds_barrier();
         {
             QuadValues sv;
-            sv.c = n_c; sv.zm = n_m; sv.zp = n_p;
+            sv.c = n_c;
+            sv.zm = down ? n_p : n_m; sv.zp = down ? n_m : n_p;                   // physical z - 1 / z + 1
             sv.ym = eb[t]; sv.yp = eb[t + 2 * qpr];
             sv.xm = and_mask(eb[t + qpr - 1].w, K.mxm); sv.xp = and_mask(eb[t + qpr + 1].x, K.mxp);
 #pragma unroll
@@ -271,15 +297,15 @@ __device__ __forceinline__ void dir_march(const PcgGeomZ& gz, const DirTile& K, 
         }
         const float4 n_n = dir_snew<FIRST>(use, beta, lut);
         if (HALO) h_c = dir_snew<FIRST>(huse, beta, lut);
-        if (!FIRST && z + 2 < ze && K.valid) st4so<NT>(s_out + (size_t)(z + 2) * plane, K.goff, n_n);
+        if (!FIRST && u + 2 < n && K.valid) st4so<NT>(s_out + (size_t)(z0 + dz * (u + 2)) * plane, K.goff, n_n);
         n_m = n_c; n_c = n_p; n_p = n_n; d_c = d_p; d_p = use.dq;
     };
-    // at plane z = zb + m D + k: own plane z + D + 1 goes into set (k + 1) % D, own plane z + 2 comes out of set (k + 2) % D; halo plane z + D into set k,
-    // halo plane z + 1 out of set (k + 1) % D
-    for (int z = zb; z < ze; z += D) {
+    // at plane u = m D + k: own plane u + D + 1 goes into set (k + 1) % D, own plane u + 2 comes out of set (k + 2) % D; halo plane u + D into set k,
+    // halo plane u + 1 out of set (k + 1) % D
+    for (int u = 0; u < n; u += D) {
 #pragma unroll
         for (int k = 0; k < D; ++k)
-            if (z + k < ze) body(z + k, own[(k + 1) % D], hal[k % D], own[(k + 2) % D], hal[(k + 1) % D]);
+            if (u + k < n) body(u + k, own[(k + 1) % D], hal[k % D], own[(k + 2) % D], hal[(k + 1) % D]);
     }
 }
 
@@ -300,11 +326,12 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     float acc = 0.0f;
     const int padded = ((gz.tiles + 7) >> 3) << 3;
     for (int it = blockIdx.x; it < padded; it += gridDim.x) {
-        const int tile = xcd_tile(it, gz.tiles);
+        const int tile = xcd_tile_pairs(it, gz);
         if (tile >= gz.tiles || !tile_flags[tile]) continue;
         const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
         const int q0 = pt * T, q = q0 + t;
         DirTile K;
+        K.down = (zci & 1) != 0 && (gz.alternate_march & 1) != 0;
         K.valid = q < gz.qpp;
         const int x0 = (q % qpr) << 2;
         K.z_begin = zci * gz.zc; K.z_end = min(K.z_begin + gz.zc, g.nz);

@@ -276,7 +276,9 @@ int blub_fluid_get_pcg_schedule(const blub_fluid* h);
  * "pcg1_max_iterations" n (default 64): solves configured with more iterations run schedule 0 even when schedule 1 is selected;
  * "pcg_launch_grid" n: launch grid of the brick-mapped PCG kernels (0: estimated from the last landed brick count) -- results do not depend on it;
  * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
- * (0 = default for the grid); "dense_kd_nt" -1|0|1: non-temporal stores of the dense direction kernel's output (-1: by grid size).
+ * (0 = default for the grid); "dense_kd_nt" -1|0|1: non-temporal stores of the dense direction kernel's output (-1: by grid size);
+ * "dense_alternate_march" -1|0..3 (default -1 = by grid size): odd z-chunks march downwards in the dense direction kernel (bit 0) / update kernel (bit 1):
+ *   the workgroups either side of a chunk interface then reach it together and share its planes through the L2; only the summation order of the dots changes.
  * "list_launch_grid" n: launch grid of the kernels that loop over a brick list (0 = estimated from the latest brick counts); results do not depend on it.
  * "fuse_divergence" 0|1|2 (default 1; 2 = also across blub_fluid_run_stage calls, for tests): inside blub_fluid_step the brick-mapped velocity solve forms div u in its init kernel (same bits; 0 = the
  *   separate divergence kernel, which blub_fluid_run_stage and the dense mapping always use).

@@ -153,8 +153,8 @@ def test_full_step_loose_solver(pair):
 
 
 def test_headline_scene_statistics_track_the_reference_schedule():
-    """corner_dams_256, reference defaults, 12 steps with each schedule: step 0 reports the same statistics (within 1 %), later
-    steps stay inside the rounding envelope (tests/test_gpu_baseline_parity.py), iteration counts stay comparable in total."""
+    """corner_dams_256, reference defaults, 12 steps with each schedule: the velocity solve of step 0 reports the same statistics (within 1 %),
+    over the 12 steps the level of the reported errors (geometric mean) agrees within a factor 2 and the iteration counts within 25 % in total."""
     import blub_amd
     out = {}
     for sched in ("reference", "single_reduction"):
@@ -177,8 +177,12 @@ def test_headline_scene_statistics_track_the_reference_schedule():
         assert len(a[w]) == len(b[w]) == 12
         ia, ib = sum(s[1] for s in a[w]), sum(s[1] for s in b[w])
         assert abs(ia - ib) <= 0.25 * ia, (w, ia, ib)
-        for (ea, na), (eb, nb) in list(zip(a[w], b[w]))[:2]:      # later steps: two chaotic trajectories, see test_gpu_baseline_parity.py
-            assert 0.25 < ea / eb < 4.0
+        # Step by step the two runs are two chaotic trajectories (tests/test_gpu_baseline_parity.py): a solve that stops at the iteration cap reports
+        # max|r| at a fixed iteration, which swings by factors between two roundings of the same recurrence (seen: 0.365 vs 0.078 for the density
+        # solve of step 1, and 0.10 vs 0.31 between two runs of the SAME schedule).  What must track is the level: the geometric mean over the steps.
+        ga, gb = np.exp(np.mean(np.log([s[0] for s in a[w]]))), np.exp(np.mean(np.log([s[0] for s in b[w]])))
+        print("solver %d: geometric mean of the reported errors %.4g (reference order) vs %.4g (single reduction)" % (w, ga, gb))
+        assert 0.5 < ga / gb < 2.0, (w, ga, gb)
     # mean particle position: two runs of the SAME schedule differ by up to 0.008 cells in y after 12 steps (measured with
     # tools/mean_y_spread.py: atomic list order -> rounding of the gathers -> unconverged density solve), so this is a sanity bound
     assert np.abs(a[2].mean(0) - b[2].mean(0)).max() < 2.5e-2
@@ -292,5 +296,35 @@ def test_work_volumes_may_hold_anything_outside_the_fluid(mapping):
         (sa, pa, ra), (sb, pb, rb) = results
         assert sa == sb and sa[1] == 13 and np.isfinite(sa[0])
         assert np.array_equal(pa[fluid], pb[fluid]) and np.array_equal(ra, rb) and np.all(pb[~fluid] == 0)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("alt", [1, 2, 3])
+def test_dense_march_direction_changes_only_the_summation_order(alt):
+    """The dense kernels march odd z-chunks downwards (by default in one of the two kernels, chosen by grid size: "dense_alternate_march") so that the
+    workgroups either side of a chunk interface share its planes through the L2.  A s of a cell keeps its physical orientation; only the order in
+    which a thread adds its planes to the dot-product partials differs.  After a fixed number of iterations every setting must therefore agree
+    with the all-upwards march to rounding of the dots (1e-5 of the field's scale) -- a mirrored or shifted plane would be off by O(1)."""
+    import blub_amd
+    pos, vel, maxp = util.make_dam(*GRID)
+    o, h = util.new_pair(*GRID, maxp)
+    try:
+        o.set_particles(pos, *vel)
+        run_until(o, "solve_velocity")
+        out = {}
+        for a in (0, alt):
+            h.set_pcg_work_mapping("rows")
+            h.set_tuning("dense_tile_planes", 4)          # several z-chunks on the 32-plane test grid
+            h.set_tuning("dense_alternate_march", a)
+            h.set_solver_config(0, error_tolerance=1e-12, max_num_iterations=6, error_check_frequency=2)
+            util.copy_state(o, h)
+            h.run_stage("solve_velocity", util.DT)
+            out[a] = ([h.read_volume(v) for v in ("pressure_velocity", "residual", "search")], h.solver_stats(0))
+        fluid = o.read_volume("marker") == 1
+        assert out[0][1][1] == out[alt][1][1] == 6
+        for ref, got, name in zip(out[0][0], out[alt][0], ("pressure", "residual", "search")):
+            scale = np.abs(ref[fluid]).max()
+            assert scale > 0 and np.abs(got[fluid] - ref[fluid]).max() <= 1e-5 * scale, (name, np.abs(got[fluid] - ref[fluid]).max(), scale)
     finally:
         h.close()
