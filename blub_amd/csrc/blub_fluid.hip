@@ -120,6 +120,7 @@ struct blub_fluid {
     int p2g_compact = -1;                     // P2G gather: 1 = the tile's non-empty lists compacted (k_gather_velocity3_s), 0 = one lane per list cell, -1 = by fill (stage_transfer)
     bool two_kernel_build = false;            // test hook ("bricks_two_kernel_build"): the list build of grids with more brick blocks than CUs
     int dense_alternate_march = -1;           // odd z-chunks of the dense kernels march downwards (blub_pcg_dense.hip.h: xcd_tile_pairs): bit 0 KD, bit 1 KU, -1 by grid size
+    bool standalone_stage = false;            // the running stage was called through blub_fluid_run_stage (test hook)
     int list_grid_forced = 0;                 // test hook ("list_launch_grid"): launch grid of the brick-list kernels
     int pcg_grid_forced = 0;                  // test hook (blub_fluid_set_tuning "pcg_launch_grid"): launch grid of the brick-mapped PCG kernels, 0 = estimated
     // PCG
@@ -350,7 +351,7 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     const uint32_t np_all = h->num_particles + h->num_ghost;
     if (np_all)
         LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, h->marker,
-               h->ll[0], h->ll[1], h->ll[2], (const float4*)h->pvel[0], (const float4*)h->pvel[1], (const float4*)h->pvel[2], h->nodes, (int)(h->solid == nullptr), (const uint32_t*)h->n_dev, N_ALL);
+               h->ll[0], h->ll[1], h->ll[2], (const float4*)h->pvel[0], (const float4*)h->pvel[1], (const float4*)h->pvel[2], h->nodes, (int)(h->solid == nullptr), (int)h->standalone_stage, (const uint32_t*)h->n_dev, N_ALL);
     {
         GatherArgs3 a;
         for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
@@ -672,6 +673,7 @@ static int run_stage(blub_fluid* h, int stage, float dt, bool standalone) {
     if (standalone && stage != BLUB_STAGE_TRANSFER && stage != BLUB_STAGE_BINNING)
         if ((rc = build_lists_from_marker(h)) != BLUB_OK) return rc;
     h->cur_stage = stage;
+    h->standalone_stage = standalone;
     if (h->divergence_deferred && stage != BLUB_STAGE_SOLVE_VELOCITY && (rc = stage_divergence(h)) != BLUB_OK) return rc;     // (not reached by blub_fluid_step's order)
     switch (stage) {
     case BLUB_STAGE_TRANSFER: return stage_transfer(h, dt);

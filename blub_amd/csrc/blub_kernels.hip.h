@@ -104,23 +104,6 @@ __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ head
     return is_first ? old_of_group - 1u : prev_particle;
 }
 
-// The cheaper form for kernels whose lists are short-lived and whose wave has other work to hide (k_advect's density list: the group search
-// above made that kernel 5 us slower): only runs of ADJACENT lanes with the same key share an atomic.
-__device__ __forceinline__ uint32_t wave_list_insert_runs(uint32_t* __restrict__ heads, int key, uint32_t particle) {
-    const int lane = threadIdx.x & 63;
-    const int prev_key = __shfl_up(key, 1, 64), next_key = __shfl_down(key, 1, 64);
-    const uint32_t prev_particle = __shfl_up(particle, 1, 64);
-    const bool is_start = lane == 0 || key != prev_key, is_end = lane == 63 || key != next_key;
-    const unsigned long long starts = __ballot(is_start);
-    uint32_t old = 0;
-    if (is_end && key >= 0) old = atomicExch(heads + key, particle + 1);
-    const unsigned long long above = lane == 63 ? 0ull : (starts >> (lane + 1));
-    const int end_lane = above ? lane + __builtin_ctzll(above) : 63;
-    const uint32_t old_of_run = __shfl(old, end_lane, 64);
-    if (key < 0) return INVALID_LL;
-    return is_start ? old_of_run - 1u : prev_particle;
-}
-
 // Gather nodes: what one hop of a P2G list walk reads, in ONE 32-byte piece -- {position, link of component c's list, velocity row c}.  Particle i
 // owns 96 consecutive bytes (three nodes), so a node never straddles a 64-byte sector and the list build writes them as one coalesced stream.
 // (The walk used to read position, row and link from three arrays: three sectors per hop, 36 useful bytes of 192.)
@@ -130,7 +113,7 @@ static_assert(sizeof(GatherNode) == 32, "GatherNode");
 __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_particles, float4* __restrict__ pos, int8_t* __restrict__ marker,
                                                      uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
                                                      const float4* __restrict__ pvx, const float4* __restrict__ pvy, const float4* __restrict__ pvz,
-                                                     GatherNode* __restrict__ nodes, int no_solid_voxels,
+                                                     GatherNode* __restrict__ nodes, int no_solid_voxels, int write_links,
                                                      const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
     num_particles = particle_count(num_particles, n_dev, n_sel);
     if (blockIdx.x * 256u >= num_particles) return;      // (uniform)
@@ -157,13 +140,29 @@ __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_partic
         const int key = (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1;
         nxt[c] = wave_list_insert(heads[c], key, i);
     }
-    if (!live) return;
-    pos[i] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[0]));      // particles_position_ll keeps the x list's links, as in the reference (the whole record: a 4-byte store is a partial sector write)
-    float4* out = reinterpret_cast<float4*>(nodes + 3 * (size_t)i);
+    // particles_position_ll keeps the x list's links, as in the reference (the whole record: a 4-byte store is a partial sector write).  Inside a step
+    // nobody reads them before k_advect overwrites the record (the walks read the nodes): the stage hook asks for them, blub_fluid_step does not.
+    if (live && write_links) pos[i] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[0]));
+    // The wave's 64 x 96 bytes of nodes are one contiguous 6 KiB run: transposed through LDS so that every store instruction writes 1 KiB of consecutive
+    // bytes (a lane storing its own six float4 makes each instruction touch 64 different sectors: six times the write requests at the L2).
+    __shared__ float4 stage[4][64 * 6];
+    float4* const st = stage[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        out[2 * c] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[c]));
-        out[2 * c + 1] = rows[c];
+        st[lane * 6 + 2 * c] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[c]));
+        st[lane * 6 + 2 * c + 1] = rows[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t wave_first = i - (uint32_t)lane;                                                  // (< num_particles: the block has live particles, waves beyond them hold none)
+    const uint32_t wave_quads = wave_first < num_particles ? min(64u, num_particles - wave_first) * 6u : 0u;
+    float4* out = reinterpret_cast<float4*>(nodes) + 6 * (size_t)wave_first;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t e = (uint32_t)(k * 64 + lane);
+        if (e < wave_quads) out[e] = st[e];
     }
 }
 
@@ -655,7 +654,9 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
             }
         }
         const int dx = (int)(np[0] - 0.5f), dy = (int)(np[1] - 0.5f), dz = (int)(np[2] - 0.5f);
-        nxt = wave_list_insert_runs(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, pi);
+        // (rounds 1-2 grouped only runs of adjacent lanes here: the full group search cost 5 us more while it was a ds_bpermute per round; as a
+        //  v_readlane loop it is as fast at 256^3 and 3 % faster with 8 M particles)
+        nxt = wave_list_insert(heads, (live && inb(g, dx, dy, dz)) ? cidx(g, dx, dy, dz) : -1, pi);
     }
     if (!live) return;
     if (brick_fluid) {   // what k_bricks_mark_particles would do for the list build that follows (one launch less per step): 16 x 8 x 4 bricks
