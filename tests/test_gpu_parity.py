@@ -816,7 +816,7 @@ def test_extrapolation_with_every_neighbour_count():
         h.close()
 
 
-@pytest.mark.parametrize("kind", ["single_full", "single_sparse", "dam", "dam_sparse"])
+@pytest.mark.parametrize("kind", ["single_full", "single_sparse", "dam", "dam_sparse", "single_full_odd_grid", "dam_odd_grid"])
 def test_transfer_gather_kernels(kind):
     """The P2G gather exists twice: one lane per list cell of the tile (k_gather_velocity3_p) and with the tile's non-empty lists compacted
     (k_gather_velocity3_s; tiles with more than 256 lists take several passes, last slots first).  Both add a face's eight partial sums in
@@ -825,11 +825,14 @@ def test_transfer_gather_kernels(kind):
     agree BIT FOR BIT (every tile cell occupied: three passes; a tenth of them: one pass).  "dam*": 8 particles per cell in random memory
     order -- the node order of a list is a race, so both kernels are held to the oracle at 1e-5 instead."""
     rng = np.random.default_rng(31)
+    GRID = (44, 36, 30) if kind.endswith("odd_grid") else globals()["GRID"]      # partial bricks on all three upper faces (16 x 8 x 4 bricks)
     if kind.startswith("single"):
         nx, ny, nz = GRID
         cells = np.stack(np.meshgrid(np.arange(1, nx - 2), np.arange(1, int(ny * 0.7)), np.arange(1, nz - 2), indexing="ij"), -1).reshape(-1, 3)
         if kind == "single_sparse":
             cells = cells[rng.random(len(cells)) < 0.1]
+        if kind.endswith("odd_grid"):           # up to the last cell layers: lists in the partial bricks
+            cells = np.stack(np.meshgrid(np.arange(1, nx - 1), np.arange(1, ny - 1), np.arange(1, nz - 1), indexing="ij"), -1).reshape(-1, 3)
         pos = (cells + 0.5 + 0.49 * rng.random(cells.shape)).astype(np.float32)
         vel = []
         for c in range(3):
@@ -839,7 +842,7 @@ def test_transfer_gather_kernels(kind):
         vel = tuple(vel)
         maxp = len(pos) + 64
     else:
-        pos, vel, maxp = util.make_dam(*GRID, seed=5)
+        pos, vel, maxp = util.make_dam(*GRID, seed=5, fill=(0.97, 0.97, 1.0) if kind.endswith("odd_grid") else (0.45, 0.6, 1.0))
         if kind == "dam_sparse":
             keep = (rng.random(len(pos)) < 0.04) & (pos[:, 1] < 0.35 * GRID[1])
             pos, vel = pos[keep], tuple(v[keep] for v in vel)
