@@ -240,16 +240,16 @@ __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, 
     if (lane == 0) { wtot[wave] = (uint32_t)__popcll(bf) | ((uint32_t)__popcll(ba) << 8) | ((uint32_t)__popcll(br) << 16); sm[wave] = (uint32_t)__popcll(bs); }
     __syncthreads();      // (also: every thread of the block has read its 27 neighbour flags before any of them is cleared below -- for THIS block's bricks;
                           //  other blocks' flags are cleared by their owners only after the grid-wide wait that follows)
+    // A block's four counts (<= 1024 each: 11 bits) and the build's tag travel in ONE 64-bit word: the store publishes them atomically, so neither
+    // a release fence (an L2 write-back) on this side nor an acquire fence and a second load on the waiting side are needed.
+    unsigned long long* const slots = reinterpret_cast<unsigned long long*>(block_counts4);      // 16 bytes per block, the first 8 used here
+    const unsigned long long tag = (unsigned long long)(seq % 0xFFFFFu) + 1ull;                    // 1 .. 2^20 - 1: never the 0 of fresh memory
     if (threadIdx.x == 0) {
         uint32_t tf = 0, ta = 0, tr = 0, ts = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) { const uint32_t q = wtot[w]; tf += q & 0xFFu; ta += (q >> 8) & 0xFFu; tr += (q >> 16) & 0xFFu; ts += sm[w]; }
-        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 0, tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 1, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 2, tr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(block_counts4 + 4 * blockIdx.x + 3, ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(block_ready + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long word = (tag << 44) | (unsigned long long)tf | ((unsigned long long)ta << 11) | ((unsigned long long)tr << 22) | ((unsigned long long)ts << 33);
+        __hip_atomic_store(slots + 2 * blockIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 0) timed_out = 0;
     if (threadIdx.x < 64) {   // one wave waits for all blocks and sums their counts: lanes stride over the blocks in order
@@ -258,11 +258,9 @@ __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, 
             // (bounded: if the blocks were NOT co-resident after all -- a masked or partitioned device -- the build ends with a wrong list and the
             //  counts carry an error mark instead of hanging the GPU; the host then reports BLUB_ERR_DEVICE and falls back to the two-kernel build)
             unsigned spins = 0;
-            while (__hip_atomic_load(block_ready + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) { timed_out = 1; break; } }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            uint32_t c[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = __hip_atomic_load(block_counts4 + 4 * k + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long word;
+            while (((word = __hip_atomic_load(slots + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 44) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) { timed_out = 1; word = 0; break; } }
+            const uint32_t c[4] = {(uint32_t)(word & 0x7FFu), (uint32_t)((word >> 11) & 0x7FFu), (uint32_t)((word >> 22) & 0x7FFu), (uint32_t)((word >> 33) & 0x7FFu)};
 #pragma unroll
             for (int q = 0; q < 4; ++q) { all[q] += c[q]; if (k < (int)blockIdx.x) before[q] += c[q]; }
         }

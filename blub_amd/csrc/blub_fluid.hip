@@ -222,7 +222,7 @@ static void prof_events(blub_fluid* h, hipEvent_t* a, hipEvent_t* b) {
 #define LAUNCH(h, kc, kernel, grid, block, ...) LAUNCH_LDS(h, kc, kernel, grid, block, 0, __VA_ARGS__)
 
 static unsigned particle_blocks(uint32_t n) { return (n + 255) / 256; }
-constexpr uint32_t N_OWN = 1u, N_GHOST = 2u, N_ALL = 3u;      // particle_count() selectors (blub_kernels.hip.h)
+[[maybe_unused]] constexpr uint32_t N_OWN = 1u, N_GHOST = 2u, N_ALL = 3u;      // particle_count() selectors (blub_kernels.hip.h)
 static unsigned stream_blocks(size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, 2048); }
 
 // NOTE: the handle's stream is non-blocking, i.e. NOT ordered against the null stream: every memset / copy of this
