@@ -54,7 +54,8 @@ constexpr int BRICK_GRID_MAX = 2048; // persistent blocks of the brick-list kern
 constexpr int STATS_RING = 32;       // pressure_solver.rs:49 NUM_PRESSURE_ERROR_BUFFER
 constexpr size_t STATS_HISTORY = 100;   // pressure_solver.rs:101
 constexpr int COUNTS_RING = 32;
-constexpr float SPARSE_PCG_MAX_FILL = 0.30f;   // fluid bricks / bricks below which the brick-list PCG kernels are used
+constexpr float SPARSE_PCG_MAX_FILL = 0.30f;   // fluid bricks / bricks below which the brick-list PCG kernels are used (single-reduction schedule; see stage_solve)
+constexpr float SPARSE_PCG_MAX_FILL_REFERENCE = 0.20f;   // ... with the reference's two-reduction order
 
 struct PendingStat { uint32_t seq; int slot; };
 
@@ -465,11 +466,15 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     if ((rc = latest_counts(h, standalone || h->counts_seq <= 2, &bc, &have)) != BLUB_OK) return rc;
     if (h->force_pcg_path >= 0) sparse = h->force_pcg_path >= 1;
     else {
-        // small grids stay launch/latency-bound however full they are: the brick mapping always wins there (dam_halfhalf, 128x64x64, 40-75 % of
-        // the bricks FLUID while it sloshes: 1647 steps/s on the brick mapping, 1115 on the dense one, and 1480-1650 from run to run while a
-        // 70 % threshold sat inside that range); large ones are byte-bound and want the 2.5-D dense mapping early
-        const float max_fill = h->N <= (size_t)1 << 20 ? 2.0f : SPARSE_PCG_MAX_FILL;
-        sparse = (have && (float)bc.n_fluid < max_fill * (float)h->bg.nb) || h->N <= (size_t)1 << 20 || h->gz.tiles < 256;   // (tiny grids: too few dense tiles to fill the chip)
+        // Measured per iteration on compact all-FLUID slabs (tools/mapping_crossover.py, profiles/r03_mapping_crossover.txt): the brick mapping costs
+        // ~6 us per 1000 FLUID bricks (+12-18 us), the dense one follows the cells of the grid; with the single-reduction schedule (ONE kernel per
+        // iteration) the bricks win up to ~8000 FLUID bricks whatever the grid (256x128x128: 23 vs 27 us half full, 45 vs 40 us full; dam_halfhalf_highres:
+        // 344 vs 270 steps/s) and up to ~30 % of the bricks on large grids; with the reference's two-reduction order only up to ~20 % / ~2000 bricks
+        // (256^3 a quarter full: 62 vs 53 us).  Grids of up to 1 M cells stay launch/latency-bound however full they are: always bricks there
+        // (dam_halfhalf, 128x64x64, 40-75 % of the bricks FLUID while it sloshes: 1647 steps/s on the brick mapping, 1115 on the dense one).
+        const bool single = h->pcg_schedule == 1 && c.max_num_iterations <= h->pcg1_max_iterations;
+        const float limit = std::max(single ? 8192.0f : 2048.0f, (single ? SPARSE_PCG_MAX_FILL : SPARSE_PCG_MAX_FILL_REFERENCE) * (float)h->bg.nb);
+        sparse = (have && (float)bc.n_fluid < limit) || h->N <= (size_t)1 << 20 || h->gz.tiles < 256;   // (tiny grids: too few dense tiles to fill the chip)
     }
     if (2 * h->gz.qpr > h->gz.T) sparse = true;   // rows wider than 2048 cells: the dense tiles cannot hold their halo rows (k_pcg_dir_z)
     const int maxit = c.max_num_iterations;

@@ -255,7 +255,8 @@ typedef struct blub_trace_event {
     double start_us, duration_us;
 } blub_trace_event;
 int blub_fluid_profile_trace(blub_fluid* h, blub_trace_event* events, int capacity, int* count_out); /* blocks */
-/* Work mapping of the PCG kernels: -1 = automatic (brick lists when < 30 % of the bricks hold fluid, dense rows otherwise),
+/* Work mapping of the PCG kernels: -1 = automatic (brick lists on grids of up to 1 M cells and while fewer than max(8192, 30 % of the) bricks hold fluid
+ * -- max(2048, 20 %) with the reference's two-reduction order --, dense rows otherwise: a measured speed choice, profiles/r03_mapping_crossover.txt),
  * 0 = dense rows, 1 (or 2, its former LDS-staged alias) = brick lists.  A performance knob only: both mappings run the same per-cell arithmetic (the
  * dot-product partial sums are grouped differently, so results agree to rounding, not bitwise).  Within a mapping the grouping depends on the
  * brick lists alone, never on launch grids or host timing: two solves on the same state give bit-identical scalars. */
