@@ -348,7 +348,7 @@ constexpr int GT_X = BX + 1, GT_Y = BY + 1, GT_Z = BZ + 1, GT_N = GT_X * GT_Y * 
 // stay in flight across the exchange (a __syncthreads() would drain vmcnt first).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct GatherArgs3 { const uint32_t* heads[3]; float* out[3]; float gravity_dt[3]; };
+struct GatherArgs3 { const uint32_t* heads[3]; float* out[3]; float gravity_dt[3]; uint32_t node_stride; };
 
 // "Partial sum" formulation.  (Round 1 moved PARTICLES to faces -- per round every thread published one particle through LDS and read
 // seven, with a 12-wave barrier per round: measured LDS-issue / barrier bound; removed.)  Every
@@ -364,19 +364,19 @@ struct GatherPartialsV { float2 part[8][GP_STRIDE]; };     // [corner][list cell
 struct GatherPartialsD { float part[8][GP_STRIDE]; };      // [corner][list cell] sum w: 24 KiB
 
 template <int COMP>
-__device__ __forceinline__ void gather_walk(const GatherNode* __restrict__ nodes, uint32_t cur, int gx, int gy, int gz, float (&v)[8], float (&ws)[8]) {
+__device__ __forceinline__ void gather_walk(const GatherNode* __restrict__ nodes, uint32_t cur, int gx, int gy, int gz, float (&v)[8], float (&ws)[8]) {      // nodes: component COMP's array
     // the two sample coordinates per axis this list reaches: faces d and d + 1 (:20, sample = face + 0.5 (+ 0.5 along COMP))
     const float sx0 = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f), sx1 = (float)(gx + 1) + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
     const float sy0 = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f), sy1 = (float)(gy + 1) + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
     const float sz0 = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f), sz1 = (float)(gz + 1) + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
     // one hop = the two halves of ONE 32-byte node (k_build_lists): {position, link}, {row}
-    const float4* nd = reinterpret_cast<const float4*>(nodes) + COMP * 2;
-    float4 p = nd[6 * (size_t)cur], r = nd[6 * (size_t)cur + 1];
+    const float4* nd = reinterpret_cast<const float4*>(nodes);
+    float4 p = nd[2 * (size_t)cur], r = nd[2 * (size_t)cur + 1];
     uint32_t nxt = __float_as_uint(p.w);
     for (int round = 0; round < GATHER_CAP_V; ++round) {                                           // :61
         const bool has_n = nxt != INVALID_LL && round + 1 < GATHER_CAP_V;
         float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
-        if (has_n) { pn = nd[6 * (size_t)nxt]; rn = nd[6 * (size_t)nxt + 1]; nn = __float_as_uint(pn.w); }   // next node in flight during the arithmetic
+        if (has_n) { pn = nd[2 * (size_t)nxt]; rn = nd[2 * (size_t)nxt + 1]; nn = __float_as_uint(pn.w); }   // next node in flight during the arithmetic
         const float tx[2] = {sx0 - p.x, sx1 - p.x}, ty[2] = {sy0 - p.y, sy1 - p.y}, tz[2] = {sz0 - p.z, sz1 - p.z};   // :20
         const float ox[2] = {satf(1.0f - fabsf(tx[0])), satf(1.0f - fabsf(tx[1]))};
         const float oy[2] = {satf(1.0f - fabsf(ty[0])), satf(1.0f - fabsf(ty[1]))};
@@ -460,9 +460,9 @@ __global__ __launch_bounds__(768) void k_gather_velocity3_p(BrickGeom bg, const 
     __shared__ GatherPartialsV sh;
     uint32_t slot, slots; int comp;
     gather3_block_role(slot, slots, comp);
-    if (comp == 0) gather_velocity_partial_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes, a.out[0], a.gravity_dt[0]);
-    else if (comp == 1) gather_velocity_partial_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes, a.out[1], a.gravity_dt[1]);
-    else gather_velocity_partial_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes, a.out[2], a.gravity_dt[2]);
+    if (comp == 0) gather_velocity_partial_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes + (size_t)0 * a.node_stride, a.out[0], a.gravity_dt[0]);
+    else if (comp == 1) gather_velocity_partial_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes + (size_t)1 * a.node_stride, a.out[1], a.gravity_dt[1]);
+    else gather_velocity_partial_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes + (size_t)2 * a.node_stride, a.out[2], a.gravity_dt[2]);
 }
 
 // ---- the same gather with the tile's NON-EMPTY lists compacted -------------------------------------------------------------------
@@ -574,9 +574,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_velocity3_s(BrickGeom bg,
     __shared__ GatherSparseShared sh;
     uint32_t slot, slots; int comp;
     gather3_block_role(slot, slots, comp);
-    if (comp == 0) gather_velocity_sparse_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes, a.out[0], a.gravity_dt[0]);
-    else if (comp == 1) gather_velocity_sparse_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes, a.out[1], a.gravity_dt[1]);
-    else gather_velocity_sparse_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes, a.out[2], a.gravity_dt[2]);
+    if (comp == 0) gather_velocity_sparse_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes + (size_t)0 * a.node_stride, a.out[0], a.gravity_dt[0]);
+    else if (comp == 1) gather_velocity_sparse_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes + (size_t)1 * a.node_stride, a.out[1], a.gravity_dt[1]);
+    else gather_velocity_sparse_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes + (size_t)2 * a.node_stride, a.out[2], a.gravity_dt[2]);
 }
 
 // R1 in the same formulation (density_projection_gather_error.comp:41-198): samples are cell centres, the list cap is 32

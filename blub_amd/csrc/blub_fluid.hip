@@ -84,7 +84,8 @@ struct blub_fluid {
     uint32_t step_counter = 0;
     // particles (hybrid_fluid.rs:114-122)
     float4 *pos = nullptr, *pos_tmp = nullptr, *pvel[3] = {nullptr, nullptr, nullptr};
-    blubk::GatherNode* nodes = nullptr;       // 3 x 32 bytes per particle: what the P2G list walks read (written by k_build_lists)
+    blubk::GatherNode* nodes = nullptr;       // 3 x 32 bytes per particle: what the P2G list walks read (written by k_build_lists); component c at nodes + c * node_stride
+    uint32_t node_stride = 0;
     // volumes (hybrid_fluid.rs:142-154; pressure_solver.rs:104-108, 332-351)
     int8_t* marker = nullptr;
     uint32_t* ll[3] = {nullptr, nullptr, nullptr};
@@ -352,10 +353,11 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
     const uint32_t np_all = h->num_particles + h->num_ghost;
     if (np_all)
         LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, h->marker,
-               h->ll[0], h->ll[1], h->ll[2], (const float4*)h->pvel[0], (const float4*)h->pvel[1], (const float4*)h->pvel[2], h->nodes, (int)(h->solid == nullptr), (int)h->standalone_stage, (const uint32_t*)h->n_dev, N_ALL);
+               h->ll[0], h->ll[1], h->ll[2], (const float4*)h->pvel[0], (const float4*)h->pvel[1], (const float4*)h->pvel[2], h->nodes, h->node_stride, (int)(h->solid == nullptr), (int)h->standalone_stage, (const uint32_t*)h->n_dev, N_ALL);
     {
         GatherArgs3 a;
         for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
+        a.node_stride = h->node_stride;
         const dim3 ggrid(3 * ((lg.active + 7) / 8) * 8);
         // Which of the two (bit-identical) gathers: the compacting one wins while a FLUID brick holds particles in a minority of its cells (headline scene: ~750
         // particles per FLUID brick, 69 against 76 us), one lane per list cell when the bricks are full (M4: ~4000 per brick, 3.7 against 4.1 ms).
@@ -775,7 +777,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     A(dev_alloc_zero(h->stream, &h->pos, P)); A(dev_alloc_zero(h->stream, &h->pos_tmp, P));
     for (int c = 0; c < 3; ++c) A(dev_alloc_zero(h->stream, &h->pvel[c], P));
-    A(dev_alloc_zero(h->stream, &h->nodes, 3 * P));
+    A(dev_alloc_zero(h->stream, &h->nodes, 3 * P)); h->node_stride = (uint32_t)P;
     if (d->volume_shift_kib != 0xFFFFFFFFu) {      // (0xFFFFFFFF: one allocation per volume)
         h->slab_shift = (size_t)(d->volume_shift_kib ? d->volume_shift_kib : 64u) * 1024u;
         const size_t per = ((h->N * 4 + 0x1FFFFFull) & ~0x1FFFFFull) + 0x400000ull;      // 2 MiB alignment + up to 2 MiB of shift

@@ -104,8 +104,8 @@ __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ head
     return is_first ? old_of_group - 1u : prev_particle;
 }
 
-// Gather nodes: what one hop of a P2G list walk reads, in ONE 32-byte piece -- {position, link of component c's list, velocity row c}.  Particle i
-// owns 96 consecutive bytes (three nodes), so a node never straddles a 64-byte sector and the list build writes them as one coalesced stream.
+// Gather nodes: what one hop of a P2G list walk reads, in ONE 32-byte piece -- {position, link of component c's list, velocity row c}.  One array of
+// nodes per component, indexed by particle: a node never straddles a 64-byte sector, consecutive particles share sectors and lines.
 // (The walk used to read position, row and link from three arrays: three sectors per hop, 36 useful bytes of 192.)
 struct alignas(16) GatherNode { float px, py, pz; uint32_t next; float4 row; };
 static_assert(sizeof(GatherNode) == 32, "GatherNode");
@@ -113,7 +113,7 @@ static_assert(sizeof(GatherNode) == 32, "GatherNode");
 __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_particles, float4* __restrict__ pos, int8_t* __restrict__ marker,
                                                      uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
                                                      const float4* __restrict__ pvx, const float4* __restrict__ pvy, const float4* __restrict__ pvz,
-                                                     GatherNode* __restrict__ nodes, int no_solid_voxels, int write_links,
+                                                     GatherNode* __restrict__ nodes, uint32_t node_stride, int no_solid_voxels, int write_links,
                                                      const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
     num_particles = particle_count(num_particles, n_dev, n_sel);
     if (blockIdx.x * 256u >= num_particles) return;      // (uniform)
@@ -143,26 +143,28 @@ __global__ __launch_bounds__(256) void k_build_lists(Grid g, uint32_t num_partic
     // particles_position_ll keeps the x list's links, as in the reference (the whole record: a 4-byte store is a partial sector write).  Inside a step
     // nobody reads them before k_advect overwrites the record (the walks read the nodes): the stage hook asks for them, blub_fluid_step does not.
     if (live && write_links) pos[i] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[0]));
-    // The wave's 64 x 96 bytes of nodes are one contiguous 6 KiB run: transposed through LDS so that every store instruction writes 1 KiB of consecutive
-    // bytes (a lane storing its own six float4 makes each instruction touch 64 different sectors: six times the write requests at the L2).
+    // Nodes are stored per component (nodes[c * node_stride + i]): the nodes of consecutive particles -- after a rebinning the members of a list -- share
+    // sectors and lines.  The wave's 64 x 32 bytes per component are one contiguous 2 KiB run: transposed through LDS so that every store instruction
+    // writes 1 KiB of consecutive bytes (a lane storing its own float4s makes each instruction touch 64 different sectors: six times the write
+    // requests at the L2).
     __shared__ float4 stage[4][64 * 6];
     float4* const st = stage[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        st[lane * 6 + 2 * c] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[c]));
-        st[lane * 6 + 2 * c + 1] = rows[c];
+        st[c * 128 + lane * 2] = make_float4(p.x, p.y, p.z, __uint_as_float(nxt[c]));
+        st[c * 128 + lane * 2 + 1] = rows[c];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t wave_first = i - (uint32_t)lane;                                                  // (< num_particles: the block has live particles, waves beyond them hold none)
-    const uint32_t wave_quads = wave_first < num_particles ? min(64u, num_particles - wave_first) * 6u : 0u;
-    float4* out = reinterpret_cast<float4*>(nodes) + 6 * (size_t)wave_first;
+    const uint32_t wave_first = i - (uint32_t)lane;                                                  // (may lie beyond the particles for the last block's trailing waves)
+    const uint32_t wave_quads = wave_first < num_particles ? min(64u, num_particles - wave_first) * 2u : 0u;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const uint32_t e = (uint32_t)(k * 64 + lane);
-        if (e < wave_quads) out[e] = st[e];
+        const int c = k >> 1;
+        const uint32_t e = (uint32_t)((k & 1) * 64 + lane);
+        if (e < wave_quads) reinterpret_cast<float4*>(nodes + (size_t)c * node_stride)[2 * (size_t)wave_first + e] = st[c * 128 + e];
     }
 }
 
