@@ -1065,7 +1065,7 @@ int blub_fluid_voxelize(blub_fluid* h, uint32_t num_meshes, const blub_mesh_desc
             static_assert(sizeof(blubk::MeshDesc) == sizeof(blub_mesh_desc), "MeshDesc mirrors blub_mesh_desc");
             blubk::MeshDesc d; memcpy(&d, &meshes[m], sizeof d);
             const uint32_t ntri = (d.index_end - d.index_begin) / 3;
-            if (ntri) hipLaunchKernelGGL(blubk::k_voxelize_mesh, dim3((ntri + 3) / 4), dim3(256), 0, h->stream, h->g, d, (const float*)h->mesh_positions, (const uint32_t*)h->mesh_indices, h->solid);
+            if (ntri) hipLaunchKernelGGL(blubk::k_voxelize_mesh, dim3((ntri + 3) / 4, blubk::VOXELIZE_SPLIT), dim3(256), 0, h->stream, h->g, d, (const float*)h->mesh_positions, (const uint32_t*)h->mesh_indices, h->solid);
         }
         // the static marker pattern changed: every brick may now differ from it (same as blub_fluid_set_solid_voxels)
         hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker);

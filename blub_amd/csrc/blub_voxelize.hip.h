@@ -1,7 +1,7 @@
 // Solid voxelisation of the scene's static objects -- compute restatement of the reference's
 // rasteriser pass: scene/voxelization.rs:116-157 draws every mesh with `conservative: true` through
 // shader/voxelize/conservative_hull.vert (dominant-axis projection) and conservative_hull.frag (three image stores per
-// fragment).  Here one wave takes one triangle and walks the pixels of its bounding box; a pixel produces a fragment when
+// fragment).  Here VOXELIZE_SPLIT waves share one triangle and walk the pixels of its bounding box; a pixel produces a fragment when
 // its unit square overlaps the projected triangle (overestimating conservative rasterisation, exact separating-axis test).
 // Choices the reference leaves to the Vulkan implementation, fixed here and in the oracle:
 //   * window coordinates are the swizzled voxel coordinates themselves (no sub-pixel snapping),
@@ -16,6 +16,7 @@
 
 namespace blubk {
 
+constexpr int VOXELIZE_SPLIT = 16;      // waves per triangle (blockIdx.y): a cube face is two triangles of thousands of pixels each
 struct MeshDesc { float m[3][4]; float vel[3]; float axis[3]; uint32_t index_begin, index_end; };
 
 __device__ __forceinline__ float f16_round(float v) { return __half2float(__float2half_rn(v)); }
@@ -77,8 +78,11 @@ __global__ __launch_bounds__(256) void k_voxelize_mesh(Grid g, MeshDesc d, const
     const int x0 = (int)xlo, y0 = (int)ylo, w = (int)xhi - x0 + 1, hgt = (int)yhi - y0 + 1;
     // edge functions of the counter-clockwise triangle, evaluated at the corner of the pixel square that maximises them
     const float e0x = bx - ax, e0y = by - ay, e1x2 = cx - bx, e1y2 = cy - by, e2x2 = ax - cx, e2y2 = ay - cy;
-    for (int64_t k = lane; k < (int64_t)w * hgt; k += 64) {
-        const int i = x0 + (int)(k % w), j = y0 + (int)(k / w);
+    // the pixels of the bounding box are dealt out to gridDim.y waves (a box is at most 4096^2 pixels: 32-bit arithmetic); every store of a voxel
+    // writes a function of the voxel's own coordinates, so the order in which fragments land does not matter
+    const uint32_t total = (uint32_t)w * (uint32_t)hgt, stride = 64u * gridDim.y;
+    for (uint32_t k = (uint32_t)lane + 64u * blockIdx.y; k < total; k += stride) {
+        const int i = x0 + (int)(k % (uint32_t)w), j = y0 + (int)(k / (uint32_t)w);
         const float fi = (float)i, fj = (float)j;
         const float c0x = e0y < 0.0f ? fi + 1.0f : fi, c0y = e0x > 0.0f ? fj + 1.0f : fj;
         const float c1x = e1y2 < 0.0f ? fi + 1.0f : fi, c1y = e1x2 > 0.0f ? fj + 1.0f : fj;
