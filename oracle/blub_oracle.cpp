@@ -5,18 +5,29 @@
 // `cpu_baseline` leg may load this library.  The product (blub_amd/, libblubhip.so) never links,
 // imports or calls anything in oracle/.
 //
-// PARITY UNPINNED: the reference ships no tests, golden vectors or CPU path, and its GLSL/wgpu/Vulkan
-// path cannot be built or run in this image (no Rust, no shaderc, no Vulkan ICD).  This file is a
-// literal restatement of the reference's compute shaders (every function cites the file:line it
-// follows, relative to /root/reference) with the GPU image semantics of SURVEY.md Appendix A:
+// PARITY PINNED (round 4) AGAINST THE REFERENCE'S OWN SHADER TEXT: the reference ships no tests or golden
+// vectors and its wgpu/Vulkan path cannot run in this image (no Rust, no shaderc, no Vulkan ICD), but its
+// arithmetic lives in GLSL that g++ can compile: oracle/glsl/ (glsl_shim.h + glsl2cpp.py, a lexical
+// preprocessor) builds the UNMODIFIED shader/simulation/**/*.comp into oracle/_ref/libblubref.so and
+// oracle/glsl/ref_fluid.py dispatches them as HybridFluid::step records them.  With `dot_mode 2` (the
+// reference's own reduction order) this file reproduces that library BIT FOR BIT -- every stage of a step
+// incl. moving solids, both PCG solves with both readings of Q1, the literal Q4 binning
+// (tests/test_oracle_vs_ref.py: committed fixtures tests/golden/ref_*.npz + live runs where
+// /root/reference exists).  What remains implementation-defined in Vulkan and is therefore a CHOICE here:
+// the hardware trilinear filter (evaluated separably in f32; bounded against the two alternatives), the
+// order of atomics (ascending invocation index), out-of-range LOD (Q1 switch), f32 division / sqrt rounding.
+//
+// This file is a literal restatement of the reference's compute shaders (every function cites the
+// file:line it follows, relative to /root/reference) with the GPU image semantics of SURVEY.md Appendix A:
 //   * out-of-bounds image/texel reads return 0, OOB stores are dropped
 //   * marker R8Snorm {+1 FLUID, -1 AIR, 0 SOLID} held as int8
 //   * all buffers/volumes zero-initialised
 //   * linked-list insertion order = ascending particle index (the GPU order is a race)
 //   * plain IEEE f32 arithmetic, no FMA contraction (build with -ffp-contract=off); dot-product
-//     reductions accumulate in f64 per z-plane (deterministic for any thread count), rounded to f32
-// What it is checked against instead: analytic known-answer tests (tests/test_oracle_kat.py), scipy's
-// sparse solver for the PCG, the published xoshiro256++/SplitMix64 vectors for the seeding RNG.
+//     reductions: f64 per z-plane by default (deterministic for any thread count), or the reference's tree
+// Also checked against: analytic known-answer tests (tests/test_oracle_kat.py), scipy's sparse solver for
+// the PCG, the published xoshiro256++/SplitMix64 vectors for the seeding RNG (the one part still unpinned:
+// rand 0.8.5 is not on disk -- parity tests never depend on it).
 // =====================================================================================================
 #include <algorithm>
 #include <chrono>
@@ -69,7 +80,8 @@ struct Oracle {
     SolverConfig cfg[2];
     SolverStats last_stats[2];
     bool pressure_cleared[2] = {false, false};
-    int dot_mode = 0;   // 0: dot products accumulated in f64 (default); 1: in f32 (row sums -> plane sums -> total): a sensitivity probe for
+    int dot_mode = 0;   // 2: the reference's own reduction order, literally (reduce_literal below; bit-exact against oracle/_ref);
+                        // 0: dot products accumulated in f64 (default); 1: in f32 (row sums -> plane sums -> total): a sensitivity probe for
                         // the reference's own f32 tree reductions (pressure_reduce.comp:37-61), see tests/test_oracle_kat.py
     int precond_mode = PRECOND_ZERO;
     int binning_mode = BINNING_FIXED;
@@ -261,6 +273,8 @@ struct Oracle {
     double precond_pass(const std::vector<float>& in, std::vector<float>& out, bool with_dot) {
         std::vector<double> part(nz, 0.0);
         const bool f32dots = dot_mode == 1;
+        const bool literal = dot_mode == 2 && with_dot;
+        if (literal) redbuf.assign(N, 0.0f);
 #pragma omp parallel for
         for (int z = 0; z < nz; ++z) { double acc = 0; float accp = 0.f; for (int y = 0; y < ny; ++y) { float accr = 0.f; for (int x = 0; x < nx; ++x) {
             if (mk(x, y, z) != CELL_FLUID) continue;
@@ -275,11 +289,49 @@ struct Oracle {
             float d = 0.f; for (int k = 0; k < 6; ++k) d += (n.m[k] != CELL_SOLID) ? 1.0f : 0.0f;
             if (d > 0.0f) res /= d;
             out[c] = res;
-            if (with_dot) { if (f32dots) accr += res * residual[c]; else acc += (double)(res * residual[c]); }
+            if (literal) { size_t a = reduce_addr(x, y, z); if (a < N) redbuf[a] = res * residual[c]; }
+            else if (with_dot) { if (f32dots) accr += res * residual[c]; else acc += (double)(res * residual[c]); }
         } accp += accr; } part[z] = f32dots ? (double)accp : acc; }
+        if (literal) return (double)reduce_literal(false);
         if (f32dots) { float s = 0.f; for (double p : part) s += (float)p; return (double)s; }
         double s = 0; for (double p : part) s += p; return s;
     }
+    // ---- dot_mode 2: the reference's own reduction, operation for operation ------------------------
+    // Level 0: every invocation of an 8x8x1-workgroup grid kernel writes its term to the WG-linear address
+    // GetReduceBufferAddress() (pressure_apply_coeff.comp:13-17); reduce_addr() is that address for cell (x, y, z).
+    // Levels 1..: pressure_reduce.comp:35-61 -- thread t of workgroup w starts from 0.0 and folds in the <= 16 elements
+    // gid + k * (1024 * numWG), then a 1024 -> 2 LDS tree (stride 512 .. 2) and shared[0] (op) shared[1]; dispatch sizes and
+    // SourceBufferSize as pressure_solver.rs:543-589 / pressure_init.comp:27-31 compute them (Q5: every indirect level uses
+    // DispatchCommandReduce0).
+    inline size_t reduce_addr(int x, int y, int z) const {
+        const int gwx = (nx + 7) / 8, gwy = (ny + 7) / 8;
+        return (size_t)((x & 7) + 8 * (y & 7)) + 64u * (((size_t)z * gwy + (size_t)(y >> 3)) * gwx + (size_t)(x >> 3));
+    }
+    std::vector<float> redbuf;   // level-0 buffer ("Buffer: DotProduct Reduce 0", N floats: addresses >= N are dropped, robust access)
+    static float reduce_workgroup(const std::vector<float>& src, size_t size, uint32_t wg, uint32_t num_wg, bool is_max) {
+        float sh[1024];
+        for (uint32_t t = 0; t < 1024; ++t) {
+            size_t addr = (size_t)wg * 1024 + t;
+            float v = 0.0f;
+            for (int k = 0; k < 16; ++k) { if (addr < size) v = is_max ? std::max(v, src[addr]) : v + src[addr]; addr += (size_t)1024 * num_wg; }
+            sh[t] = v;
+        }
+        for (uint32_t i = 512; i > 1; i /= 2) for (uint32_t t = 0; t < i; ++t) sh[t] = is_max ? std::max(sh[t], sh[t + i]) : sh[t] + sh[t + i];
+        return is_max ? std::max(sh[0], sh[1]) : sh[0] + sh[1];
+    }
+    float reduce_literal(bool is_max) {
+        const uint32_t reduce0_groups = (uint32_t)((N / 16 + 1023) / 1024);    // DispatchCommandReduce0, pressure_init.comp:29
+        std::vector<float> a(redbuf), b;
+        size_t remaining = N;
+        while (remaining > 16384) {                                            // pressure_solver.rs:561-581
+            b.assign(std::max<size_t>(reduce0_groups, a.size() / 16384 + 1), 0.0f);
+            for (uint32_t w = 0; w < reduce0_groups; ++w) b[w] = reduce_workgroup(a, remaining, w, reduce0_groups, is_max);
+            a.swap(b);
+            remaining /= 16384;
+        }
+        return reduce_workgroup(a, remaining, 0, 1, is_max);                   // final dispatch(1,1,1), :586-588
+    }
+
     static inline float eps_div(float num, float den) { return num / (den + (den < 0.0f ? -1e-10f : 1e-10f)); }   // pressure_reduce.comp:71-77
 
     void solve(int which, float dt) {
@@ -324,16 +376,20 @@ struct Oracle {
                 // S4 pressure_apply_coeff.comp:19-30
                 std::vector<double> part(nz, 0.0);
                 const bool f32dots = dot_mode == 1;
+                const bool literal = dot_mode == 2;
+                if (literal) redbuf.assign(N, 0.0f);
 #pragma omp parallel for
                 for (int z = 0; z < nz; ++z) { double acc = 0; float accp = 0.f; for (int y = 0; y < ny; ++y) { float accr = 0.f; for (int x = 0; x < nx; ++x) {
                     size_t ci = idx(x, y, z);
                     if (marker[ci] != CELL_FLUID) continue;
                     float sval = search[ci];
                     const float prod = sval * mulA(search, x, y, z, sval);
-                    if (f32dots) accr += prod; else acc += (double)prod;
+                    if (literal) { size_t a = reduce_addr(x, y, z); if (a < N) redbuf[a] = prod; }
+                    else if (f32dots) accr += prod; else acc += (double)prod;
                 } accp += accr; } part[z] = f32dots ? (double)accp : acc; }
                 double dsum = 0;
-                if (f32dots) { float fs = 0.f; for (double q : part) fs += (float)q; dsum = fs; } else for (double q : part) dsum += q;
+                if (literal) dsum = reduce_literal(false);
+                else if (f32dots) { float fs = 0.f; for (double q : part) fs += (float)q; dsum = fs; } else for (double q : part) dsum += q;
                 ab = eps_div(sigma, (float)dsum);                             // RESULTMODE_ALPHA
             }
             const bool check = (i == maxit) || (i > 0 && c.error_check_frequency > 0 && i % c.error_check_frequency == 0);   // :672-673
@@ -341,6 +397,8 @@ struct Oracle {
             if (!done) {
                 // S5 pressure_update_pressure_and_residual.comp:23-59 (A s recomputed from the *old* s: s is not written here)
                 std::vector<float> emax(nz, 0.f);
+                const bool literal = dot_mode == 2 && check;
+                if (literal) redbuf.assign(N, 0.0f);
 #pragma omp parallel for
                 for (int z = 0; z < nz; ++z) { float e = 0.f; for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
                     size_t ci = idx(x, y, z);
@@ -351,8 +409,10 @@ struct Oracle {
                     r -= ab * mulA(search, x, y, z, sval);
                     residual[ci] = r;
                     e = std::max(e, std::fabs(r));
+                    if (literal) { size_t a = reduce_addr(x, y, z); if (a < N) redbuf[a] = std::fabs(r); }
                 } emax[z] = e; }
                 for (float e : emax) err = std::max(err, e);
+                if (literal) err = reduce_literal(true);
             }
             if (check) {
                 if (!done && num_iter == 0 && (i == maxit || err < tol)) { max_err = err; num_iter = i; done = true; }   // pressure_reduce.comp:82-94

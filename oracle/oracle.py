@@ -142,8 +142,9 @@ class Oracle:
         self._L.orc_set_quirks(self._h, PRECOND[precond], BINNING[binning])
 
     def set_dot_mode(self, mode):
-        """0: PCG dot products accumulated in f64 (default), 1: in f32 (rows -> planes -> total).  A sensitivity probe: the
-        reference's own reductions are f32 trees (pressure_reduce.comp:37-61)."""
+        """0: PCG dot products accumulated in f64 (default), 1: in f32 (rows -> planes -> total; a sensitivity probe), 2: the
+        reference's own reduction, literally (WG-linear reduce buffer, 16 strided reads per thread, 1024 -> 1 tree:
+        pressure_reduce.comp:35-61, pressure_solver.rs:543-589) -- bit-exact against oracle/_ref (tests/test_oracle_vs_ref.py)."""
         self._L.orc_set_dot_mode(self._h, int(mode))
 
     def set_rebinning_frequency(self, f):

@@ -1,0 +1,114 @@
+"""Generates tests/golden/ref_*.npz from the REFERENCE'S OWN compute shaders.
+
+The shaders under /root/reference/shader/simulation are compiled with g++ through oracle/glsl/ (glsl_shim.h + glsl2cpp.py ->
+oracle/_ref/libblubref.so) and dispatched in the order HybridFluid::step / PressureSolver::solve record them
+(oracle/glsl/ref_fluid.py).  These fixtures are therefore reference outputs, not oracle outputs: they are what pins the CPU
+oracle (tests/test_oracle_vs_ref.py) and, through it and directly, the HIP engine (tests/test_gpu_vs_ref.py).
+
+Needs /root/reference (this container; the GPU box only sees the committed .npz files).  Run from the repo root:
+    python tests/golden/make_ref_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ref_scenarios as S  # noqa: E402
+from oracle.glsl import ref_fluid  # noqa: E402
+from oracle.glsl.ref_fluid import RefFluid  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def provenance():
+    with open(os.path.join(ROOT, "oracle", "_ref", "shader_sha256.txt")) as f:
+        shaders = f.read()
+    recipe = "".join(hashlib.sha256(open(os.path.join(ROOT, "oracle", "glsl", n), "rb").read()).hexdigest() + "  " + n + "\n"
+                     for n in ("glsl_shim.h", "glsl2cpp.py", "ref_runtime.cpp", "ref_fluid.py"))
+    return dict(shader_sha256=np.array(shaders), recipe_sha256=np.array(recipe))
+
+
+def step_fixture():
+    sc = S.step_scene(seed=2024, dim=S.STEP_DIM)
+    n = len(sc["pos"])
+    out = dict(provenance(), dim=sc["dim"], dt=np.float32(S.DT), gravity=sc["gravity"], solid=sc["solid"], pos_in=sc["pos"], vx_in=sc["vx"], vy_in=sc["vy"], vz_in=sc["vz"])
+    # (a) the separable evaluation of the trilinear filter: every recorded array of step 0 + the particles after steps 1 and 2
+    r = RefFluid(*sc["dim"], n + 64)
+    S.configure(r, sc, is_ref=True)
+    r.set_modes(filter="separable")
+    rec = S.run_step_recording(r)
+    for k, v in rec.items():
+        out["s0/" + k] = v
+    for step in (1, 2):
+        rec = S.run_step_recording(r)
+        out["s%d/particles" % step] = S.capture(r, "particles")
+        out["s%d/stats" % step] = np.stack([rec["solve_velocity/stats0"], rec["solve_density/stats1"]])
+        out["s%d/sha" % step] = np.array(["%s %s" % (k, sha(v)) for k, v in sorted(rec.items())])
+    # (b) the filter-dependent outputs of step 0 under the two other evaluations (Vulkan's weighted sum; 8-bit weights)
+    for flt in ("weighted", "weighted8"):
+        r = RefFluid(*sc["dim"], n + 64)
+        S.configure(r, sc, is_ref=True)
+        r.set_modes(filter=flt)
+        rec = S.run_step_recording(r)
+        out["s0_%s/advect/particles" % flt] = rec["advect/particles"]
+        out["s0_%s/correct/particles_pos" % flt] = rec["correct/particles_pos"]
+    np.savez_compressed(os.path.join(HERE, "ref_step_64x16x32.npz"), **out)
+
+
+PCG_CASES = [("zero", 0, True), ("zero", 1, True), ("zero", 4, True), ("zero", 7, True), ("zero", 8, True), ("zero", 8, False), ("zero", 32, True),
+             ("lod0", 1, True), ("lod0", 8, True)]
+PCG_FULL = {("zero", 4, True), ("zero", 8, True), ("zero", 32, True), ("lod0", 8, True)}
+
+
+def pcg_fixture():
+    prob = S.pcg_problem(seed=7, dim=S.PCG_DIM)
+    out = dict(provenance(), dim=prob["dim"], dt=np.float32(S.DT), marker=prob["marker"], b=prob["b"], p0=prob["p0"])
+    fluid = prob["marker"] == 1
+    cases = []
+    for precond, k, warm in PCG_CASES:
+        r = RefFluid(*prob["dim"], 8)
+        res = S.run_pcg(r, prob, k, precond, warm=warm, is_ref=True)
+        tag = "%s_k%d_%s" % (precond, k, "warm" if warm else "cold")
+        cases.append(tag)
+        out[tag + "/stats"] = res["stats"]
+        out[tag + "/sha"] = np.array([sha(res[q]) for q in ("p", "r", "s")])
+        if (precond, k, warm) in PCG_FULL:
+            for q in ("p", "r", "s"):
+                out[tag + "/" + q] = res[q][fluid]          # FLUID cells in memory order; p is 0 elsewhere (asserted by the hash)
+    # the reference's defaults on the same problem: tolerance 0.1, <= 32 iterations, check every 4
+    r = RefFluid(*prob["dim"], 8)
+    res = S.run_pcg(r, prob, 32, "zero", tol=0.1, warm=False, is_ref=True)
+    cases.append("default")
+    out["default/stats"] = res["stats"]
+    out["default/sha"] = np.array([sha(res[q]) for q in ("p", "r", "s")])
+    for q in ("p", "r", "s"):
+        out["default/" + q] = res[q][fluid]
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "ref_pcg_32x64x16.npz"), **out)
+
+
+def binning_fixture():
+    bs = S.binning_scene(seed=5, dim=S.STEP_DIM)
+    r = RefFluid(*bs["dim"], len(bs["pos"]) + 100)
+    r.set_particles(bs["pos"])
+    r.run_stage("binning", S.DT)
+    np.savez_compressed(os.path.join(HERE, "ref_binning_64x16x32.npz"), **dict(provenance(), dim=bs["dim"], pos_in=bs["pos"], max_num_particles=np.int64(len(bs["pos"]) + 100),
+                        pos_out=r.get_particles()[0], buffer_out=r.pos.copy(), counters=r.read_volume("linked_list")))
+
+
+if __name__ == "__main__":
+    if ref_fluid.build(force=True) is None:
+        sys.exit("the reference checkout is not available: cannot regenerate the reference fixtures")
+    step_fixture()
+    pcg_fixture()
+    binning_fixture()
+    for n in sorted(os.listdir(HERE)):
+        if n.startswith("ref_"):
+            print(n, os.path.getsize(os.path.join(HERE, n)))
