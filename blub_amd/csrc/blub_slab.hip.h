@@ -15,7 +15,7 @@ namespace blubk {
 
 constexpr float GHOST_MARGIN = 2.0f;   // cells; covers the 2-cell reach of the P2G stencil and of the marker logic
 
-struct SlabCounts { uint32_t n_stay, n_up, n_down, n_leave, n_holes, n_fill, pad0, pad1; };   // zeroed before every exchange
+struct SlabCounts { uint32_t n_stay, n_up, n_down, n_leave, n_holes, n_fill, pad0 /* leavers held back */, pad1; };   // zeroed before every exchange
 
 // One atomic per wave and destination instead of one per particle: every particle of a slab passes through these kernels several
 // times per step and nearly all of them go to the SAME destination (measured: 192 us for 1 M particles with per-particle atomics
@@ -71,17 +71,25 @@ __global__ __launch_bounds__(256) void k_slab_migrate_mark(uint32_t n, const flo
                                                            const float4* __restrict__ vz, float z0, float z1, uint32_t capacity, SlabCounts* __restrict__ counts,
                                                            float4* __restrict__ up_pos, float4* __restrict__ up_vx, float4* __restrict__ up_vy, float4* __restrict__ up_vz,
                                                            float4* __restrict__ dn_pos, float4* __restrict__ dn_vx, float4* __restrict__ dn_vy, float4* __restrict__ dn_vz,
-                                                           uint32_t* __restrict__ leave_idx, const uint32_t* __restrict__ n_dev) {
+                                                           uint32_t* __restrict__ leave_idx, const uint32_t* __restrict__ n_dev, uint32_t cap_up, uint32_t cap_dn,
+                                                           float4* __restrict__ pos_rw) {
+    // cap_up / cap_dn: what the MESSAGE of this exchange can carry (<= capacity, the size of the send buffers).  A leaver beyond it is
+    // HELD BACK: it stays an own particle of this slab for one more exchange, its z clamped just inside the range (round-3 ADVICE: a
+    // front reaching an interface that carried nothing last step used to lose what did not fit).  n_up / n_down keep counting what WANTED
+    // to travel, so the next exchange of this kind sizes its message for it.
     n = particle_count(n, n_dev, 1u);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) p = pos[i];
-    const bool up = live && p.z >= z1, down = live && p.z < z0;
+    bool up = live && p.z >= z1, down = live && p.z < z0;
     if (__ballot(up || down) == 0ull) return;          // the usual case: nobody in this wave leaves
-    const uint32_t ku = wave_alloc(&counts->n_up, up), kd = wave_alloc(&counts->n_down, down), kl = wave_alloc(&counts->n_leave, up || down);
-    if (up) { if (ku < capacity) { up_pos[ku] = p; up_vx[ku] = vx[i]; up_vy[ku] = vy[i]; up_vz[ku] = vz[i]; } }
-    else if (down) { if (kd < capacity) { dn_pos[kd] = p; dn_vx[kd] = vx[i]; dn_vy[kd] = vy[i]; dn_vz[kd] = vz[i]; } }
+    const uint32_t ku = wave_alloc(&counts->n_up, up), kd = wave_alloc(&counts->n_down, down);
+    if (up && ku >= cap_up) { up = false; pos_rw[i].z = nextafterf(z1, 0.0f); atomicAdd(&counts->pad0, 1u); }
+    if (down && kd >= cap_dn) { down = false; pos_rw[i].z = z0; atomicAdd(&counts->pad0, 1u); }
+    const uint32_t kl = wave_alloc(&counts->n_leave, up || down);
+    if (up) { up_pos[ku] = p; up_vx[ku] = vx[i]; up_vy[ku] = vy[i]; up_vz[ku] = vz[i]; }
+    else if (down) { dn_pos[kd] = p; dn_vx[kd] = vx[i]; dn_vy[kd] = vy[i]; dn_vz[kd] = vz[i]; }
     if (up || down) leave_idx[kl] = i;
 }
 __global__ __launch_bounds__(256) void k_slab_migrate_match(uint32_t n, const float4* __restrict__ pos, float z0, float z1, SlabCounts* __restrict__ counts,
@@ -138,17 +146,22 @@ __global__ __launch_bounds__(256) void k_slab_insert_density_ghosts(Grid g, uint
 // two ends derive from the number that travelled over the same link in the same exchange of the PREVIOUS step (both know it: the sender
 // from its own counters, the receiver from the header it got; it reaches the host through a pinned, sequence-tagged record, never through
 // a stream synchronisation) and carries the actual count in a 16-byte header in front of the position payload.  The receiver appends what
-// arrived behind its own particles with a kernel that reads both counts on the device.  A count beyond the capacity is flagged (the next
-// exchange returns an error): the capacity is 1.5 x the previous count + 2048.
+// arrived behind its own particles with a kernel that reads both counts on the device.  The capacity is 1.5 x the previous count + 2048;
+// what does not fit is HELD BACK at the sender for one exchange (migration) or left out for one step (ghost copies) and counted
+// (blub_slab_group_held_back); only the particle capacity of a slab itself is a hard limit (error at the next exchange).
 struct SlabXferRecord { uint32_t seq, n_up, n_down, from_below, from_above, overflow, n_own, n_ghost; };   // pinned host ring entry
 // after the select / migrate kernels: headers of the two outgoing messages, the new own count of a migration, overflow of the send buffers
 __global__ void k_slab_finish_send(const SlabCounts* __restrict__ counts, float4* __restrict__ hdr_up, float4* __restrict__ hdr_dn, uint32_t cap_up, uint32_t cap_dn,
                                    uint32_t* __restrict__ n_dev, int migrate) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // the header carries what actually travels; what did not fit was held back (migration) or is left out for this step (ghost copies:
+    // the receiver's gathers next to the interface then miss contributions for ONE step) -- counted in n_dev[3], never an error
     const uint32_t nu = counts->n_up, nd = counts->n_down;
-    if (hdr_up) *hdr_up = make_float4(__uint_as_float(nu), 0.f, 0.f, 0.f);
-    if (hdr_dn) *hdr_dn = make_float4(__uint_as_float(nd), 0.f, 0.f, 0.f);
-    if (nu > cap_up || nd > cap_dn) n_dev[2] = 1u;
+    // header = {what travels, what wanted to}: both ends size the NEXT message of this link from the second word, so they agree
+    if (hdr_up) *hdr_up = make_float4(__uint_as_float(min(nu, cap_up)), __uint_as_float(nu), 0.f, 0.f);
+    if (hdr_dn) *hdr_dn = make_float4(__uint_as_float(min(nd, cap_dn)), __uint_as_float(nd), 0.f, 0.f);
+    if (nu > cap_up) n_dev[3] += nu - cap_up;
+    if (nd > cap_dn) n_dev[3] += nd - cap_dn;
     if (migrate) { n_dev[0] = counts->n_stay; n_dev[1] = 0u; }
 }
 // after the transport: append the arrivals (headers + payloads in the staging buffers) behind the own particles, publish counts + record
@@ -156,6 +169,7 @@ struct SlabAppendArgs { const float4* below[4]; const float4* above[4]; float4* 
 __global__ __launch_bounds__(256) void k_slab_append(SlabAppendArgs a, int narr, uint32_t cap_below, uint32_t cap_above, uint32_t capacity, uint32_t* __restrict__ n_dev, int migrate,
                                                      const SlabCounts* __restrict__ counts, SlabXferRecord* __restrict__ record, uint32_t seq, uint32_t* __restrict__ done_blocks) {
     uint32_t cb = a.below[0] ? __float_as_uint(a.below[0][0].x) : 0u, ca = a.above[0] ? __float_as_uint(a.above[0][0].x) : 0u;
+    const uint32_t want_b = a.below[0] ? __float_as_uint(a.below[0][0].y) : 0u, want_a = a.above[0] ? __float_as_uint(a.above[0][0].y) : 0u;
     const uint32_t own = n_dev[0];
     bool over = cb > cap_below || ca > cap_above || (uint64_t)own + cb + ca > capacity;
     if (over) { cb = min(cb, cap_below); ca = min(ca, cap_above); if ((uint64_t)own + cb + ca > capacity) { cb = 0; ca = 0; } }
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256) void k_slab_append(SlabAppendArgs a, int narr,
             *done_blocks = 0u;
             if (over) n_dev[2] = 1u;
             if (migrate) { n_dev[0] = own + cb + ca; n_dev[1] = 0u; } else n_dev[1] = cb + ca;
-            record->n_up = counts->n_up; record->n_down = counts->n_down; record->from_below = cb; record->from_above = ca;
+            record->n_up = counts->n_up; record->n_down = counts->n_down; record->from_below = want_b; record->from_above = want_a;
             record->overflow = n_dev[2]; record->n_own = n_dev[0]; record->n_ghost = n_dev[1];
             __threadfence_system();
             record->seq = seq;

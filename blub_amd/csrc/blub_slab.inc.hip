@@ -199,7 +199,7 @@ static int slab_exchange_particles(blub_slab_group* G, int kind) {
         if (mode == XFER_MIGRATE) {
             hipLaunchKernelGGL(blubk::k_slab_migrate_mark, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
                                (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.up[0], e.up[1], e.up[2], e.up[3], e.dn[0], e.dn[1], e.dn[2], e.dn[3], e.leave_idx,
-                               (const uint32_t*)nullptr);
+                               (const uint32_t*)nullptr, G->capacity, G->capacity, h->pos);
             // (grids cover the worst case -- every particle leaves --; blocks beyond the device-side counts exit at once)
             hipLaunchKernelGGL(blubk::k_slab_migrate_match, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (float)h->slab_z0, (float)h->slab_z1, e.counts,
                                (const uint32_t*)e.leave_idx, e.hole_idx, e.fill_idx, (const uint32_t*)nullptr);
@@ -303,7 +303,7 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
                 if (++spins > 2000) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
                 if (spins > 50000000u) return set_error(BLUB_ERR_DEVICE, "timed out waiting for the record of the previous particle exchange");
             }
-            if (r->overflow) return set_error(BLUB_ERR_OUT_OF_MEMORY, "a slab particle exchange exceeded its message capacity or the particle capacity of a slab (the counts grew by more than 1.5x + 2048 within one step)");
+            if (r->overflow) return set_error(BLUB_ERR_OUT_OF_MEMORY, "the particle capacity of a slab was exceeded by a particle exchange (max_num_particles is per slab)");
             H.n_up = r->n_up; H.n_down = r->n_down; H.from_below = r->from_below; H.from_above = r->from_above; H.pending = false;
         }
         cap_up[i] = has_up(G, i) ? slab_capx(G, H.n_up) : 0u; cap_dn[i] = has_down(G, i) ? slab_capx(G, H.n_down) : 0u;
@@ -320,7 +320,7 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
         if (migrate) {
             hipLaunchKernelGGL(blubk::k_slab_migrate_mark, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
                                (const float4*)h->pvel[2], (float)h->slab_z0, (float)h->slab_z1, G->capacity, e.counts, e.up[0], e.up[1], e.up[2], e.up[3],
-                               e.dn[0], e.dn[1], e.dn[2], e.dn[3], e.leave_idx, nd);
+                               e.dn[0], e.dn[1], e.dn[2], e.dn[3], e.leave_idx, nd, cap_up[i], cap_dn[i], h->pos);
             hipLaunchKernelGGL(blubk::k_slab_migrate_match, dim3(particle_blocks(n)), dim3(256), 0, G->stream, n, (const float4*)h->pos, (float)h->slab_z0, (float)h->slab_z1, e.counts,
                                (const uint32_t*)e.leave_idx, e.hole_idx, e.fill_idx, nd);
             hipLaunchKernelGGL(blubk::k_slab_migrate_fill, dim3(particle_blocks(n)), dim3(256), 0, G->stream, (const blubk::SlabCounts*)e.counts, (const uint32_t*)e.hole_idx,
@@ -387,7 +387,7 @@ static int slab_refresh_counts(blub_slab_group* G) {
     for (size_t i = 0; i < G->slabs.size(); ++i) {
         uint32_t v[3] = {0, 0, 0};
         HIP_TRY(hipMemcpy(v, G->slabs[i]->n_dev, sizeof v, hipMemcpyDeviceToHost));
-        if (v[2]) return set_error(BLUB_ERR_OUT_OF_MEMORY, "a slab particle exchange exceeded its message capacity or the particle capacity of a slab");
+        if (v[2]) return set_error(BLUB_ERR_OUT_OF_MEMORY, "the particle capacity of a slab was exceeded by a particle exchange (max_num_particles is per slab)");
         G->slabs[i]->num_particles = v[0]; G->slabs[i]->num_ghost = v[1];
     }
     return BLUB_OK;
@@ -595,17 +595,23 @@ static int slab_drop_ghosts(blub_slab_group* G) {
     return BLUB_OK;
 }
 
-// HybridFluid::step (hybrid_fluid.rs:770-977) over all slabs in lock step
-static int slab_step(blub_slab_group* G, float dt) {
+// HybridFluid::step (hybrid_fluid.rs:770-977) over all slabs in lock step.  The step is cut into the segments below so that a test can
+// stop between them and look at every slab (blub_slab_group_run_stages); blub_slab_group_step runs all of them.
+enum SlabStage { SS_GHOSTS = 0, SS_TRANSFER, SS_DIVERGENCE, SS_SOLVE_VELOCITY, SS_BINNING, SS_PROJECT, SS_ADVECT, SS_MIGRATE, SS_DENSITY_GATHER,
+                 SS_SOLVE_DENSITY, SS_POSITION_CHANGE, SS_CORRECT, SS_MIGRATE_B, SS_FINISH, SS_COUNT };
+static int slab_step(blub_slab_group* G, float dt, int first = 0, int last = SS_FINISH) {
     int rc;
     const int S = (int)G->slabs.size();
+    blub_fluid* h0 = G->slabs[0];
 #define FOR_SLABS(call) for (int i = 0; i < S; ++i) { blub_fluid* h = G->slabs[i]; (void)h; if ((rc = (call)) != BLUB_OK) return rc; }
+#define RUNS(stage) (first <= (stage) && (stage) <= last)
     // The particle exchanges run without host synchronisation once every exchange kind has a history to size its messages from (i.e. from
     // the second step after the particles were set); all ranks take the same decision (they step in lock step).
     bool async = G->async_exchange;
     for (auto& H : G->hist) async = async && H.valid;
     auto exchange = [&](int kind) { return async ? slab_exchange_particles_async(G, kind) : slab_exchange_particles(G, kind); };
-    {   // size of this step's PCG grids: every slab contributes the newest fluid-brick count it has (a lagged, non-blocking snapshot) and
+    if (RUNS(SS_GHOSTS)) {
+        // size of this step's PCG grids: every slab contributes the newest fluid-brick count it has (a lagged, non-blocking snapshot) and
         // all of them use the same grid, from the largest count (one 4-byte gather per step).  The gathered values reach the host through a
         // pinned, tagged record and are used by the NEXT step (asynchronous path) / after the sync of the exchange below (synchronous path)
         if (async && G->cnt_pending) {
@@ -629,53 +635,61 @@ static int slab_step(blub_slab_group* G, float dt) {
             G->cnt_pending = false;
             HIP_TRY(hipMemcpyAsync(G->cnt_host, G->ex[0].gat_cnt, (size_t)G->nranks * sizeof(float), hipMemcpyDeviceToHost, G->stream));
         }
-    }
-    if ((rc = exchange(XFER_GHOST_FULL)) != BLUB_OK) return rc;
-    {
+        if ((rc = exchange(XFER_GHOST_FULL)) != BLUB_OK) return rc;
         float mx = 0.0f; bool all_known = true;
         for (int k = 0; k < G->nranks; ++k) { mx = std::max(mx, G->cnt_host[k]); all_known = all_known && G->cnt_host[k] > 0.0f; }
         int np = SLAB_NP_DEFAULT;
         if (all_known) np = (int)(mx * 9.0f / 8.0f / (float)PCG_BPB) + 8;
         G->np_cur = std::max(128, std::min(SLAB_NP_MAX, (np + 7) & ~7));
     }
-    FOR_SLABS(stage_transfer(h, dt))
-    if ((rc = slab_drop_ghosts(G)) != BLUB_OK) return rc;   // the velocity ghosts are only needed by the P2G gather
-    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
-    FOR_SLABS(stage_divergence(h))
-    if ((rc = slab_solve(G, 0, dt)) != BLUB_OK) return rc;
-    blub_fluid* h0 = G->slabs[0];
-    if (h0->rebin_freq != 0 && h0->step_counter % h0->rebin_freq == 0) FOR_SLABS(stage_binning(h))
-    for (int i = 0; i < S; ++i) {
-        blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
-               (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
+    if (RUNS(SS_TRANSFER)) {
+        FOR_SLABS(stage_transfer(h, dt))
+        if ((rc = slab_drop_ghosts(G)) != BLUB_OK) return rc;   // the velocity ghosts are only needed by the P2G gather
+        if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
     }
-    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
-    FOR_SLABS(stage_extrapolate(h))
-    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
-    FOR_SLABS(stage_advect_particles(h, dt, false))
-    if ((rc = exchange(XFER_MIGRATE)) != BLUB_OK) return rc;
-    if ((rc = exchange(XFER_GHOST_POS)) != BLUB_OK) return rc;
-    for (int i = 0; i < S; ++i) {   // marker + density list for own and ghost particles (advect_particles.comp:176-181)
-        blub_fluid* h = G->slabs[i];
-        const uint32_t n = h->num_particles + h->num_ghost;
-        if (n) hipLaunchKernelGGL(k_slab_insert_density_ghosts, dim3(particle_blocks(n)), dim3(256), 0, G->stream, h->g, 0u, n, h->pos, h->marker, h->ll[0], (const uint32_t*)h->n_dev);
+    if (RUNS(SS_DIVERGENCE)) FOR_SLABS(stage_divergence(h))
+    if (RUNS(SS_SOLVE_VELOCITY) && (rc = slab_solve(G, 0, dt)) != BLUB_OK) return rc;
+    if (RUNS(SS_BINNING) && h0->rebin_freq != 0 && h0->step_counter % h0->rebin_freq == 0) FOR_SLABS(stage_binning(h))
+    if (RUNS(SS_PROJECT)) {
+        for (int i = 0; i < S; ++i) {
+            blub_fluid* h = G->slabs[i];
+            LAUNCH(h, KC_DIVERGENCE_REMOVE, k_divergence_remove_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+                   (const float*)h->pressure[0], (const float4*)h->solid, h->vel[0], h->vel[1], h->vel[2]);
+        }
+        if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+        FOR_SLABS(stage_extrapolate(h))
+        if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
     }
-    FOR_SLABS(build_lists_from_particles(h, COMPACT_STEP_B))
-    FOR_SLABS(stage_density_gather(h, dt))
-    if ((rc = slab_drop_ghosts(G)) != BLUB_OK) return rc;
-    if ((rc = slab_solve(G, 1, dt)) != BLUB_OK) return rc;
-    for (int i = 0; i < S; ++i) {
-        blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
-               (const float*)h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
+    if (RUNS(SS_ADVECT)) FOR_SLABS(stage_advect_particles(h, dt, false))
+    if (RUNS(SS_MIGRATE)) {
+        if ((rc = exchange(XFER_MIGRATE)) != BLUB_OK) return rc;
+        if ((rc = exchange(XFER_GHOST_POS)) != BLUB_OK) return rc;
+        for (int i = 0; i < S; ++i) {   // marker + density list for own and ghost particles (advect_particles.comp:176-181)
+            blub_fluid* h = G->slabs[i];
+            const uint32_t n = h->num_particles + h->num_ghost;
+            if (n) hipLaunchKernelGGL(k_slab_insert_density_ghosts, dim3(particle_blocks(n)), dim3(256), 0, G->stream, h->g, 0u, n, h->pos, h->marker, h->ll[0], (const uint32_t*)h->n_dev);
+        }
+        FOR_SLABS(build_lists_from_particles(h, COMPACT_STEP_B))
     }
-    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
-    FOR_SLABS(stage_extrapolate(h))
-    if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
-    FOR_SLABS(stage_correct(h))
-    if ((rc = exchange(XFER_MIGRATE_B)) != BLUB_OK) return rc;
-    for (int i = 0; i < S; ++i) { G->slabs[i]->step_counter += 1; (void)poll_stats(G->slabs[i], false); }
+    if (RUNS(SS_DENSITY_GATHER)) {
+        FOR_SLABS(stage_density_gather(h, dt))
+        if ((rc = slab_drop_ghosts(G)) != BLUB_OK) return rc;
+    }
+    if (RUNS(SS_SOLVE_DENSITY) && (rc = slab_solve(G, 1, dt)) != BLUB_OK) return rc;
+    if (RUNS(SS_POSITION_CHANGE)) {
+        for (int i = 0; i < S; ++i) {
+            blub_fluid* h = G->slabs[i];
+            LAUNCH(h, KC_POSITION_CHANGE, k_position_change_b, dim3(list_grids(h).active), dim3(BRICK_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker,
+                   (const float*)h->pressure[1], dt, h->vel[0], h->vel[1], h->vel[2]);
+        }
+        if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+        FOR_SLABS(stage_extrapolate(h))
+        if ((rc = slab_halo_velocity(G)) != BLUB_OK) return rc;
+    }
+    if (RUNS(SS_CORRECT)) FOR_SLABS(stage_correct(h))
+    if (RUNS(SS_MIGRATE_B) && (rc = exchange(XFER_MIGRATE_B)) != BLUB_OK) return rc;
+    if (RUNS(SS_FINISH)) for (int i = 0; i < S; ++i) { G->slabs[i]->step_counter += 1; (void)poll_stats(G->slabs[i], false); }
+#undef RUNS
 #undef FOR_SLABS
     return check_launch(h0);
 }
@@ -952,11 +966,38 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     }
     return rc;
 }
+// TEST HOOK: segments [first, last] of one step (0 ghost exchange, 1 transfer, 2 divergence, 3 solve_velocity, 4 binning, 5 project,
+// 6 advect, 7 migration + density ghosts, 8 density_gather, 9 solve_density, 10 position_change, 11 correct, 12 second migration,
+// 13 step counter), so that every slab can be inspected between them.  All ranks must pass the same range.
+int blub_slab_group_run_stages(blub_slab_group* g, float dt, int first, int last) {
+    if (!g || first < 0 || last >= blub::SS_COUNT || first > last) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
+    return blub::slab_step(g, dt, first, last);
+}
 uint64_t blub_slab_group_transport_ops(const blub_slab_group* g) { return g ? g->comm_ops : 0; }
 int blub_slab_group_set_async_exchange(blub_slab_group* g, int enabled) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    if (g->async_exchange && !enabled) {
+        // after asynchronous steps the host-side particle counts are only BOUNDS (the counts live in n_dev) and the synchronous
+        // protocol takes them as exact: fetch them, and forget the message-size history (round-3 ADVICE)
+        if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+        int rc = blub::slab_refresh_counts(g);
+        if (rc != BLUB_OK) return rc;
+        for (auto& H : g->hist) H = blub_slab_group::Hist();
+        g->cnt_pending = false;
+    }
     g->async_exchange = enabled != 0;
     return BLUB_OK;
+}
+// Particles a migration held back at their sender for one exchange + ghost copies left out for one step because a message was sized
+// (from the previous step's count) too small; summed over the local slabs since creation.  Blocks (the counters live on the device).
+uint64_t blub_slab_group_held_back(blub_slab_group* g) {
+    uint64_t n = 0;
+    if (!g || hipSetDevice(g->device) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) return 0;
+    for (auto h : g->slabs) { uint32_t v = 0; if (hipMemcpy(&v, h->n_dev + 3, sizeof v, hipMemcpyDeviceToHost) == hipSuccess) n += v; }
+    return n;
 }
 int blub_slab_group_host_syncs(const blub_slab_group* g, uint64_t* particle_exchanges, uint64_t* done_polls) {
     if (!g || !particle_exchanges || !done_polls) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");

@@ -628,6 +628,8 @@ class SlabGroup:
                 ("blub_slab_group_set_pcg_schedule", C.c_int, [vp, C.c_int]), ("blub_slab_group_set_gather_mode", C.c_int, [vp, C.c_int]),
                 ("blub_slab_group_set_async_exchange", C.c_int, [vp, C.c_int]),
                 ("blub_slab_group_host_syncs", C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+                ("blub_slab_group_held_back", C.c_uint64, [vp]),
+                ("blub_slab_group_run_stages", C.c_int, [vp, C.c_float, C.c_int, C.c_int]),
                 ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
                 ("blub_slab_group_transport_ops", C.c_uint64, [vp]), ("blub_slab_group_transport_description", C.c_char_p, [vp]),
                 ("blub_slab_group_set_meshes", C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
@@ -739,6 +741,18 @@ class SlabGroup:
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(self._L, self._L.blub_slab_group_host_syncs(self._g, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    SLAB_STAGES = {"ghosts": 0, "transfer": 1, "divergence": 2, "solve_velocity": 3, "binning": 4, "project": 5, "advect": 6, "migrate": 7,
+                   "density_gather": 8, "solve_density": 9, "position_change": 10, "correct": 11, "migrate_b": 12, "finish": 13}
+
+    def run_stages(self, simulation_delta, first, last):
+        """TEST HOOK (include/blubhip.h: blub_slab_group_run_stages): segments first..last (names of SLAB_STAGES) of one step."""
+        _check(self._L, self._L.blub_slab_group_run_stages(self._g, float(simulation_delta), self.SLAB_STAGES[first], self.SLAB_STAGES[last]))
+
+    def held_back(self):
+        """Particles a migration held back for one exchange + ghost copies left out for one step because a message was sized too
+        small from the previous step's count (include/blubhip.h: blub_slab_group_held_back); blocks."""
+        return int(self._L.blub_slab_group_held_back(self._g))
 
     def set_gather_mode(self, mode):
         """RCCL transport of the PCG partials: "p2p" (grouped send/recv fused with the halo) | "allgather"; all ranks must agree."""

@@ -375,6 +375,16 @@ int blub_slab_group_voxelize(blub_slab_group* g, uint32_t num_meshes, const blub
 int blub_slab_group_set_async_exchange(blub_slab_group* g, int enabled);
 /* diagnostics: stream synchronisations issued inside blub_slab_group_step so far -- by particle exchanges / by looks at a solve's `done` */
 int blub_slab_group_host_syncs(const blub_slab_group* g, uint64_t* particle_exchanges, uint64_t* done_polls);
+/* Particles a migration HELD BACK at their sender for one exchange, plus ghost copies left out for one step, because a message of the
+ * host-synchronisation-free exchange was sized too small from the previous step's count (a front reaching an interface that carried
+ * nothing before).  Nothing is lost: a held-back particle stays an own particle of its slab, clamped just inside the range, and travels
+ * with the next exchange (whose message is sized for it).  Sum over the local slabs since creation; blocks. */
+uint64_t blub_slab_group_held_back(blub_slab_group* g);
+/* TEST HOOK: runs segments [first, last] of ONE step so that a test can look at every slab in between: 0 ghost-particle exchange,
+ * 1 transfer, 2 divergence, 3 solve_velocity, 4 binning, 5 project (+ extrapolation), 6 advect, 7 migration + density ghosts,
+ * 8 density_gather, 9 solve_density, 10 position_change (+ extrapolation), 11 correct, 12 second migration, 13 step counter.
+ * blub_slab_group_step == run_stages(0, 13).  All ranks must pass the same range. */
+int blub_slab_group_run_stages(blub_slab_group* g, float simulation_delta, int first, int last);
 int blub_slab_group_step(blub_slab_group* g, float simulation_delta_seconds);
 int blub_slab_group_synchronize(blub_slab_group* g);
 /* diagnostics: grouped transport operations (halo / partial / particle exchanges) issued by this process so far */

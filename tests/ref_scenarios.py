@@ -34,7 +34,11 @@ def step_scene(seed=2024, dim=STEP_DIM, solids=True):
     rng = np.random.default_rng(seed)
     nx, ny, nz = dim
     cells = np.stack(np.meshgrid(np.arange(1, 13), np.arange(1, 11), np.arange(4, 17), indexing="ij"), -1).reshape(-1, 3)
-    pos = (cells[:, None, :] + rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
+    # 8 particles per cell, one per half-cell stratum like add_fluid_cube (hybrid_fluid.rs:648-671): every staggered dual cell then holds
+    # exactly 8 of them, below the 12-entry cap of the P2G walk (transfer_gather_velocity.comp:61) -- WHICH particles a longer list
+    # keeps is the order of atomics, a race in the reference, and nothing an engine could be compared on
+    sub = np.stack(np.meshgrid([0, 1], [0, 1], [0, 1], indexing="ij"), -1).reshape(-1, 3)
+    pos = (cells[:, None, :] + 0.5 * sub[None, :, :] + 0.5 * rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
     pos = np.clip(pos, 1.001, np.array(dim, np.float32) - 1.001).astype(np.float32)
     vel = []
     for c in range(3):
@@ -108,6 +112,7 @@ def pcg_problem(seed=7, dim=PCG_DIM):
     marker[z0 + 1, 3, 11] = 1                                       # a FLUID cell walled in on all six sides: d = 0
     marker[z0, 3, 12] = 1; marker[z0 - 1, 3, 12] = -1               # one with a single opening: d = 1
     b = np.where(marker == 1, rng.standard_normal(shape), 0).astype(np.float32)
+    b[z0 + 1, 3, 11] = 0      # (A has a zero row there: any other right-hand side is inconsistent and CG diverges -- D1 itself gives 0 for such a cell)
     p0 = (rng.standard_normal(shape) * 0.3).astype(np.float32)       # also non-zero outside the fluid: S0 must clear it
     return dict(dim=np.array(dim), marker=marker, b=b, p0=p0)
 

@@ -357,3 +357,70 @@ def test_dense_z_mapping_matches_the_oracle_at_128_cubed(iters):
         assert ih == io == iters and abs(eh - eo) <= 1e-4 * abs(eo), ((eh, ih), (eo, io))
     finally:
         h.close()
+
+
+def _divergence_d1(marker, vx, vy, vz):
+    """divergence_compute.comp:59-84 on FLUID cells, vectorised, without moving solids (none of the BASELINE scenes has any): the flux of the
+    face velocities, where a face shared with a SOLID cell contributes nothing (v_wall - (v_wall - v_solid) with v_solid = 0).  Summation in
+    the shader's order, in f32."""
+    m = np.pad(marker, 1, constant_values=0)
+    pad = lambda a: np.pad(a, 1)
+    X, Y, Z = pad(vx), pad(vy), pad(vz)
+    c = (slice(1, -1),) * 3
+    sh = lambda a, dz, dy, dx: a[1 + dz:a.shape[0] - 1 + dz, 1 + dy:a.shape[1] - 1 + dy, 1 + dx:a.shape[2] - 1 + dx]
+    px, py, pz = X[c], Y[c], Z[c]
+    qx, qy, qz = sh(X, 0, 0, -1), sh(Y, 0, -1, 0), sh(Z, -1, 0, 0)
+    div = (px - qx).astype(np.float32)
+    div = div + (py - qy)
+    div = div + (pz - qz)
+    zero = np.float32(0)
+    div = div + np.where(sh(m, 0, 0, -1) == 0, qx, zero)
+    div = div + np.where(sh(m, 0, -1, 0) == 0, qy, zero)
+    div = div + np.where(sh(m, -1, 0, 0) == 0, qz, zero)
+    div = div - np.where(sh(m, 0, 0, 1) == 0, px, zero)
+    div = div - np.where(sh(m, 0, 1, 0) == 0, py, zero)
+    div = div - np.where(sh(m, 1, 0, 0) == 0, pz, zero)
+    return np.where(marker == 1, div, zero).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["corner_dams_256", "dam_halfhalf", "double_dam"])
+def test_divergence_left_after_the_pressure_projection_is_the_reported_residual(name):
+    """north_star's parity quantity as SURVEY 8c(ii) defines it, on the GPU: D1's formula (divergence_compute.comp:59-84) applied to the
+    ENGINE's velocity volumes right after D2 (divergence_remove.comp), max|.| over FLUID cells -- held against (a) the engine's own
+    statistic max|r| * dt of the solve that produced the pressure (in exact arithmetic they are the same number: r = b - A p), (b) the
+    engine's residual volume cell by cell, (c) the same quantity of the oracle stepping the same particles."""
+    scene, h, o = _pair_from_scene(name, binning="off")
+    try:
+        h.particle_rebinning_step_frequency = 0
+        for step in range(2):
+            for st in ("transfer", "divergence", "solve_velocity", "project"):
+                h.run_stage(st, util.DT)
+                o.run_stage(st, util.DT)
+            e_h, it_h = h.solver_stats(0)
+            e_o, it_o = o.solver_stats(0)
+            marker = h.read_volume("marker")
+            fluid = marker == 1
+            div = _divergence_d1(marker, h.read_volume("vel_x"), h.read_volume("vel_y"), h.read_volume("vel_z"))
+            r = np.where(fluid, h.read_volume("residual"), 0).astype(np.float32)
+            scale = max(1.0, float(np.abs(h.read_volume("vel_y")).max()))
+            # (b) the recurrence's residual IS the divergence that is left, cell by cell (rounding of ~32 updates of values of size `scale`)
+            assert np.abs(div - r).max() <= 2e-4 * scale, (np.abs(div - r).max(), scale)
+            # (a) and its max-norm is what the solver reports
+            dmax = float(np.abs(div).max()) * util.DT
+            assert abs(dmax - e_h) <= 2e-4 * scale * util.DT + 1e-3 * e_h, (dmax, e_h)
+            # (c) the oracle's velocity field after ITS projection, same formula
+            div_o = _divergence_d1(o.read_volume("marker"), o.read_volume("vel_x"), o.read_volume("vel_y"), o.read_volume("vel_z"))
+            dmax_o = float(np.abs(div_o).max()) * util.DT
+            print("%s step %d: max|div| dt after D2: engine %.4g (reports %.4g after %d iterations), oracle %.4g (reports %.4g after %d)" % (name, step, dmax, e_h, it_h, dmax_o, e_o, it_o))
+            assert abs(dmax_o - e_o) <= 2e-4 * scale * util.DT + 1e-3 * e_o
+            if step == 0:
+                assert it_h == it_o and abs(dmax - dmax_o) <= 0.02 * dmax_o, ((dmax, it_h), (dmax_o, it_o))
+            else:   # free-running: the envelope of tests above (an unconverged CG amplifies the rounding of its dots)
+                assert abs(it_h - it_o) <= 4 and 0.4 < dmax / dmax_o < 2.5
+            for st in ("advect", "density_gather", "solve_density", "position_change", "correct"):
+                h.run_stage(st, util.DT)
+                o.run_stage(st, util.DT)
+            h.step_counter = step + 1
+            o.step_counter = step + 1
+    finally:
+        h.close()

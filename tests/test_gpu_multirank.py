@@ -47,10 +47,10 @@ def _launch(mode, world, workdir, schedule="reference", gather="calibrated", tim
 
 
 @pytest.mark.parametrize("world,schedule,gather", [(2, "reference", "calibrated"), (2, "single_reduction", "p2p"), (2, "single_reduction", "allgather"),
-                                                   (4, "reference", "p2p"), (4, "single_reduction", "calibrated")])
+                                                   (4, "reference", "p2p"), (4, "single_reduction", "calibrated"), (8, "single_reduction", "p2p")])
 def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedule, gather, tmp_path):
     import blub_amd
-    rcs, outs = _launch("compare", world, tmp_path, schedule, gather)
+    rcs, outs = _launch("compare", world, tmp_path, schedule, gather, timeout=300 if world < 8 else 900)
     assert all(rc == 0 for rc in rcs), "\n".join(outs)
     ranks = [np.load(os.path.join(tmp_path, "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
     assert all(str(d["status"]) == "ok" for d in ranks), [str(d["status"]) for d in ranks]
@@ -131,3 +131,22 @@ def test_bench_gpus_2_runs_the_slab_path(tmp_path):
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] is not None and d["value"] > 0, d
     assert "rccl, 2 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
+
+
+def test_bench_gpus_8_weak_scaling_runs_the_slab_path(tmp_path):
+    """`bench.py --gpus 8 --scaling weak` as the driver would launch it on an 8-GPU node: eight ranks, eight slabs (corner_dams_128 stacked
+    eight times along z), here all on one GPU with the data plane through the preloaded stand-in.  The line must be the z-slab line."""
+    import json
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = _fake_rccl()
+    env["FAKE_RCCL_DIR"] = str(tmp_path)
+    env["BLUB_BENCH_BACKEND"] = "gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29523",
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--scene", "corner_dams_128", "--scaling", "weak", "--no-dense-pcg"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert res.returncode == 0 and lines, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] is not None and d["value"] > 0, d
+    assert "8 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
