@@ -166,11 +166,13 @@ def transfer_microbenchmark(n=256, seed=1234):
     return out
 
 
-def cpu_baseline(scene_path, dt, budget_steps=24):
-    """The CPU oracle (a restatement of the reference, kind "port") on the same scene: a bounded sample of whole steps
-    (~10 s of CPU work on the 16 usable cores of the GPU box)."""
+def cpu_baseline(scene_path, dt, steps=12, budget_s=25.0):
+    """The CPU oracle (a restatement of the reference, kind "port": pinned bit for bit against the reference's own shaders,
+    tests/test_oracle_vs_ref.py) on the same scene, timed as SURVEY 8(d) prescribes: two warm-up steps (the first holds the step-0
+    rebinning), then every step timed by itself with a steady clock, value = 1 / median over >= 10 steps (fewer only if the wall-clock
+    budget runs out first); all usable cores (OpenMP), nproc and the thread count recorded."""
     import blub_amd
-    from oracle.oracle import Oracle
+    from oracle.oracle import Oracle, num_threads
     sc = blub_amd.Scene.parse(path=scene_path).config
     dim = list(sc.grid_dimension)
     o = Oracle(dim[0], dim[1], dim[2], sc.max_num_particles)
@@ -178,18 +180,22 @@ def cpu_baseline(scene_path, dt, budget_steps=24):
     for i in range(sc.num_fluid_cubes):
         o.add_fluid_cube(np.float32(list(sc.cube_min[i])) / scale, np.float32(list(sc.cube_max[i])) / scale)
     o.set_gravity_grid(np.float32(list(sc.gravity)) / scale)
-    o.step(dt)   # warm-up (includes the step-0 rebinning)
-    t0 = time.perf_counter()
-    it0, s0 = o.solver_totals()
-    for _ in range(budget_steps):
+    for _ in range(2):
         o.step(dt)
-    el = time.perf_counter() - t0
+    it0, s0 = o.solver_totals()
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < steps and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        o.step(dt)
+        times.append(time.perf_counter() - t0)
     it1, s1 = o.solver_totals()
-    from oracle.oracle import num_threads
     threads = num_threads()
-    return {"value": round(budget_steps / el, 4), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "%d steps of the same scene after 1 warm-up step (oracle/libbluboracle.so, OpenMP, %d threads)" % (budget_steps, threads),
-            "pcg_iters_per_sec": round((it1 - it0) / max(s1 - s0, 1e-9), 2)}
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(),
+            "sample": "median of %d individually timed steps of the same scene after 2 warm-up steps (oracle/libbluboracle.so, OpenMP, %d threads; min %.3f / max %.3f s per step)"
+                      % (len(times), threads, min(times), max(times)),
+            "mean_steps_per_s": round(len(times) / sum(times), 4), "pcg_iters_per_sec": round((it1 - it0) / max(s1 - s0, 1e-9), 2)}
 
 
 def fallback_to_replicas(reason):
@@ -261,7 +267,8 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev)
         if group is not None:
             group.set_gravity_grid(gravity)
-            group.set_pcg_schedule(args.pcg_schedule)   # (opt-in like the single-GPU headline run; every rank passes the same flag)
+            if args.pcg_schedule != "default":
+                group.set_pcg_schedule(args.pcg_schedule)   # (every rank passes the same flag; "default" = the library's own choice, no call)
             group.set_particles(pos)
         del pos
     except Exception as e:   # all ranks must take the same path
@@ -321,7 +328,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling if transport != "loopback" else args.scaling + "-emulated-on-one-gpu", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "grid": list(dim), "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
-                       "parallelism": parallelism, "pcg_schedule": args.pcg_schedule},
+                       "parallelism": parallelism, "pcg_schedule": args.pcg_schedule if args.pcg_schedule != "default" else "single_reduction (library default)"},
             "pcg_iters_per_step": round((it1 - it0) / args.steps, 2), "transport_ops_per_step": round(ops_per_step, 1),
             "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}
     dist.barrier()
@@ -348,7 +355,8 @@ def main():
     ap.add_argument("--no-dense-512", action="store_true", help="skip the 512^3 repetition of the dense PCG micro-benchmark (roofline_512)")
     ap.add_argument("--no-other-schedule", action="store_true", help="skip the second window with the other PCG schedule (kernel traces of ONE schedule: tools/kstats.sh)")
     ap.add_argument("--tune", action="append", default=[], help="name=value for blub_fluid_set_tuning on every scene of the run (A/B measurements)")
-    ap.add_argument("--pcg-schedule", default="single_reduction", choices=["single_reduction", "reference"], help="schedule of the headline window (the other one is timed beside it)")
+    ap.add_argument("--pcg-schedule", default="default", choices=["default", "single_reduction", "reference"],
+                    help="schedule of the headline window: the LIBRARY'S default (no call at all) unless named; the other one is timed beside it")
     ap.add_argument("--no-fast-forward", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=1000000, help="steps of the instrumented pass (a fresh scene, same warm-up; default: the whole timed window; 0: skip)")
     ap.add_argument("--dense-only", action="store_true", help="only run the dense PCG micro-benchmark (tuning)")
@@ -410,16 +418,18 @@ def main():
         sc_ = blub_amd.Scene(path=scene_path, device=dev)
         fl_ = sc_.fluid()
         fl_.set_pcg_work_mapping(args.pcg_mapping)
-        fl_.set_pcg_schedule(schedule)
+        if schedule != "default":      # the headline window makes NO such call: value = what blub_fluid_create + blub_fluid_step do by themselves
+            fl_.set_pcg_schedule(schedule)
         for kv in args.tune:
             k_, v_ = kv.split("=")
             fl_.set_tuning(k_, int(v_))
         return sc_, fl_
 
-    # The library's default PCG schedule is the reference's (two global reductions per iteration, pressure_solver.rs:654-723).  The headline
-    # run OPTS IN to the single-reduction form of the same recurrence (one kernel per iteration; include/blubhip.h: blub_fluid_set_pcg_schedule)
-    # and the same window is timed again with the reference's order: both numbers are printed.
+    # The headline window runs the library exactly as blub_fluid_create leaves it (round-3 review: `value` must be what a drop-in caller gets).
+    # Since round 4 that default is the single-reduction form of the PCG recurrence (one kernel per iteration; include/blubhip.h:
+    # blub_fluid_set_pcg_schedule); the same window is timed again with the reference's literal two-reduction order: both numbers are printed.
     scene, fluid = new_scene(args.pcg_schedule)
+    headline_schedule = fluid.pcg_schedule()
     step, sync = (lambda: scene.step(dt)), fluid.synchronize
     nx, ny, nz = fluid.grid_dimension()
     N = nx * ny * nz
@@ -483,9 +493,9 @@ def main():
         return el, i1 - i0
 
     # ---- the same window with the OTHER schedule (round-2 review: the cost of the literal order of operations must be visible)
-    other = "reference" if args.pcg_schedule == "single_reduction" else "single_reduction"
+    other = "reference" if headline_schedule == "single_reduction" else "single_reduction"
     el_o, it_o = timed_window(other) if not args.no_other_schedule else (float("nan"), 0)
-    by_schedule = {args.pcg_schedule: {"steps_per_s": round(args.steps / elapsed, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2)},
+    by_schedule = {headline_schedule: {"steps_per_s": round(args.steps / elapsed, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "pcg_iters_per_step": round((it1 - it0) / args.steps, 2)},
                    other: ({"steps_per_s": round(args.steps / el_o, 3), "ms_per_step": round(el_o / args.steps * 1e3, 4), "pcg_iters_per_step": round(it_o / args.steps, 2)}
                            if not args.no_other_schedule else {"steps_per_s": None, "ms_per_step": None, "pcg_iters_per_step": None})}
 
@@ -550,7 +560,10 @@ def main():
                              "launches_per_step": round(prof[dominant]["launches"] / n_prof, 1)}
         pcg_ms = sum(prof[k]["total_ms"] for k in prof if k.startswith("pcg_"))
         breakdown = {"us_per_step": {k: round(v["total_ms"] / n_prof * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])},
-                     "sum_us_per_step": round(total_ms / n_prof * 1e3, 1), "launches_per_step": round(sum(v["launches"] for v in prof.values()) / n_prof, 1),
+                     "sum_us_per_step": round(total_ms / n_prof * 1e3, 1),
+                     "sum_note": "GPU-busy time of THIS instrumented pass (its own clock: profiled_pass_ms_per_step, always >= the sum); it is not a share of the headline "
+                                 "window's ms_per_step, which is a separate, uninstrumented pass",
+                     "busy_fraction_of_profiled_pass": round(total_ms / n_prof / (wall_p / n_prof * 1e3), 3), "launches_per_step": round(sum(v["launches"] for v in prof.values()) / n_prof, 1),
                      "profiled_pass_ms_per_step": round(wall_p / n_prof * 1e3, 4),
                      "window": "steps %d..%d of a fresh scene (the timed window) with profiling on: kernel durations from events inside the dispatches; the difference to the "
                                "pass's own ms per step is idle time between dependent launches" % (args.warmup, args.warmup + n_prof)}
@@ -562,7 +575,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.scene, "grid": [nx, ny, nz], "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4",
                    "rebinning": 60, "parallelism": "single GPU", "pcg_schedule": fluid.pcg_schedule(),
-                   "pcg_schedule_note": "opt-in: the library default is the reference's two-reduction order, timed beside it as value_reference_schedule",
+                   "pcg_schedule_note": ("the library's default: no schedule call was made" if args.pcg_schedule == "default" else "set by --pcg-schedule") +
+                                        "; the same window with the reference's literal two-reduction order is value_reference_schedule",
                    "window": "steps %d..%d of the scene after %d warm-up steps; the dams break and spread (256 -> ~1400 fluid bricks over the first 130 steps), so steps/s depends on the window: "
                              "the no-flag default (10 + 120) is the representative figure, a 5 + 20 window sees only the cheapest phase" % (args.warmup, args.warmup + args.steps, args.warmup)},
         "value_reference_schedule": by_schedule["reference"]["steps_per_s"],

@@ -135,7 +135,8 @@ struct blub_fluid {
     uint8_t* tile_flags = nullptr;
     PcgCtrl* ctrl[2] = {nullptr, nullptr};
     // single-reduction schedule (blub_pcg1.hip.h): second buffers of r / w / q (allocated on first use), float4 partials, scalars
-    int pcg_schedule = 0;            // 0 (default): the reference's two-reduction schedule, 1: one kernel per iteration on the brick mapping (opt-in: a different rounding)
+    int pcg_schedule = 1;            // 1 (default since round 4): one kernel per iteration on the brick mapping (single-reduction form of the same recurrence, include/blubhip.h);
+                                     // 0: the reference's two-reduction order (pressure_solver.rs:654-723), also taken by solves configured beyond pcg1_max_iterations
     float* cgbuf[3] = {nullptr, nullptr, nullptr};
     float4* part4 = nullptr;
     Pcg1Scalars* pcg1_scalars[2] = {nullptr, nullptr};

@@ -265,10 +265,15 @@ int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
  * two kernels per iteration), 1 = single-reduction (Chronopoulos-Gear) form of the same recurrence: ONE kernel per iteration, A d
  * carried by a recurrence.  Identical in exact arithmetic, a different rounding in f32 (not bit-comparable); convergence test,
  * check cadence and statistics are the same.  The dense-row mapping always runs schedule 0 (it is byte-, not launch-bound).
- * Default 0: the reference's order of operations.  1 is an opt-in for launch-bound scenes (bench.py opts in and reports both); its r and
- * q = A d are carried by recurrences, so over hundreds of iterations the recurrence residual drifts from b - A p by more than schedule 0's
- * (tests/test_gpu_pcg_schedule.py::test_long_solve_true_residual states the measured bound): solves configured with more than 64
- * iterations therefore run schedule 0 regardless ("pcg1_max_iterations", blub_fluid_set_tuning). */
+ * Default 1 (since round 4; rounds 1-3 shipped 0 and benchmarked 1): the step of the metric's configuration is bound by the number of
+ * dependent launches, and the reference's order costs 35 % of the steps/s there.  What the default rests on: fixed-k solves against the
+ * oracle AND against the reference's own shaders at the tolerances of schedule 0 (tests/test_gpu_pcg_schedule.py, tests/test_gpu_vs_ref.py),
+ * the same loose whole-step bound (0.15 cells), 600-step runs of dam_halfhalf and corner_dams_256 whose iteration-count and reported-error
+ * distributions match schedule 0's, and the measured gap between the carried residual and b - A p at the end of those solves
+ * (tests/test_gpu_pcg_schedule.py::test_600_steps_..., profiles/r04_schedule_longrun.json).  Its r and q = A d are carried by recurrences
+ * (no residual replacement: the gap stays at rounding level for the <= 64 iterations it is used for); solves configured with more than 64
+ * iterations run schedule 0 regardless ("pcg1_max_iterations", blub_fluid_set_tuning), as does the dense-row mapping.
+ * blub_fluid_set_pcg_schedule(h, 0) selects the reference's literal order of operations everywhere. */
 int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode);
 int blub_fluid_get_pcg_schedule(const blub_fluid* h);
 /* Performance knobs / test hooks by name (the library never reads the environment).  None changes a result beyond the rounding of a

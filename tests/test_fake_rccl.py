@@ -121,7 +121,7 @@ def _run(world, mode):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_grouped_exchange_allgather_allreduce(world):
     out = _run(world, "exchange")
     assert out == {r: "ok" for r in range(world)}, out

@@ -31,7 +31,7 @@ def _launch(mode, world, workdir, schedule="reference", gather="calibrated", tim
     env = dict(os.environ)
     env["LD_PRELOAD"] = _fake_rccl() + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
     env["FAKE_RCCL_DIR"] = str(workdir)
-    env["FAKE_RCCL_TIMEOUT_S"] = "20"
+    env["FAKE_RCCL_TIMEOUT_S"] = "20" if world < 8 else "180"      # (eight HIP contexts come up one after the other on the one GPU)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), mode, str(r), str(world), str(workdir), schedule, gather],
                               env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -141,6 +141,7 @@ def test_bench_gpus_8_weak_scaling_runs_the_slab_path(tmp_path):
     env["LD_PRELOAD"] = _fake_rccl()
     env["FAKE_RCCL_DIR"] = str(tmp_path)
     env["BLUB_BENCH_BACKEND"] = "gloo"
+    env["FAKE_RCCL_TIMEOUT_S"] = "180"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29523",
            os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--scene", "corner_dams_128", "--scaling", "weak", "--no-dense-pcg"]
