@@ -26,6 +26,8 @@ def scene():
 
 def main():
     mode, rank, world, workdir, schedule, gather = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+    steps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
+    iterations = int(sys.argv[8]) if len(sys.argv) > 8 else 0
     try:
         ctypes.CDLL(None).fake_rccl_marker
     except AttributeError:
@@ -46,6 +48,8 @@ def main():
             time.sleep(0.01)
         uid = open(uid_path, "rb").read()
     dim, pos, vel, cfg = scene()
+    if iterations:
+        cfg = dict(cfg, max_num_iterations=iterations)
     group = blub_amd.SlabGroup(dim, pos.shape[0], rank=rank, world=world, unique_id=uid, device=0, binning="off")
     out = {"description": group.transport_description(), "range": group.local_range(0)}
     try:
@@ -59,7 +63,6 @@ def main():
             group.set_solver_config(w, **cfg)
         fluid = group.local_fluid(0)
         out["count0"] = fluid.num_particles()
-        steps = 3
         for step in range(steps):
             if mode == "kill" and rank == 1 and step == 1:
                 os._exit(17)            # a rank disappears in the middle of the run

@@ -27,13 +27,17 @@ def _fake_rccl():
     return LIB
 
 
-def _launch(mode, world, workdir, schedule="reference", gather="calibrated", timeout=300):
+def _launch(mode, world, workdir, schedule="reference", gather="calibrated", timeout=300, steps=3, iterations=0):
     env = dict(os.environ)
+    if world >= 8:
+        # eight processes with the runtime's default four hardware queues each oversubscribe the GPU's queue slots and the scheduler falls
+        # back to rotating them on a timer (measured: ~1 s per grouped exchange instead of ~2 ms with four processes)
+        env["GPU_MAX_HW_QUEUES"] = "1"
     env["LD_PRELOAD"] = _fake_rccl() + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
     env["FAKE_RCCL_DIR"] = str(workdir)
     env["FAKE_RCCL_TIMEOUT_S"] = "20" if world < 8 else "180"      # (eight HIP contexts come up one after the other on the one GPU)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), mode, str(r), str(world), str(workdir), schedule, gather],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), mode, str(r), str(world), str(workdir), schedule, gather, str(steps), str(iterations)],
                               env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -50,11 +54,15 @@ def _launch(mode, world, workdir, schedule="reference", gather="calibrated", tim
                                                    (4, "reference", "p2p"), (4, "single_reduction", "calibrated"), (8, "single_reduction", "p2p")])
 def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedule, gather, tmp_path):
     import blub_amd
-    rcs, outs = _launch("compare", world, tmp_path, schedule, gather, timeout=300 if world < 8 else 900)
+    # (eight processes time-share the one GPU: two steps of 24 iterations instead of three of 120 keep the run to about a minute)
+    steps, iterations = (3, 0) if world < 8 else (2, 24)
+    rcs, outs = _launch("compare", world, tmp_path, schedule, gather, timeout=300, steps=steps, iterations=iterations)
     assert all(rc == 0 for rc in rcs), "\n".join(outs)
     ranks = [np.load(os.path.join(tmp_path, "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
     assert all(str(d["status"]) == "ok" for d in ranks), [str(d["status"]) for d in ranks]
     dim, pos, vel, cfg = scene()
+    if iterations:
+        cfg = dict(cfg, max_num_iterations=iterations)
     # every rank reports the same transport (the calibration's verdict is all-reduced) and the ranges tile the domain in rank order
     desc = [str(d["description"]) for d in ranks]
     assert all(x == desc[0] for x in desc) and ("%d ranks" % world) in desc[0], desc
@@ -62,7 +70,7 @@ def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedu
     rng_ = [tuple(int(v) for v in d["range"]) for d in ranks]
     assert rng_[0][0] == 0 and rng_[-1][1] == dim[2] and all(a[1] == b[0] for a, b in zip(rng_, rng_[1:]))
     counts0 = [int(d["count0"]) for d in ranks]
-    assert sum(counts0) == pos.shape[0] and all(c > 0 for c in counts0)
+    assert sum(counts0) == pos.shape[0] and all(c > 0 for c in counts0[1:-1])       # (with eight slabs the outermost two are empty: the blob spans z = 6 .. 42 of 48)
     single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     try:
         single.set_pcg_schedule(schedule)
@@ -71,7 +79,7 @@ def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedu
         single.set_particles(pos, *vel)
         for w in (0, 1):
             single.set_solver_config(w, **cfg)
-        for step in range(3):
+        for step in range(steps):
             single.step(util.DT)
             ps = single.get_particles()[0][:, :3].astype(np.float64)
             pg = np.concatenate([d["pos%d" % step] for d in ranks]).astype(np.float64)
@@ -82,12 +90,12 @@ def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedu
             dd = _match_particles(pg, ps)
             q = (np.median(dd), np.quantile(dd, 0.99), np.quantile(dd, 0.999), dd.max())
             print("step %d  %d processes vs single domain: median %.3g p99 %.3g p99.9 %.3g max %.3g" % ((step, world) + q))
-            bounds = (3e-5, 4e-4, 1.5e-3, 3e-3) if step == 0 else (2e-4, 3e-3, 3e-2, 0.1)     # (the loopback test's envelope)
+            bounds = (3e-5, 4e-4, 1.5e-3, 3e-3) if step == 0 and not iterations else (2e-4, 3e-3, 3e-2, 0.1)     # (the loopback test's envelope; 24 iterations stop short of convergence)
             for a, b in zip(q, bounds):
                 assert a <= b, (step, q, bounds)
             ops = [int(d["ops%d" % step]) for d in ranks]
             assert all(o == ops[0] for o in ops) and ops[0] > 0, ops      # every rank issued the same sequence of transport operations
-        assert [d["pos2"].shape[0] for d in ranks] != counts0, "no particle migrated between the processes"
+        assert [d["pos%d" % (steps - 1)].shape[0] for d in ranks] != counts0, "no particle migrated between the processes"
         # particle exchanges synchronise the host only in the first step (no history to size the messages from): 4 of them, then none
         assert all(int(d["host_syncs"][0]) == 4 for d in ranks), [d["host_syncs"] for d in ranks]
         st = [d["stats"] for d in ranks]
@@ -142,10 +150,12 @@ def test_bench_gpus_8_weak_scaling_runs_the_slab_path(tmp_path):
     env["FAKE_RCCL_DIR"] = str(tmp_path)
     env["BLUB_BENCH_BACKEND"] = "gloo"
     env["FAKE_RCCL_TIMEOUT_S"] = "180"
+    env["GPU_MAX_HW_QUEUES"] = "1"          # (see _launch)
+    env["BLUB_BENCH_SLAB_DEADLINE"] = "420"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29523",
-           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--scene", "corner_dams_128", "--scaling", "weak", "--no-dense-pcg"]
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--scene", "corner_dams_128", "--scaling", "weak", "--no-dense-pcg"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert res.returncode == 0 and lines, res.stdout[-2000:] + res.stderr[-4000:]
     d = json.loads(lines[-1])
