@@ -521,8 +521,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             if (h->use_tail && h->tail_first_forced >= 0) launched1 = std::min(maxit + 1, std::max(1, h->tail_first_forced));   // (test hook; K(0) is always launched)
             for (int i = 0; i < launched1; ++i) {
                 const float4* pin = part[i & 1]; float4* pout = part[(i + 1) & 1];
-                if (i == 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, 0, ctrl, sc, tol, 0, 0, -1, -1);
-                else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, 0, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1);
+                if (i == 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, 0, ctrl, sc, tol, 0, 0, -1, -1, SlabDirect{});
+                else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, 0, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1, SlabDirect{});
             }
             if (launched1 <= maxit) {
                 const dim3 tgrid((unsigned)std::min(np, h->tail_grid));     // (tail_grid: a multiple of 8, every block co-resident)

@@ -238,6 +238,71 @@ __device__ __forceinline__ float4 ld4o(const float* base, uint32_t byte_off) { r
 __device__ __forceinline__ float ld1o(const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); }
 __device__ __forceinline__ void st4o(float* base, uint32_t byte_off, const float4& v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 
+// ---- data another AGENT reads or writes while a kernel runs (z-slab groups, direct transport: blub_slab.hip.h) -----------------------
+// Write-through stores and cache-bypassing loads (sc0 sc1: system scope) instead of release / acquire fences, which cost a write-back +
+// invalidate of the whole L2 per workgroup (profiles/r03_tree_barrier_probe.txt: the recipe of cdna_hip_programming.md G16).  A producer
+// makes its write-through stores, waits for them (s_waitcnt vmcnt(0)), and only then raises a flag with st_sys_u32; a consumer polls the flag
+// with ld_sys_u32 and reads the payload with ld_sys_*.  Nothing else about these addresses may be cached by the consumer: it never reads
+// them with plain loads.
+typedef float blub_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sys_f4(float4* p, const float4& a) {
+    blub_v4f v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w;
+    // (s_nop: a store of more than 64 bits followed by a VALU write of its data registers needs a wait state the compiler inserts for its own
+    //  stores but not behind inline assembly -- without it lane 1 of the float4 came out overwritten by the next instruction's result)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_sys_u32(uint32_t* p, uint32_t a) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(a) : "memory"); }
+__device__ __forceinline__ float4 ld_sys_f4(const float4* p) {
+    blub_v4f v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t ld_sys_u32(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// What a kernel of one slab needs to exchange with the other slabs by itself (direct transport of a z-slab group): pointers into the
+// PEERS' memory (the same process in a loopback group, hipIpc mappings between processes) for what it produces, its own flag words for what
+// it consumes.  Flags carry the sequence number of the exchange (the host numbers them identically on every rank; >= compares).
+constexpr int SLAB_MAX_PEERS = 7;
+struct SlabDirect {
+    float* w_up; float* w_dn;                 // the z-neighbours' copies of the field whose boundary planes this launch produces (global grid coordinates); nullptr: none
+    float* p_up; float* p_dn;                 // ... and of the pressure field
+    float4* part_out[SLAB_MAX_PEERS];         // my segment of every other slab's partial array (this launch's parity)
+    uint32_t* flag_out[SLAB_MAX_PEERS];       // every other slab's flag word for messages from me
+    const uint32_t* flags_in;                 // my flag words, one per source rank
+    uint32_t* blocks_done;                    // my counter of finished workgroups (last one raises the flags and resets it)
+    uint32_t* error;                          // set when a wait timed out (bounded spins: a missing peer must not hang the GPU)
+    uint32_t seq_in, seq_out, wait_mask;      // wait for flags_in[r] >= seq_in for every bit r of wait_mask; publish seq_out
+    int n_out;
+};
+// every thread of the block returns once all awaited flags have arrived (or the bounded wait ran out)
+__device__ __forceinline__ void slab_wait_flags(const uint32_t* flags_in, uint32_t mask, uint32_t seq, uint32_t* error) {
+    if (threadIdx.x < 32 && ((mask >> threadIdx.x) & 1u)) {
+        unsigned spins = 0;
+        while ((int32_t)(ld_sys_u32(flags_in + threadIdx.x) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 21)) { if (error) atomicOr(error, 1u); break; }      // ~1 s
+        }
+    }
+    __syncthreads();
+}
+// after a block's write-through stores: the LAST block to finish raises the flags
+__device__ __forceinline__ void slab_publish(const SlabDirect& D, uint32_t participating_blocks) {
+    wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(D.blocks_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1u == participating_blocks) {
+            __hip_atomic_store(D.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < D.n_out; ++q) st_sys_u32(D.flag_out[q], D.seq_out);
+        }
+    }
+}
+
 __device__ __forceinline__ void st1o(float* base, uint32_t byte_off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 __device__ __forceinline__ uint32_t ldu32o(const uint8_t* base, uint32_t byte_off) { return *reinterpret_cast<const uint32_t*>(base + byte_off); }
 __device__ __forceinline__ void load_quad_values(const float* __restrict__ S, const Grid& g, int base, int x0, int y, int z, QuadValues& v) {

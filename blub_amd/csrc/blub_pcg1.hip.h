@@ -89,15 +89,27 @@ __device__ __forceinline__ void pcg1_prologue_load(const PcgCtrl* __restrict__ c
     spec_partials_load(part_in, L.spec, L.sp);
 }
 // Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
-template <bool FIRST>
+template <bool FIRST, bool COHERENT = false>
 __device__ __forceinline__ bool pcg1_prologue_finish(Pcg1PrologueLoads& L, PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in,
                                                      int num_part, float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta) {
     constexpr int NT = PCG_B_THREADS;
-    spec_partials_fix(part_in, L.spec, num_part, L.sp);
     float g = 0.0f, d = 0.0f, m = 0.0f;
+    if (COHERENT) {
+        // z-slab groups, direct transport: the other slabs' segments were written by other agents while this kernel may already have been
+        // running -- fetched with cache-bypassing loads AFTER the flag wait (the speculative plain loads of pcg1_prologue_load are not used),
+        // in the same order and grouping as below, so the sums are bit-identical to the host-transport solve
+#pragma unroll
+        for (int k = 0; k < PCG_PART_PER_THREAD; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
+            if (i < num_part && i < PCG_VBLOCKS_MAX) { const float4 p = ld_sys_f4(part_in + i); g += p.x; d += p.y; m = fmaxf(m, p.z); }
+        }
+        for (int i = (int)threadIdx.x + PCG_VBLOCKS_MAX; i < num_part; i += NT) { const float4 p = ld_sys_f4(part_in + i); g += p.x; d += p.y; m = fmaxf(m, p.z); }
+    } else {
+    spec_partials_fix(part_in, L.spec, num_part, L.sp);
 #pragma unroll
     for (int k = 0; k < PCG_PART_PER_THREAD; ++k) { g += L.sp.v[k].x; d += L.sp.v[k].y; m = fmaxf(m, L.sp.v[k].z); }
     for (int i = (int)threadIdx.x + PCG_VBLOCKS_MAX; i < num_part; i += NT) { const float4 p = part_in[i]; g += p.x; d += p.y; m = fmaxf(m, p.z); }
+    }
     g = wave_sum_dpp(g); d = wave_sum_dpp(d); m = wave_max_abs_dpp(m);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
@@ -244,7 +256,7 @@ __device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const Pcg1
         if ((unsigned)gx < (unsigned)g.nx && gy < g.ny && gz < g.nz) { L.hc = base0 + G.hrel; L.hin = true; L.hdv = (int)dvol[(uint32_t)L.hc]; }
     }
 }
-template <bool FIRST>
+template <bool FIRST, bool COHERENT = false>
 __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const float* __restrict__ r_in, const float* __restrict__ w_in, const float* __restrict__ q_in,
                                                       const float* __restrict__ dsearch, const float* __restrict__ p) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,7 +265,9 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
         L.rv[k] = zero4; L.wv[k] = zero4; L.qv[k] = zero4; L.dv4[k] = zero4; L.pv4[k] = zero4;
         if (L.base[k] < 0 || !any_fluid_d(L.dq[k])) continue;
         const uint32_t off = (uint32_t)L.base[k] * 4u;
-        L.rv[k] = ld4o(r_in, off); L.wv[k] = ld4o(w_in, off);
+        L.rv[k] = ld4o(r_in, off);
+        // (direct transport: the halo rows of w may lie in a ghost plane a z-neighbour wrote while this kernel was running)
+        if (COHERENT && k == 1) L.wv[k] = ld_sys_f4(reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w_in) + off)); else L.wv[k] = ld4o(w_in, off);
         if (!FIRST) L.qv[k] = ld4o(q_in, off);
         if (L.own[k]) { L.dv4[k] = ld4o(dsearch, off); L.pv4[k] = ld4o(p, off); }
     }
@@ -268,20 +282,27 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
 // Work and partials are organised in VIRTUAL workgroups (pcg_vblocks, blub_pcg.hip.h): the result does not depend on the launch grid.
 // SURPLUS_EXITS: launched workgroups beyond the virtual ones return at once (the tail kernel's must stay: they take part in its grid barriers).
 // vb_force / num_part_in: z-slab groups (the virtual-workgroup count every rank agreed on / the gathered partials of all slabs); 0 otherwise.
-template <bool FIRST, bool HALO, bool XMAP, bool SURPLUS_EXITS>
+template <bool FIRST, bool HALO, bool XMAP, bool SURPLUS_EXITS, bool DIRECT = false>
 __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
                                                                const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
                                                                float* __restrict__ q_out, float* __restrict__ dsearch, float* __restrict__ p,
                                                                const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part_in,
                                                                PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
-                                                               int halo_lo, int halo_hi) {
+                                                               int halo_lo, int halo_hi, const SlabDirect* __restrict__ dir = nullptr) {
     __shared__ float4 sm4[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
     __shared__ DivConst div_lut[8];
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     pcg_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
+    if (DIRECT) {
+        // z-slab groups, direct transport: this launch consumes the w plane of the z-neighbours and the partials of every slab as the
+        // PREVIOUS launch of the other slabs stored them straight into this slab's memory -- wait for their flags (unless the solve is
+        // over: every slab takes that decision alike, nobody publishes any more)
+        if (ctrl->done) return false;
+        slab_wait_flags(dir->flags_in, dir->wait_mask, dir->seq_in, dir->error);
+    }
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
     // the previous scalars and the partials.  The first list entry is requested for virtual workgroup blockIdx.x BEFORE the list length
     // (hence V) is known: with the XCD-contiguous order its position depends on V, so that speculative fetch uses the launch grid's
@@ -308,8 +329,8 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     Pcg1TileLoads TL;
     if (has_vb && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
     float alpha, beta;
-    if (!pcg1_prologue_finish<FIRST>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
-    if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p);
+    if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
+    if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p);
     StagedTile& T = tiles[half];
     bool first = true;
     for (int vb = blockIdx.x; vb < V; vb += gridDim.x) {
@@ -319,7 +340,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = first ? b0 : (have ? list[i] : 0u);
-        if (!first && have) { pcg1_tile_load_desc(TL, TG, bg, b, t, dvol); pcg1_tile_load_fields<FIRST>(TL, r_in, w_in, q_in, dsearch, p); }
+        if (!first && have) { pcg1_tile_load_desc(TL, TG, bg, b, t, dvol); pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p); }
         first = false;
         int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb); (void)bxb;
         const int y0b = byb * BY, z0b = bzb * BZ;
@@ -365,6 +386,10 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
                     st4o(r_out, off, make_float4(rn[0], rn[1], rn[2], rn[3]));
                     st4o(dsearch, off, make_float4(dn[0], dn[1], dn[2], dn[3]));
                     st4o(p, off, make_float4(pn[0], pn[1], pn[2], pn[3]));
+                    if (DIRECT) {      // the pressure halo of the z-neighbours stays current: no exchange after the solve
+                        if (gz == halo_lo && dir->p_dn) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->p_dn) + off), make_float4(pn[0], pn[1], pn[2], pn[3]));
+                        if (gz == halo_hi && dir->p_up) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->p_up) + off), make_float4(pn[0], pn[1], pn[2], pn[3]));
+                    }
                 } else if (HALO) {
                     const bool ghost = ((gz == halo_lo - 1 && z0b == halo_lo) || (gz == halo_hi + 1 && z0b + BZ - 1 == halo_hi)) && gy >= y0b && gy < y0b + BY;
                     if (ghost) {
@@ -403,6 +428,13 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
                         acc_d += wn[j] * f4(sv.c, j);
                     }
                     st4o(w_out, (uint32_t)cidx(g, x0, y, z) * 4u, make_float4(wn[0], wn[1], wn[2], wn[3]));
+                    if (DIRECT) {      // the own boundary planes of w_{i+1} go straight into the z-neighbours' ghost planes
+                        const uint32_t off = (uint32_t)cidx(g, x0, y, z) * 4u;
+                        if (z == halo_lo && dir->w_dn) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->w_dn) + off), make_float4(wn[0], wn[1], wn[2], wn[3]));
+                        if (z == halo_hi && dir->w_up) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->w_up) + off), make_float4(wn[0], wn[1], wn[2], wn[3]));
+                    }
+                } else if (DIRECT) {
+                    // (a quad without FLUID cells stores nothing; the neighbour's ghost plane keeps the zeros / stale values its descriptor masks out)
                 }
             }
         }
@@ -418,22 +450,27 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
 #pragma unroll
         for (int w = 1; w < PCG_B_THREADS / 64; ++w) { tot.x += sm4[w].x; tot.y += sm4[w].y; tot.z = fmaxf(tot.z, sm4[w].z); }
         part_out[vb] = tot;
+        if (DIRECT) {      // ... and into this slab's segment of every other slab's partial array
+            st_sys_f4(part_out + vb, tot);      // (the own copy too: the own consumer reads the whole array with cache-bypassing loads)
+            for (int q = 0; q < dir->n_out; ++q) st_sys_f4(dir->part_out[q] + vb, tot);
+        }
     }
     }
+    if (DIRECT) slab_publish(*dir, (uint32_t)min((int)gridDim.x, V));
     return true;
 }
 
 
-template <bool FIRST, bool HALO = false, bool XMAP = true>
+template <bool FIRST, bool HALO = false, bool XMAP = true, bool DIRECT = false>
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
                                                                const uint8_t* __restrict__ dvol, const float* __restrict__ r_in, float* __restrict__ r_out,
                                                                const float* __restrict__ w_in, float* __restrict__ w_out, const float* __restrict__ q_in,
                                                                float* __restrict__ q_out, float* __restrict__ dsearch, float* __restrict__ p,
                                                                const float4* __restrict__ part_in, float4* __restrict__ part_out, int num_part_in,
                                                                PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, float tolerance, int iteration, int check_prev,
-                                                               int halo_lo = -1, int halo_hi = -1) {
-    (void)pcg1_iteration<FIRST, HALO, XMAP, true>(bg, list, count, vb_force, dvol, r_in, r_out, w_in, w_out, q_in, q_out, dsearch, p, part_in, part_out, num_part_in, ctrl, sc, tolerance,
-                                                  iteration, check_prev, halo_lo, halo_hi);
+                                                               int halo_lo = -1, int halo_hi = -1, SlabDirect dir = SlabDirect{}) {
+    (void)pcg1_iteration<FIRST, HALO, XMAP, true, DIRECT>(bg, list, count, vb_force, dvol, r_in, r_out, w_in, w_out, q_in, q_out, dsearch, p, part_in, part_out, num_part_in, ctrl, sc, tolerance,
+                                                          iteration, check_prev, halo_lo, halo_hi, &dir);
 }
 
 // After K(max_num_iterations): statistics are written unconditionally if nothing converged before (pressure_reduce.comp:84).

@@ -205,16 +205,65 @@ __global__ void k_slab_publish_cnt(const float* __restrict__ gat_cnt, int nranks
 }
 
 // loopback transport: all plane copies of one halo exchange in ONE launch (a hipMemcpyAsync per plane costs ~4 us of queue time each,
-// ~100 of them per step)
+// ~100 of them per step).  DIRECT transport (peer-mapped memory): the same launch with write-through stores, and the last workgroup to
+// finish raises the destination slabs' flag words (see SlabDirect, blub_kernels.hip.h).
 struct SlabCopy { const void* src; void* dst; uint32_t bytes; uint32_t pad; };   // src, dst 16-byte aligned, bytes % 16 == 0
-constexpr int SLAB_COPY_MAX = 40;
+constexpr int SLAB_COPY_MAX = 40, SLAB_FLAG_MAX = 64;
 struct SlabCopyList { SlabCopy c[SLAB_COPY_MAX]; int n; };
+struct SlabFlagList { uint32_t* f[SLAB_FLAG_MAX]; int n; uint32_t seq; uint32_t* blocks_done; };
 __global__ __launch_bounds__(256) void k_slab_copy_planes(SlabCopyList L) {
     const SlabCopy c = L.c[blockIdx.y];
     const uint32_t n16 = c.bytes >> 4;
     const uint4* __restrict__ s = reinterpret_cast<const uint4*>(c.src);
     uint4* __restrict__ d = reinterpret_cast<uint4*>(c.dst);
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) d[i] = s[i];
+}
+__global__ __launch_bounds__(256) void k_slab_push_planes(SlabCopyList L, SlabFlagList F) {
+    if ((int)blockIdx.y < L.n) {
+        const SlabCopy c = L.c[blockIdx.y];
+        const uint32_t n16 = c.bytes >> 4;
+        const float4* __restrict__ s = reinterpret_cast<const float4*>(c.src);
+        float4* d = reinterpret_cast<float4*>(c.dst);
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) st_sys_f4(d + i, s[i]);
+    }
+    wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(F.blocks_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1u == gridDim.x * gridDim.y) {
+            __hip_atomic_store(F.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < F.n; ++k) st_sys_u32(F.f[k], F.seq);
+        }
+    }
+}
+// a stream waits for the flags of an exchange (kernels enqueued behind this one find the pushed data in place)
+// (skip_if_done: the flags of a PCG iteration that a finished solve never launched must not be waited for)
+__global__ void k_slab_wait(const uint32_t* __restrict__ flags_in, uint32_t mask, uint32_t seq, uint32_t* __restrict__ error, const PcgCtrl* __restrict__ skip_if_done) {
+    if (skip_if_done && skip_if_done->done) return;
+    slab_wait_flags(flags_in, mask, seq, error);
+}
+
+// DIRECT transport of a particle exchange: the sender copies header + what travels (the count is only known on the device) straight into the
+// receiver's staging buffer, which has the full particle capacity -- no message size to agree on, nothing to hold back
+struct SlabParticlePush { const float4* src[4]; float4* dst[4]; };      // [0]: position message (header in front), [1..3]: velocity rows; dst nullptr: no neighbour
+__global__ __launch_bounds__(256) void k_slab_push_particles(SlabParticlePush up, SlabParticlePush dn, int narr, SlabFlagList F) {
+    const SlabParticlePush& P = blockIdx.y == 0 ? up : dn;
+    if (P.dst[0]) {
+        const uint32_t n = __float_as_uint(P.src[0][0].x);      // header written by k_slab_finish_send
+        for (int q = 0; q < narr; ++q) {
+            const uint32_t cnt = n + (q == 0 ? 1u : 0u);
+            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) st_sys_f4(P.dst[q] + i, P.src[q][i]);
+        }
+    }
+    wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(F.blocks_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1u == gridDim.x * gridDim.y) {
+            __hip_atomic_store(F.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < F.n; ++k) st_sys_u32(F.f[k], F.seq);
+        }
+    }
 }
 
 // Dot products across slabs: every slab's PCG kernels write their per-block partials into segment `rank` of a gather array

@@ -56,6 +56,19 @@ struct blub_slab_group {
     uint64_t host_syncs = 0, done_polls = 0;     // stream synchronisations issued by blub_slab_group_step so far: particle exchanges / looks at a solve's `done` (diagnostics)
     int gather_mode = 0;                         // RCCL only: 0 = partials as p2p inside the halo's group, 1 = ncclAllGather (calibrated at creation)
     char transport[192] = "loopback";
+    // ---- DIRECT transport (round 4): every slab writes what its neighbours need straight into THEIR memory (the same process in a local
+    // group, hipIpc mappings between processes) and raises a flag word; consumers wait for flags -- inside the PCG iteration kernel, with a
+    // one-block wait kernel elsewhere.  No host-issued transport operation, no stream synchronisation, no message sizes.
+    bool direct = false;
+    struct Region { char* base = nullptr; size_t bytes = 0; };
+    std::vector<std::vector<Region>> regions;       // [local slab][k]: exportable allocations, the same list on every rank
+    std::vector<std::vector<char*>> peer_base;      // [rank][k]: region k of that rank's slab as mapped in THIS process (own slabs: the pointer itself)
+    std::vector<void*> ipc_opened;                  // mappings to close
+    struct Arena { char* base = nullptr; size_t bytes = 0, used = 0; };
+    std::vector<Arena> arena;                       // [local slab]: flags, gather arrays, particle staging (one allocation: one hipIpc handle)
+    std::vector<uint32_t*> flags, blocks_done, dir_error;   // [local slab]: flag words (one per source rank), finished-workgroup counter, time-out marker
+    uint32_t flag_seq = 0;                          // exchanges issued so far (the same number on every rank)
+    blubk::SlabFlagList push_flags{};               // flags the pending batched push raises
 };
 
 namespace blub {
@@ -70,11 +83,16 @@ enum { XFER_GHOST_FULL = 0, XFER_GHOST_POS = 1, XFER_MIGRATE = 2, XFER_MIGRATE_B
 
 // loopback transport: device-to-device plane copies are collected and issued as ONE kernel per exchange
 static int slab_copy_flush(blub_slab_group* G) {
-    if (G->copies.n == 0) return BLUB_OK;
+    if (G->copies.n == 0 && !(G->direct && G->push_flags.n)) return BLUB_OK;
     uint32_t mx = 0;
     for (int k = 0; k < G->copies.n; ++k) mx = std::max(mx, G->copies.c[k].bytes);
     const unsigned bx = std::max(1u, std::min(64u, (mx / 16u + 255u) / 256u));
-    hipLaunchKernelGGL(blubk::k_slab_copy_planes, dim3(bx, (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies);
+    if (G->direct) {      // write-through stores, then the flags of this exchange
+        G->push_flags.seq = G->flag_seq; G->push_flags.blocks_done = G->blocks_done[0];
+        hipLaunchKernelGGL(blubk::k_slab_push_planes, dim3(bx, (unsigned)std::max(1, G->copies.n)), dim3(256), 0, G->stream, G->copies, G->push_flags);
+        G->push_flags.n = 0;
+    } else
+        hipLaunchKernelGGL(blubk::k_slab_copy_planes, dim3(bx, (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies);
     G->copies.n = 0;
     return BLUB_OK;
 }
@@ -86,7 +104,15 @@ static int slab_copy(blub_slab_group* G, void* dst, const void* src, size_t byte
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, G->stream));
         return BLUB_OK;
     }
-    if (G->copies.n == blubk::SLAB_COPY_MAX) { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
+    if (G->copies.n == blubk::SLAB_COPY_MAX) {
+        if (G->direct) {      // (a partial flush must not raise this exchange's flags: plain batch, flags with the last one)
+            const blubk::SlabFlagList keep = G->push_flags; G->push_flags.n = 0;
+            uint32_t mx = 0; for (int k = 0; k < G->copies.n; ++k) mx = std::max(mx, G->copies.c[k].bytes);
+            blubk::SlabFlagList none{}; none.blocks_done = G->blocks_done[0]; none.seq = G->flag_seq;
+            hipLaunchKernelGGL(blubk::k_slab_push_planes, dim3(std::max(1u, std::min(64u, (mx / 16u + 255u) / 256u)), (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies, none);
+            G->copies.n = 0; G->push_flags = keep;
+        } else { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
+    }
     blubk::SlabCopy& c = G->copies.c[G->copies.n];
     c.src = src; c.dst = dst; c.bytes = (uint32_t)bytes; c.pad = 0;
     G->copies.n += 1;
@@ -98,12 +124,60 @@ static bool has_down(const blub_slab_group* G, int i) { return G->first + i > 0;
 static bool up_local(const blub_slab_group* G, int i) { return i + 1 < (int)G->slabs.size(); }
 static bool down_local(const blub_slab_group* G, int i) { return i > 0; }
 
+// ---- DIRECT transport: address translation and flags ----------------------------------------------------------------------------------
+// `mine` points into one of local slab i's exportable allocations; the same offset inside rank r's allocation of the same kind
+template <class T>
+static T* peer_ptr(const blub_slab_group* G, int i, int r, T* mine) {
+    const char* m = reinterpret_cast<const char*>(mine);
+    const auto& regs = G->regions[i];
+    for (size_t k = 0; k < regs.size(); ++k)
+        if (m >= regs[k].base && m < regs[k].base + regs[k].bytes) return reinterpret_cast<T*>(G->peer_base[r][k] + (m - regs[k].base));
+    return nullptr;
+}
+static bool rank_local(const blub_slab_group* G, int r) { return r >= G->first && r < G->first + (int)G->slabs.size(); }
+// the flag word of rank `dst` for messages from rank `src` (dst's flags live in dst's arena; translated through local slab i = the sender)
+static uint32_t* flag_of(const blub_slab_group* G, int i, int dst) { return peer_ptr(G, i, dst, G->flags[i]) + (G->first + i); }
+static int slab_push_flush(blub_slab_group* G);
+// a local slab's stream waits for the flags of the exchange just issued (not needed when every source is a local slab: one stream orders them)
+static int slab_wait(blub_slab_group* G, int i, uint32_t mask, const blubk::PcgCtrl* skip_if_done = nullptr) {
+    uint32_t remote = 0;
+    for (int r = 0; r < G->nranks; ++r) if (((mask >> r) & 1u) && !rank_local(G, r)) remote |= 1u << r;
+    if (!remote) return BLUB_OK;
+    hipLaunchKernelGGL(blubk::k_slab_wait, dim3(1), dim3(64), 0, G->stream, (const uint32_t*)G->flags[i], remote, G->flag_seq, G->dir_error[i], skip_if_done);
+    return BLUB_OK;
+}
+static uint32_t neighbour_mask(const blub_slab_group* G, int i) { return (has_up(G, i) ? 1u << (G->first + i + 1) : 0u) | (has_down(G, i) ? 1u << (G->first + i - 1) : 0u); }
+static uint32_t others_mask(const blub_slab_group* G, int i) { return ((G->nranks >= 32 ? 0xFFFFFFFFu : (1u << G->nranks) - 1u)) & ~(1u << (G->first + i)); }
+static void push_flag(blub_slab_group* G, uint32_t* f) {
+    for (int k = 0; k < G->push_flags.n; ++k) if (G->push_flags.f[k] == f) return;
+    if (G->push_flags.n < blubk::SLAB_FLAG_MAX) G->push_flags.f[G->push_flags.n++] = f;
+}
+
 // One z-plane of a volume from each z-neighbour: plane z1-1 goes up, plane z0 goes down; the receiver stores it at the
 // same global z (ghost planes z0-1 and z1).
 static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(blub_fluid*)>>& fields, size_t elem, bool own_group = true) {
     const blub_fluid* h0 = G->slabs[0];
     const size_t pb = (size_t)h0->g.nx * h0->g.ny * elem;
     if (own_group) G->comm_ops += 1;
+    if (G->direct) {
+        // every slab PUSHES its two boundary planes into its z-neighbours' ghost planes, the last workgroup of the batched launch raises the
+        // neighbours' flags, the consumers' stream waits for its own (slab_wait)
+        if (own_group) G->flag_seq += 1;
+        for (int i = 0; i < (int)G->slabs.size(); ++i) {
+            blub_fluid* h = G->slabs[i];
+            for (auto& f : fields) {
+                char* base = (char*)f(h);
+                if (has_up(G, i)) { int rc = slab_copy(G, peer_ptr(G, i, G->first + i + 1, base) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (rc != BLUB_OK) return rc; }
+                if (has_down(G, i)) { int rc = slab_copy(G, peer_ptr(G, i, G->first + i - 1, base) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (rc != BLUB_OK) return rc; }
+            }
+            if (has_up(G, i)) push_flag(G, flag_of(G, i, G->first + i + 1));
+            if (has_down(G, i)) push_flag(G, flag_of(G, i, G->first + i - 1));
+        }
+        if (!own_group) return BLUB_OK;
+        { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
+        for (int i = 0; i < (int)G->slabs.size(); ++i) { int rc = slab_wait(G, i, neighbour_mask(G, i)); if (rc != BLUB_OK) return rc; }
+        return BLUB_OK;
+    }
     if (G->rccl && own_group) NCCL_TRY(ncclGroupStart());
     for (int i = 0; i < (int)G->slabs.size(); ++i) {
         blub_fluid* h = G->slabs[i];
@@ -136,6 +210,22 @@ static int slab_halo_velocity(blub_slab_group* G) {
 static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& array_of, int seg_floats, bool own_group = true) {
     if (G->nranks == 1) return BLUB_OK;
     if (own_group) G->comm_ops += 1;
+    if (G->direct) {      // every slab pushes its own segment into every other slab's array
+        if (own_group) G->flag_seq += 1;
+        for (int i = 0; i < (int)G->slabs.size(); ++i) {
+            float* mine = array_of(i) + (size_t)(G->first + i) * seg_floats;
+            for (int r = 0; r < G->nranks; ++r) {
+                if (r == G->first + i) continue;
+                int rc = slab_copy(G, peer_ptr(G, i, r, mine), mine, (size_t)seg_floats * sizeof(float));
+                if (rc != BLUB_OK) return rc;
+                push_flag(G, flag_of(G, i, r));
+            }
+        }
+        if (!own_group) return BLUB_OK;
+        { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
+        for (int i = 0; i < (int)G->slabs.size(); ++i) { int rc = slab_wait(G, i, others_mask(G, i)); if (rc != BLUB_OK) return rc; }
+        return BLUB_OK;
+    }
     if (!G->rccl) {   // loopback: segment s of slab s's array into every other slab's array, batched with the plane copies of the same exchange
         const int S = (int)G->slabs.size();
         for (int sidx = 0; sidx < S; ++sidx)
@@ -164,6 +254,14 @@ static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& arr
 static int slab_fused(blub_slab_group* G, const std::function<int()>& halos, const std::function<int(bool)>& gather) {
     int rc;
     G->comm_ops += 1;
+    if (G->direct) {      // planes + partial segments in ONE batched push, one flag round
+        G->flag_seq += 1;
+        if ((rc = halos()) != BLUB_OK) return rc;
+        if ((rc = gather(false)) != BLUB_OK) return rc;
+        if ((rc = slab_copy_flush(G)) != BLUB_OK) return rc;
+        for (int i = 0; i < (int)G->slabs.size(); ++i) if ((rc = slab_wait(G, i, others_mask(G, i))) != BLUB_OK) return rc;
+        return BLUB_OK;
+    }
     const bool split = G->rccl && G->gather_mode == 1;
     if (G->rccl) NCCL_TRY(ncclGroupStart());
     if ((rc = halos()) != BLUB_OK) return rc;
@@ -308,6 +406,10 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
         }
         cap_up[i] = has_up(G, i) ? slab_capx(G, H.n_up) : 0u; cap_dn[i] = has_down(G, i) ? slab_capx(G, H.n_down) : 0u;
         cap_below[i] = has_down(G, i) ? slab_capx(G, H.from_below) : 0u; cap_above[i] = has_up(G, i) ? slab_capx(G, H.from_above) : 0u;
+        if (G->direct) {      // the sender writes what travels straight into staging buffers of full capacity: no message size, nothing to hold back
+            cap_up[i] = has_up(G, i) ? G->capacity : 0u; cap_dn[i] = has_down(G, i) ? G->capacity : 0u;
+            cap_below[i] = has_down(G, i) ? G->capacity : 0u; cap_above[i] = has_up(G, i) ? G->capacity : 0u;
+        }
     }
     G->xfer_seq += 1;
     for (int i = 0; i < S; ++i) {
@@ -340,8 +442,26 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
     }
     // transport: ONE grouped operation (round 2: counts, a host synchronisation, then the payload)
     G->comm_ops += 1;
-    if (G->rccl) NCCL_TRY(ncclGroupStart());
-    for (int i = 0; i < S; ++i) {
+    if (G->direct) {
+        G->flag_seq += 1;
+        for (int i = 0; i < S; ++i) {
+            auto& e = G->ex[i];
+            blubk::SlabParticlePush up{}, dn{};
+            blubk::SlabFlagList F{}; F.seq = G->flag_seq; F.blocks_done = G->blocks_done[i];
+            for (int k = 0; k < narr; ++k) {
+                up.src[k] = k == 0 ? e.up_msg : e.up[k]; dn.src[k] = k == 0 ? e.dn_msg : e.dn[k];
+                // my "up" message is the upper neighbour's "from below" staging, my "down" message the lower neighbour's "from above"
+                up.dst[k] = has_up(G, i) ? peer_ptr(G, i, G->first + i + 1, k == 0 ? e.rb_msg : e.rb[k]) : nullptr;
+                dn.dst[k] = has_down(G, i) ? peer_ptr(G, i, G->first + i - 1, k == 0 ? e.ra_msg : e.ra[k]) : nullptr;
+            }
+            if (has_up(G, i)) F.f[F.n++] = flag_of(G, i, G->first + i + 1);
+            if (has_down(G, i)) F.f[F.n++] = flag_of(G, i, G->first + i - 1);
+            if (F.n) hipLaunchKernelGGL(blubk::k_slab_push_particles, dim3(64, 2), dim3(256), 0, G->stream, up, dn, narr, F);
+        }
+        for (int i = 0; i < S; ++i) { int rc = slab_wait(G, i, neighbour_mask(G, i)); if (rc != BLUB_OK) return rc; }
+    }
+    if (G->rccl && !G->direct) NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < S && !G->direct; ++i) {
         auto& e = G->ex[i];
         for (int k = 0; k < narr; ++k) {
             const size_t hdr = k == 0 ? 1 : 0;      // the position message carries the header
@@ -363,8 +483,8 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
             }
         }
     }
-    if (G->rccl) NCCL_TRY(ncclGroupEnd());
-    { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
+    if (G->rccl && !G->direct) NCCL_TRY(ncclGroupEnd());
+    if (!G->direct) { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
         auto& e = G->ex[i];
@@ -529,7 +649,13 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
             // (the volumes differ per slab: pass the slab index through a per-call table)
             const blub_fluid* h0l = G->slabs[0];
             const size_t pb = (size_t)h0l->g.nx * h0l->g.ny * sizeof(float);
-            for (int i = 0; i < S; ++i) {
+            for (int i = 0; i < S && G->direct; ++i) {      // direct transport: push the two boundary planes into the z-neighbours' copies
+                blub_fluid* h = G->slabs[i];
+                char* base = (char*)B[i].W[wpar];
+                if (has_up(G, i)) { int r3 = slab_copy(G, peer_ptr(G, i, G->first + i + 1, base) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i + 1)); }
+                if (has_down(G, i)) { int r3 = slab_copy(G, peer_ptr(G, i, G->first + i - 1, base) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i - 1)); }
+            }
+            for (int i = 0; i < S && !G->direct; ++i) {
                 blub_fluid* h = G->slabs[i];
                 char* base = (char*)B[i].W[wpar];
                 if (has_up(G, i)) {
@@ -552,6 +678,49 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     };
     if ((rc = exchange(0, 0)) != BLUB_OK) return rc;
     int it = 0;
+    if (G->direct) {
+        // DIRECT transport: K(i) itself stores its boundary planes of w_{i+1} and of p into the z-neighbours' ghost planes and its partials into
+        // every slab's array, then raises their flags; K(i + 1) waits for the flags it needs in its prologue.  No host-issued operation between
+        // the launches, no look at `done`: every iteration up to the cap is launched, a finished solve's launches return at once (they neither
+        // wait nor publish -- every slab takes that decision alike, from bit-identical scalars).
+        for (it = 0; it <= maxit; ++it) {
+            const uint32_t seq_in = G->flag_seq;
+            G->flag_seq += 1;
+            for (int i = 0; i < S; ++i) {
+                blub_fluid* h = G->slabs[i];
+                const int halo_lo = has_down(G, i) ? h->slab_z0 : -1, halo_hi = has_up(G, i) ? h->slab_z1 - 1 : -1;
+                const float4* pin = G->ex[i].gat4[it & 1];
+                float4* pout = seg4(i, (it + 1) & 1);
+                float* wout = B[i].W[(it + 1) & 1];
+                SlabDirect D{};
+                const int me = G->first + i;
+                D.w_up = has_up(G, i) ? peer_ptr(G, i, me + 1, wout) : nullptr; D.w_dn = has_down(G, i) ? peer_ptr(G, i, me - 1, wout) : nullptr;
+                D.p_up = has_up(G, i) ? peer_ptr(G, i, me + 1, h->pressure[which]) : nullptr; D.p_dn = has_down(G, i) ? peer_ptr(G, i, me - 1, h->pressure[which]) : nullptr;
+                for (int r = 0; r < G->nranks; ++r) {
+                    if (r == me) continue;
+                    D.part_out[D.n_out] = peer_ptr(G, i, r, pout); D.flag_out[D.n_out] = flag_of(G, i, r); D.n_out += 1;
+                }
+                D.flags_in = G->flags[i]; D.blocks_done = G->blocks_done[i]; D.error = G->dir_error[i];
+                D.seq_in = seq_in; D.seq_out = G->flag_seq; D.wait_mask = others_mask(G, i);
+                if (it == 0)
+                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true, true, true, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[0], B[i].R[1], (const float*)B[i].W[0],
+                           B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi, D);
+                else
+                    LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false, true, true, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[it & 1], B[i].R[(it + 1) & 1],
+                           (const float*)B[i].W[it & 1], B[i].W[(it + 1) & 1], (const float*)B[i].Q[(it + 1) & 1], B[i].Q[it & 1], h->search, h->pressure[which], pin, pout, npall,
+                           h->ctrl[which], h->pcg1_scalars[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi, D);
+            }
+        }
+        for (int i = 0; i < S; ++i) {
+            blub_fluid* h = G->slabs[i];
+            // (a solve that ran into the iteration cap takes its statistics from the partials of K(maxit): wait for the other slabs' unless it is over)
+            if ((rc = slab_wait(G, i, others_mask(G, i), h->ctrl[which])) != BLUB_OK) return rc;
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, (const uint32_t*)nullptr, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
+            if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
+            if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
+        }
+        return BLUB_OK;      // (the pressure halo is current: every launched iteration pushed its boundary planes of p)
+    }
     for (;;) {
         for (; it < target; ++it) {
             for (int i = 0; i < S; ++i) {
@@ -561,11 +730,11 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
                 float4* pout = seg4(i, (it + 1) & 1);
                 if (it == 0)
                     LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[0], B[i].R[1], (const float*)B[i].W[0],
-                           B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi);
+                           B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi, SlabDirect{});
                 else
                     LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[it & 1], B[i].R[(it + 1) & 1],
                            (const float*)B[i].W[it & 1], B[i].W[(it + 1) & 1], (const float*)B[i].Q[(it + 1) & 1], B[i].Q[it & 1], h->search, h->pressure[which], pin, pout, npall,
-                           h->ctrl[which], h->pcg1_scalars[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi);
+                           h->ctrl[which], h->pcg1_scalars[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi, SlabDirect{});
             }
             if ((rc = exchange((it + 1) & 1, (it + 1) & 1)) != BLUB_OK) return rc;
         }
@@ -608,7 +777,7 @@ static int slab_step(blub_slab_group* G, float dt, int first = 0, int last = SS_
     // The particle exchanges run without host synchronisation once every exchange kind has a history to size its messages from (i.e. from
     // the second step after the particles were set); all ranks take the same decision (they step in lock step).
     bool async = G->async_exchange;
-    for (auto& H : G->hist) async = async && H.valid;
+    for (auto& H : G->hist) async = async && (H.valid || G->direct);      // (direct transport: no message sizes, hence no history needed)
     auto exchange = [&](int kind) { return async ? slab_exchange_particles_async(G, kind) : slab_exchange_particles(G, kind); };
     if (RUNS(SS_GHOSTS)) {
         // size of this step's PCG grids: every slab contributes the newest fluid-brick count it has (a lagged, non-blocking snapshot) and
@@ -699,12 +868,9 @@ static void slab_group_destroy(blub_slab_group* G) {
     (void)hipSetDevice(G->device);
     if (G->stream) (void)hipStreamSynchronize(G->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
-    for (auto& e : G->ex) {
-        F(e.leave_idx); F(e.hole_idx); F(e.fill_idx); F(e.up_msg); F(e.dn_msg); for (int k = 1; k < 4; ++k) { F(e.up[k]); F(e.dn[k]); }
-        F(e.counts); F(e.recv_counts); F(e.gat_dir); F(e.gat_upd); F(e.gat4[0]); F(e.gat4[1]); F(e.gat_cnt);
-        F(e.rb_msg); F(e.ra_msg); for (int k = 1; k < 4; ++k) { F(e.rb[k]); F(e.ra[k]); } F(e.append_done);
-    }
-    for (auto h : G->slabs) { F(h->n_dev); h->n_dev = nullptr; destroy(h); }
+    for (void* m : G->ipc_opened) (void)hipIpcCloseMemHandle(m);
+    for (auto& ar : G->arena) F(ar.base);
+    for (auto h : G->slabs) { h->n_dev = nullptr; destroy(h); }
     if (G->rec_host) (void)hipHostFree(G->rec_host);
     if (G->cntrec_host) (void)hipHostFree(G->cntrec_host);
     if (G->cntseq_host) (void)hipHostFree(G->cntseq_host);
@@ -800,20 +966,51 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         h->max_steps_in_flight = 0;   // every particle exchange synchronises the host anyway
         G->slabs.push_back(h);
         blub_slab_group::Extra e;
-        auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
         const size_t P = G->capacity;
-        A(dev_alloc_zero(G->stream, &e.leave_idx, P)); A(dev_alloc_zero(G->stream, &e.hole_idx, P)); A(dev_alloc_zero(G->stream, &e.fill_idx, P));
+        // everything a particle exchange or a gather touches lives in ONE allocation per slab (the "arena"): with the direct transport the
+        // neighbours write into it, so it is one of the slab's exportable regions (one hipIpc handle)
+        blub_slab_group::Arena ar;
+        ar.bytes = (size_t)3 * P * 4 + (size_t)4 * (P + 1) * 16 + (size_t)12 * P * 16 + (size_t)nranks * blubk::SLAB_NP_MAX * (4 + 8 + 16 + 16) + (size_t)nranks * 8 + 64 * 1024;
+        if (rc == BLUB_OK && hipMalloc((void**)&ar.base, ar.bytes) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipMalloc of a slab's exchange arena failed");
+        if (rc == BLUB_OK && hipMemsetAsync(ar.base, 0, ar.bytes, G->stream) != hipSuccess) rc = set_error(BLUB_ERR_DEVICE, "hipMemsetAsync failed");
+        auto sub = [&](auto** pp, size_t count) {
+            using T = std::remove_pointer_t<std::remove_pointer_t<decltype(pp)>>;
+            if (rc != BLUB_OK) return;
+            const size_t at = (ar.used + 255) & ~(size_t)255;
+            if (at + count * sizeof(T) > ar.bytes) { rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "slab exchange arena exhausted"); return; }
+            *pp = reinterpret_cast<T*>(ar.base + at);
+            ar.used = at + count * sizeof(T);
+        };
+        sub(&e.leave_idx, P); sub(&e.hole_idx, P); sub(&e.fill_idx, P);
         // send buffers (position messages carry one float4 of header in front) and the staging of what arrives
-        A(dev_alloc_zero(G->stream, &e.up_msg, P + 1)); A(dev_alloc_zero(G->stream, &e.dn_msg, P + 1)); A(dev_alloc_zero(G->stream, &e.rb_msg, P + 1)); A(dev_alloc_zero(G->stream, &e.ra_msg, P + 1));
+        sub(&e.up_msg, P + 1); sub(&e.dn_msg, P + 1); sub(&e.rb_msg, P + 1); sub(&e.ra_msg, P + 1);
         if (rc == BLUB_OK) { e.up[0] = e.up_msg + 1; e.dn[0] = e.dn_msg + 1; e.rb[0] = e.rb_msg + 1; e.ra[0] = e.ra_msg + 1; }
-        for (int k = 1; k < 4; ++k) { A(dev_alloc_zero(G->stream, &e.up[k], P)); A(dev_alloc_zero(G->stream, &e.dn[k], P)); A(dev_alloc_zero(G->stream, &e.rb[k], P)); A(dev_alloc_zero(G->stream, &e.ra[k], P)); }
-        A(dev_alloc_zero(G->stream, &e.append_done, 1));
-        A(dev_alloc_zero(G->stream, &h->n_dev, 4));
-        A(dev_alloc_zero(G->stream, &e.counts, 1)); A(dev_alloc_zero(G->stream, &e.recv_counts, 2));
-        A(dev_alloc_zero(G->stream, &e.gat_dir, (size_t)nranks * blubk::SLAB_NP_MAX)); A(dev_alloc_zero(G->stream, &e.gat_upd, (size_t)nranks * blubk::SLAB_NP_MAX));
-        A(dev_alloc_zero(G->stream, &e.gat_cnt, (size_t)nranks));
-        A(dev_alloc_zero(G->stream, &e.gat4[0], (size_t)nranks * blubk::SLAB_NP_MAX)); A(dev_alloc_zero(G->stream, &e.gat4[1], (size_t)nranks * blubk::SLAB_NP_MAX));
+        for (int k = 1; k < 4; ++k) { sub(&e.up[k], P); sub(&e.dn[k], P); sub(&e.rb[k], P); sub(&e.ra[k], P); }
+        sub(&e.append_done, 1);
+        sub(&h->n_dev, 4);
+        sub(&e.counts, 1); sub(&e.recv_counts, 2);
+        sub(&e.gat_dir, (size_t)nranks * blubk::SLAB_NP_MAX); sub(&e.gat_upd, (size_t)nranks * blubk::SLAB_NP_MAX);
+        sub(&e.gat_cnt, (size_t)nranks);
+        sub(&e.gat4[0], (size_t)nranks * blubk::SLAB_NP_MAX); sub(&e.gat4[1], (size_t)nranks * blubk::SLAB_NP_MAX);
+        uint32_t *fl = nullptr, *bd = nullptr, *de = nullptr;
+        sub(&fl, 64); sub(&bd, 16); sub(&de, 16);
+        G->flags.push_back(fl); G->blocks_done.push_back(bd); G->dir_error.push_back(de);
+        G->arena.push_back(ar);
+        if (rc == BLUB_OK) rc = ensure_pcg1_buffers(h);      // (eager: the direct transport exports them)
+        // exportable regions, the same list on every rank: the volume slab, the three extra PCG volumes, the arena
+        std::vector<blub_slab_group::Region> regs;
+        if (rc == BLUB_OK) {
+            regs.push_back({h->slab, h->slab_bytes});
+            for (int k = 0; k < 3; ++k) regs.push_back({reinterpret_cast<char*>(h->cgbuf[k]), h->N * sizeof(float)});
+            regs.push_back({ar.base, ar.bytes});
+        }
+        G->regions.push_back(regs);
         G->ex.push_back(e);
+    }
+    // peer view: the regions of every rank as addressable from here -- local slabs by their own pointers; remote ones after blub_slab_group_connect
+    if (rc == BLUB_OK) {
+        G->peer_base.assign((size_t)nranks, std::vector<char*>());
+        for (int i = 0; i < (int)G->slabs.size(); ++i) for (auto& rg : G->regions[i]) G->peer_base[(size_t)first + i].push_back(rg.base);
     }
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->counts_host, nlocal * sizeof(blubk::SlabCounts)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     if (rc == BLUB_OK && hipHostMalloc((void**)&G->recv_host, 2 * nlocal * sizeof(uint32_t)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
@@ -849,6 +1046,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
 }  // namespace blub
 
 extern "C" {
+int blub_slab_group_set_transport(blub_slab_group* g, int kind);
 int blub_rccl_unique_id(void* out128) {
     if (!out128) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
@@ -864,7 +1062,11 @@ int blub_slab_range(uint32_t nz, int num_slabs, int index, int32_t* z0, int32_t*
     *z0 = a; *z1 = std::min<int>(b, (int)nz);
     return BLUB_OK;
 }
-int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out) { return blub::slab_group_create(desc, num_slabs, 0, num_slabs, nullptr, out); }
+int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out) {
+    int rc = blub::slab_group_create(desc, num_slabs, 0, num_slabs, nullptr, out);
+    if (rc == BLUB_OK && num_slabs - 1 <= blubk::SLAB_MAX_PEERS && (*out)->slabs[0]->slab) rc = blub_slab_group_set_transport(*out, 1);      // the direct transport is the default
+    return rc;
+}
 int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out) {
     if (!unique_id_128) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null unique id");
     return blub::slab_group_create(desc, num_ranks, rank, 1, unique_id_128, out);
@@ -966,6 +1168,58 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     }
     return rc;
 }
+// ---- DIRECT transport: selection, export / connect -------------------------------------------------------------------------------------
+// 0: host-issued transport operations (device copies in a local group, RCCL between processes); 1: direct (peer-mapped stores + flags).
+// Between steps only; every rank must pass the same value.  A group of several processes needs every peer connected first.
+int blub_slab_group_set_transport(blub_slab_group* g, int kind) {
+    if (!g || kind < 0 || kind > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (kind == 1) {
+        for (int r = 0; r < g->nranks; ++r)
+            if (g->peer_base[(size_t)r].empty()) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "direct transport: a peer's memory is not mapped (blub_slab_group_connect)");
+        for (auto h : g->slabs) if (!h->slab) return blub::set_error(BLUB_ERR_UNSUPPORTED, "direct transport needs the volumes of a slab in one allocation");
+        if (g->nranks - 1 > blubk::SLAB_MAX_PEERS) return blub::set_error(BLUB_ERR_UNSUPPORTED, "direct transport: at most 8 slabs");
+    }
+    if (hipSetDevice(g->device) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "stream synchronisation failed");
+    if (g->direct != (kind == 1)) { int rc = blub::slab_refresh_counts(g); if (rc != BLUB_OK) return rc; for (auto& H : g->hist) H = blub_slab_group::Hist(); g->cnt_pending = false; }
+    g->direct = kind == 1;
+    if (g->direct) snprintf(g->transport, sizeof g->transport, "direct (peer-mapped stores + flags), %d slabs%s", g->nranks, (int)g->slabs.size() == g->nranks ? ", one process" : ", hipIpc");
+    else snprintf(g->transport, sizeof g->transport, "%s", g->rccl ? "rccl" : "loopback");
+    return BLUB_OK;
+}
+int blub_slab_group_get_transport(const blub_slab_group* g) { return g ? (g->direct ? 1 : 0) : BLUB_ERR_INVALID_ARGUMENT; }
+// What the other processes need to map this process's slab: per exportable region a hipIpc handle and its size.  Single-slab groups only.
+struct blub_slab_export_entry { hipIpcMemHandle_t handle; uint64_t bytes; };
+int blub_slab_group_export_size(const blub_slab_group* g) { return (g && g->slabs.size() == 1) ? (int)(g->regions[0].size() * sizeof(blub_slab_export_entry)) : 0; }
+int blub_slab_group_export(blub_slab_group* g, void* out, int capacity) {
+    if (!g || !out || g->slabs.size() != 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "export needs a group with one local slab");
+    const auto& regs = g->regions[0];
+    if (capacity < (int)(regs.size() * sizeof(blub_slab_export_entry))) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "export buffer too small");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    blub_slab_export_entry* e = reinterpret_cast<blub_slab_export_entry*>(out);
+    for (size_t k = 0; k < regs.size(); ++k) {
+        if (!regs[k].base) return blub::set_error(BLUB_ERR_UNSUPPORTED, "direct transport needs the volumes of a slab in one allocation");
+        HIP_TRY(hipIpcGetMemHandle(&e[k].handle, regs[k].base));
+        e[k].bytes = regs[k].bytes;
+    }
+    return BLUB_OK;
+}
+int blub_slab_group_connect(blub_slab_group* g, int rank, const void* blob, int bytes) {
+    if (!g || !blob || rank < 0 || rank >= g->nranks || blub::rank_local(g, rank)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t n = g->regions[0].size();
+    if (bytes != (int)(n * sizeof(blub_slab_export_entry))) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "export blob of the wrong size");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    const blub_slab_export_entry* e = reinterpret_cast<const blub_slab_export_entry*>(blob);
+    std::vector<char*> bases;
+    for (size_t k = 0; k < n; ++k) {
+        if (e[k].bytes != g->regions[0][k].bytes) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "peer slab has a different layout");
+        void* m = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&m, e[k].handle, hipIpcMemLazyEnablePeerAccess));
+        g->ipc_opened.push_back(m);
+        bases.push_back(reinterpret_cast<char*>(m));
+    }
+    g->peer_base[(size_t)rank] = bases;
+    return BLUB_OK;
+}
 // TEST HOOK: segments [first, last] of one step (0 ghost exchange, 1 transfer, 2 divergence, 3 solve_velocity, 4 binning, 5 project,
 // 6 advect, 7 migration + density ghosts, 8 density_gather, 9 solve_density, 10 position_change, 11 correct, 12 second migration,
 // 13 step counter), so that every slab can be inspected between them.  All ranks must pass the same range.
@@ -1009,6 +1263,10 @@ int blub_slab_group_synchronize(blub_slab_group* g) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
     for (auto h : g->slabs) { int rc = blub_fluid_synchronize(h); if (rc != BLUB_OK) return rc; }
+    for (size_t i = 0; i < g->dir_error.size(); ++i) {
+        uint32_t v = 0;
+        if (hipMemcpy(&v, g->dir_error[i], sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v) return blub::set_error(BLUB_ERR_COMM, "direct transport: a wait for a peer's flag timed out (a peer stopped stepping)");
+    }
     return blub::slab_refresh_counts(g);
 }
 }  // extern "C"

@@ -630,6 +630,9 @@ class SlabGroup:
                 ("blub_slab_group_host_syncs", C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
                 ("blub_slab_group_held_back", C.c_uint64, [vp]),
                 ("blub_slab_group_run_stages", C.c_int, [vp, C.c_float, C.c_int, C.c_int]),
+                ("blub_slab_group_set_transport", C.c_int, [vp, C.c_int]), ("blub_slab_group_get_transport", C.c_int, [vp]),
+                ("blub_slab_group_export_size", C.c_int, [vp]), ("blub_slab_group_export", C.c_int, [vp, vp, C.c_int]),
+                ("blub_slab_group_connect", C.c_int, [vp, C.c_int, vp, C.c_int]),
                 ("blub_slab_group_step", C.c_int, [vp, C.c_float]), ("blub_slab_group_synchronize", C.c_int, [vp]),
                 ("blub_slab_group_transport_ops", C.c_uint64, [vp]), ("blub_slab_group_transport_description", C.c_char_p, [vp]),
                 ("blub_slab_group_set_meshes", C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
@@ -744,6 +747,25 @@ class SlabGroup:
 
     SLAB_STAGES = {"ghosts": 0, "transfer": 1, "divergence": 2, "solve_velocity": 3, "binning": 4, "project": 5, "advect": 6, "migrate": 7,
                    "density_gather": 8, "solve_density": 9, "position_change": 10, "correct": 11, "migrate_b": 12, "finish": 13}
+
+    def set_transport(self, kind):
+        """"host": host-issued transport operations between the kernels (device copies in a local group, RCCL between processes);
+        "direct": peer-mapped stores + flags, no host in the loop (include/blubhip.h: blub_slab_group_set_transport).  Between steps; all ranks agree."""
+        _check(self._L, self._L.blub_slab_group_set_transport(self._g, {"host": 0, "direct": 1}[kind]))
+
+    def transport(self):
+        return ("host", "direct")[int(self._L.blub_slab_group_get_transport(self._g))]
+
+    def export_handles(self):
+        """bytes for the other ranks' connect(): one hipIpc handle + size per exportable allocation of the local slab"""
+        n = int(self._L.blub_slab_group_export_size(self._g))
+        buf = (C.c_uint8 * n)()
+        _check(self._L, self._L.blub_slab_group_export(self._g, buf, n))
+        return bytes(buf)
+
+    def connect(self, rank, blob):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _check(self._L, self._L.blub_slab_group_connect(self._g, int(rank), buf, len(blob)))
 
     def run_stages(self, simulation_delta, first, last):
         """TEST HOOK (include/blubhip.h: blub_slab_group_run_stages): segments first..last (names of SLAB_STAGES) of one step."""

@@ -385,6 +385,20 @@ int blub_slab_group_host_syncs(const blub_slab_group* g, uint64_t* particle_exch
  * nothing before).  Nothing is lost: a held-back particle stays an own particle of its slab, clamped just inside the range, and travels
  * with the next exchange (whose message is sized for it).  Sum over the local slabs since creation; blocks. */
 uint64_t blub_slab_group_held_back(blub_slab_group* g);
+/* Transport of a z-slab group.  0: host-issued operations between the kernels (device copies inside a local group; grouped RCCL send / recv
+ * between processes) -- the default of blub_slab_group_create_rccl.  1: DIRECT -- every slab stores what its neighbours need straight into
+ * THEIR memory (the same process in a local group, hipIpc mappings between processes: xGMI peer access on one node) and raises a flag word;
+ * consumers wait for the flags on the device (inside the PCG iteration kernel; a one-block wait kernel elsewhere).  No host-issued transport
+ * operation, no stream synchronisation, no message sizes (a particle exchange cannot outgrow anything but the particle capacity itself).
+ * The default of blub_slab_group_create_local.  Between steps only; every rank passes the same value; with several processes every peer
+ * must have been connected (below).  Results are the same to the bit as with transport 0 (same kernels, same order of every sum). */
+int blub_slab_group_set_transport(blub_slab_group* g, int kind);
+int blub_slab_group_get_transport(const blub_slab_group* g);
+/* DIRECT transport between processes: export() fills `out` (export_size() bytes: one hipIpc handle + size per exportable allocation of the
+ * local slab) -- carry it to the other ranks by any means (bench.py: torch.distributed.all_gather_object) and hand rank r's blob to connect(). */
+int blub_slab_group_export_size(const blub_slab_group* g);
+int blub_slab_group_export(blub_slab_group* g, void* out, int capacity);
+int blub_slab_group_connect(blub_slab_group* g, int rank, const void* blob, int bytes);
 /* TEST HOOK: runs segments [first, last] of ONE step so that a test can look at every slab in between: 0 ghost-particle exchange,
  * 1 transfer, 2 divergence, 3 solve_velocity, 4 binning, 5 project (+ extrapolation), 6 advect, 7 migration + density ghosts,
  * 8 density_gather, 9 solve_density, 10 position_change (+ extrapolation), 11 correct, 12 second migration, 13 step counter.

@@ -53,7 +53,26 @@ def main():
     group = blub_amd.SlabGroup(dim, pos.shape[0], rank=rank, world=world, unique_id=uid, device=0, binning="off")
     out = {"description": group.transport_description(), "range": group.local_range(0)}
     try:
-        if gather != "calibrated":
+        if gather == "direct":
+            # DIRECT transport between processes: every rank exports the hipIpc handles of its slab, maps everybody else's, and from then on the
+            # kernels store into the neighbours' memory themselves (RCCL -- here its stand-in -- only carried the group's creation)
+            blob = group.export_handles()
+            with open(os.path.join(workdir, "ipc%d.tmp" % rank), "wb") as f:
+                f.write(blob)
+            os.rename(os.path.join(workdir, "ipc%d.tmp" % rank), os.path.join(workdir, "ipc%d" % rank))
+            for r in range(world):
+                if r == rank:
+                    continue
+                path = os.path.join(workdir, "ipc%d" % r)
+                t0 = time.time()
+                while not os.path.exists(path):
+                    if time.time() - t0 > 120:
+                        raise SystemExit("no export from rank %d" % r)
+                    time.sleep(0.01)
+                group.connect(r, open(path, "rb").read())
+            group.set_transport("direct")
+            out["description"] = group.transport_description()
+        elif gather != "calibrated":
             group.set_gather_mode(gather)
         group.set_pcg_schedule(schedule)
         group.local_fluid(0).set_tuning("pcg1_max_iterations", 1000)     # (120 single-reduction iterations: the engine would otherwise switch to the reference order)

@@ -51,7 +51,8 @@ def _launch(mode, world, workdir, schedule="reference", gather="calibrated", tim
 
 
 @pytest.mark.parametrize("world,schedule,gather", [(2, "reference", "calibrated"), (2, "single_reduction", "p2p"), (2, "single_reduction", "allgather"),
-                                                   (4, "reference", "p2p"), (4, "single_reduction", "calibrated"), (8, "single_reduction", "p2p")])
+                                                   (4, "reference", "p2p"), (4, "single_reduction", "calibrated"), (8, "single_reduction", "p2p"),
+                                                   (2, "single_reduction", "direct"), (4, "single_reduction", "direct")])
 def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedule, gather, tmp_path):
     import blub_amd
     # (eight processes time-share the one GPU: two steps of 24 iterations instead of three of 120 keep the run to about a minute)
@@ -65,7 +66,7 @@ def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedu
         cfg = dict(cfg, max_num_iterations=iterations)
     # every rank reports the same transport (the calibration's verdict is all-reduced) and the ranges tile the domain in rank order
     desc = [str(d["description"]) for d in ranks]
-    assert all(x == desc[0] for x in desc) and ("%d ranks" % world) in desc[0], desc
+    assert all(x == desc[0] for x in desc) and (("%d ranks" % world) in desc[0] or ("direct" in desc[0] and "hipIpc" in desc[0] and gather == "direct")), desc
     print("transport:", desc[0])
     rng_ = [tuple(int(v) for v in d["range"]) for d in ranks]
     assert rng_[0][0] == 0 and rng_[-1][1] == dim[2] and all(a[1] == b[0] for a, b in zip(rng_, rng_[1:]))
@@ -96,8 +97,13 @@ def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedu
             ops = [int(d["ops%d" % step]) for d in ranks]
             assert all(o == ops[0] for o in ops) and ops[0] > 0, ops      # every rank issued the same sequence of transport operations
         assert [d["pos%d" % (steps - 1)].shape[0] for d in ranks] != counts0, "no particle migrated between the processes"
-        # particle exchanges synchronise the host only in the first step (no history to size the messages from): 4 of them, then none
-        assert all(int(d["host_syncs"][0]) == 4 for d in ranks), [d["host_syncs"] for d in ranks]
+        # particle exchanges synchronise the host only in the first step (no history to size the messages from): 4 of them, then none;
+        # the direct transport never does, and never looks at a solve's `done` from the host either
+        if gather == "direct":
+            assert all(tuple(int(v) for v in d["host_syncs"]) == (0, 0) for d in ranks), [d["host_syncs"] for d in ranks]
+            assert all(int(d["ops%d" % step]) == 14 for d in ranks for step in range(steps)), [int(d["ops0"]) for d in ranks]
+        else:
+            assert all(int(d["host_syncs"][0]) == 4 for d in ranks), [d["host_syncs"] for d in ranks]
         st = [d["stats"] for d in ranks]
         assert all(np.array_equal(x, st[0]) for x in st)                  # identical solver statistics on every rank (gathered partials, fixed order)
         m_single = single.read_volume("marker")

@@ -487,8 +487,8 @@ def _match_particles(a, b):
     return d
 
 
-@pytest.mark.parametrize("slabs,async_exchange", [(2, True), (3, True), (3, False)])
-def test_z_slab_decomposition_matches_single_domain(slabs, async_exchange):
+@pytest.mark.parametrize("slabs,async_exchange,transport", [(2, True, "host"), (3, True, "host"), (3, False, "host"), (2, True, "direct"), (3, True, "direct"), (8, True, "direct")])
+def test_z_slab_decomposition_matches_single_domain(slabs, async_exchange, transport):
     """the z-slab protocol (ghost particles, halo planes, all-reduced PCG scalars, migration) run as `slabs`
     slabs on ONE GPU (loopback transport) reproduces the single-domain engine.  The blob straddles the slab interfaces
     and shears across them, so every exchange carries data.
@@ -513,7 +513,14 @@ def test_z_slab_decomposition_matches_single_domain(slabs, async_exchange):
     single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     rerun = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     group = blub_amd.SlabGroup(dim, pos.shape[0], local=slabs, binning="off")
+    assert group.transport() == "direct"          # the default of a local group since round 4
+    group.set_transport(transport)
     group.set_async_exchange(async_exchange)
+    if transport == "direct":       # (solves of more than 64 iterations would otherwise run the reference's two-kernel order: its exchanges stay host-issued pushes)
+        for i in range(slabs):
+            group.local_fluid(i).set_tuning("pcg1_max_iterations", 1000)
+        single.set_tuning("pcg1_max_iterations", 1000)
+        rerun.set_tuning("pcg1_max_iterations", 1000)
     try:
         for f in (single, rerun, group):
             f.set_gravity_grid((0.0, -981.0, 0.0))
@@ -523,7 +530,8 @@ def test_z_slab_decomposition_matches_single_domain(slabs, async_exchange):
         ranges = [group.local_range(i) for i in range(slabs)]
         assert ranges[0][0] == 0 and ranges[-1][1] == dim[2] and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
         counts0 = [group.local_fluid(i).num_particles() for i in range(slabs)]
-        assert sum(counts0) == pos.shape[0] and all(c > 0 for c in counts0)
+        assert sum(counts0) == pos.shape[0] and all(c > 0 for c in counts0[1:-1])      # (eight slabs: the outermost two start empty)
+        ops0 = group.transport_ops()
         for step in range(3):
             for f in (single, rerun, group):
                 f.step(util.DT)
@@ -542,8 +550,15 @@ def test_z_slab_decomposition_matches_single_domain(slabs, async_exchange):
         assert sum(counts1) == pos.shape[0]
         assert counts1 != counts0, "no particle migrated: the test does not exercise the exchange"
         # host synchronisations by particle exchanges: four in the first step (no history to size the messages from), none afterwards --
-        # or four per step with the round-2 protocol
-        assert group.host_syncs()[0] == (4 if async_exchange else 12), group.host_syncs()
+        # or four per step with the round-2 protocol; the direct transport never synchronises the host, not for exchanges and not to look at a
+        # solve's `done`, and issues 14 transport operations per step (the 120 PCG iterations of each solve exchange from inside their kernels)
+        if transport == "direct":
+            assert group.host_syncs() == (0, 0), group.host_syncs()
+            print("direct transport: %d transport operations in 3 steps" % (group.transport_ops() - ops0))
+            assert group.transport_ops() - ops0 == 3 * 14, group.transport_ops() - ops0
+            assert group.held_back() == 0
+        else:
+            assert group.host_syncs()[0] == (4 if async_exchange else 12), group.host_syncs()
         # every slab only holds particles of its own z-range
         pgl = group.get_particles()[0]
         off = 0
@@ -580,6 +595,7 @@ def test_z_slab_solve_follows_convergence(schedule):
     pos = (cells[:, None, :] + rng.random((cells.shape[0], 8, 3))).reshape(-1, 3).astype(np.float32)
     single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     group = blub_amd.SlabGroup(dim, pos.shape[0], local=3, binning="off")
+    group.set_transport("host")       # (this test is about the host-issued operations of the copy / RCCL protocol)
     # transport operations of one solve with k launched iterations: init exchange (+ the w_0 exchange of the single-reduction
     # schedule), per iteration ONE grouped operation (single reduction) or TWO (reference schedule), the pressure halo
     solve_ops = (lambda k: 2 + k + 1) if schedule == "single_reduction" else (lambda k: 1 + 2 * k + 1)

@@ -187,6 +187,7 @@ def test_a_front_arriving_at_an_empty_interface_loses_no_particle():
     cfg = dict(error_tolerance=0.0, max_num_iterations=60, error_check_frequency=8)
     single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     group = blub_amd.SlabGroup(dim, pos.shape[0], local=2, binning="off")
+    group.set_transport("host")       # (messages with a size only exist with host-issued transport operations; the direct transport: next test)
     try:
         for f in (single, group):
             f.set_gravity_grid((0.0, 0.0, 0.0))
@@ -223,6 +224,35 @@ def test_a_front_arriving_at_an_empty_interface_loses_no_particle():
         group.close()
 
 
+def test_a_front_over_the_direct_transport_needs_no_hold_back():
+    """The same front with the direct transport: the sender writes what travels straight into staging buffers of full particle capacity, so
+    there is no message to outgrow -- nothing held back, and the group stays the single domain particle by particle."""
+    import blub_amd
+    from tests.test_gpu_parity import _match_particles
+    dim, pos, vel = _front_scene()
+    cfg = dict(error_tolerance=0.0, max_num_iterations=60, error_check_frequency=8)
+    single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
+    group = blub_amd.SlabGroup(dim, pos.shape[0], local=2, binning="off")
+    try:
+        assert group.transport() == "direct"
+        for f in (single, group):
+            f.set_gravity_grid((0.0, 0.0, 0.0))
+            f.set_particles(pos, *vel)
+            for w in (0, 1):
+                f.set_solver_config(w, **cfg)
+        for step in range(14):
+            single.step(util.DT)
+            group.step(util.DT)
+        assert group.num_particles() == pos.shape[0] and group.local_fluid(1).num_particles() > 20000
+        assert group.held_back() == 0 and group.host_syncs() == (0, 0)
+        d = _match_particles(group.get_particles()[0][:, :3].astype(np.float64), single.get_particles()[0][:, :3].astype(np.float64))
+        print("front, direct transport: slabs vs single after 14 steps: median %.3g p99 %.3g max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
+        assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 2e-2
+    finally:
+        single.close()
+        group.close()
+
+
 def test_switching_the_asynchronous_exchange_off_mid_run():
     """Round-3 ADVICE (medium): after asynchronous steps the host-side particle counts are bounds; the synchronous protocol takes them as
     exact.  blub_slab_group_set_async_exchange(g, 0) now fetches the counts first."""
@@ -232,6 +262,7 @@ def test_switching_the_asynchronous_exchange_off_mid_run():
     dim, pos, vel, cfg = scene()
     single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
     group = blub_amd.SlabGroup(dim, pos.shape[0], local=3, binning="off")
+    group.set_transport("host")
     try:
         for f in (single, group):
             f.set_gravity_grid((0.0, -981.0, 0.0))
