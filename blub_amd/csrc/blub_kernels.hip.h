@@ -263,6 +263,10 @@ __device__ __forceinline__ uint32_t ld_sys_u32(const uint32_t* p) {
     return v;
 }
 __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// several cache-bypassing loads in flight, ONE wait: issue with ld_sys_f4_issue, then ld_sys_wait on the same registers before the first use
+__device__ __forceinline__ void ld_sys_f4_issue(blub_v4f& v, const float4* p) { asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ld_sys_wait(blub_v4f& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) :: "memory"); }
+__device__ __forceinline__ void ld_sys_wait(blub_v4f& a, blub_v4f& b, blub_v4f& c, blub_v4f& d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory"); }
 
 // What a kernel of one slab needs to exchange with the other slabs by itself (direct transport of a z-slab group): pointers into the
 // PEERS' memory (the same process in a loopback group, hipIpc mappings between processes) for what it produces, its own flag words for what

@@ -98,11 +98,15 @@ __device__ __forceinline__ bool pcg1_prologue_finish(Pcg1PrologueLoads& L, PcgCt
         // z-slab groups, direct transport: the other slabs' segments were written by other agents while this kernel may already have been
         // running -- fetched with cache-bypassing loads AFTER the flag wait (the speculative plain loads of pcg1_prologue_load are not used),
         // in the same order and grouping as below, so the sums are bit-identical to the host-transport solve
+        static_assert(PCG_PART_PER_THREAD == 4, "four partial loads in flight");
+        blub_v4f pv[4];
+        const int lim = min(num_part, PCG_VBLOCKS_MAX);
 #pragma unroll
-        for (int k = 0; k < PCG_PART_PER_THREAD; ++k) {
-            const int i = (int)threadIdx.x + k * NT;
-            if (i < num_part && i < PCG_VBLOCKS_MAX) { const float4 p = ld_sys_f4(part_in + i); g += p.x; d += p.y; m = fmaxf(m, p.z); }
-        }
+        for (int k = 0; k < 4; ++k) ld_sys_f4_issue(pv[k], part_in + min((int)threadIdx.x + k * NT, max(lim - 1, 0)));      // (clamped address, masked below)
+        ld_sys_wait(pv[0], pv[1], pv[2], pv[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((int)threadIdx.x + k * NT < lim) { g += pv[k].x; d += pv[k].y; m = fmaxf(m, pv[k].z); }
         for (int i = (int)threadIdx.x + PCG_VBLOCKS_MAX; i < num_part; i += NT) { const float4 p = ld_sys_f4(part_in + i); g += p.x; d += p.y; m = fmaxf(m, p.z); }
     } else {
     spec_partials_fix(part_in, L.spec, num_part, L.sp);
@@ -260,6 +264,7 @@ template <bool FIRST, bool COHERENT = false>
 __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const float* __restrict__ r_in, const float* __restrict__ w_in, const float* __restrict__ q_in,
                                                       const float* __restrict__ dsearch, const float* __restrict__ p) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    blub_v4f wsys; bool wsys_pending = false;      // (direct transport: the halo row of w, fetched past the caches, in flight with the plain loads)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         L.rv[k] = zero4; L.wv[k] = zero4; L.qv[k] = zero4; L.dv4[k] = zero4; L.pv4[k] = zero4;
@@ -267,12 +272,13 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
         const uint32_t off = (uint32_t)L.base[k] * 4u;
         L.rv[k] = ld4o(r_in, off);
         // (direct transport: the halo rows of w may lie in a ghost plane a z-neighbour wrote while this kernel was running)
-        if (COHERENT && k == 1) L.wv[k] = ld_sys_f4(reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w_in) + off)); else L.wv[k] = ld4o(w_in, off);
+        if (COHERENT && k == 1) { ld_sys_f4_issue(wsys, reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w_in) + off)); wsys_pending = true; } else L.wv[k] = ld4o(w_in, off);
         if (!FIRST) L.qv[k] = ld4o(q_in, off);
         if (L.own[k]) { L.dv4[k] = ld4o(dsearch, off); L.pv4[k] = ld4o(p, off); }
     }
     L.hr = 0.f; L.hw = 0.f; L.hq = 0.f;
     if (L.hc >= 0 && (L.hdv & 0x80)) { const uint32_t off = (uint32_t)L.hc * 4u; L.hr = ld1o(r_in, off); L.hw = ld1o(w_in, off); if (!FIRST) L.hq = ld1o(q_in, off); }
+    if (COHERENT && wsys_pending) { ld_sys_wait(wsys); L.wv[1] = make_float4(wsys.x, wsys.y, wsys.z, wsys.w); }
 }
 
 // K(i): one whole PCG iteration.  HALO (z-slab groups): the block also stores the r_{i+1} / q_i it computed for the ghost plane
@@ -296,13 +302,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     pcg_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
-    if (DIRECT) {
-        // z-slab groups, direct transport: this launch consumes the w plane of the z-neighbours and the partials of every slab as the
-        // PREVIOUS launch of the other slabs stored them straight into this slab's memory -- wait for their flags (unless the solve is
-        // over: every slab takes that decision alike, nobody publishes any more)
-        if (ctrl->done) return false;
-        slab_wait_flags(dir->flags_in, dir->wait_mask, dir->seq_in, dir->error);
-    }
+
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
     // the previous scalars and the partials.  The first list entry is requested for virtual workgroup blockIdx.x BEFORE the list length
     // (hence V) is known: with the XCD-contiguous order its position depends on V, so that speculative fetch uses the launch grid's
@@ -328,6 +328,13 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     // round trip 2: the first brick's descriptors, in flight during the reduction; its fields follow the reduction
     Pcg1TileLoads TL;
     if (has_vb && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
+    if (DIRECT) {
+        // z-slab groups, direct transport: this launch consumes the w plane of the z-neighbours and the partials of every slab as the
+        // PREVIOUS launch of the other slabs stored them straight into this slab's memory -- wait for their flags (the solve is not over:
+        // `done` was tested above; every slab takes that decision alike, so nobody waits for a flag that is never raised).  The flag loads
+        // ride with the descriptor loads just issued; everything that comes from a peer is only requested after them.
+        slab_wait_flags(dir->flags_in, dir->wait_mask, dir->seq_in, dir->error);
+    }
     float alpha, beta;
     if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
     if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p);

@@ -173,11 +173,13 @@ __global__ __launch_bounds__(256) void k_slab_append(SlabAppendArgs a, int narr,
     const uint32_t own = n_dev[0];
     bool over = cb > cap_below || ca > cap_above || (uint64_t)own + cb + ca > capacity;
     if (over) { cb = min(cb, cap_below); ca = min(ca, cap_above); if ((uint64_t)own + cb + ca > capacity) { cb = 0; ca = 0; } }
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k < cb) {
-        for (int q = 0; q < narr; ++q) a.dst[q][own + k] = a.below[q][k + (q == 0 ? 1u : 0u)];
-    } else if (k - cb < ca) {
-        for (int q = 0; q < narr; ++q) a.dst[q][own + k] = a.above[q][k - cb + (q == 0 ? 1u : 0u)];
+    // (grid-stride: the launch grid is sized from message capacities -- with the direct transport the full particle capacity -- not from what arrived)
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < cb + ca; k += gridDim.x * 256) {
+        if (k < cb) {
+            for (int q = 0; q < narr; ++q) a.dst[q][own + k] = a.below[q][k + (q == 0 ? 1u : 0u)];
+        } else {
+            for (int q = 0; q < narr; ++q) a.dst[q][own + k] = a.above[q][k - cb + (q == 0 ? 1u : 0u)];
+        }
     }
     // the last block to finish publishes the counts (every append of this launch is done by then for the kernels that follow on the stream;
     // the host only reads the record)

@@ -13,7 +13,7 @@ from blub_amd import slab_scene  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(scene="corner_dams_256", slabs=2, steps=60, warmup=5, schedule="single_reduction", async_exchange=1):
+def main(scene="corner_dams_256", slabs=2, steps=60, warmup=5, schedule="single_reduction", async_exchange=1, transport="direct"):
     dt = blub_amd.default_simulation_delta()
     path = os.path.join(ROOT, "scenes", scene + ".json")
     cfg = blub_amd.Scene.parse(path=path).config
@@ -21,6 +21,7 @@ def main(scene="corner_dams_256", slabs=2, steps=60, warmup=5, schedule="single_
     pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
     g = blub_amd.SlabGroup(dim, len(pos) + 64, local=slabs)
     g.set_gravity_grid(gravity)
+    g.set_transport(transport)
     g.set_pcg_schedule(schedule)
     g.set_async_exchange(bool(async_exchange))
     g.set_particles(pos)
@@ -50,9 +51,9 @@ def main(scene="corner_dams_256", slabs=2, steps=60, warmup=5, schedule="single_
     print(json.dumps({"scene": scene, "slabs_on_one_gpu": slabs, "grid": list(dim), "particles": len(pos), "steps": steps,
                       "slab_group_ms_per_step": round(el / steps * 1e3, 3), "single_domain_one_copy_ms_per_step": round(el1 / steps * 1e3, 3),
                       "protocol_overhead_vs_n_sequential_copies": round(el / (slabs * el1), 3), "transport_ops_per_step": round(ops, 1),
-                      "pcg_schedule": schedule, "async_particle_exchange": bool(async_exchange), "host_syncs_particle_exchanges_total": syncs[0], "host_syncs_done_polls_total": syncs[1]}))
+                      "pcg_schedule": schedule, "transport": transport, "async_particle_exchange": bool(async_exchange), "host_syncs_particle_exchanges_total": syncs[0], "host_syncs_done_polls_total": syncs[1]}))
 
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    main(*(a[0:1] or ["corner_dams_256"]), *[int(v) for v in a[1:4]], *(a[4:5]), *[int(v) for v in a[5:6]])
+    main(*(a[0:1] or ["corner_dams_256"]), *[int(v) for v in a[1:4]], *(a[4:5]), *[int(v) for v in a[5:6]], *(a[6:7]))
