@@ -508,7 +508,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             float* Q[2] = {h->aux_temp, h->cgbuf[2]};
             float4* part[2] = {h->part4, h->part4 + PCG_GRID_MAX};
             Pcg1Scalars* sc = h->pcg1_scalars[which];
-            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, 0, part[0], 1);
+            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, 0, part[0], 1, 0u);
             // Launch as many iterations as the last few solves needed (+ `tail_margin_checks` check intervals); ONE persistent kernel covers
             // the rest (k_pcg1_tail_s): it normally finds the solve finished and only publishes the statistics.  Only while the solve is
             // launch-bound (an iteration inside the tail -- <= 256 blocks, a grid barrier -- costs more than a launched one).
@@ -529,7 +529,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
                 LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_tail_s<true>, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, R[0], R[1], W[0], W[1], Q[0], Q[1], h->search, p,
                        part[0], part[1], ctrl, sc, tol, launched1, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
             } else
-                LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], 0, nfl, maxit, h->solve_seq[which], stat_slot);
+                LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), ctrl, (const float4*)part[(maxit + 1) & 1], 0, nfl, maxit, h->solve_seq[which], stat_slot, 0u, (uint32_t*)nullptr);
             // the residual of a full-length solve ends in R[(maxit + 1) & 1]; keep BLUB_VOLUME_RESIDUAL pointing at it
             if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
             return enqueue_stats_readback(h, which, dt, true);

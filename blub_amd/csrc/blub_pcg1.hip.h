@@ -89,25 +89,57 @@ __device__ __forceinline__ void pcg1_prologue_load(const PcgCtrl* __restrict__ c
     spec_partials_load(part_in, L.spec, L.sp);
 }
 // Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
+// direct transport: tagged partials (see pcg1_prologue_finish)
+struct Pcg1PartialLoads { blub_v4f v[4]; };
+__device__ __forceinline__ void pcg1_partials_issue(Pcg1PartialLoads& P, const float4* __restrict__ part_in, int num_part_in) {
+    const int lim = min(num_part_in, PCG_VBLOCKS_MAX);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ld_sys_f4_issue(P.v[k], part_in + min((int)threadIdx.x + k * PCG_B_THREADS, max(lim - 1, 0)));      // (clamped address, masked by the consumer)
+}
+__device__ __forceinline__ float4 pcg1_partial_spin(const float4* p, uint32_t tag, uint32_t* err) {
+    float4 v = ld_sys_f4(p);
+    unsigned spins = 0;
+    while (__float_as_uint(v.w) != tag) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 21)) { if (err) atomicOr(err, 1u); break; }      // ~1 s: a missing peer must not hang the GPU
+        v = ld_sys_f4(p);
+    }
+    return v;
+}
+__device__ __forceinline__ float4 pcg1_partial_validated(Pcg1PartialLoads& P, int k, const float4* p, uint32_t tag, uint32_t* err) {
+    if (__float_as_uint(P.v[k].w) == tag) return make_float4(P.v[k].x, P.v[k].y, P.v[k].z, P.v[k].w);
+    return pcg1_partial_spin(p, tag, err);
+}
 template <bool FIRST, bool COHERENT = false>
 __device__ __forceinline__ bool pcg1_prologue_finish(Pcg1PrologueLoads& L, PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in,
-                                                     int num_part, float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta) {
+                                                     int num_part, float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta,
+                                                     Pcg1PartialLoads* pre = nullptr, uint32_t tag_in = 0u, uint32_t* err = nullptr) {
     constexpr int NT = PCG_B_THREADS;
     float g = 0.0f, d = 0.0f, m = 0.0f;
     if (COHERENT) {
-        // z-slab groups, direct transport: the other slabs' segments were written by other agents while this kernel may already have been
-        // running -- fetched with cache-bypassing loads AFTER the flag wait (the speculative plain loads of pcg1_prologue_load are not used),
-        // in the same order and grouping as below, so the sums are bit-identical to the host-transport solve
-        static_assert(PCG_PART_PER_THREAD == 4, "four partial loads in flight");
-        blub_v4f pv[4];
+        // z-slab groups, direct transport: every partial carries the sequence number of the exchange it belongs to in its fourth word.  The
+        // first four of this thread were requested past the caches at the very start of the kernel (pcg1_partials_issue) and are accepted
+        // here when their tags match -- a partial is only stored after the stores of its whole workgroup have landed, so the tags of all
+        // workgroups of a slab vouch for its boundary planes too: no flag round trip, no fence.  Same order and grouping as below: the sums
+        // are bit-identical to the host-transport solve.
         const int lim = min(num_part, PCG_VBLOCKS_MAX);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ld_sys_f4_issue(pv[k], part_in + min((int)threadIdx.x + k * NT, max(lim - 1, 0)));      // (clamped address, masked below)
-        ld_sys_wait(pv[0], pv[1], pv[2], pv[3]);
+        for (int k = 0; k < 4; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
+            if (i < lim) { const float4 p = pcg1_partial_validated(*pre, k, part_in + i, tag_in, err); g += p.x; d += p.y; m = fmaxf(m, p.z); }
+        }
+        // (the gathered arrays of groups of more than 1024 partials: four loads in flight per round, as above)
+        for (int base = PCG_VBLOCKS_MAX; base < num_part; base += 4 * NT) {
+            Pcg1PartialLoads Q;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((int)threadIdx.x + k * NT < lim) { g += pv[k].x; d += pv[k].y; m = fmaxf(m, pv[k].z); }
-        for (int i = (int)threadIdx.x + PCG_VBLOCKS_MAX; i < num_part; i += NT) { const float4 p = ld_sys_f4(part_in + i); g += p.x; d += p.y; m = fmaxf(m, p.z); }
+            for (int k = 0; k < 4; ++k) ld_sys_f4_issue(Q.v[k], part_in + min(base + (int)threadIdx.x + k * NT, num_part - 1));
+            ld_sys_wait(Q.v[0], Q.v[1], Q.v[2], Q.v[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + (int)threadIdx.x + k * NT;
+                if (i < num_part) { const float4 p = pcg1_partial_validated(Q, k, part_in + i, tag_in, err); g += p.x; d += p.y; m = fmaxf(m, p.z); }
+            }
+        }
     } else {
     spec_partials_fix(part_in, L.spec, num_part, L.sp);
 #pragma unroll
@@ -151,7 +183,8 @@ __device__ __forceinline__ uint32_t st_read_quad_u(const StagedTile& T, int t, Q
 // w_0 = A u_0 (u_0 = M^-1 r_0 was written to the search volume by k_pcg_init_b) + partials {gamma_0 (virtual block 0 only), delta_0, 0}
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
                                                              const uint8_t* __restrict__ dvol, const float* __restrict__ u, float* __restrict__ w_out,
-                                                             const float2* __restrict__ part_init, int num_part_in, float4* __restrict__ part_out, int gamma_owner) {
+                                                             const float2* __restrict__ part_init, int num_part_in, float4* __restrict__ part_out, int gamma_owner,
+                                                             uint32_t tag = 0u) {
     __shared__ float sm[8];
     __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const
         const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
         // gamma_0 (already reduced over ALL partials of the init kernels) enters the partial array exactly once: virtual block 0 of the one
         // domain, or of the first slab of a z-slab group
-        if (threadIdx.x == 0) part_out[vb] = make_float4((vb == 0 && gamma_owner) ? red0.x : 0.0f, tot, 0.0f, 0.0f);
+        if (threadIdx.x == 0) part_out[vb] = make_float4((vb == 0 && gamma_owner) ? red0.x : 0.0f, tot, 0.0f, __uint_as_float(tag));      // (tag: direct transport of z-slab groups)
     }
 }
 
@@ -302,7 +335,8 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     pcg_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
-
+    Pcg1PartialLoads PP;
+    if (DIRECT) pcg1_partials_issue(PP, part_in, num_part_in);      // past the caches, in flight with everything below
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
     // the previous scalars and the partials.  The first list entry is requested for virtual workgroup blockIdx.x BEFORE the list length
     // (hence V) is known: with the XCD-contiguous order its position depends on V, so that speculative fetch uses the launch grid's
@@ -328,15 +362,11 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     // round trip 2: the first brick's descriptors, in flight during the reduction; its fields follow the reduction
     Pcg1TileLoads TL;
     if (has_vb && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
-    if (DIRECT) {
-        // z-slab groups, direct transport: this launch consumes the w plane of the z-neighbours and the partials of every slab as the
-        // PREVIOUS launch of the other slabs stored them straight into this slab's memory -- wait for their flags (the solve is not over:
-        // `done` was tested above; every slab takes that decision alike, so nobody waits for a flag that is never raised).  The flag loads
-        // ride with the descriptor loads just issued; everything that comes from a peer is only requested after them.
-        slab_wait_flags(dir->flags_in, dir->wait_mask, dir->seq_in, dir->error);
-    }
+    if (DIRECT) ld_sys_wait(PP.v[0], PP.v[1], PP.v[2], PP.v[3]);      // (one wait for the whole first batch)
     float alpha, beta;
-    if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta)) return false;
+    // (direct transport: the tags of ALL partials of the previous launch have been seen before anything else that came from a peer -- the halo
+    //  rows of w below -- is requested)
+    if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta, &PP, DIRECT ? dir->seq_in : 0u, DIRECT ? dir->error : nullptr)) return false;
     if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p);
     StagedTile& T = tiles[half];
     bool first = true;
@@ -449,6 +479,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     }
     // one combined block reduction of the three partials of this virtual workgroup
     acc_g = wave_sum_dpp(acc_g); acc_d = wave_sum_dpp(acc_d); emax = wave_max_abs_dpp(emax);
+    if (DIRECT) wait_stores();      // every store of this wave -- the pushed boundary planes among them -- has landed before the tagged partial goes out
     __syncthreads();          // (a workgroup without bricks reaches this point straight from the prologue's reads of sm4)
     if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = make_float4(acc_g, acc_d, emax, 0.0f);
     __syncthreads();
@@ -456,14 +487,14 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
         float4 tot = sm4[0];
 #pragma unroll
         for (int w = 1; w < PCG_B_THREADS / 64; ++w) { tot.x += sm4[w].x; tot.y += sm4[w].y; tot.z = fmaxf(tot.z, sm4[w].z); }
-        part_out[vb] = tot;
-        if (DIRECT) {      // ... and into this slab's segment of every other slab's partial array
-            st_sys_f4(part_out + vb, tot);      // (the own copy too: the own consumer reads the whole array with cache-bypassing loads)
+        if (DIRECT) {      // tagged with this exchange's number, into this slab's segment of EVERY slab's partial array (the own one too: its
+                           // consumer reads the whole array past the caches)
+            tot.w = __uint_as_float(dir->seq_out);
+            st_sys_f4(part_out + vb, tot);
             for (int q = 0; q < dir->n_out; ++q) st_sys_f4(dir->part_out[q] + vb, tot);
-        }
+        } else part_out[vb] = tot;
     }
     }
-    if (DIRECT) slab_publish(*dir, (uint32_t)min((int)gridDim.x, V));
     return true;
 }
 
@@ -482,11 +513,23 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_iter_s(BrickGeom bg, con
 
 // After K(max_num_iterations): statistics are written unconditionally if nothing converged before (pressure_reduce.comp:84).
 // num_part > 0: that many partials (z-slab groups); 0: the V of the solve.
+// tag != 0 (z-slab groups, direct transport): the partials of K(max) are accepted by their tags, past the caches -- unless the solve is over
 __global__ __launch_bounds__(256) void k_pcg1_finalize(PcgCtrl* __restrict__ ctrl, const float4* __restrict__ part, int num_part, const uint32_t* __restrict__ count_fluid,
-                                                       int iteration, uint32_t seq, PcgCtrl* __restrict__ host_snapshot) {
+                                                       int iteration, uint32_t seq, PcgCtrl* __restrict__ host_snapshot, uint32_t tag = 0u, uint32_t* err = nullptr) {
     __shared__ float4 sm4[4];
     const int done = ctrl->done;
-    const float4 red = reduce_partials4<256>(part, num_part > 0 ? num_part : pcg_vblocks(*count_fluid, 0), sm4);
+    float4 red;
+    if (tag != 0u && !done) {
+        float g = 0.0f, d = 0.0f, m = 0.0f;
+        for (int i = threadIdx.x; i < num_part; i += 256) { const float4 p = pcg1_partial_spin(part + i, tag, err); g += p.x; d += p.y; m = fmaxf(m, p.z); }
+        g = wave_sum_dpp(g); d = wave_sum_dpp(d); m = wave_max_abs_dpp(m);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = make_float4(g, d, m, 0.0f);
+        __syncthreads();
+        red = sm4[0];
+        for (int w = 1; w < 4; ++w) { red.x += sm4[w].x; red.y += sm4[w].y; red.z = fmaxf(red.z, sm4[w].z); }
+    } else
+    red = reduce_partials4<256>(part, num_part > 0 ? num_part : pcg_vblocks(*count_fluid, 0), sm4);
     if (threadIdx.x == 0) {
         if (!done) { ctrl->max_err = red.z; ctrl->num_iter = (float)iteration; ctrl->done = 1; }
         ctrl->seq = seq;

@@ -641,8 +641,9 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
         B[i] = Bufs{{h->residual, h->cgbuf[0]}, {h->aux, h->cgbuf[1]}, {h->aux_temp, h->cgbuf[2]}};
+        // (direct transport: the partials carry the number of the exchange they travel with -- the one issued right below -- as their tag)
         LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
-               seg4(i, 0), (int)(G->first + i == 0));
+               seg4(i, 0), (int)(G->first + i == 0), G->direct ? G->flag_seq + 1u : 0u);
     }
     auto exchange = [&](int wpar, int ppar) -> int {   // plane of W[wpar] to the z-neighbours + partials of parity ppar to every slab
         return slab_fused(G, [&]() -> int {
@@ -713,9 +714,9 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
         }
         for (int i = 0; i < S; ++i) {
             blub_fluid* h = G->slabs[i];
-            // (a solve that ran into the iteration cap takes its statistics from the partials of K(maxit): wait for the other slabs' unless it is over)
-            if ((rc = slab_wait(G, i, others_mask(G, i), h->ctrl[which])) != BLUB_OK) return rc;
-            LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, (const uint32_t*)nullptr, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
+            // (a solve that ran into the iteration cap takes its statistics from the partials of K(maxit): accepted by their tags unless it is over)
+            LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, (const uint32_t*)nullptr, maxit, h->solve_seq[which], (PcgCtrl*)nullptr,
+                   G->flag_seq, G->dir_error[i]);
             if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
             if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
         }
@@ -747,7 +748,8 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, (const uint32_t*)nullptr, maxit, h->solve_seq[which], (PcgCtrl*)nullptr);
+        LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_finalize, dim3(1), dim3(256), h->ctrl[which], (const float4*)G->ex[i].gat4[(maxit + 1) & 1], npall, (const uint32_t*)nullptr, maxit, h->solve_seq[which], (PcgCtrl*)nullptr,
+               0u, (uint32_t*)nullptr);
         if ((maxit + 1) & 1) std::swap(h->residual, h->cgbuf[0]);
         if ((rc = enqueue_stats_readback(h, which, dt)) != BLUB_OK) return rc;
     }

@@ -19,7 +19,9 @@ def main(scene="corner_dams_256", slabs=2, steps=60, warmup=5, schedule="single_
     cfg = blub_amd.Scene.parse(path=path).config
     dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, slabs)
     pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
-    g = blub_amd.SlabGroup(dim, len(pos) + 64, local=slabs)
+    # max_num_particles is PER SLAB: a quarter more than an even share (every slab holds one copy of the scene) -- particle kernels are launched
+    # for the capacity once the counts live on the device, so handing every slab the capacity of the whole domain costs N^2 empty workgroups
+    g = blub_amd.SlabGroup(dim, len(pos) // slabs * 5 // 4 + 65536, local=slabs)
     g.set_gravity_grid(gravity)
     g.set_transport(transport)
     g.set_pcg_schedule(schedule)
