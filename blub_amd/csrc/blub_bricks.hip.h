@@ -198,7 +198,8 @@ __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uin
 __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, int all_touched, int own_bz_lo, int own_bz_hi, uint8_t* __restrict__ brick_fluid,
                                                        uint8_t* __restrict__ brick_active, uint8_t* __restrict__ brick_touched, uint32_t* block_counts4 /* 4 per block */,
                                                        uint32_t* block_ready, uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
-                                                       uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq, BrickCounts* __restrict__ host_snapshot) {
+                                                       uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq, BrickCounts* __restrict__ host_snapshot,
+                                                       uint32_t* __restrict__ sticky_timeout) {
     __shared__ uint32_t sm[17];
     __shared__ uint32_t base[4], total[4];
     __shared__ uint32_t wtot[16];
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, 
             //  counts carry an error mark instead of hanging the GPU; the host then reports BLUB_ERR_DEVICE and falls back to the two-kernel build)
             unsigned spins = 0;
             unsigned long long word;
-            while (((word = __hip_atomic_load(slots + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 44) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) { timed_out = 1; word = 0; break; } }
+            while (((word = __hip_atomic_load(slots + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 44) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) { timed_out = 1; word = 0; if (sticky_timeout) *sticky_timeout = 1u; break; } }      // (sticky: a pinned word no later build overwrites)
             const uint32_t c[4] = {(uint32_t)(word & 0x7FFu), (uint32_t)((word >> 11) & 0x7FFu), (uint32_t)((word >> 22) & 0x7FFu), (uint32_t)((word >> 33) & 0x7FFu)};
 #pragma unroll
             for (int q = 0; q < 4; ++q) { all[q] += c[q]; if (k < (int)blockIdx.x) before[q] += c[q]; }

@@ -282,7 +282,7 @@ static int build_lists(blub_fluid* h, int phase) {
     if (nblk <= h->num_cus && !h->two_kernel_build) {      // every block co-resident: classification and scatter in ONE launch (k_bricks_build)
         hipLaunchKernelGGL(k_bricks_build, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, h->brick_fluid, h->brick_active,
                            h->brick_touched, reinterpret_cast<uint32_t*>(h->brick_block_counts), h->brick_block_ready, h->list_fluid, h->list_active, h->list_reset, h->counts,
-                           h->counts_seq, h->counts_host_dev + (h->counts_seq % COUNTS_RING));
+                           h->counts_seq, h->counts_host_dev + (h->counts_seq % COUNTS_RING), &(h->counts_host_dev + COUNTS_RING)->pad0);
         if (phase == COMPACT_STEP_A) h->all_touched = false;
         return BLUB_OK;
     }
@@ -303,6 +303,14 @@ static int drop_brick_marks(blub_fluid* h) {
 }
 static int build_lists_from_marker(blub_fluid* h) { return build_lists(h, COMPACT_ALL_ACTIVE); }
 // newest snapshot of the brick counts that has landed (never waits unless `block`): only steers a performance choice
+static int bricks_timeout_check(blub_fluid* h) {
+    if (h->counts_host && ((const volatile BrickCounts*)h->counts_host)[COUNTS_RING].pad0) {
+        h->counts_host[COUNTS_RING].pad0 = 0;
+        h->num_cus = 0;   // (two-kernel build from now on)
+        return set_error(BLUB_ERR_DEVICE, "a brick list build timed out waiting for its workgroups (device shared or partitioned?): the step that contained it is invalid; later steps use the two-kernel build");
+    }
+    return BLUB_OK;
+}
 static int latest_counts(blub_fluid* h, bool block, BrickCounts* out, bool* have) {
     *have = false;
     if (h->counts_seq == 0) return BLUB_OK;
@@ -834,9 +842,11 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
         else { memset(hp, 0, 64); h->steps_done_host = (volatile uint32_t*)hp; }
     }
     if (rc == BLUB_OK) {
-        if (hipHostMalloc((void**)&h->counts_host, COUNTS_RING * sizeof(BrickCounts), hipHostMallocMapped) != hipSuccess ||
+        // (one entry beyond the ring: its pad0 is the STICKY time-out mark of k_bricks_build -- a ring slot is overwritten 32 builds later,
+        //  possibly before the host has looked at it: round-3 ADVICE)
+        if (hipHostMalloc((void**)&h->counts_host, (COUNTS_RING + 1) * sizeof(BrickCounts), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void**)&h->counts_host_dev, h->counts_host, 0) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
-        else memset(h->counts_host, 0, COUNTS_RING * sizeof(BrickCounts));
+        else memset(h->counts_host, 0, (COUNTS_RING + 1) * sizeof(BrickCounts));
     }
     for (int w = 0; w < 2 && rc == BLUB_OK; ++w) {
         if (hipHostMalloc((void**)&h->stats_host[w], STATS_RING * sizeof(PcgCtrl), hipHostMallocMapped) != hipSuccess ||
@@ -951,6 +961,7 @@ int blub_fluid_run_stage(blub_fluid* h, int stage, float dt) {
 int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
     REQUIRE_HANDLE(h);
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
+    { int rc0 = blub::bricks_timeout_check(h); if (rc0 != BLUB_OK) return rc0; }      // (sticky mark of an earlier step's list build)
     // Bounded run-ahead ("steps in flight"): on ROCm 7.2 / gfx950 a stream with more than ~1000 queued kernel launches
     // executes 3x slower (measured: 1.38 ms/step with <= 4 steps = 692 launches queued, 4.35 ms/step with 6), so the host waits here
     // until step n - max_steps_in_flight has finished.  The wait polls a counter the device writes into pinned host
@@ -981,6 +992,7 @@ int blub_fluid_update_statistics(blub_fluid* h) { REQUIRE_HANDLE(h); return blub
 int blub_fluid_synchronize(blub_fluid* h) {
     REQUIRE_HANDLE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
+    { int rc = blub::bricks_timeout_check(h); if (rc != BLUB_OK) return rc; }
     return blub::poll_stats(h, true);
 }
 int blub_fluid_set_solver_config(blub_fluid* h, int which, const blub_solver_config* cfg) {
