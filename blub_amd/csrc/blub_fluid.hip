@@ -145,6 +145,7 @@ struct blub_fluid {
     int tail_margin_checks = 1;
     int pcg1_max_iterations = 64;    // solves with more iterations run the reference order even when schedule 1 is selected (drift of the recurrence residual)
     int tail_grid = 256, tail_grid_max = 256;   // co-resident blocks of the tail kernel: occupancy x CUs (set at creation)
+    bool tail_inject_timeout = false;   // test hook (blub_fluid_set_tuning "pcg_tail_inject_timeout"): the next tail kernel finds its grid barrier timed out
     int tail_first_forced = -1;      // test hook (blub_fluid_set_tuning "pcg_tail_first"): hand over to the tail after exactly this many launched iterations
     blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
     bool pressure_initialised[2] = {false, false};
@@ -533,6 +534,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
                 else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, 0, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1, SlabDirect{});
             }
             if (launched1 <= maxit) {
+                if (h->tail_inject_timeout) { const int one = 1; HIP_TRY(hipMemcpyAsync(&h->tail_sync[which]->timed_out, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); h->tail_inject_timeout = false; }
                 const dim3 tgrid((unsigned)std::min(np, h->tail_grid));     // (tail_grid: a multiple of 8, every block co-resident)
                 LAUNCH(h, KC_PCG_FINALIZE, k_pcg1_tail_s<true>, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, R[0], R[1], W[0], W[1], Q[0], Q[1], h->search, p,
                        part[0], part[1], ctrl, sc, tol, launched1, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
@@ -563,6 +565,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
                    (const float*)part_dir, part_upd, 0, (const PcgCtrl*)ctrl, i);
         }
         if (launched <= maxit) {
+            if (h->tail_inject_timeout) { const int one = 1; HIP_TRY(hipMemcpyAsync(&h->tail_sync[which]->timed_out, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); h->tail_inject_timeout = false; }
             const dim3 tgrid((unsigned)std::min(np, h->tail_grid));
             LAUNCH(h, KC_PCG_FINALIZE, k_pcg_tail_s, tgrid, block, h->bg, LIST(h, fluid), (const uint8_t*)h->dvol, h->residual, sbuf[0], sbuf[1], p, part_upd, part_dir, ctrl, tol,
                    launched, maxit, freq, h->tail_sync[which], h->solve_seq[which], stat_slot);
@@ -861,7 +864,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     return BLUB_OK;
 }
 
-static int poll_stats(blub_fluid* h, bool wait) {   // retrieve_new_error_samples, pressure_solver.rs:148-174
+static int poll_stats(blub_fluid* h, bool wait, bool report = true) {   // retrieve_new_error_samples, pressure_solver.rs:148-174
     if (wait) HIP_TRY(hipStreamSynchronize(h->stream));
     for (int w = 0; w < 2; ++w) {
         while (!h->stats_pending[w].empty()) {
@@ -889,7 +892,7 @@ static int poll_stats(blub_fluid* h, bool wait) {   // retrieve_new_error_sample
             h->total_iterations += (uint64_t)s.iteration_count;
         }
     }
-    if (h->failed_solves != h->failed_solves_reported) {
+    if (report && h->failed_solves != h->failed_solves_reported) {      // (report = false: a caller that drops the status must not consume the error)
         h->failed_solves_reported = h->failed_solves;
         return set_error(BLUB_ERR_DEVICE, "a pressure solve did not finish: the persistent tail kernel timed out on a grid barrier (device shared or partitioned?); the tail is now disabled for this handle");
     }
@@ -985,7 +988,7 @@ int blub_fluid_step(blub_fluid* h, float dt) {   // hybrid_fluid.rs:770-977
     for (int s : after_binning) if ((rc = blub::run_stage(h, s, dt, false)) != BLUB_OK) return rc;
     h->step_counter += 1;   // :976
     h->steps_enqueued += 1;   // (k_correct, the last kernel of the step, publishes this number: stage_correct)
-    (void)blub::poll_stats(h, false);   // the reference polls old read-backs inside solve (:612)
+    (void)blub::poll_stats(h, false, false);   // the reference polls old read-backs inside solve (:612); an unfinished solve stays pending for synchronize / update_statistics
     return blub::check_launch(h);
 }
 int blub_fluid_update_statistics(blub_fluid* h) { REQUIRE_HANDLE(h); return blub::poll_stats(h, false); }
@@ -1168,6 +1171,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     if (k == "pcg_tail") h->use_tail = value != 0 && h->tail_grid >= 8;
     else if (k == "pcg_tail_grid") h->tail_grid = std::max(8, (std::min(value, h->tail_grid_max) / 8) * 8);
     else if (k == "pcg_tail_first") h->tail_first_forced = value;
+    else if (k == "pcg_tail_inject_timeout") h->tail_inject_timeout = value != 0;
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
     else if (k == "dense_kd_nt") h->dense_kd_nt = value;

@@ -560,6 +560,8 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_tail_s(BrickGeom bg, con
         if (host_snapshot) { host_snapshot->max_err = ctrl->max_err; host_snapshot->num_iter = ctrl->num_iter; __threadfence_system(); host_snapshot->seq = seq; }
     };
     if (ctrl->done) { if (leader) publish(); return; }      // uniform
+    // (a barrier of THIS solve already gave up -- or the test hook "pcg_tail_inject_timeout" says so: the solve is reported unfinished)
+    if (__hip_atomic_load(&sync->timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (leader) { ctrl->num_iter = -1.0f; ctrl->done = 1; publish(); } return; }
     float* R[2] = {r0, r1}; float* W[2] = {w0, w1}; float* Q[2] = {q0, q1}; float4* part[2] = {part0, part1};
     uint32_t barrier_no = 0;
     for (int it = first_iteration; it <= max_iterations; ++it) {

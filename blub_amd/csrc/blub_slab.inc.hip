@@ -859,7 +859,7 @@ static int slab_step(blub_slab_group* G, float dt, int first = 0, int last = SS_
     }
     if (RUNS(SS_CORRECT)) FOR_SLABS(stage_correct(h))
     if (RUNS(SS_MIGRATE_B) && (rc = exchange(XFER_MIGRATE_B)) != BLUB_OK) return rc;
-    if (RUNS(SS_FINISH)) for (int i = 0; i < S; ++i) { G->slabs[i]->step_counter += 1; (void)poll_stats(G->slabs[i], false); }
+    if (RUNS(SS_FINISH)) for (int i = 0; i < S; ++i) { G->slabs[i]->step_counter += 1; (void)poll_stats(G->slabs[i], false, false); }
 #undef RUNS
 #undef FOR_SLABS
     return check_launch(h0);

@@ -279,6 +279,8 @@ int blub_fluid_get_pcg_schedule(const blub_fluid* h);
 /* Performance knobs / test hooks by name (the library never reads the environment).  None changes a result beyond the rounding of a
  * dot-product tree.  "pcg_tail" 0|1: persistent tail kernel of the single-reduction solves; "pcg_tail_first" n: hand over to the tail after
  * exactly n launched iterations (-1: predicted from the last solves); "pcg_tail_margin" n: check intervals launched beyond the prediction;
+ * "pcg_tail_inject_timeout" 1 (test hook): the next tail kernel finds its grid barrier timed out -- the solve is reported unfinished
+ *   (BLUB_ERR_DEVICE at the next synchronize / update_statistics) and the handle stops using the tail;
  * "pcg1_max_iterations" n (default 64): solves configured with more iterations run schedule 0 even when schedule 1 is selected;
  * "pcg_launch_grid" n: launch grid of the brick-mapped PCG kernels (0: estimated from the last landed brick count) -- results do not depend on it;
  * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
