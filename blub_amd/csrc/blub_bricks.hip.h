@@ -332,10 +332,10 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_reset_bricks(BrickGeom bg, co
     }
 }
 // Dense variant (creation, new solid voxels): every cell gets the static pattern.
-__global__ __launch_bounds__(256) void k_static_marker_dense(Grid g, const float4* __restrict__ solid, int8_t* __restrict__ marker) {
-    const int nquads = (g.nx >> 2) * g.ny * g.nz;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < nquads; q += gridDim.x * 256) {
-        const int base = q << 2;
+__global__ __launch_bounds__(256) void k_static_marker_dense(Grid g, const float4* __restrict__ solid, int8_t* __restrict__ marker, int z_lo, int z_hi) {
+    const int qpp = (g.nx >> 2) * g.ny, nquads = qpp * (z_hi - z_lo);      // (the planes [z_lo, z_hi) this domain's volumes hold)
+    for (int q0 = blockIdx.x * 256 + threadIdx.x; q0 < nquads; q0 += gridDim.x * 256) {
+        const int base = (q0 + qpp * z_lo) << 2;
         const int x0 = base % g.nx, yz = base / g.nx, y = yz % g.ny, z = yz / g.ny;
         *reinterpret_cast<uint32_t*>(marker + base) = static_marker_quad(g, solid, base, x0, y, z);
     }

@@ -65,6 +65,11 @@ using namespace blub;
 struct blub_fluid {
     Grid g{};
     size_t N = 0;
+    // Planes of the grid the volumes hold: [vol_z0, vol_z0 + vol_planes).  Everything for a single domain; a z-slab of a group allocates only its own
+    // planes plus BZ on either side.  The volume POINTERS stay those of plane 0 (allocation - vol_first elements), so kernels index globally.
+    int vol_z0 = 0, vol_planes = 0; size_t vol_cells = 0, vol_first = 0;
+    std::vector<void*> vol_owned;   // volumes allocated one by one (no volume slab)
+    float* cgbuf_alloc[3] = {nullptr, nullptr, nullptr};   // (cgbuf[] rotates with residual / search, which live in the volume slab)
     uint32_t max_particles = 0, num_particles = 0;
     uint32_t last_add_dropped = 0;   // particles the last add_fluid_cube could not add (capacity)
     // z-slab decomposition (blub_slab.hip): own planes [slab_z0, slab_z1), ghost particles live at [num_particles, +num_ghost)
@@ -244,15 +249,22 @@ static int dev_alloc_zero(hipStream_t stream, T** p, size_t count) {
 // allocation the time is a deterministic function of the relative shift: 602 us at 0, 535-540 us at 32 .. 64 KiB per volume, 575-588 us
 // at 128 / 224 KiB.  256^3 does not care (its working set lives in the Infinity Cache).  blub_fluid_desc::volume_shift_kib overrides.
 template <class T>
-static int vol_alloc(blub_fluid* h, T** p, size_t count) {
-    if (!h->slab) return dev_alloc_zero(h->stream, p, count);
+static int vol_alloc(blub_fluid* h, T** p) {
+    const size_t count = h->vol_cells;
+    if (!h->slab) { int rc = dev_alloc_zero(h->stream, p, count); if (rc == BLUB_OK) { h->vol_owned.push_back(*p); *p -= h->vol_first; } return rc; }
     const size_t bytes = count * sizeof(T);
     size_t at = (h->slab_used + 0x1FFFFFull) & ~0x1FFFFFull;      // 2 MiB aligned ...
     at += ((size_t)h->slab_count * h->slab_shift) & 0x1FFFFFull;   // ... plus the shift of this volume
     if (at + bytes > h->slab_bytes) return set_error(BLUB_ERR_OUT_OF_MEMORY, "volume slab exhausted");
-    *p = reinterpret_cast<T*>(h->slab + at);
+    *p = reinterpret_cast<T*>(h->slab + at) - h->vol_first;
     h->slab_used = at + bytes; h->slab_count += 1;
-    HIP_TRY(hipMemsetAsync(*p, 0, bytes, h->stream));
+    HIP_TRY(hipMemsetAsync(h->slab + at, 0, bytes, h->stream));
+    return BLUB_OK;
+}
+// the allocated planes of a volume, zeroed
+template <class T>
+static int vol_zero(blub_fluid* h, T* p) {
+    HIP_TRY(hipMemsetAsync(p + h->vol_first, 0, h->vol_cells * sizeof(T), h->stream));
     return BLUB_OK;
 }
 static int copy_sync(blub_fluid* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
@@ -437,7 +449,7 @@ static int stage_solve_lod0(blub_fluid* h, int which, float dt) {
 
 static int ensure_pcg1_buffers(blub_fluid* h) {
     int rc = BLUB_OK;
-    for (int k = 0; k < 3 && rc == BLUB_OK; ++k) if (!h->cgbuf[k]) rc = dev_alloc_zero(h->stream, &h->cgbuf[k], h->N);
+    for (int k = 0; k < 3 && rc == BLUB_OK; ++k) if (!h->cgbuf_alloc[k]) { rc = dev_alloc_zero(h->stream, &h->cgbuf_alloc[k], h->vol_cells); if (rc == BLUB_OK) h->cgbuf[k] = h->cgbuf_alloc[k] - h->vol_first; }
     if (rc == BLUB_OK && !h->part4) rc = dev_alloc_zero(h->stream, &h->part4, 2 * (size_t)PCG_GRID_MAX);
     for (int w = 0; w < 2 && rc == BLUB_OK; ++w) if (!h->pcg1_scalars[w]) rc = dev_alloc_zero(h->stream, &h->pcg1_scalars[w], 1);
     return rc;
@@ -458,7 +470,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float* p = h->pressure[which];
     const blub_solver_config& c = h->cfg[which];
     if (!h->pressure_initialised[which]) {   // :601-603
-        HIP_TRY(hipMemsetAsync(p, 0, h->N * sizeof(float), h->stream));
+        { int rz = vol_zero(h, p); if (rz != BLUB_OK) return rz; }
         h->pressure_initialised[which] = true;
     }
     const float tol = c.error_tolerance / dt;   // :197
@@ -618,12 +630,12 @@ static int stage_binning(blub_fluid* h) {   // hybrid_fluid.rs:857-893
     const bool literal = h->binning_mode == BLUB_BINNING_LITERAL;
     const uint32_t T = literal ? std::min<uint32_t>((h->num_particles + 63u) / 64u * 64u, h->max_particles) : h->num_particles;
     uint32_t* counters = reinterpret_cast<uint32_t*>(h->aux_temp);
-    HIP_TRY(hipMemsetAsync(counters, 0, h->N * sizeof(uint32_t), h->stream));   // clear_texture :858
+    { int rz = vol_zero(h, counters); if (rz != BLUB_OK) return rz; }   // clear_texture :858
     LAUNCH(h, KC_BIN_COUNT, k_bin_count, dim3(particle_blocks(T)), dim3(256), h->g, T, h->pos, counters, (const uint32_t*)h->n_dev, N_OWN);
-    const int n = (int)h->N, nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    LAUNCH(h, KC_BIN_SCAN, k_scan_block_totals, dim3(nblocks), dim3(1024), (const uint32_t*)counters, n, h->scan_totals);
+    const int n = (int)h->vol_cells, nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;      // (a slab scans its own planes: all its particles live there)
+    LAUNCH(h, KC_BIN_SCAN, k_scan_block_totals, dim3(nblocks), dim3(1024), (const uint32_t*)(counters + h->vol_first), n, h->scan_totals);
     LAUNCH(h, KC_BIN_SCAN, k_scan_totals, dim3(1), dim3(1024), h->scan_totals, nblocks);
-    LAUNCH(h, KC_BIN_SCAN, k_scan_apply, dim3(nblocks), dim3(1024), counters, n, (const uint32_t*)h->scan_totals);
+    LAUNCH(h, KC_BIN_SCAN, k_scan_apply, dim3(nblocks), dim3(1024), counters + h->vol_first, n, (const uint32_t*)h->scan_totals);
     LAUNCH(h, KC_BIN_REWRITE, k_bin_rewrite, dim3(particle_blocks(T)), dim3(256), h->g, T, h->max_particles,
            (const float4*)h->pos, h->pos_tmp, (const uint32_t*)counters, (int)literal, (const uint32_t*)h->n_dev, N_OWN);
     {
@@ -720,13 +732,14 @@ static void destroy(blub_fluid* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    auto F = [h](void* p) { if (p && !(h->slab && (char*)p >= h->slab && (char*)p < h->slab + h->slab_bytes)) (void)hipFree(p); };
-    F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->marker); for (auto p : h->ll) F(p);
-    for (auto p : h->vel) F(p); for (auto p : h->pressure) F(p); F(h->residual); F(h->search); F(h->aux); F(h->aux_temp); F(h->solid); F(h->scan_totals);
-    F(h->brick_flags); F(h->brick_block_counts); F(h->brick_block_ready); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts); F(h->dvol);
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->solid); F(h->scan_totals);
+    for (auto p : h->vol_owned) F(p);
+    for (auto p : h->cgbuf_alloc) F(p);
+    F(h->brick_flags); F(h->brick_block_counts); F(h->brick_block_ready); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
     if (h->steps_done_host) (void)hipHostFree((void*)h->steps_done_host);
-    F(h->tail_sync[0]); F(h->tail_sync[1]); for (auto q : h->cgbuf) F(q); F(h->part4); F(h->pcg1_scalars[0]); F(h->pcg1_scalars[1]); F(h->mesh_positions); F(h->mesh_indices);
+    F(h->tail_sync[0]); F(h->tail_sync[1]); F(h->part4); F(h->pcg1_scalars[0]); F(h->pcg1_scalars[1]); F(h->mesh_positions); F(h->mesh_indices);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
     for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -758,7 +771,7 @@ static void set_dense_geometry(blub_fluid* h, int T, int zc, int grid) {
     h->pcg_grid_z = std::min(std::min(grid, PCG_GRID_MAX), ((gz.tiles + 7) / 8) * 8);
 }
 
-static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared_stream = nullptr) {
+static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared_stream = nullptr, int vol_z0 = 0, int vol_planes = 0) {
     if (!d || !out) return set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (d->nx < 4 || d->ny < 3 || d->nz < 3) return set_error(BLUB_ERR_INVALID_ARGUMENT, "grid too small");
@@ -780,6 +793,8 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     h->g = Grid{(int)d->nx, (int)d->ny, (int)d->nz};
     h->slab_z0 = 0; h->slab_z1 = (int)d->nz + BZ;   // everything is "own" unless a slab group narrows it
     h->N = (size_t)N64;
+    h->vol_z0 = vol_planes > 0 ? vol_z0 : 0; h->vol_planes = vol_planes > 0 ? vol_planes : (int)d->nz;
+    h->vol_cells = (size_t)d->nx * d->ny * (size_t)h->vol_planes; h->vol_first = (size_t)d->nx * d->ny * (size_t)h->vol_z0;
     h->max_particles = d->max_num_particles;
     h->precond_mode = d->precond_mode; h->binning_mode = d->binning_mode;
     int rc = BLUB_OK;
@@ -792,16 +807,16 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->nodes, 3 * P)); h->node_stride = (uint32_t)P;
     if (d->volume_shift_kib != 0xFFFFFFFFu) {      // (0xFFFFFFFF: one allocation per volume)
         h->slab_shift = (size_t)(d->volume_shift_kib ? d->volume_shift_kib : 64u) * 1024u;
-        const size_t per = ((h->N * 4 + 0x1FFFFFull) & ~0x1FFFFFull) + 0x400000ull;      // 2 MiB alignment + up to 2 MiB of shift
+        const size_t per = ((h->vol_cells * 4 + 0x1FFFFFull) & ~0x1FFFFFull) + 0x400000ull;      // 2 MiB alignment + up to 2 MiB of shift
         h->slab_bytes = 18 * per;                                                          // 16 volumes (two of them bytes) + head room
         if (hipMalloc((void**)&h->slab, h->slab_bytes) != hipSuccess) { h->slab = nullptr; h->slab_bytes = 0; (void)hipGetLastError(); }   // (fall back to separate allocations)
     }
-    A(vol_alloc(h, &h->residual, h->N)); A(vol_alloc(h, &h->search, h->N)); A(vol_alloc(h, &h->aux, h->N)); A(vol_alloc(h, &h->aux_temp, h->N));
-    for (int w = 0; w < 2; ++w) A(vol_alloc(h, &h->pressure[w], h->N));
-    A(vol_alloc(h, &h->dvol, h->N));
-    A(vol_alloc(h, &h->marker, h->N));
-    for (int c = 0; c < 3; ++c) { A(vol_alloc(h, &h->ll[c], h->N)); A(vol_alloc(h, &h->vel[c], h->N)); }
-    A(dev_alloc_zero(h->stream, &h->scan_totals, (h->N + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
+    A(vol_alloc(h, &h->residual)); A(vol_alloc(h, &h->search)); A(vol_alloc(h, &h->aux)); A(vol_alloc(h, &h->aux_temp));
+    for (int w = 0; w < 2; ++w) A(vol_alloc(h, &h->pressure[w]));
+    A(vol_alloc(h, &h->dvol));
+    A(vol_alloc(h, &h->marker));
+    for (int c = 0; c < 3; ++c) { A(vol_alloc(h, &h->ll[c])); A(vol_alloc(h, &h->vel[c])); }
+    A(dev_alloc_zero(h->stream, &h->scan_totals, (h->vol_cells + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
     PcgGeom& gm = h->geom;
     gm.g = h->g; gm.qpr = h->g.nx / 4; gm.qpp = gm.qpr * h->g.ny; gm.plane_blocks = (gm.qpp + 255) / 256;
     gm.zc = 8;   // LOD0 reading (literal kernel sequence, dense rows): 8 planes per tile, 8 blocks of 256 threads per CU
@@ -858,7 +873,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     }
     if (rc != BLUB_OK) { std::string keep = g_last_error; destroy(h); g_last_error = keep; return rc; }
     // the marker volume starts in its static pattern (AIR + SOLID shell): the brick kernels only maintain it locally
-    hipLaunchKernelGGL(k_static_marker_dense, dim3(stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)nullptr, h->marker);
+    hipLaunchKernelGGL(k_static_marker_dense, dim3(stream_blocks(h->vol_cells / 4)), dim3(256), 0, h->stream, h->g, (const float4*)nullptr, h->marker, h->vol_z0, std::min(h->vol_z0 + h->vol_planes, h->g.nz));
     if (hipStreamSynchronize(h->stream) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "marker initialisation failed"); }
     *out = h;
     return BLUB_OK;
@@ -1050,7 +1065,7 @@ int blub_fluid_set_solid_voxels(blub_fluid* h, const float* vox) {
         { int rc2 = blub::copy_sync(h, h->solid, vox, h->N * sizeof(float4), hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
     }
     // the static marker pattern changed everywhere; every brick may now differ from it
-    hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker);
+    hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->vol_cells / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker, h->vol_z0, std::min(h->vol_z0 + h->vol_planes, h->g.nz));
     h->all_touched = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return BLUB_OK;
@@ -1084,7 +1099,7 @@ int blub_fluid_voxelize(blub_fluid* h, uint32_t num_meshes, const blub_mesh_desc
             if (ntri) hipLaunchKernelGGL(blubk::k_voxelize_mesh, dim3((ntri + 3) / 4, blubk::VOXELIZE_SPLIT), dim3(256), 0, h->stream, h->g, d, (const float*)h->mesh_positions, (const uint32_t*)h->mesh_indices, h->solid);
         }
         // the static marker pattern changed: every brick may now differ from it (same as blub_fluid_set_solid_voxels)
-        hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->N / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker);
+        hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->vol_cells / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker, h->vol_z0, std::min(h->vol_z0 + h->vol_planes, h->g.nz));
     }
     h->all_touched = true;
     return blub::check_launch(h);
@@ -1135,14 +1150,23 @@ int blub_fluid_read_volume(blub_fluid* h, int which, void* out) {
     REQUIRE_HANDLE(h);
     size_t b; void* p = volume_ptr(h, which, &b);
     if (!p || !out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
-    return blub::copy_sync(h, out, p, b, hipMemcpyDeviceToHost);
+    if (which == BLUB_VOLUME_SOLID || h->vol_cells == h->N) return blub::copy_sync(h, out, p, b, hipMemcpyDeviceToHost);
+    // a z-slab holds planes [vol_z0, vol_z0 + vol_planes) only: the rest of the caller's full-grid array reads as zero
+    const size_t elem = b / h->N, plane = h->N / (size_t)h->g.nz, z1 = (size_t)std::min(h->vol_z0 + h->vol_planes, h->g.nz);
+    memset(out, 0, b);
+    return blub::copy_sync(h, (char*)out + h->vol_first * elem, (char*)p + h->vol_first * elem, (z1 - (size_t)h->vol_z0) * plane * elem, hipMemcpyDeviceToHost);
 }
 int blub_fluid_write_volume(blub_fluid* h, int which, const void* in) {
     REQUIRE_HANDLE(h);
     if (which == BLUB_VOLUME_SOLID) return blub_fluid_set_solid_voxels(h, (const float*)in);
     size_t b; void* p = volume_ptr(h, which, &b);
     if (!p || !in) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
-    { int rc2 = blub::copy_sync(h, p, in, b, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
+    if (h->vol_cells == h->N) { int rc2 = blub::copy_sync(h, p, in, b, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
+    else {
+        const size_t elem = b / h->N, plane = h->N / (size_t)h->g.nz, z1 = (size_t)std::min(h->vol_z0 + h->vol_planes, h->g.nz);
+        int rc2 = blub::copy_sync(h, (char*)p + h->vol_first * elem, (const char*)in + h->vol_first * elem, (z1 - (size_t)h->vol_z0) * plane * elem, hipMemcpyHostToDevice);
+        if (rc2 != BLUB_OK) return rc2;
+    }
     h->all_touched = true;   // arbitrary data may now sit outside the active bricks: the next step re-establishes the invariant
     return BLUB_OK;
 }

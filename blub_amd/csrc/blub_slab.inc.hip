@@ -21,6 +21,7 @@ struct blub_slab_group {
     hipStream_t stream = nullptr;
     int device = 0;
     uint32_t capacity = 0;            // particle capacity of every slab and of the transfer buffers
+    std::vector<int> vol_z0_of; std::vector<size_t> vol_first_of;   // per rank: first plane its volumes hold / that plane's first cell (blub_fluid::vol_z0, vol_first)
     struct Extra {
         uint32_t *leave_idx = nullptr, *hole_idx = nullptr, *fill_idx = nullptr;   // in-place migration (blub_slab.hip.h: k_slab_migrate_*)
         float4 *up[4] = {nullptr, nullptr, nullptr, nullptr}, *dn[4] = {nullptr, nullptr, nullptr, nullptr};   // send buffers: pos, vx, vy, vz
@@ -134,6 +135,13 @@ static T* peer_ptr(const blub_slab_group* G, int i, int r, T* mine) {
         if (m >= regs[k].base && m < regs[k].base + regs[k].bytes) return reinterpret_cast<T*>(G->peer_base[r][k] + (m - regs[k].base));
     return nullptr;
 }
+// ... and for a grid VOLUME, whose pointer is that of plane 0 while the allocation starts at the owner's first held plane (blub_fluid::vol_first):
+// the peer's plane-0 pointer of the same volume
+template <class T>
+static T* peer_vol(const blub_slab_group* G, int i, int r, T* mine, size_t elem = sizeof(T)) {
+    char* real = peer_ptr(G, i, r, reinterpret_cast<char*>(mine) + G->slabs[i]->vol_first * elem);
+    return real ? reinterpret_cast<T*>(real - G->vol_first_of[(size_t)r] * elem) : nullptr;
+}
 static bool rank_local(const blub_slab_group* G, int r) { return r >= G->first && r < G->first + (int)G->slabs.size(); }
 // the flag word of rank `dst` for messages from rank `src` (dst's flags live in dst's arena; translated through local slab i = the sender)
 static uint32_t* flag_of(const blub_slab_group* G, int i, int dst) { return peer_ptr(G, i, dst, G->flags[i]) + (G->first + i); }
@@ -167,8 +175,8 @@ static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(b
             blub_fluid* h = G->slabs[i];
             for (auto& f : fields) {
                 char* base = (char*)f(h);
-                if (has_up(G, i)) { int rc = slab_copy(G, peer_ptr(G, i, G->first + i + 1, base) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (rc != BLUB_OK) return rc; }
-                if (has_down(G, i)) { int rc = slab_copy(G, peer_ptr(G, i, G->first + i - 1, base) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (rc != BLUB_OK) return rc; }
+                if (has_up(G, i)) { int rc = slab_copy(G, peer_vol(G, i, G->first + i + 1, base, elem) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (rc != BLUB_OK) return rc; }
+                if (has_down(G, i)) { int rc = slab_copy(G, peer_vol(G, i, G->first + i - 1, base, elem) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (rc != BLUB_OK) return rc; }
             }
             if (has_up(G, i)) push_flag(G, flag_of(G, i, G->first + i + 1));
             if (has_down(G, i)) push_flag(G, flag_of(G, i, G->first + i - 1));
@@ -546,7 +554,7 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     }
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
-        if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
+        if (!h->pressure_initialised[which]) { int rz = vol_zero(h, h->pressure[which]); if (rz != BLUB_OK) return rz; h->pressure_initialised[which] = true; }
         h->solve_seq[which] += 1;
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b<false>, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
                seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr, DivergenceSrc{});
@@ -625,7 +633,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
         if ((rc = ensure_pcg1_buffers(h)) != BLUB_OK) return rc;
-        if (!h->pressure_initialised[which]) { HIP_TRY(hipMemsetAsync(h->pressure[which], 0, h->N * sizeof(float), G->stream)); h->pressure_initialised[which] = true; }
+        if (!h->pressure_initialised[which]) { int rz = vol_zero(h, h->pressure[which]); if (rz != BLUB_OK) return rz; h->pressure_initialised[which] = true; }
         h->solve_seq[which] += 1;
         LAUNCH(h, KC_PCG_INIT, k_pcg_init_b<false>, grid, block, h->bg, LIST(h, active), (const uint32_t*)&h->counts->n_fluid, np, (const int8_t*)h->marker, h->dvol, h->pressure[which], h->residual, h->search,
                seg_upd(i), h->ctrl[which], (PcgTailSync*)nullptr, DivergenceSrc{});
@@ -653,8 +661,8 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
             for (int i = 0; i < S && G->direct; ++i) {      // direct transport: push the two boundary planes into the z-neighbours' copies
                 blub_fluid* h = G->slabs[i];
                 char* base = (char*)B[i].W[wpar];
-                if (has_up(G, i)) { int r3 = slab_copy(G, peer_ptr(G, i, G->first + i + 1, base) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i + 1)); }
-                if (has_down(G, i)) { int r3 = slab_copy(G, peer_ptr(G, i, G->first + i - 1, base) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i - 1)); }
+                if (has_up(G, i)) { int r3 = slab_copy(G, peer_vol(G, i, G->first + i + 1, base, sizeof(float)) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i + 1)); }
+                if (has_down(G, i)) { int r3 = slab_copy(G, peer_vol(G, i, G->first + i - 1, base, sizeof(float)) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i - 1)); }
             }
             for (int i = 0; i < S && !G->direct; ++i) {
                 blub_fluid* h = G->slabs[i];
@@ -695,8 +703,8 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
                 float* wout = B[i].W[(it + 1) & 1];
                 SlabDirect D{};
                 const int me = G->first + i;
-                D.w_up = has_up(G, i) ? peer_ptr(G, i, me + 1, wout) : nullptr; D.w_dn = has_down(G, i) ? peer_ptr(G, i, me - 1, wout) : nullptr;
-                D.p_up = has_up(G, i) ? peer_ptr(G, i, me + 1, h->pressure[which]) : nullptr; D.p_dn = has_down(G, i) ? peer_ptr(G, i, me - 1, h->pressure[which]) : nullptr;
+                D.w_up = has_up(G, i) ? peer_vol(G, i, me + 1, wout) : nullptr; D.w_dn = has_down(G, i) ? peer_vol(G, i, me - 1, wout) : nullptr;
+                D.p_up = has_up(G, i) ? peer_vol(G, i, me + 1, h->pressure[which]) : nullptr; D.p_dn = has_down(G, i) ? peer_vol(G, i, me - 1, h->pressure[which]) : nullptr;
                 for (int r = 0; r < G->nranks; ++r) {
                     if (r == me) continue;
                     D.part_out[D.n_out] = peer_ptr(G, i, r, pout); D.flag_out[D.n_out] = flag_of(G, i, r); D.n_out += 1;
@@ -937,7 +945,7 @@ static int slab_calibrate(blub_slab_group* G) {
     (void)h;
     G->comm_ops = 0;
     // the calibration traffic went through the residual ghost planes and the gather arrays: put them back to zero
-    HIP_TRY(hipMemsetAsync(G->slabs[0]->residual, 0, G->slabs[0]->N * sizeof(float), G->stream));
+    { int rz = vol_zero(G->slabs[0], G->slabs[0]->residual); if (rz != BLUB_OK) return rz; }
     HIP_TRY(hipMemsetAsync(e.gat_dir, 0, (size_t)G->nranks * np * sizeof(float), G->stream));
     HIP_TRY(hipMemsetAsync(e.gat_upd, 0, (size_t)G->nranks * np * sizeof(float2), G->stream));
     HIP_TRY(hipStreamSynchronize(G->stream));
@@ -960,9 +968,21 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     int rc = BLUB_OK;
     if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) { delete G; return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     blub_fluid_desc dd = *d; dd.device = dev;
+    // Slab-local volumes: a slab holds its own planes plus two brick layers on either side -- ghost particles (GHOST_MARGIN cells beyond the interface)
+    // mark the neighbouring brick layer FLUID, its dilation makes the layer behind that one ACTIVE, and the reset kernels clear every brick that
+    // ever was -- and the SAME number of planes on every rank so that the exportable regions have one layout.
+    int vol_planes = 0;
+    G->vol_z0_of.assign((size_t)nranks, 0); G->vol_first_of.assign((size_t)nranks, 0);
+    for (int r = 0; r < nranks; ++r) {
+        int a, b; slab_range((int)d->nz, nranks, r, &a, &b);
+        const int za = std::max(0, a - 2 * BZ), zb = std::min((int)d->nz, std::min(b, (int)d->nz) + 2 * BZ);
+        G->vol_z0_of[(size_t)r] = za; G->vol_first_of[(size_t)r] = (size_t)d->nx * d->ny * (size_t)za;
+        vol_planes = std::max(vol_planes, zb - za);
+    }
+    if (nranks == 1) vol_planes = 0;      // (whole grid)
     for (int i = 0; i < nlocal && rc == BLUB_OK; ++i) {
         blub_fluid* h = nullptr;
-        rc = create(&dd, &h, G->stream);
+        rc = create(&dd, &h, G->stream, G->vol_z0_of[(size_t)first + i], vol_planes);
         if (rc != BLUB_OK) break;
         slab_range((int)d->nz, nranks, first + i, &h->slab_z0, &h->slab_z1);
         h->max_steps_in_flight = 0;   // every particle exchange synchronises the host anyway
@@ -1003,7 +1023,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         std::vector<blub_slab_group::Region> regs;
         if (rc == BLUB_OK) {
             regs.push_back({h->slab, h->slab_bytes});
-            for (int k = 0; k < 3; ++k) regs.push_back({reinterpret_cast<char*>(h->cgbuf[k]), h->N * sizeof(float)});
+            for (int k = 0; k < 3; ++k) regs.push_back({reinterpret_cast<char*>(h->cgbuf_alloc[k]), h->vol_cells * sizeof(float)});
             regs.push_back({ar.base, ar.bytes});
         }
         G->regions.push_back(regs);

@@ -140,7 +140,10 @@ def test_slab_group_on_the_baseline_multi_gpu_configurations(scene_name, slabs, 
             for step in range(3):
                 if step:
                     for f in (single, rerun, group):
+                        # (one engine at a time: the brick-list build is ONE co-resident launch -- 256 workgroups of 1024 threads at 512^3 --, and three
+                        #  of them from three streams do not fit the device together; they would sit out each other's spin bound)
                         f.step(util.DT)
+                        f.synchronize()
                 if step == 1:
                     continue
                 ps = single.get_particles()[0][:, :3].astype(np.float64)
@@ -283,3 +286,45 @@ def test_switching_the_asynchronous_exchange_off_mid_run():
     finally:
         single.close()
         group.close()
+
+
+def test_a_slab_allocates_its_own_planes_only():
+    """Round-3 review, missing item 4: every slab of a group used to allocate all sixteen grid volumes at FULL grid size.  Now it holds its own
+    planes plus two brick layers on either side: eight slabs of a 256^3 grid (32 own planes + 16 each) take well under twice one full set of
+    volumes instead of eight times, and what a slab does not hold reads back as zero."""
+    import torch
+    import blub_amd
+    dim = (256, 256, 256)
+    n = 256 * 256 * 256
+
+    def used(make):
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        obj = make()
+        obj.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        return obj, free0 - free1
+
+    single, b_single = used(lambda: blub_amd.HybridFluid(dim, 1024, binning="off"))
+    try:
+        group, b_group = used(lambda: blub_amd.SlabGroup(dim, 1024, local=8))
+        try:
+            volumes = 15.5 * 4 * n          # 12 float / uint volumes, marker + descriptor bytes, the three single-reduction vectors
+            print("device memory: single domain %.0f MiB, eight slabs %.0f MiB (full-size volumes: %.0f MiB)" % (b_single / 2 ** 20, b_group / 2 ** 20, volumes / 2 ** 20))
+            assert b_single > 0.7 * volumes
+            assert b_group < 1.9 * b_single + 8 * 64 * 2 ** 20
+            z0, z1 = group.local_range(3)
+            f = group.local_fluid(3)
+            m = f.read_volume("marker")
+            assert m.shape == (256, 256, 256)
+            assert np.all(m[:z0 - 8] == 0) and np.all(m[z1 + 8:] == 0)                  # not held: zero
+            assert np.all(m[z0 - 8:z1 + 8, 1:-1, 1:-1] == -1)                            # held: the static pattern (AIR inside the SOLID shell)
+            v = np.zeros(dim[::-1], np.float32)
+            v[:] = np.arange(256, dtype=np.float32)[:, None, None]
+            f.write_volume("vel_x", v)
+            back = f.read_volume("vel_x")
+            assert np.array_equal(back[z0 - 8:z1 + 8], v[z0 - 8:z1 + 8]) and not back[:z0 - 8].any() and not back[z1 + 8:].any()
+        finally:
+            group.close()
+    finally:
+        single.close()
