@@ -69,6 +69,7 @@ struct blub_fluid {
     // planes plus BZ on either side.  The volume POINTERS stay those of plane 0 (allocation - vol_first elements), so kernels index globally.
     int vol_z0 = 0, vol_planes = 0; size_t vol_cells = 0, vol_first = 0;
     std::vector<void*> vol_owned;   // volumes allocated one by one (no volume slab)
+    float4* solid_alloc = nullptr;   // (solid = solid_alloc - vol_first)
     float* cgbuf_alloc[3] = {nullptr, nullptr, nullptr};   // (cgbuf[] rotates with residual / search, which live in the volume slab)
     uint32_t max_particles = 0, num_particles = 0;
     uint32_t last_add_dropped = 0;   // particles the last add_fluid_cube could not add (capacity)
@@ -265,6 +266,12 @@ static int vol_alloc(blub_fluid* h, T** p) {
 template <class T>
 static int vol_zero(blub_fluid* h, T* p) {
     HIP_TRY(hipMemsetAsync(p + h->vol_first, 0, h->vol_cells * sizeof(T), h->stream));
+    return BLUB_OK;
+}
+static int solid_ensure(blub_fluid* h) {      // the solid-voxel volume exists only once a caller voxelises or uploads one
+    if (h->solid) return BLUB_OK;
+    HIP_TRY(hipMalloc((void**)&h->solid_alloc, h->vol_cells * sizeof(float4)));
+    h->solid = h->solid_alloc - h->vol_first;
     return BLUB_OK;
 }
 static int copy_sync(blub_fluid* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
@@ -733,7 +740,7 @@ static void destroy(blub_fluid* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
-    F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->solid); F(h->scan_totals);
+    F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->solid_alloc); F(h->scan_totals);
     for (auto p : h->vol_owned) F(p);
     for (auto p : h->cgbuf_alloc) F(p);
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_block_ready); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts);
@@ -1059,10 +1066,11 @@ int blub_fluid_get_device_views(const blub_fluid* h, blub_device_views* v) {
 int blub_fluid_set_solid_voxels(blub_fluid* h, const float* vox) {
     REQUIRE_HANDLE(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!vox) { if (h->solid) { (void)hipFree(h->solid); h->solid = nullptr; } }
+    if (!vox) { if (h->solid) { (void)hipFree(h->solid_alloc); h->solid_alloc = nullptr; h->solid = nullptr; } }
     else {
-        if (!h->solid) HIP_TRY(hipMalloc((void**)&h->solid, h->N * sizeof(float4)));
-        { int rc2 = blub::copy_sync(h, h->solid, vox, h->N * sizeof(float4), hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
+        { int rc2 = blub::solid_ensure(h); if (rc2 != BLUB_OK) return rc2; }
+        const size_t held = (size_t)(std::min(h->vol_z0 + h->vol_planes, h->g.nz) - h->vol_z0) * (h->N / (size_t)h->g.nz);
+        { int rc2 = blub::copy_sync(h, h->solid_alloc, vox + 4 * h->vol_first, held * sizeof(float4), hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
     }
     // the static marker pattern changed everywhere; every brick may now differ from it
     hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->vol_cells / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker, h->vol_z0, std::min(h->vol_z0 + h->vol_planes, h->g.nz));
@@ -1088,15 +1096,15 @@ int blub_fluid_voxelize(blub_fluid* h, uint32_t num_meshes, const blub_mesh_desc
     if (num_meshes && !meshes) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     for (uint32_t m = 0; m < num_meshes; ++m)
         if (meshes[m].index_begin > meshes[m].index_end || meshes[m].index_end > h->mesh_num_indices) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "mesh index range outside the uploaded index buffer");
-    if (!h->solid) HIP_TRY(hipMalloc((void**)&h->solid, h->N * sizeof(float4)));
+    { int rc2 = blub::solid_ensure(h); if (rc2 != BLUB_OK) return rc2; }
     {
         blub::ProfScope ps(h, blub::KC_VOXELIZE);
-        HIP_TRY(hipMemsetAsync(h->solid, 0, h->N * sizeof(float4), h->stream));   // encoder.clear_texture, :123
+        HIP_TRY(hipMemsetAsync(h->solid_alloc, 0, h->vol_cells * sizeof(float4), h->stream));   // encoder.clear_texture, :123
         for (uint32_t m = 0; m < num_meshes; ++m) {
             static_assert(sizeof(blubk::MeshDesc) == sizeof(blub_mesh_desc), "MeshDesc mirrors blub_mesh_desc");
             blubk::MeshDesc d; memcpy(&d, &meshes[m], sizeof d);
             const uint32_t ntri = (d.index_end - d.index_begin) / 3;
-            if (ntri) hipLaunchKernelGGL(blubk::k_voxelize_mesh, dim3((ntri + 3) / 4, blubk::VOXELIZE_SPLIT), dim3(256), 0, h->stream, h->g, d, (const float*)h->mesh_positions, (const uint32_t*)h->mesh_indices, h->solid);
+            if (ntri) hipLaunchKernelGGL(blubk::k_voxelize_mesh, dim3((ntri + 3) / 4, blubk::VOXELIZE_SPLIT), dim3(256), 0, h->stream, h->g, d, (const float*)h->mesh_positions, (const uint32_t*)h->mesh_indices, h->solid, h->vol_z0, std::min(h->vol_z0 + h->vol_planes, h->g.nz));
         }
         // the static marker pattern changed: every brick may now differ from it (same as blub_fluid_set_solid_voxels)
         hipLaunchKernelGGL(blubk::k_static_marker_dense, dim3(blub::stream_blocks(h->vol_cells / 4)), dim3(256), 0, h->stream, h->g, (const float4*)h->solid, h->marker, h->vol_z0, std::min(h->vol_z0 + h->vol_planes, h->g.nz));
@@ -1150,7 +1158,7 @@ int blub_fluid_read_volume(blub_fluid* h, int which, void* out) {
     REQUIRE_HANDLE(h);
     size_t b; void* p = volume_ptr(h, which, &b);
     if (!p || !out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
-    if (which == BLUB_VOLUME_SOLID || h->vol_cells == h->N) return blub::copy_sync(h, out, p, b, hipMemcpyDeviceToHost);
+    if (h->vol_cells == h->N) return blub::copy_sync(h, out, p, b, hipMemcpyDeviceToHost);
     // a z-slab holds planes [vol_z0, vol_z0 + vol_planes) only: the rest of the caller's full-grid array reads as zero
     const size_t elem = b / h->N, plane = h->N / (size_t)h->g.nz, z1 = (size_t)std::min(h->vol_z0 + h->vol_planes, h->g.nz);
     memset(out, 0, b);

@@ -30,7 +30,7 @@ __device__ __forceinline__ void unswizzle_clamp(const Grid& g, int side, float s
     out[2] = fminf(fmaxf(z, 0.0f), (float)g.nz - 1.0f);
 }
 // conservative_hull.frag:20-26 + the imageStore
-__device__ __forceinline__ void store_voxel(const Grid& g, const MeshDesc& d, const float vp[3], float4* __restrict__ solid) {
+__device__ __forceinline__ void store_voxel(const Grid& g, const MeshDesc& d, const float vp[3], float4* __restrict__ solid, int z_lo, int z_hi) {
     const float px = vp[0] - d.m[0][3], py = vp[1] - d.m[1][3], pz = vp[2] - d.m[2][3];
     const float dt = px * d.axis[0] + py * d.axis[1] + pz * d.axis[2];
     const float tx = px - dt * d.axis[0], ty = py - dt * d.axis[1], tz = pz - dt * d.axis[2];
@@ -38,10 +38,11 @@ __device__ __forceinline__ void store_voxel(const Grid& g, const MeshDesc& d, co
     const float vy = (d.axis[2] * tx - d.axis[0] * tz) + d.vel[1];
     const float vz = (d.axis[0] * ty - d.axis[1] * tx) + d.vel[2];
     const int ix = (int)vp[0], iy = (int)vp[1], iz = (int)vp[2];
+    if (iz < z_lo || iz >= z_hi) return;      // (a z-slab holds planes [z_lo, z_hi) only)
     solid[cidx(g, ix, iy, iz)] = make_float4(f16_round(vx), f16_round(vy), f16_round(vz), 1.0f);
 }
 
-__global__ __launch_bounds__(256) void k_voxelize_mesh(Grid g, MeshDesc d, const float* __restrict__ positions, const uint32_t* __restrict__ indices, float4* __restrict__ solid) {
+__global__ __launch_bounds__(256) void k_voxelize_mesh(Grid g, MeshDesc d, const float* __restrict__ positions, const uint32_t* __restrict__ indices, float4* __restrict__ solid, int z_lo, int z_hi) {
     const uint32_t tri = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t first = d.index_begin + tri * 3;
@@ -97,9 +98,9 @@ __global__ __launch_bounds__(256) void k_voxelize_mesh(Grid g, MeshDesc d, const
         if (!(z >= 0.0f && z <= viewport)) continue;   // depth clipping
         float vp[3];
         unswizzle_clamp(g, side, truncf(pcx), truncf(pcy), truncf(z), vp);   // conservative_hull.frag:35-36
-        store_voxel(g, d, vp, solid);
-        if (floorf(z) != floorf(z - max_change)) { unswizzle_clamp(g, side, pcx, pcy, z - 1.0f, vp); store_voxel(g, d, vp, solid); }   // :46-49
-        if (floorf(z) != floorf(z + max_change)) { unswizzle_clamp(g, side, pcx, pcy, z + 1.0f, vp); store_voxel(g, d, vp, solid); }   // :50-53
+        store_voxel(g, d, vp, solid, z_lo, z_hi);
+        if (floorf(z) != floorf(z - max_change)) { unswizzle_clamp(g, side, pcx, pcy, z - 1.0f, vp); store_voxel(g, d, vp, solid, z_lo, z_hi); }   // :46-49
+        if (floorf(z) != floorf(z + max_change)) { unswizzle_clamp(g, side, pcx, pcy, z + 1.0f, vp); store_voxel(g, d, vp, solid, z_lo, z_hi); }   // :50-53
     }
 }
 
