@@ -244,7 +244,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
     transport = os.environ.get("BLUB_BENCH_TRANSPORT", "rccl")
     scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
     watchdog = None
-    if transport == "rccl":
+    if transport != "loopback":
         watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), fallback_to_replicas, args=("no progress within the deadline",))
         watchdog.daemon = True
         watchdog.start()
@@ -265,6 +265,12 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
                 group = blub_amd.SlabGroup(dim, P + 64, local=world, device=dev)
         else:
             group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev)
+        if group is not None and transport == "direct":
+            # opt-in (BLUB_BENCH_TRANSPORT=direct): peer-mapped slabs over hipIpc, kernels store into the neighbours' memory themselves.  NOT the
+            # default of a driver run: it has only ever run between processes on ONE GPU (tests/test_gpu_multirank.py), and a bad peer mapping
+            # on a real multi-GPU node is a memory fault, not an error code -- there would be no line at all
+            if not group.connect_direct_over_torch_distributed():
+                sys.stderr.write("rank %d: hipIpc mapping unavailable on some rank; staying on the RCCL transport\n" % rank)
         if group is not None:
             group.set_gravity_grid(gravity)
             if args.pcg_schedule != "default":
@@ -322,7 +328,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
         if transport == "loopback":
             parallelism = "%d z-slabs EMULATED on one GPU (loopback transport, rank 0 only): protocol cost without a wire, not a scaling result" % world
         else:
-            parallelism = "z-slab decomposition over RCCL: %d slabs, 1 rank per GPU" % world
+            parallelism = "z-slab decomposition over %s: %d slabs, 1 rank per GPU" % ("peer-mapped memory (hipIpc)" if group.transport() == "direct" else "RCCL", world)
         line = {
             "metric": METRIC, "value": round(args.steps / elapsed, 3), "unit": "steps/s (global steps of the whole domain)", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,

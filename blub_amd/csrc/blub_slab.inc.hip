@@ -500,7 +500,8 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
         for (int k = 0; k < 4; ++k) { a.below[k] = has_down(G, i) ? (k == 0 ? e.rb_msg : e.rb[k]) : nullptr; a.above[k] = has_up(G, i) ? (k == 0 ? e.ra_msg : e.ra[k]) : nullptr; }
         a.dst[0] = h->pos; a.dst[1] = h->pvel[0]; a.dst[2] = h->pvel[1]; a.dst[3] = h->pvel[2];
         blubk::SlabXferRecord* rec = G->rec_dev + ((size_t)i * XFER_KINDS + kind) * XFER_RING + G->xfer_seq % XFER_RING;
-        hipLaunchKernelGGL(blubk::k_slab_append, dim3(std::max(1u, std::min(512u, particle_blocks(cap_below[i] + cap_above[i])))), dim3(256), 0, G->stream, a, narr, cap_below[i], cap_above[i], G->capacity,
+        // (<= 64 workgroups, grid-stride: every workgroup ends with an atomic on ONE counter -- 512 of them took 11-13 us to append a few thousand records)
+        hipLaunchKernelGGL(blubk::k_slab_append, dim3(std::max(1u, std::min(64u, particle_blocks(cap_below[i] + cap_above[i])))), dim3(256), 0, G->stream, a, narr, cap_below[i], cap_above[i], G->capacity,
                            h->n_dev, (int)migrate, (const blubk::SlabCounts*)e.counts, rec, G->xfer_seq, e.append_done);
         blub_slab_group::Hist& H = G->hist[(size_t)i * XFER_KINDS + kind];
         H.pending = true; H.seq = G->xfer_seq;

@@ -675,6 +675,32 @@ class SlabGroup:
         dist.broadcast_object_list(payload, src=0)
         return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning)
 
+    def connect_direct_over_torch_distributed(self):
+        """DIRECT transport between the ranks of the default process group: every rank's hipIpc handles are all-gathered over the control plane,
+        every rank maps everybody else's slab, and all ranks switch together -- or none does (returns False; the RCCL transport stays)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        try:
+            blob = self.export_handles()
+        except BlubError:
+            blob = None
+        blobs = [None] * world
+        dist.all_gather_object(blobs, blob)
+        ok = all(b is not None for b in blobs)
+        if ok:
+            try:
+                for r in range(world):
+                    if r != rank:
+                        self.connect(r, blobs[r])
+            except BlubError:
+                ok = False
+        verdict = [None] * world
+        dist.all_gather_object(verdict, ok)
+        if not all(verdict):
+            return False
+        self.set_transport("direct")
+        return True
+
     def close(self):
         if getattr(self, "_g", None):
             self._L.blub_slab_group_destroy(self._g)

@@ -128,11 +128,14 @@ def test_a_rank_that_dies_gives_its_peers_a_communication_error_instead_of_a_han
         assert "pos0" in d.files and "pos1" not in d.files                                      # step 0 completed, step 1 failed
 
 
-def test_bench_gpus_2_runs_the_slab_path(tmp_path):
+@pytest.mark.parametrize("transport", ["rccl", "direct"])
+def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per "GPU"), control plane over gloo, data plane through
-    the preloaded fake: the z-slab path must produce the JSON line itself -- not the replicas fallback."""
+    the preloaded fake: the z-slab path must produce the JSON line itself -- not the replicas fallback.  BLUB_BENCH_TRANSPORT=direct: the opt-in
+    that exchanges hipIpc handles over the control plane and lets the kernels store into the neighbour's slab."""
     import json
     env = dict(os.environ)
+    env["BLUB_BENCH_TRANSPORT"] = transport
     env["LD_PRELOAD"] = _fake_rccl()
     env["FAKE_RCCL_DIR"] = str(tmp_path)
     env["BLUB_BENCH_BACKEND"] = "gloo"
@@ -144,7 +147,10 @@ def test_bench_gpus_2_runs_the_slab_path(tmp_path):
     assert res.returncode == 0 and lines, res.stdout[-2000:] + res.stderr[-4000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] is not None and d["value"] > 0, d
-    assert "rccl, 2 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
+    if transport == "direct":
+        assert "direct" in d["transport"] and "hipIpc" in d["config"]["parallelism"] and d["transport_ops_per_step"] == 14, d
+    else:
+        assert "rccl, 2 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
 
 
 def test_bench_gpus_8_weak_scaling_runs_the_slab_path(tmp_path):
