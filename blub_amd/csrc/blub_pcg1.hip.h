@@ -90,12 +90,6 @@ __device__ __forceinline__ void pcg1_prologue_load(const PcgCtrl* __restrict__ c
 }
 // Returns false when the solve is finished (every block takes the same branch: the reductions are deterministic).
 // direct transport: tagged partials (see pcg1_prologue_finish)
-struct Pcg1PartialLoads { blub_v4f v[4]; };
-__device__ __forceinline__ void pcg1_partials_issue(Pcg1PartialLoads& P, const float4* __restrict__ part_in, int num_part_in) {
-    const int lim = min(num_part_in, PCG_VBLOCKS_MAX);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ld_sys_f4_issue(P.v[k], part_in + min((int)threadIdx.x + k * PCG_B_THREADS, max(lim - 1, 0)));      // (clamped address, masked by the consumer)
-}
 __device__ __forceinline__ float4 pcg1_partial_spin(const float4* p, uint32_t tag, uint32_t* err) {
     float4 v = ld_sys_f4(p);
     unsigned spins = 0;
@@ -106,39 +100,34 @@ __device__ __forceinline__ float4 pcg1_partial_spin(const float4* p, uint32_t ta
     }
     return v;
 }
-__device__ __forceinline__ float4 pcg1_partial_validated(Pcg1PartialLoads& P, int k, const float4* p, uint32_t tag, uint32_t* err) {
-    if (__float_as_uint(P.v[k].w) == tag) return make_float4(P.v[k].x, P.v[k].y, P.v[k].z, P.v[k].w);
-    return pcg1_partial_spin(p, tag, err);
-}
 template <bool FIRST, bool COHERENT = false>
 __device__ __forceinline__ bool pcg1_prologue_finish(Pcg1PrologueLoads& L, PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in,
                                                      int num_part, float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta,
-                                                     Pcg1PartialLoads* pre = nullptr, uint32_t tag_in = 0u, uint32_t* err = nullptr) {
+                                                     uint32_t tag_in = 0u, uint32_t* err = nullptr) {
     constexpr int NT = PCG_B_THREADS;
     float g = 0.0f, d = 0.0f, m = 0.0f;
     if (COHERENT) {
-        // z-slab groups, direct transport: every partial carries the sequence number of the exchange it belongs to in its fourth word.  The
-        // first four of this thread were requested past the caches at the very start of the kernel (pcg1_partials_issue) and are accepted
-        // here when their tags match -- a partial is only stored after the stores of its whole workgroup have landed, so the tags of all
-        // workgroups of a slab vouch for its boundary planes too: no flag round trip, no fence.  Same order and grouping as below: the sums
-        // are bit-identical to the host-transport solve.
+        // z-slab groups, direct transport: every partial carries the sequence number of the exchange it belongs to in its fourth word.  A partial
+        // is only stored after the stores of its whole workgroup have landed, so the tags of all workgroups of a slab vouch for its boundary
+        // planes too: no flag round trip, no fence.  First attempt: the ORDINARY loads of the prologue (through the L2 -- every workgroup
+        // reads the whole array, so these are L2 hits after the first workgroup of an XCD; past the caches the same few lines were requested
+        // ~600 x per launch from the memory side: +3.5 us per launch, measured in loopback).  What a peer stored after the line was cached
+        // shows an old tag and is read again past the caches until its tag is right.  Same order and grouping as below: the sums are
+        // bit-identical to the host-transport solve.
         const int lim = min(num_part, PCG_VBLOCKS_MAX);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PCG_PART_PER_THREAD; ++k) {
             const int i = (int)threadIdx.x + k * NT;
-            if (i < lim) { const float4 p = pcg1_partial_validated(*pre, k, part_in + i, tag_in, err); g += p.x; d += p.y; m = fmaxf(m, p.z); }
-        }
-        // (the gathered arrays of groups of more than 1024 partials: four loads in flight per round, as above)
-        for (int base = PCG_VBLOCKS_MAX; base < num_part; base += 4 * NT) {
-            Pcg1PartialLoads Q;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ld_sys_f4_issue(Q.v[k], part_in + min(base + (int)threadIdx.x + k * NT, num_part - 1));
-            ld_sys_wait(Q.v[0], Q.v[1], Q.v[2], Q.v[3]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = base + (int)threadIdx.x + k * NT;
-                if (i < num_part) { const float4 p = pcg1_partial_validated(Q, k, part_in + i, tag_in, err); g += p.x; d += p.y; m = fmaxf(m, p.z); }
+            if (i < lim) {
+                float4 p = i < L.spec ? L.sp.v[k] : part_in[i];
+                if (__float_as_uint(p.w) != tag_in) p = pcg1_partial_spin(part_in + i, tag_in, err);
+                g += p.x; d += p.y; m = fmaxf(m, p.z);
             }
+        }
+        for (int i = (int)threadIdx.x + PCG_VBLOCKS_MAX; i < num_part; i += NT) {      // (the gathered arrays of groups of more than 1024 partials)
+            float4 p = part_in[i];
+            if (__float_as_uint(p.w) != tag_in) p = pcg1_partial_spin(part_in + i, tag_in, err);
+            g += p.x; d += p.y; m = fmaxf(m, p.z);
         }
     } else {
     spec_partials_fix(part_in, L.spec, num_part, L.sp);
@@ -239,6 +228,7 @@ struct Pcg1TileLoads {
     uint32_t dq[2]; float4 rv[2], wv[2], qv[2], dv4[2], pv4[2]; int base[2];   // base < 0: element not loaded (outside the grid / corner row)
     int hdv; float hr, hw, hq; bool hin;
     bool own[2]; int hc;
+    int gz1;      // grid plane of the pass-1 (face-halo) element: z-slab groups fetch it past the caches when it is a ghost plane
 };
 // Only ~1/4 of the cells of a fluid brick are FLUID in the headline scene (1 M particles @ 256^3: 150 k FLUID cells in 1300 bricks
 // of 512), and the kernel is bound by the bytes it pulls through the fabric (every kernel boundary invalidates the L2s), not by
@@ -279,11 +269,13 @@ __device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const Pcg1
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         L.base[k] = -1; L.dq[k] = 0; L.own[k] = false;
+        if (k == 1) L.gz1 = -1;
         if (!G.need[k]) continue;
         const int gy = y0b + G.ry[k] - 1, gz = z0b + G.rz[k] - 1, gx = x0b + G.q4[k];
         if (!((unsigned)gy < (unsigned)g.ny && (unsigned)gz < (unsigned)g.nz && gx < g.nx)) continue;
         const int base = base0 + G.rel[k];
         L.base[k] = base;
+        if (k == 1) L.gz1 = gz;
         L.dq[k] = *reinterpret_cast<const uint32_t*>(dvol + (uint32_t)base);
         L.own[k] = G.own[k] != 0;
     }
@@ -295,7 +287,7 @@ __device__ __forceinline__ void pcg1_tile_load_desc(Pcg1TileLoads& L, const Pcg1
 }
 template <bool FIRST, bool COHERENT = false>
 __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const float* __restrict__ r_in, const float* __restrict__ w_in, const float* __restrict__ q_in,
-                                                      const float* __restrict__ dsearch, const float* __restrict__ p) {
+                                                      const float* __restrict__ dsearch, const float* __restrict__ p, int ghost_lo = -2, int ghost_hi = -2) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     blub_v4f wsys; bool wsys_pending = false;      // (direct transport: the halo row of w, fetched past the caches, in flight with the plain loads)
 #pragma unroll
@@ -304,8 +296,9 @@ __device__ __forceinline__ void pcg1_tile_load_fields(Pcg1TileLoads& L, const fl
         if (L.base[k] < 0 || !any_fluid_d(L.dq[k])) continue;
         const uint32_t off = (uint32_t)L.base[k] * 4u;
         L.rv[k] = ld4o(r_in, off);
-        // (direct transport: the halo rows of w may lie in a ghost plane a z-neighbour wrote while this kernel was running)
-        if (COHERENT && k == 1) { ld_sys_f4_issue(wsys, reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w_in) + off)); wsys_pending = true; } else L.wv[k] = ld4o(w_in, off);
+        // (direct transport: the GHOST planes of w -- `ghost_lo` / `ghost_hi`, -2 = none -- are stored by the z-neighbours, possibly while this
+        //  kernel is running; every other halo row is this slab's own data of the previous launch and comes through the L2 like the rest)
+        if (COHERENT && k == 1 && (L.gz1 == ghost_lo || L.gz1 == ghost_hi)) { ld_sys_f4_issue(wsys, reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w_in) + off)); wsys_pending = true; } else L.wv[k] = ld4o(w_in, off);
         if (!FIRST) L.qv[k] = ld4o(q_in, off);
         if (L.own[k]) { L.dv4[k] = ld4o(dsearch, off); L.pv4[k] = ld4o(p, off); }
     }
@@ -335,8 +328,8 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     pcg_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
-    Pcg1PartialLoads PP;
-    if (DIRECT) pcg1_partials_issue(PP, part_in, num_part_in);      // past the caches, in flight with everything below
+    const int ghost_lo = (DIRECT && halo_lo >= 0) ? halo_lo - 1 : -2, ghost_hi = (DIRECT && halo_hi >= 0) ? halo_hi + 1 : -2;
+    bool pushed = false;      // this thread stored into a peer's memory
     // round trip 1: list length, the block's first list entry (list[] has an entry per brick of the grid: always in bounds), `done`,
     // the previous scalars and the partials.  The first list entry is requested for virtual workgroup blockIdx.x BEFORE the list length
     // (hence V) is known: with the XCD-contiguous order its position depends on V, so that speculative fetch uses the launch grid's
@@ -362,12 +355,11 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     // round trip 2: the first brick's descriptors, in flight during the reduction; its fields follow the reduction
     Pcg1TileLoads TL;
     if (has_vb && i0 < n) pcg1_tile_load_desc(TL, TG, bg, b0, t, dvol);
-    if (DIRECT) ld_sys_wait(PP.v[0], PP.v[1], PP.v[2], PP.v[3]);      // (one wait for the whole first batch)
     float alpha, beta;
     // (direct transport: the tags of ALL partials of the previous launch have been seen before anything else that came from a peer -- the halo
     //  rows of w below -- is requested)
-    if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta, &PP, DIRECT ? dir->seq_in : 0u, DIRECT ? dir->error : nullptr)) return false;
-    if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p);
+    if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta, DIRECT ? dir->seq_in : 0u, DIRECT ? dir->error : nullptr)) return false;
+    if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p, ghost_lo, ghost_hi);
     StagedTile& T = tiles[half];
     bool first = true;
     for (int vb = blockIdx.x; vb < V; vb += gridDim.x) {
@@ -377,7 +369,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
         const uint32_t i = ib * PCG_BPB + half;
         const bool have = i < n;
         const uint32_t b = first ? b0 : (have ? list[i] : 0u);
-        if (!first && have) { pcg1_tile_load_desc(TL, TG, bg, b, t, dvol); pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p); }
+        if (!first && have) { pcg1_tile_load_desc(TL, TG, bg, b, t, dvol); pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p, ghost_lo, ghost_hi); }
         first = false;
         int bxb, byb, bzb; brick_coords(bg, b, bxb, byb, bzb); (void)bxb;
         const int y0b = byb * BY, z0b = bzb * BZ;
@@ -424,6 +416,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
                     st4o(dsearch, off, make_float4(dn[0], dn[1], dn[2], dn[3]));
                     st4o(p, off, make_float4(pn[0], pn[1], pn[2], pn[3]));
                     if (DIRECT) {      // the pressure halo of the z-neighbours stays current: no exchange after the solve
+                        pushed = pushed || (gz == halo_lo && dir->p_dn) || (gz == halo_hi && dir->p_up);
                         if (gz == halo_lo && dir->p_dn) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->p_dn) + off), make_float4(pn[0], pn[1], pn[2], pn[3]));
                         if (gz == halo_hi && dir->p_up) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->p_up) + off), make_float4(pn[0], pn[1], pn[2], pn[3]));
                     }
@@ -467,6 +460,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
                     st4o(w_out, (uint32_t)cidx(g, x0, y, z) * 4u, make_float4(wn[0], wn[1], wn[2], wn[3]));
                     if (DIRECT) {      // the own boundary planes of w_{i+1} go straight into the z-neighbours' ghost planes
                         const uint32_t off = (uint32_t)cidx(g, x0, y, z) * 4u;
+                        pushed = pushed || (z == halo_lo && dir->w_dn) || (z == halo_hi && dir->w_up);
                         if (z == halo_lo && dir->w_dn) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->w_dn) + off), make_float4(wn[0], wn[1], wn[2], wn[3]));
                         if (z == halo_hi && dir->w_up) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir->w_up) + off), make_float4(wn[0], wn[1], wn[2], wn[3]));
                     }
@@ -479,7 +473,9 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     }
     // one combined block reduction of the three partials of this virtual workgroup
     acc_g = wave_sum_dpp(acc_g); acc_d = wave_sum_dpp(acc_d); emax = wave_max_abs_dpp(emax);
-    if (DIRECT) wait_stores();      // every store of this wave -- the pushed boundary planes among them -- has landed before the tagged partial goes out
+    // every store a wave pushed into a z-neighbour's planes has landed before the tagged partial goes out (waves without such stores -- all but
+    // the two boundary brick layers -- do not wait for their own stores' acknowledgements)
+    if (DIRECT && __builtin_amdgcn_ballot_w64(pushed) != 0ull) wait_stores();
     __syncthreads();          // (a workgroup without bricks reaches this point straight from the prologue's reads of sm4)
     if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = make_float4(acc_g, acc_d, emax, 0.0f);
     __syncthreads();
