@@ -523,7 +523,7 @@ def main():
 
     # ---- informational: the same window with the reference's tunable `particle_rebinning_step_frequency` (hybrid_fluid.rs:20-21, GUI range
     # 0..300, default 60) at the value that suits this GPU.  NOT the headline value: BASELINE quotes the metric at the default (60).  The particle
-    # kernels cost about twice as much 59 steps after a rebinning as right after it, and a rebinning costs ~0.17 ms here.
+    # kernels cost about twice as much 59 steps after a rebinning as right after it (docs/DESIGN_rounds_1-3.md 5c), and a rebinning costs ~0.17 ms here.
     rebinning_tuned = None
     if not args.no_fast_forward:
         rebinning_tuned = {"note": "informational: same scene and window with particle_rebinning_step_frequency (a tunable of the reference, default 60) changed", "runs": []}
@@ -560,7 +560,7 @@ def main():
         dominant = max(prof, key=lambda k: prof[k]["total_ms"])
         avg_ms = prof[dominant]["total_ms"] / prof[dominant]["launches"]
         ach = algorithmic_bytes(dominant, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
-        roofline_workload = {"bound": "fabric latency / launch count (see DESIGN.md 6): a few MB per launch", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        roofline_workload = {"bound": "fabric latency / launch count (see DESIGN.md 5.2, 6): a few MB per launch", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(avg_ms * 1e3, 2),
                              "share_of_step": round(prof[dominant]["total_ms"] / total_ms, 3), "fluid_cells_at_end": F, "active_brick_cells_at_end": A, "fluid_brick_cells_at_end": Fb,
                              "launches_per_step": round(prof[dominant]["launches"] / n_prof, 1)}
