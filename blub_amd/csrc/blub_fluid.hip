@@ -136,6 +136,8 @@ struct blub_fluid {
     PcgGeom geom{};
     int pcg_grid = 0;
     PcgGeomZ gz{};            // 2.5-D dense mapping (blub_pcg_dense.hip.h)
+    PcgGeomZ gzd{};           // ... as the direction kernel sees it: `dense_kd_chunk_factor` chunks of gz per tile
+    int dense_kd_chunk_factor = 0;   // 0 = by grid size (set_dense_geometry)
     int pcg_grid_z = 0;
     float *part_sas = nullptr, *part_sigma[2] = {nullptr, nullptr}, *part_max = nullptr;
     uint8_t* tile_flags = nullptr;
@@ -592,7 +594,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             LAUNCH(h, KC_PCG_FINALIZE, k_pcg_finalize, dim3(1), dim3(256), ctrl, (const float2*)part_upd, 0, nfl, maxit, h->solve_seq[which], stat_slot);
     } else {
         const int np = h->pcg_grid_z;
-        const dim3 grid(np);
+        const int npd = std::min(np, ((h->gzd.tiles + 7) / 8) * 8);      // the direction kernel's own grid (it may march deeper tiles: set_dense_geometry)
+        const dim3 grid(np), gridd(npd);
         const size_t lds_dir = dense_dir_lds_bytes(h->gz.T, h->gz.qpr);
 #define BLUB_LAUNCH_Z(TT, NTU, NTD, DD)                                                                                                                           \
         {                                                                                                                                                       \
@@ -600,13 +603,13 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             LAUNCH(h, KC_PCG_INIT, k_pcg_init_z<TT>, grid, block, h->gz, (const int8_t*)h->marker, h->dvol, p, h->residual, sbuf[0], part_upd, h->tile_flags, ctrl);   \
             for (int i = 0; i <= maxit; ++i) {                                                                                                                  \
                 if (i == 0)                                                                                                                                     \
-                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true, NTD, DD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
+                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, true, NTD, DD>), gridd, block, lds_dir, h->gzd, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[0], sbuf[0],   \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, 0);                                              \
                 else                                                                                                                                            \
-                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD, DD>), grid, block, lds_dir, h->gz, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
+                    LAUNCH_LDS(h, KC_PCG_DIR, (k_pcg_dir_z<TT, false, NTD, DD>), gridd, block, lds_dir, h->gzd, (const uint8_t*)h->dvol, (const float*)h->residual, (const float*)sbuf[(i - 1) & 1], sbuf[i & 1], \
                            (const float2*)part_upd, part_dir, np, (const uint8_t*)h->tile_flags, ctrl, tol, i, (int)is_check(i - 1));                           \
                 LAUNCH(h, KC_PCG_UPDATE, (k_pcg_update_z<TT, NTU>), grid, block, h->gz, (const uint8_t*)h->dvol, (const float*)sbuf[i & 1], p, h->residual,     \
-                       (const float*)part_dir, part_upd, np, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
+                       (const float*)part_dir, part_upd, npd, (const uint8_t*)h->tile_flags, (const PcgCtrl*)ctrl, i);                                           \
             }                                                                                                                                                   \
         }
         // p / r of KU are touched exactly once per kernel: non-temporal (66.8 -> 62.5 us at 256^3); s_out of KD is re-read as a halo: default policy
@@ -776,6 +779,17 @@ static void set_dense_geometry(blub_fluid* h, int T, int zc, int grid) {
     gz.alternate_march = h->dense_alternate_march >= 0 ? h->dense_alternate_march : (h->N >= ((size_t)1 << 26) ? 1 : 2);
     if (grid <= 0) grid = 2048;
     h->pcg_grid_z = std::min(std::min(grid, PCG_GRID_MAX), ((gz.tiles + 7) / 8) * 8);
+    gz.flag_factor = 1; gz.flag_chunks = gz.z_chunks;
+    // The direction kernel reads r and s with two z-halo planes per tile (1.10x its algorithmic bytes at 32 planes); the update kernel has no halo on
+    // p and r and loses from deeper tiles (fewer workgroups).  Beyond the Infinity Cache the direction kernel therefore marches several of the update
+    // kernel's chunks per tile, as many as leave 4096 waves of tiles (profiles/r04_dense_sweep.txt, 512^3: KD 310.7 us with 32 planes, 317.7 with 64,
+    // 302.4 with 128; KU 502 / 531 / 527 us).
+    int f = h->dense_kd_chunk_factor;
+    if (f <= 0) { f = 1; if (h->N >= ((size_t)1 << 26)) while (f < 4 && (size_t)gz.plane_tiles * (size_t)((gz.z_chunks + 2 * f - 1) / (2 * f)) * (size_t)(T / 64) >= 4096) f *= 2; }
+    PcgGeomZ& gd = h->gzd;
+    gd = gz;
+    gd.zc = gz.zc * f; gd.z_chunks = (h->g.nz + gd.zc - 1) / gd.zc; gd.tiles = gd.plane_tiles * gd.z_chunks;
+    gd.flag_factor = f; gd.flag_chunks = gz.z_chunks;
 }
 
 static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared_stream = nullptr, int vol_z0 = 0, int vol_planes = 0) {
@@ -1207,6 +1221,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "pcg_tail_margin") h->tail_margin_checks = std::max(0, value);
     else if (k == "pcg_launch_grid") h->pcg_grid_forced = std::max(0, value);
     else if (k == "dense_kd_nt") h->dense_kd_nt = value;
+    else if (k == "dense_kd_chunk_factor") { h->dense_kd_chunk_factor = std::max(0, value); set_dense_geometry(h, h->gz.T, h->gz.zc, h->pcg_grid_z); }
     else if (k == "dense_alternate_march") { h->dense_alternate_march = value < 0 ? -1 : (value & 3); set_dense_geometry(h, h->gz.T, h->gz.zc, h->pcg_grid_z); }
     else if (k == "list_launch_grid") h->list_grid_forced = value;
     else if (k == "fuse_divergence") h->fuse_divergence = std::max(0, std::min(2, value));

@@ -23,7 +23,16 @@ struct PcgGeomZ {
     int zc, z_chunks;
     int tiles;
     int alternate_march;  // odd z-chunks march downwards (xcd_tile_pairs): bit 0 in k_pcg_dir_z, bit 1 in k_pcg_update_z
+    // the tile flags (k_pcg_init_z) are those of the UPDATE kernel's geometry; the direction kernel may march `flag_factor` of those chunks in one
+    // tile (its z-halo planes are 2 / zc of what it reads, the update kernel has none on p and r): its flag is the OR of the chunks it covers
+    int flag_factor, flag_chunks;
 };
+__device__ __forceinline__ bool tile_has_fluid(const PcgGeomZ& gz, const uint8_t* __restrict__ tile_flags, int pt, int zci) {
+    if (gz.flag_factor == 1) return tile_flags[zci * gz.plane_tiles + pt] != 0;
+    bool any = false;
+    for (int j = 0; j < gz.flag_factor; ++j) { const int zf = zci * gz.flag_factor + j; if (zf < gz.flag_chunks) any = any || tile_flags[zf * gz.plane_tiles + pt] != 0; }
+    return any;
+}
 
 // XCD-contiguous tile order: block b runs on XCD b % 8 (observed dispatch order, a speed hint only), so give XCD k the
 // contiguous tile range [k*tiles/8, (k+1)*tiles/8): y-adjacent tiles then share an L2 for their halo rows.
@@ -327,8 +336,9 @@ __global__ __launch_bounds__(T) void k_pcg_dir_z(PcgGeomZ gz, const uint8_t* __r
     const int padded = ((gz.tiles + 7) >> 3) << 3;
     for (int it = blockIdx.x; it < padded; it += gridDim.x) {
         const int tile = xcd_tile_pairs(it, gz);
-        if (tile >= gz.tiles || !tile_flags[tile]) continue;
+        if (tile >= gz.tiles) continue;
         const int pt = tile % gz.plane_tiles, zci = tile / gz.plane_tiles;
+        if (!tile_has_fluid(gz, tile_flags, pt, zci)) continue;
         const int q0 = pt * T, q = q0 + t;
         DirTile K;
         K.down = (zci & 1) != 0 && (gz.alternate_march & 1) != 0;

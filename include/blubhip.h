@@ -270,7 +270,7 @@ int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
  * oracle AND against the reference's own shaders at the tolerances of schedule 0 (tests/test_gpu_pcg_schedule.py, tests/test_gpu_vs_ref.py),
  * the same loose whole-step bound (0.15 cells), 600-step runs of dam_halfhalf and corner_dams_256 whose iteration-count and reported-error
  * distributions match schedule 0's, and the measured gap between the carried residual and b - A p at the end of those solves
- * (tests/test_gpu_pcg_schedule.py::test_600_steps_..., profiles/r04_schedule_longrun.json).  Its r and q = A d are carried by recurrences
+ * (tests/test_gpu_pcg_schedule.py::test_600_steps_..., profiles/r04_schedule_longrun_{dam_halfhalf,corner_dams_256}.json).  Its r and q = A d are carried by recurrences
  * (no residual replacement: the gap stays at rounding level for the <= 64 iterations it is used for); solves configured with more than 64
  * iterations run schedule 0 regardless ("pcg1_max_iterations", blub_fluid_set_tuning), as does the dense-row mapping.
  * blub_fluid_set_pcg_schedule(h, 0) selects the reference's literal order of operations everywhere. */
@@ -359,7 +359,10 @@ int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blu
 int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out);
 void blub_slab_group_destroy(blub_slab_group* g);
 int blub_slab_group_num_local(const blub_slab_group* g);
-blub_fluid* blub_slab_group_local_fluid(blub_slab_group* g, int local_index);   /* for read_volume / statistics of one slab */
+/* For read_volume / statistics of one slab (borrowed: do not destroy).  A slab holds the planes [z0 - 8, z1 + 8) of every grid volume only (its own
+ * range plus two brick layers: ghost particles, the dilated active bricks, stale bricks): blub_fluid_read_volume fills the rest of the
+ * full-grid host array with zeros, blub_fluid_write_volume / set_solid_voxels take the held planes of the full-grid input. */
+blub_fluid* blub_slab_group_local_fluid(blub_slab_group* g, int local_index);
 int blub_slab_group_local_range(const blub_slab_group* g, int local_index, int32_t* z0, int32_t* z1);
 /* every rank passes the same global arrays; each slab keeps the particles of its z-range */
 int blub_slab_group_set_particles(blub_slab_group* g, uint32_t n, const float* pos_ll, const float* vx, const float* vy, const float* vz);
