@@ -213,6 +213,19 @@ def fallback_to_replicas(reason):
     os.execve(sys.executable, [sys.executable] + sys.argv, env)
 
 
+def fallback_to_rccl(reason):
+    """N > 1, direct transport only: a failure or stall of the peer-store transport gets ONE second attempt over RCCL before the replicas
+    fallback (same mechanism: every rank re-executes itself and they meet again on MASTER_PORT + 17)."""
+    sys.stderr.write("rank %s: the direct transport failed (%s); re-running over RCCL\n" % (os.environ.get("RANK", "0"), reason))
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env["BLUB_BENCH_TRANSPORT"] = "rccl"
+    env["BLUB_BENCH_DIRECT_FAILED"] = str(reason)[:400]
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
+    env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+    os.execve(sys.executable, [sys.executable] + sys.argv, env)
+
+
 METRIC = "simulation steps/sec, 1M particles @ 256^3 grid"
 
 
@@ -241,11 +254,27 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
     import blub_amd
     from blub_amd import slab_scene
     dt = blub_amd.default_simulation_delta()
-    transport = os.environ.get("BLUB_BENCH_TRANSPORT", "rccl")
+    # auto (default): the direct transport when a probe on THIS node's GPUs says it works (blub_amd/direct_probe.py: child processes, so a bad
+    # peer mapping costs the probe and not the job), RCCL otherwise; rccl / direct force one (direct without the probe); loopback: see above
+    transport = os.environ.get("BLUB_BENCH_TRANSPORT", "auto")
+    probe = None
+    if transport == "auto":
+        from blub_amd import direct_probe
+        try:
+            ok_probe, why = direct_probe.run(rank, world, dev)
+        except Exception as e:   # (a rendezvous problem inside the probe itself: all ranks see it)
+            ok_probe, why = False, "%s: %s" % (type(e).__name__, e)
+        probe = {"passed": bool(ok_probe), "detail": why}
+        if rank == 0:
+            sys.stderr.write("direct-transport probe: %s\n" % ("passed" if ok_probe else "failed (%s); using RCCL" % why))
+        transport = "direct" if ok_probe else "rccl"
     scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
+    if os.environ.get("BLUB_BENCH_DIRECT_FAILED"):
+        probe = {"passed": True, "detail": "the probe passed but the run over the direct transport failed (%s); this line is the second attempt, over RCCL" % os.environ["BLUB_BENCH_DIRECT_FAILED"]}
+    bail = fallback_to_rccl if transport == "direct" else fallback_to_replicas
     watchdog = None
     if transport != "loopback":
-        watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), fallback_to_replicas, args=("no progress within the deadline",))
+        watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), bail, args=("no progress within the deadline",))
         watchdog.daemon = True
         watchdog.start()
     ok = torch.ones(1, device=ctl)
@@ -266,9 +295,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
         else:
             group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev)
         if group is not None and transport == "direct":
-            # opt-in (BLUB_BENCH_TRANSPORT=direct): peer-mapped slabs over hipIpc, kernels store into the neighbours' memory themselves.  NOT the
-            # default of a driver run: it has only ever run between processes on ONE GPU (tests/test_gpu_multirank.py), and a bad peer mapping
-            # on a real multi-GPU node is a memory fault, not an error code -- there would be no line at all
+            # peer-mapped slabs over hipIpc, kernels store into the neighbours' memory themselves (after the probe above, or forced)
             if not group.connect_direct_over_torch_distributed():
                 sys.stderr.write("rank %d: hipIpc mapping unavailable on some rank; staying on the RCCL transport\n" % rank)
         if group is not None:
@@ -287,7 +314,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             group.close()
         if watchdog is not None:
             watchdog.cancel()
-        fallback_to_replicas("z-slab group could not be created on every rank" + (" (%s)" % err if err else ""))
+        bail("z-slab group could not be created on every rank" + (" (%s)" % err if err else ""))
     active = group is not None
 
     def barrier():
@@ -299,6 +326,8 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
         for _ in range(args.warmup):
             if active:
                 group.step(dt)
+        if transport == "direct" and os.environ.get("BLUB_BENCH_FAIL_DIRECT"):      # (test hook: the second attempt over RCCL)
+            raise RuntimeError("injected failure of the direct transport")
         barrier()
         fluid0 = group.local_fluid(0) if active else None
         it0 = fluid0.total_solver_iterations() if active else 0
@@ -311,7 +340,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     except Exception as e:
-        fallback_to_replicas("z-slab step failed: %s" % e)
+        bail("z-slab step failed: %s" % e)
     if watchdog is not None:
         watchdog.cancel()
     t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
@@ -336,7 +365,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             "config": {"workload": workload, "grid": list(dim), "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
                        "parallelism": parallelism, "pcg_schedule": args.pcg_schedule if args.pcg_schedule != "default" else "single_reduction (library default)"},
             "pcg_iters_per_step": round((it1 - it0) / args.steps, 2), "transport_ops_per_step": round(ops_per_step, 1),
-            "transport": group.transport_description(), "roofline": None, "cpu_baseline": None}
+            "transport": group.transport_description(), "direct_transport_probe": probe, "roofline": None, "cpu_baseline": None}
     dist.barrier()
     if active:
         group.close()

@@ -128,11 +128,13 @@ def test_a_rank_that_dies_gives_its_peers_a_communication_error_instead_of_a_han
         assert "pos0" in d.files and "pos1" not in d.files                                      # step 0 completed, step 1 failed
 
 
-@pytest.mark.parametrize("transport", ["rccl", "direct"])
+@pytest.mark.parametrize("transport", ["rccl", "direct", "auto"])
 def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per "GPU"), control plane over gloo, data plane through
     the preloaded fake: the z-slab path must produce the JSON line itself -- not the replicas fallback.  BLUB_BENCH_TRANSPORT=direct: the opt-in
-    that exchanges hipIpc handles over the control plane and lets the kernels store into the neighbour's slab."""
+    that exchanges hipIpc handles over the control plane and lets the kernels store into the neighbour's slab.  auto (what the driver gets):
+    every rank first runs blub_amd/direct_probe.py in a child process -- a small slab group of its own over the direct transport, checked against
+    the single-domain engine -- and the job uses the direct transport because the probe passed."""
     import json
     env = dict(os.environ)
     env["BLUB_BENCH_TRANSPORT"] = transport
@@ -147,8 +149,10 @@ def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
     assert res.returncode == 0 and lines, res.stdout[-2000:] + res.stderr[-4000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] is not None and d["value"] > 0, d
-    if transport == "direct":
+    if transport in ("direct", "auto"):
         assert "direct" in d["transport"] and "hipIpc" in d["config"]["parallelism"] and d["transport_ops_per_step"] == 14, d
+        if transport == "auto":
+            assert d["direct_transport_probe"] == {"passed": True, "detail": "ok"}, d["direct_transport_probe"]
     else:
         assert "rccl, 2 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
 
@@ -163,6 +167,7 @@ def test_bench_gpus_8_weak_scaling_runs_the_slab_path(tmp_path):
     env["BLUB_BENCH_BACKEND"] = "gloo"
     env["FAKE_RCCL_TIMEOUT_S"] = "180"
     env["GPU_MAX_HW_QUEUES"] = "1"          # (see _launch)
+    env["BLUB_BENCH_TRANSPORT"] = "rccl"    # (the probe of the default "auto" would put eight more processes on the one GPU)
     env["BLUB_BENCH_SLAB_DEADLINE"] = "420"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29523",
@@ -173,3 +178,42 @@ def test_bench_gpus_8_weak_scaling_runs_the_slab_path(tmp_path):
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] is not None and d["value"] > 0, d
     assert "8 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
+
+
+def test_a_failing_direct_probe_leaves_the_job_on_rccl(tmp_path):
+    """The probe's children are made to fail (an unusable device ordinal): every rank agrees on the verdict and the job runs over RCCL."""
+    import json
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = _fake_rccl()
+    env["FAKE_RCCL_DIR"] = str(tmp_path)
+    env["BLUB_BENCH_BACKEND"] = "gloo"
+    env["BLUB_DIRECT_PROBE_DEVICE"] = "63"      # test hook of blub_amd/direct_probe.py: the device ordinal the children are given
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scene", "corner_dams_128", "--no-dense-pcg"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert res.returncode == 0 and lines, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads(lines[-1])
+    assert d["value"] is not None and d["value"] > 0 and "rccl, 2 ranks" in d["transport"], d
+    assert d["direct_transport_probe"]["passed"] is False and "probe child" in d["direct_transport_probe"]["detail"], d["direct_transport_probe"]
+
+
+def test_a_direct_run_that_fails_gets_a_second_attempt_over_rccl(tmp_path):
+    """The probe passes, then the run over the direct transport fails (injected after the warm-up steps): every rank re-executes itself
+    over RCCL and the line says so -- a scaling result, not the replicas fallback."""
+    import json
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = _fake_rccl()
+    env["FAKE_RCCL_DIR"] = str(tmp_path)
+    env["BLUB_BENCH_BACKEND"] = "gloo"
+    env["BLUB_BENCH_FAIL_DIRECT"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scene", "corner_dams_128", "--no-dense-pcg"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert res.returncode == 0 and lines, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads(lines[-1])
+    assert d["scaling"] == "strong" and d["value"] is not None and d["value"] > 0 and "rccl, 2 ranks" in d["transport"], d
+    assert "second attempt, over RCCL" in d["direct_transport_probe"]["detail"] and "injected failure" in d["direct_transport_probe"]["detail"], d["direct_transport_probe"]
