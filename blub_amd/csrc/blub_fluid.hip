@@ -538,7 +538,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             float* Q[2] = {h->aux_temp, h->cgbuf[2]};
             float4* part[2] = {h->part4, h->part4 + PCG_GRID_MAX};
             Pcg1Scalars* sc = h->pcg1_scalars[which];
-            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, 0, part[0], 1, 0u);
+            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s<false>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, 0, part[0], 1, 0u, -1, -1, SlabDirect{});
             // Launch as many iterations as the last few solves needed (+ `tail_margin_checks` check intervals); ONE persistent kernel covers
             // the rest (k_pcg1_tail_s): it normally finds the solve finished and only publishes the statistics.  Only while the solve is
             // launch-bound (an iteration inside the tail -- <= 256 blocks, a grid barrier -- costs more than a launched one).

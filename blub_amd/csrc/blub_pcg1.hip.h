@@ -170,10 +170,13 @@ __device__ __forceinline__ uint32_t st_read_quad_u(const StagedTile& T, int t, Q
 }
 
 // w_0 = A u_0 (u_0 = M^-1 r_0 was written to the search volume by k_pcg_init_b) + partials {gamma_0 (virtual block 0 only), delta_0, 0}
+// DIRECT (z-slab groups, direct transport): like K(i) the kernel stores its boundary planes of w_0 into the z-neighbours' ghost planes and its
+// tagged partial into every slab's array -- no exchange of its own between this kernel and K(0).
+template <bool DIRECT = false>
 __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int vb_force,
                                                              const uint8_t* __restrict__ dvol, const float* __restrict__ u, float* __restrict__ w_out,
                                                              const float2* __restrict__ part_init, int num_part_in, float4* __restrict__ part_out, int gamma_owner,
-                                                             uint32_t tag = 0u) {
+                                                             uint32_t tag, int halo_lo, int halo_hi, SlabDirect dir) {
     __shared__ float sm[8];
     __shared__ float2 sm2[PCG_B_THREADS / 64 > 4 ? PCG_B_THREADS / 64 : 4];
     __shared__ StagedTile tiles[PCG_BPB];
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
     const float2 red0 = reduce_partials2<PCG_B_THREADS>(part_init, num_part_in > 0 ? num_part_in : V, sm2);
     StagedTile& T = tiles[half];
+    bool pushed = false;
     for (int vb = blockIdx.x; vb < V; vb += gridDim.x) {
         float acc = 0.0f;
         for (uint32_t ib = (uint32_t)vb; ib * PCG_BPB < n; ib += (uint32_t)V) {
@@ -210,15 +214,28 @@ __global__ __launch_bounds__(PCG_B_THREADS) void k_pcg1_w0_s(BrickGeom bg, const
                         for (int j = 0; j < 4; ++j)
                             if (dbyte(m.c, j) & 0x80) { wn[j] = quad_mulA_d(m, sv, j); acc += wn[j] * f4(sv.c, j); }
                         *reinterpret_cast<float4*>(w_out + cidx(g, x0, y, z)) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+                        if (DIRECT) {
+                            const uint32_t off = (uint32_t)cidx(g, x0, y, z) * 4u;
+                            pushed = pushed || (z == halo_lo && dir.w_dn) || (z == halo_hi && dir.w_up);
+                            if (z == halo_lo && dir.w_dn) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir.w_dn) + off), make_float4(wn[0], wn[1], wn[2], wn[3]));
+                            if (z == halo_hi && dir.w_up) st_sys_f4(reinterpret_cast<float4*>(reinterpret_cast<char*>(dir.w_up) + off), make_float4(wn[0], wn[1], wn[2], wn[3]));
+                        }
                     }
                 }
             }
             __syncthreads();
         }
+        if (DIRECT && __builtin_amdgcn_ballot_w64(pushed) != 0ull) wait_stores();      // (the pushed planes have landed before the tagged partial goes out)
         const float tot = block_reduce<PCG_B_THREADS, false>(acc, sm);
         // gamma_0 (already reduced over ALL partials of the init kernels) enters the partial array exactly once: virtual block 0 of the one
         // domain, or of the first slab of a z-slab group
-        if (threadIdx.x == 0) part_out[vb] = make_float4((vb == 0 && gamma_owner) ? red0.x : 0.0f, tot, 0.0f, __uint_as_float(tag));      // (tag: direct transport of z-slab groups)
+        if (threadIdx.x == 0) {
+            const float4 tot4 = make_float4((vb == 0 && gamma_owner) ? red0.x : 0.0f, tot, 0.0f, __uint_as_float(tag));      // (tag: direct transport of z-slab groups)
+            if (DIRECT) {
+                st_sys_f4(part_out + vb, tot4);
+                for (int q = 0; q < dir.n_out; ++q) st_sys_f4(dir.part_out[q] + vb, tot4);
+            } else part_out[vb] = tot4;
+        }
     }
 }
 

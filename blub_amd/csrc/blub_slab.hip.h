@@ -212,7 +212,26 @@ __global__ void k_slab_publish_cnt(const float* __restrict__ gat_cnt, int nranks
 struct SlabCopy { const void* src; void* dst; uint32_t bytes; uint32_t pad; };   // src, dst 16-byte aligned, bytes % 16 == 0
 constexpr int SLAB_COPY_MAX = 40, SLAB_FLAG_MAX = 64;
 struct SlabCopyList { SlabCopy c[SLAB_COPY_MAX]; int n; };
-struct SlabFlagList { uint32_t* f[SLAB_FLAG_MAX]; int n; uint32_t seq; uint32_t* blocks_done; };
+// Acknowledgements (processes on different GPUs only): before a push kernel of exchange `seq` writes into a peer's ghost planes / staging buffers,
+// that peer must have finished every kernel that reads what the PREVIOUS exchanges delivered there.  Its own push kernel of exchange `seq` is
+// enqueued behind those kernels, so it raises an acknowledgement word in each of its destinations first thing, and every push kernel waits for
+// the words of the ranks it is about to write to (the exchanges are symmetric: whoever I push to pushes to me).  Not needed when all slabs
+// share one stream.  (K(i) pushes without it: its targets are double buffered by iteration parity.)
+struct SlabFlagList { uint32_t* f[SLAB_FLAG_MAX]; int n; uint32_t seq; uint32_t* blocks_done; uint32_t* ack_out[8]; int ack_src[8]; int n_ack; const uint32_t* ack_in; uint32_t* error; };
+__device__ __forceinline__ void slab_ack_handshake(const SlabFlagList& F) {
+    if (F.n_ack == 0) return;      // (uniform)
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && blockIdx.y == 0) for (int q = 0; q < F.n_ack; ++q) st_sys_u32(F.ack_out[q], F.seq);
+        for (int q = 0; q < F.n_ack; ++q) {
+            unsigned spins = 0;
+            while ((int32_t)(ld_sys_u32(F.ack_in + F.ack_src[q]) - F.seq) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 21)) { if (F.error) atomicOr(F.error, 1u); break; }      // ~1 s: a missing peer must not hang the GPU
+            }
+        }
+    }
+    __syncthreads();
+}
 __global__ __launch_bounds__(256) void k_slab_copy_planes(SlabCopyList L) {
     const SlabCopy c = L.c[blockIdx.y];
     const uint32_t n16 = c.bytes >> 4;
@@ -221,6 +240,7 @@ __global__ __launch_bounds__(256) void k_slab_copy_planes(SlabCopyList L) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) d[i] = s[i];
 }
 __global__ __launch_bounds__(256) void k_slab_push_planes(SlabCopyList L, SlabFlagList F) {
+    slab_ack_handshake(F);
     if ((int)blockIdx.y < L.n) {
         const SlabCopy c = L.c[blockIdx.y];
         const uint32_t n16 = c.bytes >> 4;
@@ -249,6 +269,7 @@ __global__ void k_slab_wait(const uint32_t* __restrict__ flags_in, uint32_t mask
 // receiver's staging buffer, which has the full particle capacity -- no message size to agree on, nothing to hold back
 struct SlabParticlePush { const float4* src[4]; float4* dst[4]; };      // [0]: position message (header in front), [1..3]: velocity rows; dst nullptr: no neighbour
 __global__ __launch_bounds__(256) void k_slab_push_particles(SlabParticlePush up, SlabParticlePush dn, int narr, SlabFlagList F) {
+    slab_ack_handshake(F);
     const SlabParticlePush& P = blockIdx.y == 0 ? up : dn;
     if (P.dst[0]) {
         const uint32_t n = __float_as_uint(P.src[0][0].x);      // header written by k_slab_finish_send

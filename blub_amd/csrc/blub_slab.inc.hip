@@ -91,7 +91,7 @@ static int slab_copy_flush(blub_slab_group* G) {
     if (G->direct) {      // write-through stores, then the flags of this exchange
         G->push_flags.seq = G->flag_seq; G->push_flags.blocks_done = G->blocks_done[0];
         hipLaunchKernelGGL(blubk::k_slab_push_planes, dim3(bx, (unsigned)std::max(1, G->copies.n)), dim3(256), 0, G->stream, G->copies, G->push_flags);
-        G->push_flags.n = 0;
+        G->push_flags.n = 0; G->push_flags.n_ack = 0;
     } else
         hipLaunchKernelGGL(blubk::k_slab_copy_planes, dim3(bx, (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies);
     G->copies.n = 0;
@@ -109,7 +109,7 @@ static int slab_copy(blub_slab_group* G, void* dst, const void* src, size_t byte
         if (G->direct) {      // (a partial flush must not raise this exchange's flags: plain batch, flags with the last one)
             const blubk::SlabFlagList keep = G->push_flags; G->push_flags.n = 0;
             uint32_t mx = 0; for (int k = 0; k < G->copies.n; ++k) mx = std::max(mx, G->copies.c[k].bytes);
-            blubk::SlabFlagList none{}; none.blocks_done = G->blocks_done[0]; none.seq = G->flag_seq;
+            blubk::SlabFlagList none = keep; none.n = 0; none.blocks_done = G->blocks_done[0]; none.seq = G->flag_seq;      // (no flags yet; only all-local groups ever get here: no acknowledgements either)
             hipLaunchKernelGGL(blubk::k_slab_push_planes, dim3(std::max(1u, std::min(64u, (mx / 16u + 255u) / 256u)), (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies, none);
             G->copies.n = 0; G->push_flags = keep;
         } else { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
@@ -156,10 +156,18 @@ static int slab_wait(blub_slab_group* G, int i, uint32_t mask, const blubk::PcgC
 }
 static uint32_t neighbour_mask(const blub_slab_group* G, int i) { return (has_up(G, i) ? 1u << (G->first + i + 1) : 0u) | (has_down(G, i) ? 1u << (G->first + i - 1) : 0u); }
 static uint32_t others_mask(const blub_slab_group* G, int i) { return ((G->nranks >= 32 ? 0xFFFFFFFFu : (1u << G->nranks) - 1u)) & ~(1u << (G->first + i)); }
-static void push_flag(blub_slab_group* G, uint32_t* f) {
-    for (int k = 0; k < G->push_flags.n; ++k) if (G->push_flags.f[k] == f) return;
-    if (G->push_flags.n < blubk::SLAB_FLAG_MAX) G->push_flags.f[G->push_flags.n++] = f;
+// acknowledgement words live behind the flag words of a slab's flag array: [32 + source rank]
+constexpr int SLAB_ACK_OFFSET = 32;
+static void flag_list_add(const blub_slab_group* G, blubk::SlabFlagList& F, int i, int dst) {
+    uint32_t* f = flag_of(G, i, dst);
+    for (int k = 0; k < F.n; ++k) if (F.f[k] == f) return;
+    if (F.n < blubk::SLAB_FLAG_MAX) F.f[F.n++] = f;
+    if (!rank_local(G, dst) && F.n_ack < 8) {      // another process: handshake before writing into its memory (blub_slab.hip.h: slab_ack_handshake)
+        F.ack_out[F.n_ack] = f + SLAB_ACK_OFFSET; F.ack_src[F.n_ack] = dst; F.n_ack += 1;
+        F.ack_in = G->flags[i] + SLAB_ACK_OFFSET; F.error = G->dir_error[i];
+    }
 }
+static void push_flag_to(blub_slab_group* G, int i, int dst) { flag_list_add(G, G->push_flags, i, dst); }
 
 // One z-plane of a volume from each z-neighbour: plane z1-1 goes up, plane z0 goes down; the receiver stores it at the
 // same global z (ghost planes z0-1 and z1).
@@ -178,8 +186,8 @@ static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(b
                 if (has_up(G, i)) { int rc = slab_copy(G, peer_vol(G, i, G->first + i + 1, base, elem) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (rc != BLUB_OK) return rc; }
                 if (has_down(G, i)) { int rc = slab_copy(G, peer_vol(G, i, G->first + i - 1, base, elem) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (rc != BLUB_OK) return rc; }
             }
-            if (has_up(G, i)) push_flag(G, flag_of(G, i, G->first + i + 1));
-            if (has_down(G, i)) push_flag(G, flag_of(G, i, G->first + i - 1));
+            if (has_up(G, i)) push_flag_to(G, i, G->first + i + 1);
+            if (has_down(G, i)) push_flag_to(G, i, G->first + i - 1);
         }
         if (!own_group) return BLUB_OK;
         { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
@@ -226,7 +234,7 @@ static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& arr
                 if (r == G->first + i) continue;
                 int rc = slab_copy(G, peer_ptr(G, i, r, mine), mine, (size_t)seg_floats * sizeof(float));
                 if (rc != BLUB_OK) return rc;
-                push_flag(G, flag_of(G, i, r));
+                push_flag_to(G, i, r);
             }
         }
         if (!own_group) return BLUB_OK;
@@ -462,8 +470,8 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
                 up.dst[k] = has_up(G, i) ? peer_ptr(G, i, G->first + i + 1, k == 0 ? e.rb_msg : e.rb[k]) : nullptr;
                 dn.dst[k] = has_down(G, i) ? peer_ptr(G, i, G->first + i - 1, k == 0 ? e.ra_msg : e.ra[k]) : nullptr;
             }
-            if (has_up(G, i)) F.f[F.n++] = flag_of(G, i, G->first + i + 1);
-            if (has_down(G, i)) F.f[F.n++] = flag_of(G, i, G->first + i - 1);
+            if (has_up(G, i)) flag_list_add(G, F, i, G->first + i + 1);
+            if (has_down(G, i)) flag_list_add(G, F, i, G->first + i - 1);
             if (F.n) hipLaunchKernelGGL(blubk::k_slab_push_particles, dim3(64, 2), dim3(256), 0, G->stream, up, dn, narr, F);
         }
         for (int i = 0; i < S; ++i) { int rc = slab_wait(G, i, neighbour_mask(G, i)); if (rc != BLUB_OK) return rc; }
@@ -650,9 +658,21 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
     for (int i = 0; i < S; ++i) {
         blub_fluid* h = G->slabs[i];
         B[i] = Bufs{{h->residual, h->cgbuf[0]}, {h->aux, h->cgbuf[1]}, {h->aux_temp, h->cgbuf[2]}};
-        // (direct transport: the partials carry the number of the exchange they travel with -- the one issued right below -- as their tag)
-        LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
-               seg4(i, 0), (int)(G->first + i == 0), G->direct ? G->flag_seq + 1u : 0u);
+        if (G->direct) {
+            // direct transport: the kernel pushes its boundary planes of w_0 and its partials itself, tagged with the number K(0) expects
+            const int halo_lo = has_down(G, i) ? h->slab_z0 : -1, halo_hi = has_up(G, i) ? h->slab_z1 - 1 : -1;
+            SlabDirect D{};
+            const int me = G->first + i;
+            D.w_up = has_up(G, i) ? peer_vol(G, i, me + 1, B[i].W[0]) : nullptr; D.w_dn = has_down(G, i) ? peer_vol(G, i, me - 1, B[i].W[0]) : nullptr;
+            for (int r = 0; r < G->nranks; ++r) {
+                if (r == me) continue;
+                D.part_out[D.n_out] = peer_ptr(G, i, r, seg4(i, 0)); D.n_out += 1;
+            }
+            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s<true>, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
+                   seg4(i, 0), (int)(G->first + i == 0), G->flag_seq + 1u, halo_lo, halo_hi, D);
+        } else
+            LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s<false>, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
+                   seg4(i, 0), (int)(G->first + i == 0), 0u, -1, -1, SlabDirect{});
     }
     auto exchange = [&](int wpar, int ppar) -> int {   // plane of W[wpar] to the z-neighbours + partials of parity ppar to every slab
         return slab_fused(G, [&]() -> int {
@@ -662,8 +682,8 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
             for (int i = 0; i < S && G->direct; ++i) {      // direct transport: push the two boundary planes into the z-neighbours' copies
                 blub_fluid* h = G->slabs[i];
                 char* base = (char*)B[i].W[wpar];
-                if (has_up(G, i)) { int r3 = slab_copy(G, peer_vol(G, i, G->first + i + 1, base, sizeof(float)) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i + 1)); }
-                if (has_down(G, i)) { int r3 = slab_copy(G, peer_vol(G, i, G->first + i - 1, base, sizeof(float)) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (r3 != BLUB_OK) return r3; push_flag(G, flag_of(G, i, G->first + i - 1)); }
+                if (has_up(G, i)) { int r3 = slab_copy(G, peer_vol(G, i, G->first + i + 1, base, sizeof(float)) + (size_t)(h->slab_z1 - 1) * pb, base + (size_t)(h->slab_z1 - 1) * pb, pb); if (r3 != BLUB_OK) return r3; push_flag_to(G, i, G->first + i + 1); }
+                if (has_down(G, i)) { int r3 = slab_copy(G, peer_vol(G, i, G->first + i - 1, base, sizeof(float)) + (size_t)h->slab_z0 * pb, base + (size_t)h->slab_z0 * pb, pb); if (r3 != BLUB_OK) return r3; push_flag_to(G, i, G->first + i - 1); }
             }
             for (int i = 0; i < S && !G->direct; ++i) {
                 blub_fluid* h = G->slabs[i];
@@ -686,7 +706,8 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
             return BLUB_OK;
         }, [&](bool own_group) { return slab_gather(G, [G, ppar](int i) { return reinterpret_cast<float*>(G->ex[i].gat4[ppar]); }, 4 * np, own_group); });
     };
-    if ((rc = exchange(0, 0)) != BLUB_OK) return rc;
+    if (G->direct) G->flag_seq += 1;      // (the number the w_0 kernels tagged their partials with: no exchange of its own)
+    else if ((rc = exchange(0, 0)) != BLUB_OK) return rc;
     int it = 0;
     if (G->direct) {
         // DIRECT transport: K(i) itself stores its boundary planes of w_{i+1} and of p into the z-neighbours' ghost planes and its partials into

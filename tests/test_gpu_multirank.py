@@ -101,7 +101,7 @@ def test_multi_process_slab_group_matches_the_single_domain_engine(world, schedu
         # the direct transport never does, and never looks at a solve's `done` from the host either
         if gather == "direct":
             assert all(tuple(int(v) for v in d["host_syncs"]) == (0, 0) for d in ranks), [d["host_syncs"] for d in ranks]
-            assert all(int(d["ops%d" % step]) == 14 for d in ranks for step in range(steps)), [int(d["ops0"]) for d in ranks]
+            assert all(int(d["ops%d" % step]) == 12 for d in ranks for step in range(steps)), [int(d["ops0"]) for d in ranks]
         else:
             assert all(int(d["host_syncs"][0]) == 4 for d in ranks), [d["host_syncs"] for d in ranks]
         st = [d["stats"] for d in ranks]
@@ -150,7 +150,7 @@ def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] is not None and d["value"] > 0, d
     if transport in ("direct", "auto"):
-        assert "direct" in d["transport"] and "hipIpc" in d["config"]["parallelism"] and d["transport_ops_per_step"] == 14, d
+        assert "direct" in d["transport"] and "hipIpc" in d["config"]["parallelism"] and d["transport_ops_per_step"] == 12, d
         if transport == "auto":
             assert d["direct_transport_probe"] == {"passed": True, "detail": "ok"}, d["direct_transport_probe"]
     else:

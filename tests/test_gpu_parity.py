@@ -551,11 +551,11 @@ def test_z_slab_decomposition_matches_single_domain(slabs, async_exchange, trans
         assert counts1 != counts0, "no particle migrated: the test does not exercise the exchange"
         # host synchronisations by particle exchanges: four in the first step (no history to size the messages from), none afterwards --
         # or four per step with the round-2 protocol; the direct transport never synchronises the host, not for exchanges and not to look at a
-        # solve's `done`, and issues 14 transport operations per step (the 120 PCG iterations of each solve exchange from inside their kernels)
+        # solve's `done`, and issues 12 transport operations per step (the 120 PCG iterations of each solve exchange from inside their kernels)
         if transport == "direct":
             assert group.host_syncs() == (0, 0), group.host_syncs()
             print("direct transport: %d transport operations in 3 steps" % (group.transport_ops() - ops0))
-            assert group.transport_ops() - ops0 == 3 * 14, group.transport_ops() - ops0
+            assert group.transport_ops() - ops0 == 3 * 12, group.transport_ops() - ops0
             assert group.held_back() == 0
         else:
             assert group.host_syncs()[0] == (4 if async_exchange else 12), group.host_syncs()
