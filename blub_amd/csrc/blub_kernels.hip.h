@@ -283,13 +283,16 @@ struct SlabDirect {
     uint32_t seq_in, seq_out, wait_mask;      // wait for flags_in[r] >= seq_in for every bit r of wait_mask; publish seq_out
     int n_out;
 };
+constexpr unsigned SLAB_SPIN_LIMIT = 1u << 24;
+__device__ __forceinline__ bool slab_gave_up(const uint32_t* error) { return error && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
 // every thread of the block returns once all awaited flags have arrived (or the bounded wait ran out)
 __device__ __forceinline__ void slab_wait_flags(const uint32_t* flags_in, uint32_t mask, uint32_t seq, uint32_t* error) {
     if (threadIdx.x < 32 && ((mask >> threadIdx.x) & 1u)) {
         unsigned spins = 0;
         while ((int32_t)(ld_sys_u32(flags_in + threadIdx.x) - seq) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 21)) { if (error) atomicOr(error, 1u); break; }      // ~1 s
+            // (~8 s: ranks may be seconds apart at start-up; once ANY wait of this slab has run out -- a peer stopped stepping -- the later ones give up at once)
+            if (++spins > SLAB_SPIN_LIMIT || ((spins & 1023u) == 0u && slab_gave_up(error))) { if (error) atomicOr(error, 1u); break; }
         }
     }
     __syncthreads();

@@ -95,7 +95,7 @@ __device__ __forceinline__ float4 pcg1_partial_spin(const float4* p, uint32_t ta
     unsigned spins = 0;
     while (__float_as_uint(v.w) != tag) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 21)) { if (err) atomicOr(err, 1u); break; }      // ~1 s: a missing peer must not hang the GPU
+        if (++spins > SLAB_SPIN_LIMIT || ((spins & 1023u) == 0u && slab_gave_up(err))) { if (err) atomicOr(err, 1u); break; }      // a missing peer must not hang the GPU
         v = ld_sys_f4(p);
     }
     return v;

@@ -226,7 +226,7 @@ __device__ __forceinline__ void slab_ack_handshake(const SlabFlagList& F) {
             unsigned spins = 0;
             while ((int32_t)(ld_sys_u32(F.ack_in + F.ack_src[q]) - F.seq) < 0) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 21)) { if (F.error) atomicOr(F.error, 1u); break; }      // ~1 s: a missing peer must not hang the GPU
+                if (++spins > SLAB_SPIN_LIMIT || ((spins & 1023u) == 0u && slab_gave_up(F.error))) { if (F.error) atomicOr(F.error, 1u); break; }      // a missing peer must not hang the GPU
             }
         }
     }
