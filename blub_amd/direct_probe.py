@@ -19,6 +19,7 @@ import numpy as np
 DT = 1.0 / 120.0
 STEPS = 3
 DIM = (32, 32, 48)
+WAIT_S = float(os.environ.get("BLUB_DIRECT_PROBE_WAIT_S", "60"))      # how long a child waits for a file of another child
 
 
 def scene():
@@ -52,13 +53,13 @@ def child(rank, world, device, workdir):
     if rank == 0:
         _publish(uid_path, blub_amd.SlabGroup.unique_id())
     else:
-        _wait_for(uid_path, 60)
+        _wait_for(uid_path, WAIT_S)
     group = blub_amd.SlabGroup(DIM, pos.shape[0], rank=rank, world=world, unique_id=open(uid_path, "rb").read(), device=device, binning="off")
     try:
         _publish(os.path.join(workdir, "ipc%d" % rank), group.export_handles())
         for r in range(world):
             if r != rank:
-                _wait_for(os.path.join(workdir, "ipc%d" % r), 60)
+                _wait_for(os.path.join(workdir, "ipc%d" % r), WAIT_S)
                 group.connect(r, open(os.path.join(workdir, "ipc%d" % r), "rb").read())
         group.set_transport("direct")
         group.set_pcg_schedule("single_reduction")
@@ -82,7 +83,7 @@ def child(rank, world, device, workdir):
     # child 0: the gathered result against the single-domain engine
     from scipy.spatial import cKDTree
     for r in range(world):
-        _wait_for(os.path.join(workdir, "rank%d.npz" % r), 90)
+        _wait_for(os.path.join(workdir, "rank%d.npz" % r), 1.5 * WAIT_S)
     ranks = [np.load(os.path.join(workdir, "rank%d.npz" % r)) for r in range(world)]
     single = blub_amd.HybridFluid(DIM, pos.shape[0], device=device, binning="off")
     verdict = "ok"

@@ -74,3 +74,37 @@ def test_slab_ranges_are_whole_brick_layers():
         assert r[0][0] == 0 and r[-1][1] == nz
         assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(a[0] % 4 == 0 and a[1] > a[0] for a in r)
         assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 4
+
+
+PROBE_WORKER = textwrap.dedent("""
+    import os, sys
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from blub_amd import direct_probe
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% sys.argv[1], rank=int(sys.argv[2]), world_size=2)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ok, why = direct_probe.run(rank, world, 0, timeout=120.0)
+    verdicts = [None, None]
+    dist.all_gather_object(verdicts, (ok, why))
+    assert verdicts[0] == verdicts[1], verdicts              # every rank holds the same verdict and the same reason
+    assert ok is False and "probe child" in why, (ok, why)    # (no GPU here: the children cannot create their slab group)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %%d ok: %%s" %% (rank, why[:120]))
+""")
+
+
+def test_the_direct_transport_probe_reaches_one_verdict_on_all_ranks(tmp_path):
+    """blub_amd/direct_probe.py (what `bench.py --gpus N` runs before it relies on the direct transport), two ranks over gloo, no GPU: the probe's
+    children fail -- without a HIP device they cannot create their slab group -- and both ranks come back with the SAME negative verdict and
+    reason, i.e. both would stay on the RCCL transport.  (The passing case needs GPUs: tests/test_gpu_multirank.py.)"""
+    script = tmp_path / "probe_worker.py"
+    script.write_text(PROBE_WORKER % ROOT)
+    port = str(31500 + os.getpid() % 2000)
+    env = dict(os.environ, OMP_NUM_THREADS="2", BLUB_DIRECT_PROBE_WAIT_S="5")
+    procs = [subprocess.Popen([sys.executable, str(script), port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "rank %d ok" % r in o
