@@ -11,6 +11,8 @@ tests/test_gpu_parity.py:
   * PCG: fixed k in {4, 8} iterations 3e-4 of the field scale, identical statistics; 32 iterations: the pressure within 1e-3; the reference's default configuration:
     the same convergence decision, pressure within 1e-3 relative L2
   * literal Q4 binning: the same multiset of records per cell as the reference's three binning shaders leave.
+  * FREE-RUNNING: eight steps with converged solves stay on the reference's trajectory particle by particle (4e-6 cells after one step,
+    median 1e-4 / p99 2e-3 after eight).
 """
 import os
 
@@ -207,3 +209,50 @@ def test_literal_binning_against_the_reference_shaders():
         assert np.array_equal(np.floor(got).astype(int), np.floor(want).astype(int))     # slot by slot the same CELL (the bins are identical)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("schedule", ["single_reduction", "reference"])
+def test_eight_free_running_steps_with_converged_solves_track_the_reference_shaders(schedule):
+    """FREE-RUNNING parity against the reference's own shaders (tests/golden/ref_freerun_64x16x32.npz: eight steps of the step scene -- three
+    solids, one of them moving -- with both solves converged to 1e-4, 36 - 52 iterations each).  With the reference's loose default tolerance two
+    trajectories that differ in the rounding of a dot product drift apart by construction (the CG stops unconverged); converged, the
+    trajectory is a property of the algorithm, and the engine -- its own dot-product trees, its own order of the gather additions -- stays on
+    the reference's, particle by particle (no binning: the order of the particles is the input's), step after step."""
+    import blub_amd
+    fx = dict(np.load(os.path.join(GOLD, "ref_freerun_64x16x32.npz")))
+    dim = tuple(int(v) for v in fx["dim"])
+    max_iter, tol, freq = fx["solver"]
+    h = blub_amd.HybridFluid(dim, len(fx["pos_in"]) + 64, binning="off")
+    try:
+        h.set_pcg_schedule(schedule)
+        h.set_tuning("pcg1_max_iterations", 1000)      # (the single-reduction schedule hands solves of more than 64 iterations to the reference order otherwise)
+        h.set_gravity_grid(tuple(float(v) for v in fx["gravity"]))
+        for w in (0, 1):
+            h.set_solver_config(w, error_tolerance=float(tol), max_num_iterations=int(max_iter), error_check_frequency=int(freq))
+        h.set_solid_voxels(fx["solid"])
+        h.set_particles(fx["pos_in"], fx["vx_in"], fx["vy_in"], fx["vz_in"])
+        worst = 0.0
+        for step in range(8):
+            h.step(float(fx["dt"]))
+            got = h.get_particles()[0][:, :3].astype(np.float64)
+            want = fx["s%d/pos" % step].astype(np.float64)
+            d = np.abs(got - want).max(axis=1)
+            it = (h.solver_stats(0)[1], h.solver_stats(1)[1])
+            q = (np.median(d), np.quantile(d, 0.99), np.quantile(d, 0.999), d.max())
+            print("%s, step %d: |engine - reference shaders| median %.3g p99 %.3g p99.9 %.3g max %.3g cells; iterations %s (reference %s)" % (
+                (schedule, step) + q + (it, tuple(int(v) for v in fx["s%d/stats" % step][:, 1]))))
+            worst = max(worst, q[3])
+            bounds = FREERUN_BOUNDS[min(step, len(FREERUN_BOUNDS) - 1)]
+            for a, b in zip(q, bounds):
+                assert a <= b, (step, q, bounds)
+    finally:
+        h.close()
+
+
+# (median, p99, p99.9, max) of |engine - reference| in cells, per step.  Measured (both schedules alike -- what separates the trajectories is the order
+# of the gather additions and of the atomic list insertions, not the dot products): step 0 median 0 / p99 1e-6 / max 4e-6 .. 2.5e-5; step 3
+# 2e-5 / 5e-4 / 3e-3; step 7 1e-4 / 1.7e-3 / 0.039 (one particle next to a solid); a run whose first solve takes one check interval more
+# than the reference's (48 vs 44 iterations: the convergence decision sits at 1e-4) starts at median 2e-6 / max 2e-5.  The bounds leave a factor of 5 - 10
+FREERUN_BOUNDS = [(1e-5, 5e-5, 2e-4, 1e-3), (5e-5, 2e-3, 4e-3, 1e-2), (2e-4, 4e-3, 8e-3, 2e-2), (3e-4, 5e-3, 1e-2, 3e-2),
+                  (4e-4, 6e-3, 1.2e-2, 0.1), (6e-4, 8e-3, 2e-2, 0.3), (8e-4, 1.2e-2, 3e-2, 0.6), (1e-3, 1.6e-2, 5e-2, 1.0)]
+# (the MAXIMUM of the later steps is one particle at a solid wall taking the other branch of the wall handling: 0.04 in one run, 0.30 in another)

@@ -61,7 +61,7 @@ def step_fx():
 def test_reference_fixtures_are_current():
     """The fixtures name the shader sources and the recipe they were made from; where the reference is present they must still match."""
     ref_shaders = "/root/reference/shader"
-    for name in ("ref_step_64x16x32.npz", "ref_pcg_32x64x16.npz", "ref_binning_64x16x32.npz"):
+    for name in ("ref_step_64x16x32.npz", "ref_pcg_32x64x16.npz", "ref_binning_64x16x32.npz", "ref_freerun_64x16x32.npz"):
         fx = np.load(os.path.join(GOLD, name))
         listed = dict(line.split("  ")[::-1] for line in str(fx["shader_sha256"]).strip().split("\n"))
         assert len(listed) >= 28 and "simulation/transfer_gather_velocity.comp" in listed
@@ -103,6 +103,23 @@ def test_three_chained_steps_match_the_reference_shaders_bit_for_bit(step_fx):
         bad = [k for k, v in sorted(rec.items()) if sha(v) != want[k]]
         assert not bad, "step %d: %s differ from the reference" % (step, bad)
         assert_bits("particles after step %d" % step, S.capture(o, "particles"), step_fx["s%d/particles" % step])
+
+
+def test_eight_free_running_steps_with_converged_solves_match_the_reference_shaders_bit_for_bit():
+    """Free-running, not stage by stage: eight steps with solves converged to 1e-4 (36 - 52 iterations each).  The oracle in the reference's
+    literal reduction order reproduces every particle position of every step and the solver statistics exactly."""
+    fx = dict(np.load(os.path.join(GOLD, "ref_freerun_64x16x32.npz")))
+    sc = scene_from_fixture(fx)
+    max_iter, tol, freq = fx["solver"]
+    o = Oracle(*sc["dim"], len(sc["pos"]) + 64)
+    S.configure(o, sc, max_iter=int(max_iter), tol=float(tol), freq=int(freq))
+    steps = sum(1 for k in fx if k.endswith("/pos"))
+    assert steps == 8
+    for step in range(steps):
+        o.step(float(fx["dt"]))
+        assert_bits("particle positions after step %d" % step, S.capture(o, "particles_pos"), fx["s%d/pos" % step])
+        stats = np.array([o.solver_stats(0), o.solver_stats(1)], np.float64)
+        assert np.array_equal(stats[:, 1], fx["s%d/stats" % step][:, 1]) and np.allclose(stats[:, 0], fx["s%d/stats" % step][:, 0], rtol=1e-6, atol=0), (step, stats, fx["s%d/stats" % step])
 
 
 def test_the_hardware_filter_is_the_only_implementation_defined_arithmetic(step_fx):
