@@ -157,6 +157,7 @@ struct blub_fluid {
     int tail_first_forced = -1;      // test hook (blub_fluid_set_tuning "pcg_tail_first"): hand over to the tail after exactly this many launched iterations
     blub_solver_config cfg[2] = {{0.1f, 32, 4}, {0.1f, 32, 4}};   // hybrid_fluid.rs:253-257
     bool pressure_initialised[2] = {false, false};
+    int last_schedule[2] = {-1, -1}, last_mapping[2] = {-1, -1};   // what the most recently enqueued solve actually ran (blub_fluid_last_solve_path)
     // statistics read-back ring (pressure_solver.rs:118-126, 148-209)
     PcgCtrl* stats_host[2] = {nullptr, nullptr};   // pinned ring of STATS_RING control-block snapshots, tagged by seq
     PcgCtrl* stats_host_dev[2] = {nullptr, nullptr};
@@ -490,6 +491,7 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     if (h->precond_mode != BLUB_PRECOND_ZERO) {
         if (div_pending && (rc = stage_divergence(h)) != BLUB_OK) return rc;
         HIP_TRY(hipMemsetAsync(ctrl, 0, sizeof(PcgCtrl), h->stream));
+        h->last_schedule[which] = 0; h->last_mapping[which] = 2;
         if ((rc = stage_solve_lod0(h, which, dt)) != BLUB_OK) return rc;
         return enqueue_stats_readback(h, which, dt);
     }
@@ -520,6 +522,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
     float2* part_upd = reinterpret_cast<float2*>(h->part_sigma[0]);   // {(M^-1 r).r, max|r|} partials (init / update kernels)
     float* part_dir = h->part_sas;                                    // s.As partials (direction kernel)
     if (div_pending && !sparse && (rc = stage_divergence(h)) != BLUB_OK) return rc;     // the dense mapping reads b from the residual volume
+    h->last_mapping[which] = sparse ? 1 : 0;
+    h->last_schedule[which] = (sparse && h->pcg_schedule == 1 && c.max_num_iterations <= h->pcg1_max_iterations) ? 1 : 0;
     if (sparse) {
         const int np = pcg_brick_grid(h, have, bc);
         const dim3 grid(np), block(PCG_B_THREADS);
@@ -1172,7 +1176,9 @@ int blub_fluid_read_volume(blub_fluid* h, int which, void* out) {
     REQUIRE_HANDLE(h);
     size_t b; void* p = volume_ptr(h, which, &b);
     if (!p || !out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
-    if (h->vol_cells == h->N) return blub::copy_sync(h, out, p, b, hipMemcpyDeviceToHost);
+    // (the whole-grid copy only when the volume really holds planes [0, nz): a slab whose plane COUNT equals nz but whose first plane is not 0 -- every rank
+    //  of a group allocates the maximum count -- must take the held-plane path: its pointers are allocation - vol_first; round-4 ADVICE)
+    if (h->vol_z0 == 0 && h->vol_planes >= h->g.nz) return blub::copy_sync(h, out, p, b, hipMemcpyDeviceToHost);
     // a z-slab holds planes [vol_z0, vol_z0 + vol_planes) only: the rest of the caller's full-grid array reads as zero
     const size_t elem = b / h->N, plane = h->N / (size_t)h->g.nz, z1 = (size_t)std::min(h->vol_z0 + h->vol_planes, h->g.nz);
     memset(out, 0, b);
@@ -1183,7 +1189,7 @@ int blub_fluid_write_volume(blub_fluid* h, int which, const void* in) {
     if (which == BLUB_VOLUME_SOLID) return blub_fluid_set_solid_voxels(h, (const float*)in);
     size_t b; void* p = volume_ptr(h, which, &b);
     if (!p || !in) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "volume unavailable");
-    if (h->vol_cells == h->N) { int rc2 = blub::copy_sync(h, p, in, b, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
+    if (h->vol_z0 == 0 && h->vol_planes >= h->g.nz) { int rc2 = blub::copy_sync(h, p, in, b, hipMemcpyHostToDevice); if (rc2 != BLUB_OK) return rc2; }
     else {
         const size_t elem = b / h->N, plane = h->N / (size_t)h->g.nz, z1 = (size_t)std::min(h->vol_z0 + h->vol_planes, h->g.nz);
         int rc2 = blub::copy_sync(h, (char*)p + h->vol_first * elem, (const char*)in + h->vol_first * elem, (z1 - (size_t)h->vol_z0) * plane * elem, hipMemcpyHostToDevice);
@@ -1208,6 +1214,13 @@ int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode) {
     return BLUB_OK;
 }
 int blub_fluid_get_pcg_schedule(const blub_fluid* h) { return h ? h->pcg_schedule : BLUB_ERR_INVALID_ARGUMENT; }
+int blub_fluid_last_solve_path(const blub_fluid* h, int which, int* schedule, int* mapping) {
+    if (!h || which < 0 || which > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (h->last_schedule[which] < 0) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "no solve of this kind has been enqueued yet");
+    if (schedule) *schedule = h->last_schedule[which];
+    if (mapping) *mapping = h->last_mapping[which];
+    return BLUB_OK;
+}
 // Performance knobs and test hooks by name: none changes results beyond the rounding of a dot-product tree; the library never reads the
 // environment.  (Benchmarks and sweeps call this; nothing of the HybridFluid surface does.)
 int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {

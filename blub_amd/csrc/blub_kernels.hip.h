@@ -252,6 +252,7 @@ __device__ __forceinline__ void st_sys_f4(float4* p, const float4& a) {
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void st_sys_u32(uint32_t* p, uint32_t a) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(a) : "memory"); }
+__device__ __forceinline__ void st_sys_u8(uint8_t* p, uint32_t a) { asm volatile("global_store_byte %0, %1, off sc0 sc1" :: "v"(p), "v"(a) : "memory"); }
 __device__ __forceinline__ float4 ld_sys_f4(const float4* p) {
     blub_v4f v;
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");

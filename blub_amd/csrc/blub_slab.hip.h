@@ -167,7 +167,8 @@ __global__ void k_slab_finish_send(const SlabCounts* __restrict__ counts, float4
 // after the transport: append the arrivals (headers + payloads in the staging buffers) behind the own particles, publish counts + record
 struct SlabAppendArgs { const float4* below[4]; const float4* above[4]; float4* dst[4]; };    // [0] = positions (header in front), [1..3] = velocity rows
 __global__ __launch_bounds__(256) void k_slab_append(SlabAppendArgs a, int narr, uint32_t cap_below, uint32_t cap_above, uint32_t capacity, uint32_t* __restrict__ n_dev, int migrate,
-                                                     const SlabCounts* __restrict__ counts, SlabXferRecord* __restrict__ record, uint32_t seq, uint32_t* __restrict__ done_blocks) {
+                                                     const SlabCounts* __restrict__ counts, SlabXferRecord* __restrict__ record, uint32_t seq, uint32_t* __restrict__ done_blocks,
+                                                     const uint32_t* __restrict__ dir_error) {
     uint32_t cb = a.below[0] ? __float_as_uint(a.below[0][0].x) : 0u, ca = a.above[0] ? __float_as_uint(a.above[0][0].x) : 0u;
     const uint32_t want_b = a.below[0] ? __float_as_uint(a.below[0][0].y) : 0u, want_a = a.above[0] ? __float_as_uint(a.above[0][0].y) : 0u;
     const uint32_t own = n_dev[0];
@@ -192,7 +193,10 @@ __global__ __launch_bounds__(256) void k_slab_append(SlabAppendArgs a, int narr,
             if (over) n_dev[2] = 1u;
             if (migrate) { n_dev[0] = own + cb + ca; n_dev[1] = 0u; } else n_dev[1] = cb + ca;
             record->n_up = counts->n_up; record->n_down = counts->n_down; record->from_below = want_b; record->from_above = want_a;
-            record->overflow = n_dev[2]; record->n_own = n_dev[0]; record->n_ghost = n_dev[1];
+            // bit 0: the particle capacity of the slab was exceeded; bit 1 (direct transport): a bounded wait for a peer ran out in a kernel enqueued before
+            // this one -- the host finds both at the start of the next exchange of this kind, without a stream synchronisation (round-4 ADVICE)
+            record->overflow = (n_dev[2] ? 1u : 0u) | ((dir_error && __hip_atomic_load(dir_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 2u : 0u);
+            record->n_own = n_dev[0]; record->n_ghost = n_dev[1];
             __threadfence_system();
             record->seq = seq;
         }
@@ -209,7 +213,11 @@ __global__ void k_slab_publish_cnt(const float* __restrict__ gat_cnt, int nranks
 // loopback transport: all plane copies of one halo exchange in ONE launch (a hipMemcpyAsync per plane costs ~4 us of queue time each,
 // ~100 of them per step).  DIRECT transport (peer-mapped memory): the same launch with write-through stores, and the last workgroup to
 // finish raises the destination slabs' flag words (see SlabDirect, blub_kernels.hip.h).
-struct SlabCopy { const void* src; void* dst; uint32_t bytes; uint32_t pad; };   // src, dst 16-byte aligned, bytes % 16 == 0
+// `unit`: 0 = src, dst 16-byte aligned and bytes % 16 == 0 (every plane of a grid with nx * ny % 16 == 0, every particle message); 1 = all three 4-byte
+// aligned (a 4-byte count segment; f32 planes of nx * ny % 4 != 0 cannot occur, nx % 4 == 0 is enforced); 2 = bytes (the 1-byte descriptor plane of grids
+// such as 20 x 30).  Round-4 ADVICE: the unaligned case used to leave the batch (a flush that raised the exchange's flags early + a plain hipMemcpyAsync
+// into the peer's memory without the acknowledgement handshake); now every store of an exchange goes through the one push kernel.
+struct SlabCopy { const void* src; void* dst; uint32_t bytes; uint32_t unit; };
 constexpr int SLAB_COPY_MAX = 40, SLAB_FLAG_MAX = 64;
 struct SlabCopyList { SlabCopy c[SLAB_COPY_MAX]; int n; };
 // Acknowledgements (processes on different GPUs only): before a push kernel of exchange `seq` writes into a peer's ghost planes / staging buffers,
@@ -234,19 +242,39 @@ __device__ __forceinline__ void slab_ack_handshake(const SlabFlagList& F) {
 }
 __global__ __launch_bounds__(256) void k_slab_copy_planes(SlabCopyList L) {
     const SlabCopy c = L.c[blockIdx.y];
-    const uint32_t n16 = c.bytes >> 4;
-    const uint4* __restrict__ s = reinterpret_cast<const uint4*>(c.src);
-    uint4* __restrict__ d = reinterpret_cast<uint4*>(c.dst);
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) d[i] = s[i];
+    if (c.unit == 0u) {
+        const uint32_t n16 = c.bytes >> 4;
+        const uint4* __restrict__ s = reinterpret_cast<const uint4*>(c.src);
+        uint4* __restrict__ d = reinterpret_cast<uint4*>(c.dst);
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) d[i] = s[i];
+    } else if (c.unit == 1u) {
+        const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(c.src);
+        uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(c.dst);
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (c.bytes >> 2); i += gridDim.x * 256) d[i] = s[i];
+    } else {
+        const uint8_t* __restrict__ s = reinterpret_cast<const uint8_t*>(c.src);
+        uint8_t* __restrict__ d = reinterpret_cast<uint8_t*>(c.dst);
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < c.bytes; i += gridDim.x * 256) d[i] = s[i];
+    }
 }
 __global__ __launch_bounds__(256) void k_slab_push_planes(SlabCopyList L, SlabFlagList F) {
     slab_ack_handshake(F);
     if ((int)blockIdx.y < L.n) {
         const SlabCopy c = L.c[blockIdx.y];
-        const uint32_t n16 = c.bytes >> 4;
-        const float4* __restrict__ s = reinterpret_cast<const float4*>(c.src);
-        float4* d = reinterpret_cast<float4*>(c.dst);
-        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) st_sys_f4(d + i, s[i]);
+        if (c.unit == 0u) {
+            const uint32_t n16 = c.bytes >> 4;
+            const float4* __restrict__ s = reinterpret_cast<const float4*>(c.src);
+            float4* d = reinterpret_cast<float4*>(c.dst);
+            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) st_sys_f4(d + i, s[i]);
+        } else if (c.unit == 1u) {
+            const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(c.src);
+            uint32_t* d = reinterpret_cast<uint32_t*>(c.dst);
+            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (c.bytes >> 2); i += gridDim.x * 256) st_sys_u32(d + i, s[i]);
+        } else {
+            const uint8_t* __restrict__ s = reinterpret_cast<const uint8_t*>(c.src);
+            uint8_t* d = reinterpret_cast<uint8_t*>(c.dst);
+            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < c.bytes; i += gridDim.x * 256) st_sys_u8(d + i, (uint32_t)s[i]);
+        }
     }
     wait_stores();
     __syncthreads();

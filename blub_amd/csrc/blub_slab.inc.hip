@@ -21,6 +21,7 @@ struct blub_slab_group {
     hipStream_t stream = nullptr;
     int device = 0;
     uint32_t capacity = 0;            // particle capacity of every slab and of the transfer buffers
+    std::vector<int> cuts;            // nranks + 1 cut planes (multiples of the brick depth): slab r owns [cuts[r], cuts[r + 1]); uniform unless the caller passed its own
     std::vector<int> vol_z0_of; std::vector<size_t> vol_first_of;   // per rank: first plane its volumes hold / that plane's first cell (blub_fluid::vol_z0, vol_first)
     struct Extra {
         uint32_t *leave_idx = nullptr, *hole_idx = nullptr, *fill_idx = nullptr;   // in-place migration (blub_slab.hip.h: k_slab_migrate_*)
@@ -80,14 +81,22 @@ namespace blub {
         if (_r != ncclSuccess) { char _b[256]; snprintf(_b, sizeof _b, "%s failed: %s", #expr, ncclGetErrorString(_r)); return set_error(BLUB_ERR_COMM, _b); } \
     } while (0)
 
+// exchange sequence numbers never take the value 0: flag / acknowledgement words start at 0 and a partial's tag 0 means "never written" (k_pcg1_finalize);
+// ordering is by signed difference, so the wrap after 2^32 exchanges (~14 h of stepping at 1200 steps/s) is harmless otherwise (round-4 ADVICE)
+static inline uint32_t seq_after(uint32_t s) { return s + 1u ? s + 1u : 1u; }
+
 enum { XFER_GHOST_FULL = 0, XFER_GHOST_POS = 1, XFER_MIGRATE = 2, XFER_MIGRATE_B = 3, XFER_KINDS = 4, XFER_RING = 4 };   // (MIGRATE_B: the second migration of a step; same protocol, its own history)
 
 // loopback transport: device-to-device plane copies are collected and issued as ONE kernel per exchange
+// launch width of a batch: the largest copy decides (items = 16-byte, 4-byte or 1-byte units, see SlabCopy)
+static unsigned slab_copy_width(const blub_slab_group* G) {
+    uint32_t mx = 0;
+    for (int k = 0; k < G->copies.n; ++k) { const auto& c = G->copies.c[k]; mx = std::max(mx, c.unit == 0u ? c.bytes / 16u : (c.unit == 1u ? c.bytes / 4u : c.bytes)); }
+    return std::max(1u, std::min(64u, (mx + 255u) / 256u));
+}
 static int slab_copy_flush(blub_slab_group* G) {
     if (G->copies.n == 0 && !(G->direct && G->push_flags.n)) return BLUB_OK;
-    uint32_t mx = 0;
-    for (int k = 0; k < G->copies.n; ++k) mx = std::max(mx, G->copies.c[k].bytes);
-    const unsigned bx = std::max(1u, std::min(64u, (mx / 16u + 255u) / 256u));
+    const unsigned bx = slab_copy_width(G);
     if (G->direct) {      // write-through stores, then the flags of this exchange
         G->push_flags.seq = G->flag_seq; G->push_flags.blocks_done = G->blocks_done[0];
         hipLaunchKernelGGL(blubk::k_slab_push_planes, dim3(bx, (unsigned)std::max(1, G->copies.n)), dim3(256), 0, G->stream, G->copies, G->push_flags);
@@ -99,7 +108,10 @@ static int slab_copy_flush(blub_slab_group* G) {
 }
 static int slab_copy(blub_slab_group* G, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return BLUB_OK;
-    if (bytes % 16 != 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15) || bytes > 0xFFFFFFF0u) {
+    if (bytes > 0xFFFFFFF0u) {
+        // (no plane or message of a supported grid is this large; the direct transport must not leave its one push kernel -- a plain copy into a peer's
+        //  memory would skip the acknowledgement handshake and a flush here would raise this exchange's flags early: round-4 ADVICE)
+        if (G->direct) return set_error(BLUB_ERR_UNSUPPORTED, "direct transport: a single transfer of 4 GiB or more");
         int rc = slab_copy_flush(G);
         if (rc != BLUB_OK) return rc;
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, G->stream));
@@ -108,14 +120,14 @@ static int slab_copy(blub_slab_group* G, void* dst, const void* src, size_t byte
     if (G->copies.n == blubk::SLAB_COPY_MAX) {
         if (G->direct) {      // (a partial flush must not raise this exchange's flags: plain batch, flags with the last one)
             const blubk::SlabFlagList keep = G->push_flags; G->push_flags.n = 0;
-            uint32_t mx = 0; for (int k = 0; k < G->copies.n; ++k) mx = std::max(mx, G->copies.c[k].bytes);
-            blubk::SlabFlagList none = keep; none.n = 0; none.blocks_done = G->blocks_done[0]; none.seq = G->flag_seq;      // (no flags yet; only all-local groups ever get here: no acknowledgements either)
-            hipLaunchKernelGGL(blubk::k_slab_push_planes, dim3(std::max(1u, std::min(64u, (mx / 16u + 255u) / 256u)), (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies, none);
+            blubk::SlabFlagList none = keep; none.n = 0; none.blocks_done = G->blocks_done[0]; none.seq = G->flag_seq;      // (no flags yet; the acknowledgement handshake of `keep` runs in front of these stores too)
+            hipLaunchKernelGGL(blubk::k_slab_push_planes, dim3(slab_copy_width(G), (unsigned)G->copies.n), dim3(256), 0, G->stream, G->copies, none);
             G->copies.n = 0; G->push_flags = keep;
         } else { int rc = slab_copy_flush(G); if (rc != BLUB_OK) return rc; }
     }
     blubk::SlabCopy& c = G->copies.c[G->copies.n];
-    c.src = src; c.dst = dst; c.bytes = (uint32_t)bytes; c.pad = 0;
+    const uintptr_t al = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+    c.src = src; c.dst = dst; c.bytes = (uint32_t)bytes; c.unit = (al & 15) == 0 ? 0u : ((al & 3) == 0 ? 1u : 2u);
     G->copies.n += 1;
     return BLUB_OK;
 }
@@ -178,7 +190,7 @@ static int slab_halo(blub_slab_group* G, const std::vector<std::function<void*(b
     if (G->direct) {
         // every slab PUSHES its two boundary planes into its z-neighbours' ghost planes, the last workgroup of the batched launch raises the
         // neighbours' flags, the consumers' stream waits for its own (slab_wait)
-        if (own_group) G->flag_seq += 1;
+        if (own_group) G->flag_seq = seq_after(G->flag_seq);
         for (int i = 0; i < (int)G->slabs.size(); ++i) {
             blub_fluid* h = G->slabs[i];
             for (auto& f : fields) {
@@ -227,7 +239,7 @@ static int slab_gather(blub_slab_group* G, const std::function<float*(int)>& arr
     if (G->nranks == 1) return BLUB_OK;
     if (own_group) G->comm_ops += 1;
     if (G->direct) {      // every slab pushes its own segment into every other slab's array
-        if (own_group) G->flag_seq += 1;
+        if (own_group) G->flag_seq = seq_after(G->flag_seq);
         for (int i = 0; i < (int)G->slabs.size(); ++i) {
             float* mine = array_of(i) + (size_t)(G->first + i) * seg_floats;
             for (int r = 0; r < G->nranks; ++r) {
@@ -271,7 +283,7 @@ static int slab_fused(blub_slab_group* G, const std::function<int()>& halos, con
     int rc;
     G->comm_ops += 1;
     if (G->direct) {      // planes + partial segments in ONE batched push, one flag round
-        G->flag_seq += 1;
+        G->flag_seq = seq_after(G->flag_seq);
         if ((rc = halos()) != BLUB_OK) return rc;
         if ((rc = gather(false)) != BLUB_OK) return rc;
         if ((rc = slab_copy_flush(G)) != BLUB_OK) return rc;
@@ -417,7 +429,9 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
                 if (++spins > 2000) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
                 if (spins > 50000000u) return set_error(BLUB_ERR_DEVICE, "timed out waiting for the record of the previous particle exchange");
             }
-            if (r->overflow) return set_error(BLUB_ERR_OUT_OF_MEMORY, "the particle capacity of a slab was exceeded by a particle exchange (max_num_particles is per slab)");
+            if (r->overflow & 1u) return set_error(BLUB_ERR_OUT_OF_MEMORY, "the particle capacity of a slab was exceeded by a particle exchange (max_num_particles is per slab)");
+            if (r->overflow & 2u) return set_error(BLUB_ERR_COMM, "direct transport: a wait for a peer's flag timed out in an earlier step (a peer stopped stepping or fell seconds behind); "
+                                                                  "what was stepped since is invalid -- blub_slab_group_synchronize reports and clears the condition");
             H.n_up = r->n_up; H.n_down = r->n_down; H.from_below = r->from_below; H.from_above = r->from_above; H.pending = false;
         }
         cap_up[i] = has_up(G, i) ? slab_capx(G, H.n_up) : 0u; cap_dn[i] = has_down(G, i) ? slab_capx(G, H.n_down) : 0u;
@@ -459,7 +473,7 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
     // transport: ONE grouped operation (round 2: counts, a host synchronisation, then the payload)
     G->comm_ops += 1;
     if (G->direct) {
-        G->flag_seq += 1;
+        G->flag_seq = seq_after(G->flag_seq);
         for (int i = 0; i < S; ++i) {
             auto& e = G->ex[i];
             blubk::SlabParticlePush up{}, dn{};
@@ -510,7 +524,7 @@ static int slab_exchange_particles_async(blub_slab_group* G, int kind) {
         blubk::SlabXferRecord* rec = G->rec_dev + ((size_t)i * XFER_KINDS + kind) * XFER_RING + G->xfer_seq % XFER_RING;
         // (<= 64 workgroups, grid-stride: every workgroup ends with an atomic on ONE counter -- 512 of them took 11-13 us to append a few thousand records)
         hipLaunchKernelGGL(blubk::k_slab_append, dim3(std::max(1u, std::min(64u, particle_blocks(cap_below[i] + cap_above[i])))), dim3(256), 0, G->stream, a, narr, cap_below[i], cap_above[i], G->capacity,
-                           h->n_dev, (int)migrate, (const blubk::SlabCounts*)e.counts, rec, G->xfer_seq, e.append_done);
+                           h->n_dev, (int)migrate, (const blubk::SlabCounts*)e.counts, rec, G->xfer_seq, e.append_done, G->direct ? (const uint32_t*)G->dir_error[i] : (const uint32_t*)nullptr);
         blub_slab_group::Hist& H = G->hist[(size_t)i * XFER_KINDS + kind];
         H.pending = true; H.seq = G->xfer_seq;
         h->num_ghost = migrate ? 0u : cap_below[i] + cap_above[i];      // (bound)
@@ -543,7 +557,9 @@ static int slab_solve(blub_slab_group* G, int which, float dt) {
     const int S = (int)G->slabs.size();
     blub_fluid* h0 = G->slabs[0];
     if (h0->precond_mode != BLUB_PRECOND_ZERO) return set_error(BLUB_ERR_UNSUPPORTED, "z-slab groups support the default preconditioner reading only");
-    if (h0->pcg_schedule == 1 && h0->cfg[which].max_num_iterations <= h0->pcg1_max_iterations) return slab_solve_single_reduction(G, which, dt);
+    const bool single = h0->pcg_schedule == 1 && h0->cfg[which].max_num_iterations <= h0->pcg1_max_iterations;
+    for (auto h : G->slabs) { h->last_schedule[which] = single ? 1 : 0; h->last_mapping[which] = 1; }      // (slab solves always run on the brick mapping)
+    if (single) return slab_solve_single_reduction(G, which, dt);
     const blub_solver_config c = h0->cfg[which];
     const float tol = c.error_tolerance / dt;
     const int maxit = c.max_num_iterations, freq = c.error_check_frequency;
@@ -669,7 +685,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
                 D.part_out[D.n_out] = peer_ptr(G, i, r, seg4(i, 0)); D.n_out += 1;
             }
             LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s<true>, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
-                   seg4(i, 0), (int)(G->first + i == 0), G->flag_seq + 1u, halo_lo, halo_hi, D);
+                   seg4(i, 0), (int)(G->first + i == 0), seq_after(G->flag_seq), halo_lo, halo_hi, D);
         } else
             LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s<false>, grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)h->search, B[i].W[0], (const float2*)G->ex[i].gat_upd, npall,
                    seg4(i, 0), (int)(G->first + i == 0), 0u, -1, -1, SlabDirect{});
@@ -706,7 +722,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
             return BLUB_OK;
         }, [&](bool own_group) { return slab_gather(G, [G, ppar](int i) { return reinterpret_cast<float*>(G->ex[i].gat4[ppar]); }, 4 * np, own_group); });
     };
-    if (G->direct) G->flag_seq += 1;      // (the number the w_0 kernels tagged their partials with: no exchange of its own)
+    if (G->direct) G->flag_seq = seq_after(G->flag_seq);      // (the number the w_0 kernels tagged their partials with: no exchange of its own)
     else if ((rc = exchange(0, 0)) != BLUB_OK) return rc;
     int it = 0;
     if (G->direct) {
@@ -716,7 +732,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
         // wait nor publish -- every slab takes that decision alike, from bit-identical scalars).
         for (it = 0; it <= maxit; ++it) {
             const uint32_t seq_in = G->flag_seq;
-            G->flag_seq += 1;
+            G->flag_seq = seq_after(G->flag_seq);
             for (int i = 0; i < S; ++i) {
                 blub_fluid* h = G->slabs[i];
                 const int halo_lo = has_down(G, i) ? h->slab_z0 : -1, halo_hi = has_up(G, i) ? h->slab_z1 - 1 : -1;
@@ -922,6 +938,48 @@ static void slab_range(int nz, int nranks, int index, int* z0, int* z1) {
     *z0 = lo * BZ;
     *z1 = std::min(hi * BZ, index + 1 == nranks ? nz + BZ : hi * BZ);
 }
+// Cut planes of a group: the caller's (validated: cuts[0] = 0, strictly increasing multiples of the brick depth, the last one covers nz) or uniform
+static int slab_cuts(int nz, int nranks, const int32_t* cuts, std::vector<int>& out) {
+    const int nbz = (nz + BZ - 1) / BZ;
+    out.assign((size_t)nranks + 1, 0);
+    if (!cuts) { for (int r = 0; r < nranks; ++r) { int a, b; slab_range(nz, nranks, r, &a, &b); out[(size_t)r] = a; out[(size_t)r + 1] = b; } return BLUB_OK; }
+    if (cuts[0] != 0) return set_error(BLUB_ERR_INVALID_ARGUMENT, "slab cuts: the first cut plane must be 0");
+    for (int r = 0; r <= nranks; ++r) {
+        if (cuts[r] % BZ != 0 && !(r == nranks && cuts[r] == nz)) return set_error(BLUB_ERR_INVALID_ARGUMENT, "slab cuts: every cut plane must be a multiple of the brick depth (4)");
+        if (r > 0 && cuts[r] <= cuts[r - 1]) return set_error(BLUB_ERR_INVALID_ARGUMENT, "slab cuts: cut planes must increase strictly (every slab owns at least one brick layer)");
+        out[(size_t)r] = cuts[r];
+    }
+    if (cuts[nranks] < nz || cuts[nranks] > nbz * BZ) return set_error(BLUB_ERR_INVALID_ARGUMENT, "slab cuts: the last cut plane must be the top of the grid");
+    out[(size_t)nranks] = nbz * BZ;      // (whole bricks, like slab_range)
+    return BLUB_OK;
+}
+// Contiguous partition of the brick layers into `nranks` slabs that minimises the heaviest slab (ties: the most even layer counts): dynamic programme
+// over (slabs used, layers covered), O(nranks x layers^2) -- 64 .. 128 layers.  Every slab gets at least `min_layers`.
+static int slab_partition_layers(const std::vector<double>& w, int nranks, int min_layers, std::vector<int>& first_layer) {
+    const int L = (int)w.size();
+    min_layers = std::max(1, min_layers);
+    if ((int64_t)nranks * min_layers > L) return set_error(BLUB_ERR_INVALID_ARGUMENT, "more slabs (x minimum layers) than brick layers in z");
+    std::vector<double> pre((size_t)L + 1, 0.0);
+    for (int l = 0; l < L; ++l) pre[(size_t)l + 1] = pre[(size_t)l] + w[(size_t)l];
+    struct Cost { double mx, sq; };
+    auto better = [](const Cost& a, const Cost& b) { return a.mx < b.mx * (1.0 - 1e-12) || (a.mx <= b.mx * (1.0 + 1e-12) && a.sq < b.sq); };
+    const Cost INF{1e300, 1e300};
+    std::vector<std::vector<Cost>> best((size_t)nranks + 1, std::vector<Cost>((size_t)L + 1, INF));
+    std::vector<std::vector<int>> from((size_t)nranks + 1, std::vector<int>((size_t)L + 1, -1));
+    best[0][0] = Cost{0.0, 0.0};
+    for (int k = 1; k <= nranks; ++k)
+        for (int j = k * min_layers; j <= L - (nranks - k) * min_layers; ++j)
+            for (int i = (k - 1) * min_layers; i <= j - min_layers; ++i) {
+                if (best[(size_t)k - 1][(size_t)i].mx >= 1e300) continue;
+                const double ww = pre[(size_t)j] - pre[(size_t)i];
+                const Cost c{std::max(best[(size_t)k - 1][(size_t)i].mx, ww), best[(size_t)k - 1][(size_t)i].sq + (double)(j - i) * (double)(j - i)};
+                if (better(c, best[(size_t)k][(size_t)j])) { best[(size_t)k][(size_t)j] = c; from[(size_t)k][(size_t)j] = i; }
+            }
+    first_layer.assign((size_t)nranks + 1, 0);
+    int j = L;
+    for (int k = nranks; k >= 1; --k) { first_layer[(size_t)k] = j; j = from[(size_t)k][(size_t)j]; if (j < 0) return set_error(BLUB_ERR_INVALID_ARGUMENT, "no partition found"); }
+    return BLUB_OK;
+}
 
 // RCCL transport of the PCG partials, chosen by measurement on the hardware at hand (the two candidates cannot be ranked
 // on the 1-GPU development box): per candidate, 30 rounds of what one PCG iteration issues; the slowest rank's time decides
@@ -974,10 +1032,12 @@ static int slab_calibrate(blub_slab_group* G) {
     return rc;
 }
 
-static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, int nlocal, const void* nccl_id, blub_slab_group** out) {
+static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, int nlocal, const void* nccl_id, blub_slab_group** out, const int32_t* cuts = nullptr) {
     if (!d || !out || nranks < 1 || nlocal < 1 || first < 0 || first + nlocal > nranks || nlocal > 8) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad slab group arguments");
     *out = nullptr;
     if ((int)((d->nz + BZ - 1) / BZ) < nranks) return set_error(BLUB_ERR_INVALID_ARGUMENT, "more slabs than brick layers in z");
+    std::vector<int> cut_planes;
+    { int rcc = slab_cuts((int)d->nz, nranks, cuts, cut_planes); if (rcc != BLUB_OK) return rcc; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(BLUB_ERR_NO_DEVICE, "no HIP device (libblubhip has no CPU fallback)");
     int dev = d->device;
@@ -987,6 +1047,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     if (!G) return set_error(BLUB_ERR_OUT_OF_MEMORY, "host allocation failed");
     G->nranks = nranks; G->first = first; G->device = dev; G->capacity = std::max<uint32_t>(d->max_num_particles, 1);
     G->rccl = nccl_id != nullptr;
+    G->cuts = cut_planes;
     int rc = BLUB_OK;
     if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) { delete G; return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     blub_fluid_desc dd = *d; dd.device = dev;
@@ -996,7 +1057,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     int vol_planes = 0;
     G->vol_z0_of.assign((size_t)nranks, 0); G->vol_first_of.assign((size_t)nranks, 0);
     for (int r = 0; r < nranks; ++r) {
-        int a, b; slab_range((int)d->nz, nranks, r, &a, &b);
+        const int a = G->cuts[(size_t)r], b = G->cuts[(size_t)r + 1];
         const int za = std::max(0, a - 2 * BZ), zb = std::min((int)d->nz, std::min(b, (int)d->nz) + 2 * BZ);
         G->vol_z0_of[(size_t)r] = za; G->vol_first_of[(size_t)r] = (size_t)d->nx * d->ny * (size_t)za;
         vol_planes = std::max(vol_planes, zb - za);
@@ -1006,7 +1067,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         blub_fluid* h = nullptr;
         rc = create(&dd, &h, G->stream, G->vol_z0_of[(size_t)first + i], vol_planes);
         if (rc != BLUB_OK) break;
-        slab_range((int)d->nz, nranks, first + i, &h->slab_z0, &h->slab_z1);
+        h->slab_z0 = G->cuts[(size_t)first + i]; h->slab_z1 = G->cuts[(size_t)first + i + 1];
         h->max_steps_in_flight = 0;   // every particle exchange synchronises the host anyway
         G->slabs.push_back(h);
         blub_slab_group::Extra e;
@@ -1106,14 +1167,58 @@ int blub_slab_range(uint32_t nz, int num_slabs, int index, int32_t* z0, int32_t*
     *z0 = a; *z1 = std::min<int>(b, (int)nz);
     return BLUB_OK;
 }
-int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out) {
-    int rc = blub::slab_group_create(desc, num_slabs, 0, num_slabs, nullptr, out);
-    if (rc == BLUB_OK && num_slabs - 1 <= blubk::SLAB_MAX_PEERS && (*out)->slabs[0]->slab) rc = blub_slab_group_set_transport(*out, 1);      // the direct transport is the default
-    return rc;
+int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out) { return blub_slab_group_create_local_cuts(desc, num_slabs, nullptr, out); }
+int blub_slab_group_create_local_cuts(const blub_fluid_desc* desc, int num_slabs, const int32_t* cuts, blub_slab_group** out) {
+    int rc = blub::slab_group_create(desc, num_slabs, 0, num_slabs, nullptr, out, cuts);
+    if (rc != BLUB_OK) return rc;
+    // The direct transport is the default where it is available (every slab's volumes in one allocation -- a slab that fell back to per-volume
+    // allocations under memory pressure has none --, at most 8 slabs); otherwise the group keeps the host-issued copies it was created with.  A
+    // creation that succeeded never turns into an error here (round-4 ADVICE: it used to return the status of set_transport with *out still set).
+    bool can = num_slabs - 1 <= blubk::SLAB_MAX_PEERS;
+    for (auto h : (*out)->slabs) can = can && h->slab != nullptr;
+    if (can && blub_slab_group_set_transport(*out, 1) != BLUB_OK) (void)blub_slab_group_set_transport(*out, 0);
+    return BLUB_OK;
 }
 int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out) {
+    return blub_slab_group_create_rccl_cuts(desc, rank, num_ranks, unique_id_128, nullptr, out);
+}
+int blub_slab_group_create_rccl_cuts(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, const int32_t* cuts, blub_slab_group** out) {
     if (!unique_id_128) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null unique id");
-    return blub::slab_group_create(desc, num_ranks, rank, 1, unique_id_128, out);
+    return blub::slab_group_create(desc, num_ranks, rank, 1, unique_id_128, out, cuts);
+}
+// Host only.  Cut planes that give every slab about the same number of FLUID bricks (the unit the PCG kernels, the list walks and -- through the
+// particles per brick -- the particle kernels scale with): weight of a brick layer = distinct bricks of it that hold a particle, plus a small constant so
+// that empty stretches are shared out instead of all going to one neighbour.  The headline scene's two dams sit in z < 32 and z >= 224 of 256: uniform
+// cuts into 8 leave six slabs without fluid.
+int blub_slab_balanced_cuts(const uint32_t grid_dim[3], uint32_t n, const float* pos_ll, int num_slabs, int min_layers, int32_t* cuts_out, uint32_t* fluid_bricks_out) {
+    if (!grid_dim || (n && !pos_ll) || !cuts_out || num_slabs < 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    const int nx = (int)grid_dim[0], ny = (int)grid_dim[1], nz = (int)grid_dim[2];
+    const int nbx = (nx + blubk::BX - 1) / blubk::BX, nby = (ny + blubk::BY - 1) / blubk::BY, nbz = (nz + blubk::BZ - 1) / blubk::BZ;
+    if (nbz < num_slabs) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "more slabs than brick layers in z");
+    std::vector<uint8_t> mark((size_t)nbx * nby * nbz, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const int x = (int)pos_ll[4 * (size_t)i], y = (int)pos_ll[4 * (size_t)i + 1], z = (int)pos_ll[4 * (size_t)i + 2];
+        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+        mark[((size_t)(z / blubk::BZ) * nby + (size_t)(y / blubk::BY)) * nbx + (size_t)(x / blubk::BX)] = 1;
+    }
+    std::vector<double> w((size_t)nbz, 0.0);
+    double total = 0.0;
+    for (int l = 0; l < nbz; ++l) { for (size_t k = 0; k < (size_t)nbx * nby; ++k) w[(size_t)l] += mark[(size_t)l * nbx * nby + k]; total += w[(size_t)l]; }
+    std::vector<double> bricks = w;
+    const double eps = std::max(1.0, total) / (double)nbz * 0.02;
+    for (auto& v : w) v += eps;
+    std::vector<int> first;
+    int rc = blub::slab_partition_layers(w, num_slabs, min_layers, first);
+    if (rc != BLUB_OK) return rc;
+    for (int r = 0; r <= num_slabs; ++r) cuts_out[r] = first[(size_t)r] * blubk::BZ;
+    if (fluid_bricks_out)
+        for (int r = 0; r < num_slabs; ++r) { double b = 0.0; for (int l = first[(size_t)r]; l < first[(size_t)r + 1]; ++l) b += bricks[(size_t)l]; fluid_bricks_out[r] = (uint32_t)b; }
+    return BLUB_OK;
+}
+int blub_slab_group_cuts(const blub_slab_group* g, int32_t* cuts_out) {
+    if (!g || !cuts_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    for (int r = 0; r <= g->nranks; ++r) cuts_out[r] = r == g->nranks ? std::min(g->cuts[(size_t)r], g->slabs[0]->g.nz) : g->cuts[(size_t)r];
+    return BLUB_OK;
 }
 void blub_slab_group_destroy(blub_slab_group* g) { blub::slab_group_destroy(g); }
 int blub_slab_group_num_local(const blub_slab_group* g) { return g ? (int)g->slabs.size() : 0; }
@@ -1226,6 +1331,7 @@ int blub_slab_group_set_transport(blub_slab_group* g, int kind) {
     if (hipSetDevice(g->device) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "stream synchronisation failed");
     if (g->direct != (kind == 1)) { int rc = blub::slab_refresh_counts(g); if (rc != BLUB_OK) return rc; for (auto& H : g->hist) H = blub_slab_group::Hist(); g->cnt_pending = false; }
     g->direct = kind == 1;
+    for (auto de : g->dir_error) (void)hipMemset(de, 0, sizeof(uint32_t));      // a time-out of the transport that is being left (or re-entered) is history (round-4 ADVICE)
     if (g->direct) snprintf(g->transport, sizeof g->transport, "direct (peer-mapped stores + flags), %d slabs%s", g->nranks, (int)g->slabs.size() == g->nranks ? ", one process" : ", hipIpc");
     else snprintf(g->transport, sizeof g->transport, "%s", g->rccl ? "rccl" : "loopback");
     return BLUB_OK;
@@ -1307,9 +1413,17 @@ int blub_slab_group_synchronize(blub_slab_group* g) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
     for (auto h : g->slabs) { int rc = blub_fluid_synchronize(h); if (rc != BLUB_OK) return rc; }
+    bool timed_out = false;
     for (size_t i = 0; i < g->dir_error.size(); ++i) {
         uint32_t v = 0;
-        if (hipMemcpy(&v, g->dir_error[i], sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v) return blub::set_error(BLUB_ERR_COMM, "direct transport: a wait for a peer's flag timed out (a peer stopped stepping)");
+        if (hipMemcpy(&v, g->dir_error[i], sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v) {
+            timed_out = true;
+            (void)hipMemset(g->dir_error[i], 0, sizeof v);      // reported once: later waits wait again (a peer that was only late is back in step: sequence numbers compare by >=)
+        }
+    }
+    if (timed_out) {
+        for (auto& H : g->hist) H.pending = false;            // (the records of the steps in between carry the same mark)
+        return blub::set_error(BLUB_ERR_COMM, "direct transport: a wait for a peer's flag timed out (a peer stopped stepping or fell seconds behind); the steps since are invalid");
     }
     return blub::slab_refresh_counts(g);
 }

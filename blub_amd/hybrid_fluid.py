@@ -169,6 +169,7 @@ def load_library():
         "blub_fluid_get_brick_counts": (C.c_int, [vp, vp]),
         "blub_fluid_set_pcg_schedule": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_pcg_schedule": (C.c_int, [vp]),
+        "blub_fluid_last_solve_path": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
         "blub_fluid_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "blub_scene_mesh_desc_at_time": (C.c_int, [C.POINTER(SceneConfig), u32, C.c_uint64, C.c_uint64, C.POINTER(MeshDesc)]),
@@ -440,6 +441,13 @@ class HybridFluid:
     def pcg_schedule(self):
         return ("reference", "single_reduction")[int(self._L.blub_fluid_get_pcg_schedule(self._h))]
 
+    def last_solve_path(self, which):
+        """(schedule, mapping) the most recently enqueued solve `which` ACTUALLY ran (include/blubhip.h: blub_fluid_last_solve_path): the selected
+        schedule is a request -- dense rows, the LOD0 reading and solves beyond "pcg1_max_iterations" always run the reference's order."""
+        a, b = C.c_int(), C.c_int()
+        _check(self._L, self._L.blub_fluid_last_solve_path(self._h, int(which), C.byref(a), C.byref(b)))
+        return ("reference", "single_reduction")[a.value], ("rows", "bricks", "lod0_literal")[b.value]
+
     def set_tuning(self, name, value):
         """Performance knobs / test hooks by name (include/blubhip.h: blub_fluid_set_tuning); the library never reads the environment."""
         _check(self._L, self._L.blub_fluid_set_tuning(self._h, name.encode(), int(value)))
@@ -611,7 +619,7 @@ class SlabGroup:
                    torch.distributed by `SlabGroup.from_torch_distributed`.
     """
 
-    def __init__(self, grid_dimension, max_num_particles, local=None, rank=None, world=None, unique_id=None, device=-1, binning="fixed"):
+    def __init__(self, grid_dimension, max_num_particles, local=None, rank=None, world=None, unique_id=None, device=-1, binning="fixed", cuts=None):
         self._L = load_library()
         L = self._L
         vp = C.c_void_p
@@ -619,6 +627,9 @@ class SlabGroup:
                 ("blub_rccl_unique_id", C.c_int, [vp]), ("blub_slab_range", C.c_int, [C.c_uint32, C.c_int, C.c_int, vp, vp]),
                 ("blub_slab_group_create_local", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.POINTER(vp)]),
                 ("blub_slab_group_create_rccl", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, C.POINTER(vp)]),
+                ("blub_slab_group_create_local_cuts", C.c_int, [C.POINTER(_FluidDesc), C.c_int, vp, C.POINTER(vp)]),
+                ("blub_slab_group_create_rccl_cuts", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, vp, C.POINTER(vp)]),
+                ("blub_slab_group_cuts", C.c_int, [vp, vp]),
                 ("blub_slab_group_destroy", None, [vp]), ("blub_slab_group_num_local", C.c_int, [vp]),
                 ("blub_slab_group_local_fluid", vp, [vp, C.c_int]), ("blub_slab_group_local_range", C.c_int, [vp, C.c_int, vp, vp]),
                 ("blub_slab_group_set_particles", C.c_int, [vp, C.c_uint32, vp, vp, vp, vp]), ("blub_slab_group_num_particles", C.c_uint32, [vp]),
@@ -642,11 +653,15 @@ class SlabGroup:
         self.grid = tuple(int(v) for v in grid_dimension)
         d = _FluidDesc(self.grid[0], self.grid[1], self.grid[2], int(max_num_particles), int(device), 0, BINNING[binning], 0)
         self._g = vp()
+        self.num_slabs = int(local if local is not None else world)
+        cut_arr = None if cuts is None else np.ascontiguousarray(cuts, np.int32)      # cut planes (include/blubhip.h: blub_slab_group_create_*_cuts); None = uniform
+        if cut_arr is not None and cut_arr.shape != (self.num_slabs + 1,):
+            raise ValueError("cuts must hold num_slabs + 1 planes")
         if local is not None:
-            _check(L, L.blub_slab_group_create_local(C.byref(d), int(local), C.byref(self._g)))
+            _check(L, L.blub_slab_group_create_local_cuts(C.byref(d), int(local), _ptr(cut_arr), C.byref(self._g)))
         else:
             buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
-            _check(L, L.blub_slab_group_create_rccl(C.byref(d), int(rank), int(world), buf, C.byref(self._g)))
+            _check(L, L.blub_slab_group_create_rccl_cuts(C.byref(d), int(rank), int(world), buf, _ptr(cut_arr), C.byref(self._g)))
 
     @staticmethod
     def unique_id():
@@ -666,14 +681,46 @@ class SlabGroup:
         return a.value, b.value
 
     @staticmethod
-    def from_torch_distributed(grid_dimension, max_num_particles, device=-1, binning="fixed"):
+    def balanced_cuts(grid_dimension, pos, num_slabs, min_layers=1):
+        """Host-only: (cuts, fluid_bricks_per_slab) -- cut planes that give every slab about the same number of FLUID bricks for these particle
+        positions (include/blubhip.h: blub_slab_balanced_cuts)."""
+        L = load_library()
+        L.blub_slab_balanced_cuts.restype = C.c_int
+        L.blub_slab_balanced_cuts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        dim = np.asarray(grid_dimension, np.uint32)
+        pos = np.asarray(pos, np.float32)
+        p4 = pos if (pos.ndim == 2 and pos.shape[1] == 4 and pos.flags.c_contiguous) else np.concatenate([pos[:, :3], np.zeros((len(pos), 1), np.float32)], axis=1)
+        p4 = np.ascontiguousarray(p4, np.float32)
+        cuts, bricks = np.zeros(num_slabs + 1, np.int32), np.zeros(num_slabs, np.uint32)
+        _check(L, L.blub_slab_balanced_cuts(_ptr(dim), len(p4), _ptr(p4), int(num_slabs), int(min_layers), _ptr(cuts), _ptr(bricks)))
+        return [int(c) for c in cuts], [int(b) for b in bricks]
+
+    @staticmethod
+    def fluid_bricks_per_slab(grid_dimension, pos, cuts):
+        """Host-only: FLUID 16x8x4 bricks (bricks that hold a particle) inside each of the slabs the cut planes define."""
+        pos = np.asarray(pos, np.float32)
+        nx, ny, nz = (int(v) for v in grid_dimension)
+        b = (pos[:, :3].astype(np.int64) // np.array([16, 8, 4]))
+        key = np.unique((b[:, 2] * ((ny + 7) // 8) + b[:, 1]) * ((nx + 15) // 16) + b[:, 0])
+        layer = key // (((ny + 7) // 8) * ((nx + 15) // 16))
+        edges = np.asarray(cuts, np.int64) // 4
+        edges[-1] = (nz + 3) // 4
+        return [int(((layer >= edges[r]) & (layer < edges[r + 1])).sum()) for r in range(len(cuts) - 1)]
+
+    def cuts(self):
+        out = np.zeros(self.num_slabs + 1, np.int32)
+        _check(self._L, self._L.blub_slab_group_cuts(self._g, _ptr(out)))
+        return [int(c) for c in out]
+
+    @staticmethod
+    def from_torch_distributed(grid_dimension, max_num_particles, device=-1, binning="fixed", cuts=None):
         """One slab per rank of the default process group; rank 0's RCCL id is broadcast (works over gloo or nccl)."""
         import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
         payload = [SlabGroup.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(payload, src=0)
-        return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning)
+        return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning, cuts=cuts)
 
     def connect_direct_over_torch_distributed(self):
         """DIRECT transport between the ranks of the default process group: every rank's hipIpc handles are all-gathered over the control plane,

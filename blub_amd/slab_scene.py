@@ -31,9 +31,10 @@ def seed_scene_particles(grid_dimension, max_particles, cubes):
     return np.concatenate(parts) if parts else np.zeros((0, 4), np.float32)
 
 
-def partition_particles(pos, nz, num_slabs, index):
-    """Indices of the particles slab `index` owns: z in [z0, z1), the first / last slab also keep what lies outside."""
-    z0, z1 = SlabGroup.slab_range(nz, num_slabs, index)
+def partition_particles(pos, nz, num_slabs, index, cuts=None):
+    """Indices of the particles slab `index` owns: z in [z0, z1), the first / last slab also keep what lies outside.  `cuts`: the group's cut
+    planes (SlabGroup.cuts()); None = uniform."""
+    z0, z1 = SlabGroup.slab_range(nz, num_slabs, index) if cuts is None else (int(cuts[index]), min(int(cuts[index + 1]), nz))
     z = pos[:, 2]
     keep = np.ones(len(pos), bool)
     if index > 0:

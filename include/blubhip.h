@@ -276,6 +276,12 @@ int blub_fluid_set_pcg_work_mapping(blub_fluid* h, int mode);
  * blub_fluid_set_pcg_schedule(h, 0) selects the reference's literal order of operations everywhere. */
 int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode);
 int blub_fluid_get_pcg_schedule(const blub_fluid* h);
+/* What the most recently enqueued solve `which` (0 velocity, 1 density) ACTUALLY ran -- the selected schedule is a request: the dense-row mapping, the
+ * LOD0 preconditioner reading and solves configured beyond "pcg1_max_iterations" always run the reference's order.  *schedule: 0 = the reference's
+ * two-reduction order (pressure_solver.rs:654-723 literally), 1 = single-reduction; *mapping: 0 = dense rows, 1 = brick lists, 2 = the literal kernel
+ * sequence of the LOD0 reading.  Either pointer may be NULL.  BLUB_ERR_INVALID_ARGUMENT before the first solve.  (Round-4 ADVICE: a drop-in caller
+ * must be able to tell which rounding of the recurrence produced a pressure field.) */
+int blub_fluid_last_solve_path(const blub_fluid* h, int which, int* schedule, int* mapping);
 /* Performance knobs / test hooks by name (the library never reads the environment).  None changes a result beyond the rounding of a
  * dot-product tree.  "pcg_tail" 0|1: persistent tail kernel of the single-reduction solves; "pcg_tail_first" n: hand over to the tail after
  * exactly n launched iterations (-1: predicted from the last solves); "pcg_tail_margin" n: check intervals launched beyond the prediction;
@@ -357,6 +363,18 @@ int blub_rccl_unique_id(void* out128);
 int blub_slab_range(uint32_t nz, int num_slabs, int index, int32_t* z0, int32_t* z1);   /* host only */
 int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out);
 int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out);
+/* The same with the caller's cut planes instead of uniform ones: cuts[num_slabs + 1], cuts[0] = 0, strictly increasing multiples of the brick depth (4),
+ * cuts[num_slabs] = nz; slab r owns the planes [cuts[r], cuts[r + 1]).  NULL = uniform.  Every slab allocates the plane count of the thickest one (one
+ * export layout for the direct transport).  Every rank must pass the same cuts.  (Round-4 review: the metric's scene keeps its fluid in z < 32 and
+ * z >= 224 of 256 -- uniform cuts into 8 leave six ranks without fluid.) */
+int blub_slab_group_create_local_cuts(const blub_fluid_desc* desc, int num_slabs, const int32_t* cuts, blub_slab_group** out);
+int blub_slab_group_create_rccl_cuts(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, const int32_t* cuts, blub_slab_group** out);
+/* Host only: cut planes that give every slab about the same number of FLUID bricks for the given particle positions (16-byte records, as
+ * blub_fluid_set_particles takes them) -- the contiguous partition of the brick layers that minimises the heaviest slab, every slab at least
+ * `min_layers` brick layers thick (>= 1).  cuts_out: num_slabs + 1 planes; fluid_bricks_out (may be NULL): FLUID bricks per slab at these positions. */
+int blub_slab_balanced_cuts(const uint32_t grid_dim[3], uint32_t num_particles, const float* pos_ll, int num_slabs, int min_layers, int32_t* cuts_out, uint32_t* fluid_bricks_out);
+/* The cut planes a group was created with (num_slabs + 1 values, the last one = nz). */
+int blub_slab_group_cuts(const blub_slab_group* g, int32_t* cuts_out);
 void blub_slab_group_destroy(blub_slab_group* g);
 int blub_slab_group_num_local(const blub_slab_group* g);
 /* For read_volume / statistics of one slab (borrowed: do not destroy).  A slab holds the planes [z0 - 8, z1 + 8) of every grid volume only (its own

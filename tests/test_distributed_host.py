@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from tests.conftest import ROOT
 
@@ -74,6 +75,42 @@ def test_slab_ranges_are_whole_brick_layers():
         assert r[0][0] == 0 and r[-1][1] == nz
         assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(a[0] % 4 == 0 and a[1] > a[0] for a in r)
         assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 4
+
+
+def test_balanced_cuts_share_out_the_fluid_bricks():
+    """blub_slab_balanced_cuts (host only): the contiguous partition of the brick layers that minimises the heaviest slab.  The metric's scene keeps its
+    fluid in z < 32 and z >= 224 of 256: uniform cuts into 8 leave six slabs empty (round-4 review), balanced ones give every slab an eighth."""
+    import numpy as np
+    import blub_amd
+    from blub_amd import slab_scene
+    cfg = blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", "corner_dams_256.json")).config
+    dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, 1)
+    pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
+    for n in (1, 2, 4, 8):
+        cuts, bricks = blub_amd.SlabGroup.balanced_cuts(dim, pos, n)
+        assert cuts[0] == 0 and cuts[-1] == 256 and all(c % 4 == 0 for c in cuts) and all(b > a for a, b in zip(cuts, cuts[1:]))
+        assert sum(bricks) == 256 and max(bricks) == 256 // n, (cuts, bricks)
+        assert bricks == blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos, cuts)
+        # the partition agrees with how the group hands out particles (slab_scene.partition_particles with the same cuts)
+        owned = [len(slab_scene.partition_particles(pos, dim[2], n, i, cuts)[0]) for i in range(n)]
+        assert sum(owned) == len(pos) and min(owned) > 0
+    uniform = [blub_amd.SlabGroup.slab_range(256, 8, i)[0] for i in range(8)] + [256]
+    assert blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos, uniform) == [128, 0, 0, 0, 0, 0, 0, 128]
+    # a minimum thickness is honoured, ties go to the most even layer counts, no fluid at all gives the uniform cuts
+    cuts, _ = blub_amd.SlabGroup.balanced_cuts(dim, pos, 8, min_layers=4)
+    assert min(b - a for a, b in zip(cuts, cuts[1:])) >= 16
+    cuts, bricks = blub_amd.SlabGroup.balanced_cuts((64, 64, 64), np.zeros((0, 4), np.float32), 4)
+    assert cuts == [0, 16, 32, 48, 64] and bricks == [0, 0, 0, 0]
+    with pytest.raises(blub_amd.BlubError):
+        blub_amd.SlabGroup.balanced_cuts((64, 64, 16), pos[:10], 8)          # more slabs than brick layers
+
+
+@pytest.mark.parametrize("cuts", [(4, 32, 64), (0, 30, 64), (0, 32, 32), (0, 32, 60), (0, 40, 32)])
+def test_bad_cut_planes_are_rejected_before_anything_is_allocated(cuts):
+    import blub_amd
+    with pytest.raises(blub_amd.BlubError) as e:
+        blub_amd.SlabGroup((64, 64, 64), 1024, local=2, cuts=list(cuts))
+    assert e.value.status == -1, str(e.value)          # BLUB_ERR_INVALID_ARGUMENT (not BLUB_ERR_NO_DEVICE: the cuts are checked first)
 
 
 PROBE_WORKER = textwrap.dedent("""
