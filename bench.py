@@ -245,57 +245,67 @@ def roofline_object(dense, where):
     return obj
 
 
-def multi_gpu(args, torch, dist, rank, world, dev, ctl):
-    """N > 1: ONE domain cut into z-slabs (SURVEY 8e).  --scaling strong (default): the scene itself (the 256^3 / 1 M particle
-    domain of the metric, BASELINE configs 4-5) split over N slabs, value = steps/s of that one domain.  --scaling weak: N copies
-    stacked along z, value = steps/s of the N-times larger domain.  Transport: RCCL (one slab per rank / GPU); BLUB_BENCH_TRANSPORT=
-    loopback keeps all N slabs on rank 0's GPU (development on a 1-GPU box: the other ranks only take part in the control plane)."""
-    import threading
+def shared_device_queue_limit(world):
+    """Development boxes only: when the ranks of a job outnumber the GPUs, several processes share a device and every process asks for its own four
+    hardware queues; beyond the device's queue slots the scheduler rotates them on a timer, and kernels that spin on words another process' kernels
+    write (the direct transport) only make progress when the timer fires.  GPU_MAX_HW_QUEUES must be in the environment before the HIP runtime
+    starts, i.e. before `import torch` (profiles/r05_multiproc_direct.jsonl: what it changes)."""
+    if world <= 1 or os.environ.get("GPU_MAX_HW_QUEUES"):
+        return None
+    try:
+        nodes = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = 0
+        for n in os.listdir(nodes):
+            props = dict(l.split()[:2] for l in open(os.path.join(nodes, n, "properties")) if len(l.split()) >= 2)
+            gpus += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return None
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if gpus and local_world > gpus:
+        # measured with 4 processes on one MI355X (profiles/r05_multiproc_direct.jsonl): the runtime's default of 4 hardware queues per process and 2 both
+        # run the direct transport at the same speed (984 / 987 steps/s); with ONE queue per process a flag wait times out (the run falls back to RCCL)
+        os.environ["GPU_MAX_HW_QUEUES"] = "2"
+        return "2"
+    return None
+
+
+def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, steps, warmup, scaling, memory="coarse"):
+    """One z-slab group over the ranks of the job stepping `scene_name`: creation (fluid-weighted cut planes unless BLUB_BENCH_CUTS=uniform), warm-up,
+    the timed window bracketed by barriers, one more step to count transport operations.  Raises on any failure (the caller decides what a failure
+    costs); every rank returns the same timing, rank-local details under "local"."""
     import blub_amd
     from blub_amd import slab_scene
     dt = blub_amd.default_simulation_delta()
-    # auto (default): the direct transport when a probe on THIS node's GPUs says it works (blub_amd/direct_probe.py: child processes, so a bad
-    # peer mapping costs the probe and not the job), RCCL otherwise; rccl / direct force one (direct without the probe); loopback: see above
-    transport = os.environ.get("BLUB_BENCH_TRANSPORT", "auto")
-    probe = None
-    if transport == "auto":
-        from blub_amd import direct_probe
-        try:
-            ok_probe, why = direct_probe.run(rank, world, dev)
-        except Exception as e:   # (a rendezvous problem inside the probe itself: all ranks see it)
-            ok_probe, why = False, "%s: %s" % (type(e).__name__, e)
-        probe = {"passed": bool(ok_probe), "detail": why}
-        if rank == 0:
-            sys.stderr.write("direct-transport probe: %s\n" % ("passed" if ok_probe else "failed (%s); using RCCL" % why))
-        transport = "direct" if ok_probe else "rccl"
-    scene_path = os.path.join(ROOT, "scenes", args.scene + ".json")
-    if os.environ.get("BLUB_BENCH_DIRECT_FAILED"):
-        probe = {"passed": True, "detail": "the probe passed but the run over the direct transport failed (%s); this line is the second attempt, over RCCL" % os.environ["BLUB_BENCH_DIRECT_FAILED"]}
-    bail = fallback_to_rccl if transport == "direct" else fallback_to_replicas
-    watchdog = None
-    if transport != "loopback":
-        watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), bail, args=("no progress within the deadline",))
-        watchdog.daemon = True
-        watchdog.start()
+    scene_path = os.path.join(ROOT, "scenes", scene_name + ".json")
     ok = torch.ones(1, device=ctl)
     group, err = None, ""
+    res = {}
     try:
         cfg = blub_amd.Scene.parse(path=scene_path).config
-        if args.scaling == "weak":
+        if scaling == "weak":
             dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, world)
-            workload = "%s stacked x%d along z (weak scaling: every slab is one copy)" % (args.scene, world)
+            res["workload"] = "%s stacked x%d along z (weak scaling: every slab is one copy)" % (scene_name, world)
         else:
             dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, 1)
-            workload = "%s, ONE domain cut into %d z-slabs (strong scaling)" % (args.scene, world)
+            res["workload"] = "%s, ONE domain cut into %d z-slabs (strong scaling)" % (scene_name, world)
         pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
         P = len(pos)
+        # Cut planes: every rank holds the same particles here, so every rank derives the same cuts.  Weighted (default): every slab starts with
+        # about 1/N of the FLUID bricks (round-4 review: uniform cuts of the metric's scene leave six of eight ranks without fluid).
+        uniform = [blub_amd.SlabGroup.slab_range(dim[2], world, i)[0] for i in range(world)] + [dim[2]]
+        cuts_mode = os.environ.get("BLUB_BENCH_CUTS", "weighted")
+        cuts = blub_amd.SlabGroup.balanced_cuts(dim, pos, world)[0] if cuts_mode == "weighted" else uniform
+        res.update(grid=list(dim), particles=P, dt=dt, cuts=list(cuts), cuts_mode=cuts_mode,
+                   fluid_bricks_per_rank=blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos, cuts),
+                   fluid_bricks_per_rank_uniform_cuts=blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos, uniform))
+        # capacity per slab: the whole particle set (strong scaling: a slab may come to own all of it)
         if transport == "loopback":
             if rank == 0:
-                group = blub_amd.SlabGroup(dim, P + 64, local=world, device=dev)
+                group = blub_amd.SlabGroup(dim, P + 64, local=world, device=dev, cuts=cuts, memory=memory)
         else:
-            group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev)
+            group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev, cuts=cuts, memory=memory)
         if group is not None and transport == "direct":
-            # peer-mapped slabs over hipIpc, kernels store into the neighbours' memory themselves (after the probe above, or forced)
+            # peer-mapped slabs over hipIpc, kernels store into the neighbours' memory themselves (after the probe, or forced)
             if not group.connect_direct_over_torch_distributed():
                 sys.stderr.write("rank %d: hipIpc mapping unavailable on some rank; staying on the RCCL transport\n" % rank)
         if group is not None:
@@ -312,9 +322,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
     if float(ok.item()) == 0.0:
         if group is not None:
             group.close()
-        if watchdog is not None:
-            watchdog.cancel()
-        bail("z-slab group could not be created on every rank" + (" (%s)" % err if err else ""))
+        raise RuntimeError("z-slab group could not be created on every rank" + (" (%s)" % err if err else ""))
     active = group is not None
 
     def barrier():
@@ -323,7 +331,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
         if active:
             group.synchronize()
     try:
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             if active:
                 group.step(dt)
         if transport == "direct" and os.environ.get("BLUB_BENCH_FAIL_DIRECT"):      # (test hook: the second attempt over RCCL)
@@ -332,44 +340,127 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
         fluid0 = group.local_fluid(0) if active else None
         it0 = fluid0.total_solver_iterations() if active else 0
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             if active:
                 group.step(dt)
         if active:
             group.synchronize()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res["elapsed"] = float(t.item())
+        dist.barrier()
+        if active:
+            it1 = fluid0.total_solver_iterations()
+            ops0 = group.transport_ops()
+            group.step(dt)
+            group.synchronize()
+            res.update(pcg_iters_per_step=round((it1 - it0) / steps, 2), transport_ops_per_step=round(group.transport_ops() - ops0, 1),
+                       transport=group.transport_description(), transport_kind=group.transport(),
+                       particles_per_local_slab=[group.local_fluid(i).num_particles() for i in range(group.num_local())])
+        dist.barrier()
+    finally:
+        if active:
+            group.close()
+    res["active"] = active
+    return res
+
+
+def multi_gpu(args, torch, dist, rank, world, dev, ctl):
+    """N > 1: ONE domain cut into z-slabs (SURVEY 8e).  --scaling strong (default): the scene itself (the 256^3 / 1 M particle
+    domain of the metric, BASELINE configs 4-5) split over N slabs, value = steps/s of that one domain; the line also carries `secondary`:
+    corner_dams_512 (512^3, 8 M particles: BASELINE configs[4], the size the decomposition is for) cut the same way.  --scaling weak: N copies
+    stacked along z, value = steps/s of the N-times larger domain.  Transport: RCCL (one slab per rank / GPU) or, after a probe, the direct one;
+    BLUB_BENCH_TRANSPORT=loopback keeps all N slabs on rank 0's GPU (development on a 1-GPU box: the other ranks only take part in the control
+    plane).  Cut planes: fluid-weighted unless BLUB_BENCH_CUTS=uniform."""
+    import threading
+    # auto (default): the direct transport when a probe on THIS node's GPUs says it works (blub_amd/direct_probe.py: child processes, so a bad
+    # peer mapping costs the probe and not the job), RCCL otherwise; rccl / direct force one (direct without the probe); loopback: see above
+    transport = os.environ.get("BLUB_BENCH_TRANSPORT", "auto")
+    probe, memory = None, os.environ.get("BLUB_BENCH_SLAB_MEMORY", "coarse")      # (slab memory mode: what the probe found to work, or forced)
+    if transport == "auto":
+        from blub_amd import direct_probe
+        try:
+            ok_probe, why, memory = direct_probe.run(rank, world, dev)
+        except Exception as e:   # (a rendezvous problem inside the probe itself: all ranks see it)
+            ok_probe, why, memory = False, "%s: %s" % (type(e).__name__, e), None
+        probe = {"passed": bool(ok_probe), "detail": why, "slab_memory": memory,
+                 "checks": "121 + 3 x 121 PCG iterations, RCCL vs direct, per-iteration scalars and final pressure bit for bit on every rank; 3 free-running steps vs the single domain"}
+        if rank == 0:
+            sys.stderr.write("direct-transport probe: %s\n" % ("passed" if ok_probe else "failed (%s); using RCCL" % why))
+        transport = "direct" if ok_probe else "rccl"
+        memory = memory or "coarse"
+    if os.environ.get("BLUB_BENCH_DIRECT_FAILED"):
+        probe = {"passed": True, "detail": "the probe passed but the run over the direct transport failed (%s); this line is the second attempt, over RCCL" % os.environ["BLUB_BENCH_DIRECT_FAILED"]}
+    bail = fallback_to_rccl if transport == "direct" else fallback_to_replicas
+    watchdog = None
+    if transport != "loopback":
+        watchdog = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), bail, args=("no progress within the deadline",))
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        res = slab_run(args, torch, dist, rank, world, dev, ctl, transport, args.scene, args.steps, args.warmup, args.scaling, memory)
     except Exception as e:
-        bail("z-slab step failed: %s" % e)
+        if watchdog is not None:
+            watchdog.cancel()
+        bail("z-slab run failed: %s" % e)
     if watchdog is not None:
         watchdog.cancel()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    dist.barrier()
+    elapsed = res["elapsed"]
     line = None
-    if active:
-        it1 = fluid0.total_solver_iterations()
-        ops0 = group.transport_ops()
-        group.step(dt)
-        group.synchronize()
-        ops_per_step = group.transport_ops() - ops0
+    if res["active"]:
         if transport == "loopback":
             parallelism = "%d z-slabs EMULATED on one GPU (loopback transport, rank 0 only): protocol cost without a wire, not a scaling result" % world
         else:
-            parallelism = "z-slab decomposition over %s: %d slabs, 1 rank per GPU" % ("peer-mapped memory (hipIpc)" if group.transport() == "direct" else "RCCL", world)
+            parallelism = "z-slab decomposition over %s: %d slabs, 1 rank per GPU" % ("peer-mapped memory (hipIpc)" if res["transport_kind"] == "direct" else "RCCL", world)
         line = {
             "metric": METRIC, "value": round(args.steps / elapsed, 3), "unit": "steps/s (global steps of the whole domain)", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling if transport != "loopback" else args.scaling + "-emulated-on-one-gpu", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "grid": list(dim), "particles": P, "dt": dt, "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
-                       "parallelism": parallelism, "pcg_schedule": args.pcg_schedule if args.pcg_schedule != "default" else "single_reduction (library default)"},
-            "pcg_iters_per_step": round((it1 - it0) / args.steps, 2), "transport_ops_per_step": round(ops_per_step, 1),
-            "transport": group.transport_description(), "direct_transport_probe": probe, "roofline": None, "cpu_baseline": None}
-    dist.barrier()
-    if active:
-        group.close()
+            "config": {"workload": res["workload"], "grid": res["grid"], "particles": res["particles"], "dt": res["dt"], "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
+                       "parallelism": parallelism, "pcg_schedule": args.pcg_schedule if args.pcg_schedule != "default" else "single_reduction (library default)",
+                       "slab_cuts": res["cuts"], "slab_cuts_mode": res["cuts_mode"]},
+            "fluid_bricks_per_rank": res["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": res["fluid_bricks_per_rank_uniform_cuts"],
+            "pcg_iters_per_step": res["pcg_iters_per_step"], "transport_ops_per_step": res["transport_ops_per_step"],
+            "transport": res["transport"], "direct_transport_probe": probe, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "roofline": None, "cpu_baseline": None}
+    # ---- secondary: the size the decomposition is for (BASELINE configs[4]): corner_dams_512, strong scaling over the same ranks.  A failure or stall
+    # here costs only this object: the primary result above is printed either way.
+    secondary = None
+    want_secondary = args.scaling == "strong" and args.scene == "corner_dams_256" and not args.no_secondary and os.environ.get("BLUB_BENCH_NO_SECONDARY", "0") in ("", "0")
+    if want_secondary:
+        def give_up():
+            if rank == 0 and line is not None:
+                line["secondary"] = {"workload": "corner_dams_512", "error": "no progress within the deadline"}
+                print(json.dumps(line))
+                sys.stdout.flush()
+            os._exit(0)
+        wd2 = None
+        if transport != "loopback":
+            wd2 = threading.Timer(float(os.environ.get("BLUB_BENCH_SLAB_DEADLINE", "180")), give_up)
+            wd2.daemon = True
+            wd2.start()
+        s_steps, s_warm = max(4, min(args.steps, 30)), max(2, min(args.warmup, 5))
+        try:
+            r2 = slab_run(args, torch, dist, rank, world, dev, ctl, transport, "corner_dams_512", s_steps, s_warm, "strong", memory)
+            if r2["active"]:
+                secondary = {"workload": r2["workload"], "grid": r2["grid"], "particles": r2["particles"], "value": round(s_steps / r2["elapsed"], 3), "unit": "steps/s",
+                             "ms_per_step": round(r2["elapsed"] / s_steps * 1e3, 4), "steps": s_steps, "warmup": s_warm, "single_gpu_reference": "bench.py --scene corner_dams_512 (profiles/r04_other_scenes.txt: 298 steps/s)",
+                             "slab_cuts": r2["cuts"], "fluid_bricks_per_rank": r2["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": r2["fluid_bricks_per_rank_uniform_cuts"],
+                             "pcg_iters_per_step": r2["pcg_iters_per_step"], "transport_ops_per_step": r2["transport_ops_per_step"], "transport": r2["transport"]}
+        except Exception as e:
+            secondary = {"workload": "corner_dams_512", "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            if wd2 is not None:
+                wd2.cancel()
+            if rank == 0 and line is not None:      # (the other ranks may be blocked in a transport operation of the failed run: do not wait for them)
+                line["secondary"] = secondary
+                print(json.dumps(line))
+                sys.stdout.flush()
+            os._exit(0)
+        if wd2 is not None:
+            wd2.cancel()
     if rank == 0 and line is not None:
+        line["secondary"] = secondary
         if not args.no_dense_pcg:   # the roofline kernel is a single-GPU micro-benchmark: rank 0 runs it while the others wait
             line["roofline"] = roofline_object(dense_pcg_benchmark(256, 32), "rank 0")
         print(json.dumps(line))
@@ -393,6 +484,7 @@ def main():
     ap.add_argument("--pcg-schedule", default="default", choices=["default", "single_reduction", "reference"],
                     help="schedule of the headline window: the LIBRARY'S default (no call at all) unless named; the other one is timed beside it")
     ap.add_argument("--no-fast-forward", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the corner_dams_512 strong-scaling run that rides along as `secondary`")
     ap.add_argument("--profile-steps", type=int, default=1000000, help="steps of the instrumented pass (a fresh scene, same warm-up; default: the whole timed window; 0: skip)")
     ap.add_argument("--dense-only", action="store_true", help="only run the dense PCG micro-benchmark (tuning)")
     ap.add_argument("--dense-size", type=int, default=256)
@@ -405,8 +497,11 @@ def main():
     ap.add_argument("--transfer-only", action="store_true", help="only run the 256^3 transfer micro-benchmark M4 (65 M particles)")
     args = ap.parse_args()
 
+    hwq = shared_device_queue_limit(int(os.environ.get("WORLD_SIZE", "1")))      # (before the HIP runtime starts)
     import torch
     import blub_amd
+    if hwq and int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("bench.py: more ranks than GPUs on this node: GPU_MAX_HW_QUEUES=%s\n" % hwq)
 
     if args.dense_only:
         tuning = {k_: v_ for k_, v_ in (("dense_tile_quads", args.dense_tile_quads), ("dense_tile_planes", args.dense_tile_planes), ("dense_grid", args.dense_grid)) if v_}

@@ -70,6 +70,7 @@ struct blub_fluid {
     int vol_z0 = 0, vol_planes = 0; size_t vol_cells = 0, vol_first = 0;
     std::vector<void*> vol_owned;   // volumes allocated one by one (no volume slab)
     float4* solid_alloc = nullptr;   // (solid = solid_alloc - vol_first)
+    int mem_mode = 0;                // BLUB_SLAB_MEMORY_*: how the volume slab and the recurrence volumes are allocated (slabs of a group only)
     float* cgbuf_alloc[3] = {nullptr, nullptr, nullptr};   // (cgbuf[] rotates with residual / search, which live in the volume slab)
     uint32_t max_particles = 0, num_particles = 0;
     uint32_t last_add_dropped = 0;   // particles the last add_fluid_cube could not add (capacity)
@@ -148,6 +149,7 @@ struct blub_fluid {
     float* cgbuf[3] = {nullptr, nullptr, nullptr};
     float4* part4 = nullptr;
     Pcg1Scalars* pcg1_scalars[2] = {nullptr, nullptr};
+    float4* scalar_log[2] = {nullptr, nullptr};   // diagnostic ("pcg_scalar_log" tuning): 1024 entries per solver, see SlabDirect::log / blub_fluid_read_scalar_log
     PcgTailSync* tail_sync[2] = {nullptr, nullptr};
     bool use_tail = true;            // persistent tail kernel of the single-reduction solves (blub_fluid_set_tuning "pcg_tail")
     int tail_margin_checks = 1;
@@ -240,6 +242,12 @@ static unsigned stream_blocks(size_t items) { return (unsigned)std::min<size_t>(
 
 // NOTE: the handle's stream is non-blocking, i.e. NOT ordered against the null stream: every memset / copy of this
 // library is issued on the handle's stream (a null-stream hipMemset may still be in flight when a kernel starts).
+// Memory that another agent writes while kernels of this process run (the direct transport of a z-slab group, include/blubhip.h: BLUB_SLAB_MEMORY_*)
+static hipError_t shared_malloc(void** p, size_t bytes, int mem_mode) {
+    if (mem_mode == BLUB_SLAB_MEMORY_FINE_GRAINED) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    if (mem_mode == BLUB_SLAB_MEMORY_UNCACHED) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+    return hipMalloc(p, bytes);
+}
 template <class T>
 static int dev_alloc_zero(hipStream_t stream, T** p, size_t count) {
     HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
@@ -459,7 +467,14 @@ static int stage_solve_lod0(blub_fluid* h, int which, float dt) {
 
 static int ensure_pcg1_buffers(blub_fluid* h) {
     int rc = BLUB_OK;
-    for (int k = 0; k < 3 && rc == BLUB_OK; ++k) if (!h->cgbuf_alloc[k]) { rc = dev_alloc_zero(h->stream, &h->cgbuf_alloc[k], h->vol_cells); if (rc == BLUB_OK) h->cgbuf[k] = h->cgbuf_alloc[k] - h->vol_first; }
+    for (int k = 0; k < 3 && rc == BLUB_OK; ++k) if (!h->cgbuf_alloc[k]) {
+        if (h->mem_mode == BLUB_SLAB_MEMORY_COARSE) rc = dev_alloc_zero(h->stream, &h->cgbuf_alloc[k], h->vol_cells);
+        else {
+            if (shared_malloc((void**)&h->cgbuf_alloc[k], h->vol_cells * sizeof(float), h->mem_mode) != hipSuccess) { h->cgbuf_alloc[k] = nullptr; (void)hipGetLastError(); rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "allocation of a recurrence volume failed"); }
+            else HIP_TRY(hipMemsetAsync(h->cgbuf_alloc[k], 0, h->vol_cells * sizeof(float), h->stream));
+        }
+        if (rc == BLUB_OK) h->cgbuf[k] = h->cgbuf_alloc[k] - h->vol_first;
+    }
     if (rc == BLUB_OK && !h->part4) rc = dev_alloc_zero(h->stream, &h->part4, 2 * (size_t)PCG_GRID_MAX);
     for (int w = 0; w < 2 && rc == BLUB_OK; ++w) if (!h->pcg1_scalars[w]) rc = dev_alloc_zero(h->stream, &h->pcg1_scalars[w], 1);
     return rc;
@@ -542,6 +557,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             float* Q[2] = {h->aux_temp, h->cgbuf[2]};
             float4* part[2] = {h->part4, h->part4 + PCG_GRID_MAX};
             Pcg1Scalars* sc = h->pcg1_scalars[which];
+            SlabDirect nodir{}; nodir.log = h->scalar_log[which];
+            if (nodir.log) HIP_TRY(hipMemsetAsync(nodir.log, 0xFF, 1024 * sizeof(float4), h->stream));
             LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s<false>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, 0, part[0], 1, 0u, -1, -1, SlabDirect{});
             // Launch as many iterations as the last few solves needed (+ `tail_margin_checks` check intervals); ONE persistent kernel covers
             // the rest (k_pcg1_tail_s): it normally finds the solve finished and only publishes the statistics.  Only while the solve is
@@ -555,8 +572,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             if (h->use_tail && h->tail_first_forced >= 0) launched1 = std::min(maxit + 1, std::max(1, h->tail_first_forced));   // (test hook; K(0) is always launched)
             for (int i = 0; i < launched1; ++i) {
                 const float4* pin = part[i & 1]; float4* pout = part[(i + 1) & 1];
-                if (i == 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, 0, ctrl, sc, tol, 0, 0, -1, -1, SlabDirect{});
-                else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, 0, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1, SlabDirect{});
+                if (i == 0) LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[0], R[1], (const float*)W[0], W[1], (const float*)Q[1], Q[0], h->search, p, pin, pout, 0, ctrl, sc, tol, 0, 0, -1, -1, nodir);
+                else LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false>), grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)R[i & 1], R[(i + 1) & 1], (const float*)W[i & 1], W[(i + 1) & 1], (const float*)Q[(i + 1) & 1], Q[i & 1], h->search, p, pin, pout, 0, ctrl, sc, tol, i, (int)is_check(i - 1), -1, -1, nodir);
             }
             if (launched1 <= maxit) {
                 if (h->tail_inject_timeout) { const int one = 1; HIP_TRY(hipMemcpyAsync(&h->tail_sync[which]->timed_out, &one, sizeof one, hipMemcpyHostToDevice, h->stream)); h->tail_inject_timeout = false; }
@@ -753,6 +770,7 @@ static void destroy(blub_fluid* h) {
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_block_ready); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts);
     if (h->counts_host) (void)hipHostFree(h->counts_host);
     if (h->steps_done_host) (void)hipHostFree((void*)h->steps_done_host);
+    F(h->scalar_log[0]); F(h->scalar_log[1]);
     F(h->tail_sync[0]); F(h->tail_sync[1]); F(h->part4); F(h->pcg1_scalars[0]); F(h->pcg1_scalars[1]); F(h->mesh_positions); F(h->mesh_indices);
     F(h->part_sas); F(h->part_sigma[0]); F(h->part_sigma[1]); F(h->part_max); F(h->tile_flags); F(h->ctrl[0]); F(h->ctrl[1]);
     for (int w = 0; w < 2; ++w) if (h->stats_host[w]) (void)hipHostFree(h->stats_host[w]);
@@ -796,7 +814,7 @@ static void set_dense_geometry(blub_fluid* h, int T, int zc, int grid) {
     gd.flag_factor = f; gd.flag_chunks = gz.z_chunks;
 }
 
-static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared_stream = nullptr, int vol_z0 = 0, int vol_planes = 0) {
+static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared_stream = nullptr, int vol_z0 = 0, int vol_planes = 0, int mem_mode = 0) {
     if (!d || !out) return set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (d->nx < 4 || d->ny < 3 || d->nz < 3) return set_error(BLUB_ERR_INVALID_ARGUMENT, "grid too small");
@@ -822,6 +840,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     h->vol_cells = (size_t)d->nx * d->ny * (size_t)h->vol_planes; h->vol_first = (size_t)d->nx * d->ny * (size_t)h->vol_z0;
     h->max_particles = d->max_num_particles;
     h->precond_mode = d->precond_mode; h->binning_mode = d->binning_mode;
+    h->mem_mode = mem_mode;
     int rc = BLUB_OK;
     auto A = [&](int r) { if (rc == BLUB_OK) rc = r; };
     const size_t P = std::max<size_t>(h->max_particles, 1);
@@ -834,7 +853,7 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
         h->slab_shift = (size_t)(d->volume_shift_kib ? d->volume_shift_kib : 64u) * 1024u;
         const size_t per = ((h->vol_cells * 4 + 0x1FFFFFull) & ~0x1FFFFFull) + 0x400000ull;      // 2 MiB alignment + up to 2 MiB of shift
         h->slab_bytes = 18 * per;                                                          // 16 volumes (two of them bytes) + head room
-        if (hipMalloc((void**)&h->slab, h->slab_bytes) != hipSuccess) { h->slab = nullptr; h->slab_bytes = 0; (void)hipGetLastError(); }   // (fall back to separate allocations)
+        if (shared_malloc((void**)&h->slab, h->slab_bytes, mem_mode) != hipSuccess) { h->slab = nullptr; h->slab_bytes = 0; (void)hipGetLastError(); }   // (fall back to separate allocations)
     }
     A(vol_alloc(h, &h->residual)); A(vol_alloc(h, &h->search)); A(vol_alloc(h, &h->aux)); A(vol_alloc(h, &h->aux_temp));
     for (int w = 0; w < 2; ++w) A(vol_alloc(h, &h->pressure[w]));
@@ -1214,6 +1233,19 @@ int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode) {
     return BLUB_OK;
 }
 int blub_fluid_get_pcg_schedule(const blub_fluid* h) { return h ? h->pcg_schedule : BLUB_ERR_INVALID_ARGUMENT; }
+int blub_fluid_read_scalar_log(blub_fluid* h, int which, float* out, int capacity, int* count_out) {
+    REQUIRE_HANDLE(h);
+    if (which < 0 || which > 1 || !count_out || (capacity > 0 && !out)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!h->scalar_log[which]) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "the scalar log is off (blub_fluid_set_tuning \"pcg_scalar_log\" 1)");
+    std::vector<float> buf(4 * 1024);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(buf.data(), h->scalar_log[which], buf.size() * sizeof(float), hipMemcpyDeviceToHost));
+    int n = 0;
+    while (n < 1024) { uint32_t w[4]; memcpy(w, &buf[4 * (size_t)n], sizeof w); if ((w[0] & w[1] & w[2] & w[3]) == 0xFFFFFFFFu) break; ++n; }
+    *count_out = n;
+    for (int i = 0; i < n && i < capacity; ++i) memcpy(out + 4 * (size_t)i, &buf[4 * (size_t)i], 4 * sizeof(float));
+    return BLUB_OK;
+}
 int blub_fluid_last_solve_path(const blub_fluid* h, int which, int* schedule, int* mapping) {
     if (!h || which < 0 || which > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
     if (h->last_schedule[which] < 0) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "no solve of this kind has been enqueued yet");
@@ -1241,6 +1273,13 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);
     else if (k == "bricks_two_kernel_build") h->two_kernel_build = value != 0;
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);
+    else if (k == "pcg_scalar_log") {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int w = 0; w < 2; ++w) {
+            if (value && !h->scalar_log[w]) { HIP_TRY(hipMalloc((void**)&h->scalar_log[w], 1024 * sizeof(float4))); HIP_TRY(hipMemset(h->scalar_log[w], 0xFF, 1024 * sizeof(float4))); }
+            if (!value && h->scalar_log[w]) { (void)hipFree(h->scalar_log[w]); h->scalar_log[w] = nullptr; }
+        }
+    }
     else if (k == "dense_tile_quads" || k == "dense_tile_planes" || k == "dense_grid") {
         HIP_TRY(hipStreamSynchronize(h->stream));
         blub::set_dense_geometry(h, k == "dense_tile_quads" ? value : h->gz.T, k == "dense_tile_planes" ? value : (k == "dense_tile_quads" ? 0 : h->gz.zc), k == "dense_grid" ? value : 0);

@@ -283,6 +283,7 @@ struct SlabDirect {
     uint32_t* error;                          // set when a wait timed out (bounded spins: a missing peer must not hang the GPU)
     uint32_t seq_in, seq_out, wait_mask;      // wait for flags_in[r] >= seq_in for every bit r of wait_mask; publish seq_out
     int n_out;
+    float4* log;                              // diagnostic (any transport, also the single domain; nullptr = off): entry i = {gamma_i, delta_i, max|r_i|, alpha_i} as K(i) reduced them
 };
 constexpr unsigned SLAB_SPIN_LIMIT = 1u << 24;
 __device__ __forceinline__ bool slab_gave_up(const uint32_t* error) { return error && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }

@@ -103,7 +103,7 @@ __device__ __forceinline__ float4 pcg1_partial_spin(const float4* p, uint32_t ta
 template <bool FIRST, bool COHERENT = false>
 __device__ __forceinline__ bool pcg1_prologue_finish(Pcg1PrologueLoads& L, PcgCtrl* __restrict__ ctrl, Pcg1Scalars* __restrict__ sc, const float4* __restrict__ part_in,
                                                      int num_part, float tolerance, int iteration, int check_prev, float4* sm4, float& alpha, float& beta,
-                                                     uint32_t tag_in = 0u, uint32_t* err = nullptr) {
+                                                     uint32_t tag_in = 0u, uint32_t* err = nullptr, float4* log = nullptr) {
     constexpr int NT = PCG_B_THREADS;
     float g = 0.0f, d = 0.0f, m = 0.0f;
     if (COHERENT) {
@@ -155,7 +155,12 @@ __device__ __forceinline__ bool pcg1_prologue_finish(Pcg1PrologueLoads& L, PcgCt
     } else {
         alpha = eps_div(red.x, red.y);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gamma[iteration & 1] = red.x; sc->alpha[iteration & 1] = alpha; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->gamma[iteration & 1] = red.x; sc->alpha[iteration & 1] = alpha;
+        // (diagnostic log of the scalars every workgroup of every slab derives alike: the direct-transport probe compares it bit for bit between ranks and
+        //  between transports -- a stale partial or ghost plane shows up here in the iteration it happens)
+        if (log && iteration < 1024) log[iteration] = make_float4(red.x, red.y, red.z, alpha);
+    }
     return true;
 }
 
@@ -375,7 +380,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     float alpha, beta;
     // (direct transport: the tags of ALL partials of the previous launch have been seen before anything else that came from a peer -- the halo
     //  rows of w below -- is requested)
-    if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta, DIRECT ? dir->seq_in : 0u, DIRECT ? dir->error : nullptr)) return false;
+    if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta, DIRECT ? dir->seq_in : 0u, DIRECT ? dir->error : nullptr, dir ? dir->log : nullptr)) return false;
     if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p, ghost_lo, ghost_hi);
     StagedTile& T = tiles[half];
     bool first = true;

@@ -21,6 +21,7 @@ struct blub_slab_group {
     hipStream_t stream = nullptr;
     int device = 0;
     uint32_t capacity = 0;            // particle capacity of every slab and of the transfer buffers
+    int mem_mode = 0;                 // BLUB_SLAB_MEMORY_*: what the exportable regions were allocated with
     std::vector<int> cuts;            // nranks + 1 cut planes (multiples of the brick depth): slab r owns [cuts[r], cuts[r + 1]); uniform unless the caller passed its own
     std::vector<int> vol_z0_of; std::vector<size_t> vol_first_of;   // per rank: first plane its volumes hold / that plane's first cell (blub_fluid::vol_z0, vol_first)
     struct Extra {
@@ -668,6 +669,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
             int r2 = slab_halo(G, {[](blub_fluid* h) { return (void*)h->dvol; }}, 1, false);
             return r2 != BLUB_OK ? r2 : slab_halo(G, {[](blub_fluid* h) { return (void*)h->residual; }, [](blub_fluid* h) { return (void*)h->search; }}, 4, false);
         }, gather_upd)) != BLUB_OK) return rc;
+    for (auto h : G->slabs) if (h->scalar_log[which]) HIP_TRY(hipMemsetAsync(h->scalar_log[which], 0xFF, 1024 * sizeof(float4), G->stream));
     // per-slab buffer roles of this solve (see stage_solve)
     struct Bufs { float* R[2]; float* W[2]; float* Q[2]; };
     std::vector<Bufs> B(S);
@@ -748,7 +750,7 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
                     D.part_out[D.n_out] = peer_ptr(G, i, r, pout); D.flag_out[D.n_out] = flag_of(G, i, r); D.n_out += 1;
                 }
                 D.flags_in = G->flags[i]; D.blocks_done = G->blocks_done[i]; D.error = G->dir_error[i];
-                D.seq_in = seq_in; D.seq_out = G->flag_seq; D.wait_mask = others_mask(G, i);
+                D.seq_in = seq_in; D.seq_out = G->flag_seq; D.wait_mask = others_mask(G, i); D.log = h->scalar_log[which];
                 if (it == 0)
                     LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true, true, true, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[0], B[i].R[1], (const float*)B[i].W[0],
                            B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi, D);
@@ -775,13 +777,14 @@ static int slab_solve_single_reduction(blub_slab_group* G, int which, float dt) 
                 const int halo_lo = has_down(G, i) ? h->slab_z0 : -1, halo_hi = has_up(G, i) ? h->slab_z1 - 1 : -1;
                 const float4* pin = G->ex[i].gat4[it & 1];
                 float4* pout = seg4(i, (it + 1) & 1);
+                SlabDirect Dlog{}; Dlog.log = h->scalar_log[which];
                 if (it == 0)
                     LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<true, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[0], B[i].R[1], (const float*)B[i].W[0],
-                           B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi, SlabDirect{});
+                           B[i].W[1], (const float*)B[i].Q[1], B[i].Q[0], h->search, h->pressure[which], pin, pout, npall, h->ctrl[which], h->pcg1_scalars[which], tol, 0, 0, halo_lo, halo_hi, Dlog);
                 else
                     LAUNCH(h, KC_PCG_ITER, (k_pcg1_iter_s<false, true>), grid, block, h->bg, LIST(h, fluid), np, (const uint8_t*)h->dvol, (const float*)B[i].R[it & 1], B[i].R[(it + 1) & 1],
                            (const float*)B[i].W[it & 1], B[i].W[(it + 1) & 1], (const float*)B[i].Q[(it + 1) & 1], B[i].Q[it & 1], h->search, h->pressure[which], pin, pout, npall,
-                           h->ctrl[which], h->pcg1_scalars[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi, SlabDirect{});
+                           h->ctrl[which], h->pcg1_scalars[which], tol, it, (int)is_check(it - 1), halo_lo, halo_hi, Dlog);
             }
             if ((rc = exchange((it + 1) & 1, (it + 1) & 1)) != BLUB_OK) return rc;
         }
@@ -1032,10 +1035,11 @@ static int slab_calibrate(blub_slab_group* G) {
     return rc;
 }
 
-static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, int nlocal, const void* nccl_id, blub_slab_group** out, const int32_t* cuts = nullptr) {
+static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, int nlocal, const void* nccl_id, blub_slab_group** out, const int32_t* cuts = nullptr, uint32_t mem_mode = 0) {
     if (!d || !out || nranks < 1 || nlocal < 1 || first < 0 || first + nlocal > nranks || nlocal > 8) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad slab group arguments");
     *out = nullptr;
     if ((int)((d->nz + BZ - 1) / BZ) < nranks) return set_error(BLUB_ERR_INVALID_ARGUMENT, "more slabs than brick layers in z");
+    if (mem_mode > BLUB_SLAB_MEMORY_UNCACHED) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad slab memory mode");
     std::vector<int> cut_planes;
     { int rcc = slab_cuts((int)d->nz, nranks, cuts, cut_planes); if (rcc != BLUB_OK) return rcc; }
     int ndev = 0;
@@ -1047,7 +1051,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     if (!G) return set_error(BLUB_ERR_OUT_OF_MEMORY, "host allocation failed");
     G->nranks = nranks; G->first = first; G->device = dev; G->capacity = std::max<uint32_t>(d->max_num_particles, 1);
     G->rccl = nccl_id != nullptr;
-    G->cuts = cut_planes;
+    G->cuts = cut_planes; G->mem_mode = (int)mem_mode;
     int rc = BLUB_OK;
     if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) { delete G; return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     blub_fluid_desc dd = *d; dd.device = dev;
@@ -1065,7 +1069,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     if (nranks == 1) vol_planes = 0;      // (whole grid)
     for (int i = 0; i < nlocal && rc == BLUB_OK; ++i) {
         blub_fluid* h = nullptr;
-        rc = create(&dd, &h, G->stream, G->vol_z0_of[(size_t)first + i], vol_planes);
+        rc = create(&dd, &h, G->stream, G->vol_z0_of[(size_t)first + i], vol_planes, (int)mem_mode);
         if (rc != BLUB_OK) break;
         h->slab_z0 = G->cuts[(size_t)first + i]; h->slab_z1 = G->cuts[(size_t)first + i + 1];
         h->max_steps_in_flight = 0;   // every particle exchange synchronises the host anyway
@@ -1076,7 +1080,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         // neighbours write into it, so it is one of the slab's exportable regions (one hipIpc handle)
         blub_slab_group::Arena ar;
         ar.bytes = (size_t)3 * P * 4 + (size_t)4 * (P + 1) * 16 + (size_t)12 * P * 16 + (size_t)nranks * blubk::SLAB_NP_MAX * (4 + 8 + 16 + 16) + (size_t)nranks * 8 + 64 * 1024;
-        if (rc == BLUB_OK && hipMalloc((void**)&ar.base, ar.bytes) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipMalloc of a slab's exchange arena failed");
+        if (rc == BLUB_OK && shared_malloc((void**)&ar.base, ar.bytes, (int)mem_mode) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "allocation of a slab's exchange arena failed");
         if (rc == BLUB_OK && hipMemsetAsync(ar.base, 0, ar.bytes, G->stream) != hipSuccess) rc = set_error(BLUB_ERR_DEVICE, "hipMemsetAsync failed");
         auto sub = [&](auto** pp, size_t count) {
             using T = std::remove_pointer_t<std::remove_pointer_t<decltype(pp)>>;
@@ -1167,9 +1171,9 @@ int blub_slab_range(uint32_t nz, int num_slabs, int index, int32_t* z0, int32_t*
     *z0 = a; *z1 = std::min<int>(b, (int)nz);
     return BLUB_OK;
 }
-int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out) { return blub_slab_group_create_local_cuts(desc, num_slabs, nullptr, out); }
-int blub_slab_group_create_local_cuts(const blub_fluid_desc* desc, int num_slabs, const int32_t* cuts, blub_slab_group** out) {
-    int rc = blub::slab_group_create(desc, num_slabs, 0, num_slabs, nullptr, out, cuts);
+int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out) { return blub_slab_group_create_local_ex(desc, num_slabs, nullptr, BLUB_SLAB_MEMORY_COARSE, out); }
+int blub_slab_group_create_local_ex(const blub_fluid_desc* desc, int num_slabs, const int32_t* cuts, uint32_t memory_mode, blub_slab_group** out) {
+    int rc = blub::slab_group_create(desc, num_slabs, 0, num_slabs, nullptr, out, cuts, memory_mode);
     if (rc != BLUB_OK) return rc;
     // The direct transport is the default where it is available (every slab's volumes in one allocation -- a slab that fell back to per-volume
     // allocations under memory pressure has none --, at most 8 slabs); otherwise the group keeps the host-issued copies it was created with.  A
@@ -1180,11 +1184,11 @@ int blub_slab_group_create_local_cuts(const blub_fluid_desc* desc, int num_slabs
     return BLUB_OK;
 }
 int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out) {
-    return blub_slab_group_create_rccl_cuts(desc, rank, num_ranks, unique_id_128, nullptr, out);
+    return blub_slab_group_create_rccl_ex(desc, rank, num_ranks, unique_id_128, nullptr, BLUB_SLAB_MEMORY_COARSE, out);
 }
-int blub_slab_group_create_rccl_cuts(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, const int32_t* cuts, blub_slab_group** out) {
+int blub_slab_group_create_rccl_ex(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, const int32_t* cuts, uint32_t memory_mode, blub_slab_group** out) {
     if (!unique_id_128) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null unique id");
-    return blub::slab_group_create(desc, num_ranks, rank, 1, unique_id_128, out, cuts);
+    return blub::slab_group_create(desc, num_ranks, rank, 1, unique_id_128, out, cuts, memory_mode);
 }
 // Host only.  Cut planes that give every slab about the same number of FLUID bricks (the unit the PCG kernels, the list walks and -- through the
 // particles per brick -- the particle kernels scale with): weight of a brick layer = distinct bricks of it that hold a particle, plus a small constant so
@@ -1332,7 +1336,8 @@ int blub_slab_group_set_transport(blub_slab_group* g, int kind) {
     if (g->direct != (kind == 1)) { int rc = blub::slab_refresh_counts(g); if (rc != BLUB_OK) return rc; for (auto& H : g->hist) H = blub_slab_group::Hist(); g->cnt_pending = false; }
     g->direct = kind == 1;
     for (auto de : g->dir_error) (void)hipMemset(de, 0, sizeof(uint32_t));      // a time-out of the transport that is being left (or re-entered) is history (round-4 ADVICE)
-    if (g->direct) snprintf(g->transport, sizeof g->transport, "direct (peer-mapped stores + flags), %d slabs%s", g->nranks, (int)g->slabs.size() == g->nranks ? ", one process" : ", hipIpc");
+    if (g->direct) snprintf(g->transport, sizeof g->transport, "direct (peer-mapped stores + flags), %d slabs%s, %s memory", g->nranks, (int)g->slabs.size() == g->nranks ? ", one process" : ", hipIpc",
+                            g->mem_mode == BLUB_SLAB_MEMORY_COARSE ? "coarse-grained" : (g->mem_mode == BLUB_SLAB_MEMORY_FINE_GRAINED ? "fine-grained" : "uncached"));
     else snprintf(g->transport, sizeof g->transport, "%s", g->rccl ? "rccl" : "loopback");
     return BLUB_OK;
 }

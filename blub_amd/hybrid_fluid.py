@@ -170,6 +170,7 @@ def load_library():
         "blub_fluid_set_pcg_schedule": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_pcg_schedule": (C.c_int, [vp]),
         "blub_fluid_last_solve_path": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "blub_fluid_read_scalar_log": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
         "blub_fluid_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "blub_scene_mesh_desc_at_time": (C.c_int, [C.POINTER(SceneConfig), u32, C.c_uint64, C.c_uint64, C.POINTER(MeshDesc)]),
@@ -448,6 +449,14 @@ class HybridFluid:
         _check(self._L, self._L.blub_fluid_last_solve_path(self._h, int(which), C.byref(a), C.byref(b)))
         return ("reference", "single_reduction")[a.value], ("rows", "bricks", "lod0_literal")[b.value]
 
+    def scalar_log(self, which):
+        """(iterations, 4) float32: {gamma, delta, max|r|, alpha} of every iteration of the last single-reduction solve `which`
+        (include/blubhip.h: blub_fluid_read_scalar_log; needs set_tuning("pcg_scalar_log", 1))."""
+        out = np.zeros((1024, 4), np.float32)
+        n = C.c_int()
+        _check(self._L, self._L.blub_fluid_read_scalar_log(self._h, int(which), _ptr(out), 1024, C.byref(n)))
+        return out[:n.value].copy()
+
     def set_tuning(self, name, value):
         """Performance knobs / test hooks by name (include/blubhip.h: blub_fluid_set_tuning); the library never reads the environment."""
         _check(self._L, self._L.blub_fluid_set_tuning(self._h, name.encode(), int(value)))
@@ -619,7 +628,9 @@ class SlabGroup:
                    torch.distributed by `SlabGroup.from_torch_distributed`.
     """
 
-    def __init__(self, grid_dimension, max_num_particles, local=None, rank=None, world=None, unique_id=None, device=-1, binning="fixed", cuts=None):
+    MEMORY_MODES = {"coarse": 0, "fine_grained": 1, "uncached": 2}      # include/blubhip.h: BLUB_SLAB_MEMORY_*
+
+    def __init__(self, grid_dimension, max_num_particles, local=None, rank=None, world=None, unique_id=None, device=-1, binning="fixed", cuts=None, memory="coarse"):
         self._L = load_library()
         L = self._L
         vp = C.c_void_p
@@ -627,8 +638,8 @@ class SlabGroup:
                 ("blub_rccl_unique_id", C.c_int, [vp]), ("blub_slab_range", C.c_int, [C.c_uint32, C.c_int, C.c_int, vp, vp]),
                 ("blub_slab_group_create_local", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.POINTER(vp)]),
                 ("blub_slab_group_create_rccl", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, C.POINTER(vp)]),
-                ("blub_slab_group_create_local_cuts", C.c_int, [C.POINTER(_FluidDesc), C.c_int, vp, C.POINTER(vp)]),
-                ("blub_slab_group_create_rccl_cuts", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, vp, C.POINTER(vp)]),
+                ("blub_slab_group_create_local_ex", C.c_int, [C.POINTER(_FluidDesc), C.c_int, vp, C.c_uint32, C.POINTER(vp)]),
+                ("blub_slab_group_create_rccl_ex", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, vp, C.c_uint32, C.POINTER(vp)]),
                 ("blub_slab_group_cuts", C.c_int, [vp, vp]),
                 ("blub_slab_group_destroy", None, [vp]), ("blub_slab_group_num_local", C.c_int, [vp]),
                 ("blub_slab_group_local_fluid", vp, [vp, C.c_int]), ("blub_slab_group_local_range", C.c_int, [vp, C.c_int, vp, vp]),
@@ -658,10 +669,10 @@ class SlabGroup:
         if cut_arr is not None and cut_arr.shape != (self.num_slabs + 1,):
             raise ValueError("cuts must hold num_slabs + 1 planes")
         if local is not None:
-            _check(L, L.blub_slab_group_create_local_cuts(C.byref(d), int(local), _ptr(cut_arr), C.byref(self._g)))
+            _check(L, L.blub_slab_group_create_local_ex(C.byref(d), int(local), _ptr(cut_arr), self.MEMORY_MODES[memory], C.byref(self._g)))
         else:
             buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
-            _check(L, L.blub_slab_group_create_rccl_cuts(C.byref(d), int(rank), int(world), buf, _ptr(cut_arr), C.byref(self._g)))
+            _check(L, L.blub_slab_group_create_rccl_ex(C.byref(d), int(rank), int(world), buf, _ptr(cut_arr), self.MEMORY_MODES[memory], C.byref(self._g)))
 
     @staticmethod
     def unique_id():
@@ -713,14 +724,14 @@ class SlabGroup:
         return [int(c) for c in out]
 
     @staticmethod
-    def from_torch_distributed(grid_dimension, max_num_particles, device=-1, binning="fixed", cuts=None):
+    def from_torch_distributed(grid_dimension, max_num_particles, device=-1, binning="fixed", cuts=None, memory="coarse"):
         """One slab per rank of the default process group; rank 0's RCCL id is broadcast (works over gloo or nccl)."""
         import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
         payload = [SlabGroup.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(payload, src=0)
-        return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning, cuts=cuts)
+        return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning, cuts=cuts, memory=memory)
 
     def connect_direct_over_torch_distributed(self):
         """DIRECT transport between the ranks of the default process group: every rank's hipIpc handles are all-gathered over the control plane,

@@ -282,12 +282,18 @@ int blub_fluid_get_pcg_schedule(const blub_fluid* h);
  * sequence of the LOD0 reading.  Either pointer may be NULL.  BLUB_ERR_INVALID_ARGUMENT before the first solve.  (Round-4 ADVICE: a drop-in caller
  * must be able to tell which rounding of the recurrence produced a pressure field.) */
 int blub_fluid_last_solve_path(const blub_fluid* h, int which, int* schedule, int* mapping);
+/* Diagnostic (blub_fluid_set_tuning "pcg_scalar_log" 1 switches it on): the scalars of the most recent single-reduction solve `which`, 4 floats per
+ * iteration i -- {gamma_i = r.u, delta_i = w.u, max|r_i|, alpha_i} exactly as K(i) reduced them from the partial array (pressure_solver.rs:654-723 keeps
+ * the same quantities in its 16-float control buffer).  *count_out = iterations that ran (<= 1024); at most `capacity` entries are copied.  Every slab of
+ * a z-slab group derives bit-identical scalars, whatever the transport: the direct-transport probe compares the logs between ranks and transports. Blocks. */
+int blub_fluid_read_scalar_log(blub_fluid* h, int which, float* out, int capacity, int* count_out);
 /* Performance knobs / test hooks by name (the library never reads the environment).  None changes a result beyond the rounding of a
  * dot-product tree.  "pcg_tail" 0|1: persistent tail kernel of the single-reduction solves; "pcg_tail_first" n: hand over to the tail after
  * exactly n launched iterations (-1: predicted from the last solves); "pcg_tail_margin" n: check intervals launched beyond the prediction;
  * "pcg_tail_inject_timeout" 1 (test hook): the next tail kernel finds its grid barrier timed out -- the solve is reported unfinished
  *   (BLUB_ERR_DEVICE at the next synchronize / update_statistics) and the handle stops using the tail;
  * "pcg1_max_iterations" n (default 64): solves configured with more iterations run schedule 0 even when schedule 1 is selected;
+ * "pcg_scalar_log" 0|1: keep the per-iteration scalars of the single-reduction solves for blub_fluid_read_scalar_log (one 16-byte store per launch);
  * "pcg_launch_grid" n: launch grid of the brick-mapped PCG kernels (0: estimated from the last landed brick count) -- results do not depend on it;
  * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
  * (0 = default for the grid); "dense_kd_nt" -1|0|1: non-temporal stores of the dense direction kernel's output (-1: by grid size);
@@ -363,12 +369,20 @@ int blub_rccl_unique_id(void* out128);
 int blub_slab_range(uint32_t nz, int num_slabs, int index, int32_t* z0, int32_t* z1);   /* host only */
 int blub_slab_group_create_local(const blub_fluid_desc* desc, int num_slabs, blub_slab_group** out);
 int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, blub_slab_group** out);
-/* The same with the caller's cut planes instead of uniform ones: cuts[num_slabs + 1], cuts[0] = 0, strictly increasing multiples of the brick depth (4),
- * cuts[num_slabs] = nz; slab r owns the planes [cuts[r], cuts[r + 1]).  NULL = uniform.  Every slab allocates the plane count of the thickest one (one
- * export layout for the direct transport).  Every rank must pass the same cuts.  (Round-4 review: the metric's scene keeps its fluid in z < 32 and
- * z >= 224 of 256 -- uniform cuts into 8 leave six ranks without fluid.) */
-int blub_slab_group_create_local_cuts(const blub_fluid_desc* desc, int num_slabs, const int32_t* cuts, blub_slab_group** out);
-int blub_slab_group_create_rccl_cuts(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, const int32_t* cuts, blub_slab_group** out);
+/* The same with the caller's cut planes instead of uniform ones and a choice of the memory the slabs live in.
+ * cuts[num_slabs + 1]: cuts[0] = 0, strictly increasing multiples of the brick depth (4), cuts[num_slabs] = nz; slab r owns the planes [cuts[r], cuts[r + 1]).
+ *   NULL = uniform.  Every slab allocates the plane count of the thickest one (one export layout for the direct transport).  Every rank passes the same
+ *   cuts.  (Round-4 review: the metric's scene keeps its fluid in z < 32 and z >= 224 of 256 -- uniform cuts into 8 leave six ranks without fluid.)
+ * memory_mode (what the DIRECT transport's peers write into while kernels run: the volume slab with its ghost planes, the three recurrence volumes, the
+ *   exchange arena with flags / partials / particle staging): BLUB_SLAB_MEMORY_COARSE = hipMalloc.  HIP promises visibility of another agent's writes
+ *   to coarse-grained memory only at kernel boundaries; the transport's write-through stores and cache-bypassing loads (sc0 sc1) are measured to work
+ *   between the XCDs of one device and between processes on one device, but across xGMI that is outside the documented model.
+ *   BLUB_SLAB_MEMORY_FINE_GRAINED / _UNCACHED = hipExtMallocWithFlags(hipDeviceMallocFinegrained / hipDeviceMallocUncached): the documented way to share
+ *   memory between agents while kernels run; cost on one device: profiles/r05_slab_memory_modes.jsonl.  bench.py's probe (blub_amd/direct_probe.py)
+ *   tries COARSE first, then FINE_GRAINED, then falls back to RCCL.  Every rank passes the same mode. */
+enum { BLUB_SLAB_MEMORY_COARSE = 0, BLUB_SLAB_MEMORY_FINE_GRAINED = 1, BLUB_SLAB_MEMORY_UNCACHED = 2 };
+int blub_slab_group_create_local_ex(const blub_fluid_desc* desc, int num_slabs, const int32_t* cuts, uint32_t memory_mode, blub_slab_group** out);
+int blub_slab_group_create_rccl_ex(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, const int32_t* cuts, uint32_t memory_mode, blub_slab_group** out);
 /* Host only: cut planes that give every slab about the same number of FLUID bricks for the given particle positions (16-byte records, as
  * blub_fluid_set_particles takes them) -- the contiguous partition of the brick layers that minimises the heaviest slab, every slab at least
  * `min_layers` brick layers thick (>= 1).  cuts_out: num_slabs + 1 planes; fluid_bricks_out (may be NULL): FLUID bricks per slab at these positions. */

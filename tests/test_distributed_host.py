@@ -121,11 +121,11 @@ PROBE_WORKER = textwrap.dedent("""
 
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% sys.argv[1], rank=int(sys.argv[2]), world_size=2)
     rank, world = dist.get_rank(), dist.get_world_size()
-    ok, why = direct_probe.run(rank, world, 0, timeout=120.0)
+    ok, why, memory = direct_probe.run(rank, world, 0, timeout=120.0)
     verdicts = [None, None]
     dist.all_gather_object(verdicts, (ok, why))
     assert verdicts[0] == verdicts[1], verdicts              # every rank holds the same verdict and the same reason
-    assert ok is False and "probe child" in why, (ok, why)    # (no GPU here: the children cannot create their slab group)
+    assert ok is False and memory is None and "probe child" in why and "coarse:" in why and "fine_grained:" in why, (ok, why)      # (every memory mode was tried)    # (no GPU here: the children cannot create their slab group)
     dist.barrier()
     dist.destroy_process_group()
     print("rank %%d ok: %%s" %% (rank, why[:120]))

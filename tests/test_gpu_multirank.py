@@ -131,7 +131,7 @@ def test_a_rank_that_dies_gives_its_peers_a_communication_error_instead_of_a_han
         assert "pos0" in d.files and "pos1" not in d.files                                      # step 0 completed, step 1 failed
 
 
-@pytest.mark.parametrize("transport", ["rccl", "direct", "auto"])
+@pytest.mark.parametrize("transport", ["rccl", "direct", "auto", "auto_fine_grained"])
 def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per "GPU"), control plane over gloo, data plane through
     the preloaded fake: the z-slab path must produce the JSON line itself -- not the replicas fallback.  BLUB_BENCH_TRANSPORT=direct: the opt-in
@@ -140,6 +140,10 @@ def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
     the single-domain engine -- and the job uses the direct transport because the probe passed."""
     import json
     env = dict(os.environ)
+    fine = transport == "auto_fine_grained"      # the probe is only offered fine-grained slabs (what a node where coarse-grained memory fails it would end up with)
+    if fine:
+        transport = "auto"
+        env["BLUB_DIRECT_PROBE_MODES"] = "fine_grained"
     env["BLUB_BENCH_TRANSPORT"] = transport
     env["LD_PRELOAD"] = _fake_rccl()
     env["FAKE_RCCL_DIR"] = str(tmp_path)
@@ -155,7 +159,10 @@ def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
     if transport in ("direct", "auto"):
         assert "direct" in d["transport"] and "hipIpc" in d["config"]["parallelism"] and d["transport_ops_per_step"] == 12, d
         if transport == "auto":
-            assert d["direct_transport_probe"] == {"passed": True, "detail": "ok"}, d["direct_transport_probe"]
+            pr = d["direct_transport_probe"]
+            assert pr["passed"] is True and pr["detail"] == "ok" and pr["slab_memory"] == ("fine_grained" if fine else "coarse"), pr
+            assert ("fine-grained memory" if fine else "coarse-grained memory") in d["transport"], d["transport"]
+        assert len(d["fluid_bricks_per_rank"]) == 2 and min(d["fluid_bricks_per_rank"]) > 0 and d["config"]["slab_cuts_mode"] == "weighted", d
     else:
         assert "rccl, 2 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
 
