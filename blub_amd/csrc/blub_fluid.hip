@@ -87,6 +87,7 @@ struct blub_fluid {
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     uint32_t precond_mode = BLUB_PRECOND_ZERO, binning_mode = BLUB_BINNING_FIXED;
+    int filter_mode = BLUB_FILTER_SEPARABLE;   // arithmetic of the trilinear filter in R3 and in A1's push-out (blub_fluid_set_filter_mode)
     uint32_t rebin_freq = 60;   // hybrid_fluid.rs:603-605
     uint32_t step_counter = 0;
     // particles (hybrid_fluid.rs:114-122)
@@ -689,10 +690,13 @@ static int stage_advect_particles(blub_fluid* h, float dt, bool insert_lists, bo
     // the reset list (active + stale bricks of this step, own AND ghost bricks) is a superset of the active list
     LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(list_grids(h).reset), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0],
            (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
-    if (h->num_particles)
-        LAUNCH(h, KC_ADVECT, k_advect, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
-               h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, insert_lists ? h->ll[0] : (uint32_t*)nullptr,
-               mark_bricks ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby, (const uint32_t*)h->n_dev, N_OWN);
+    if (h->num_particles) {
+#define BLUB_ADVECT(F) LAUNCH(h, KC_ADVECT, k_advect<F>, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2], \
+               h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, insert_lists ? h->ll[0] : (uint32_t*)nullptr, \
+               mark_bricks ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby, (const uint32_t*)h->n_dev, N_OWN)
+        if (h->filter_mode == BLUB_FILTER_WEIGHTED) BLUB_ADVECT(1); else if (h->filter_mode == BLUB_FILTER_WEIGHTED8) BLUB_ADVECT(2); else BLUB_ADVECT(0);
+#undef BLUB_ADVECT
+    }
     h->bricks_premarked = mark_bricks && h->num_particles != 0;
     return BLUB_OK;
 }
@@ -716,9 +720,11 @@ static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
 static int stage_correct(blub_fluid* h, bool step_done = false) {   // :969-973
     const bool mark = step_done && h->num_ghost == 0;
     if (h->num_particles) {
-        LAUNCH(h, KC_CORRECT, k_correct, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2],
-               step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u, mark ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby,
-               (const uint32_t*)h->n_dev, N_OWN);
+#define BLUB_CORRECT(F) LAUNCH(h, KC_CORRECT, k_correct<F>, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2], \
+               step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u, mark ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby, \
+               (const uint32_t*)h->n_dev, N_OWN)
+        if (h->filter_mode == BLUB_FILTER_WEIGHTED) BLUB_CORRECT(1); else if (h->filter_mode == BLUB_FILTER_WEIGHTED8) BLUB_CORRECT(2); else BLUB_CORRECT(0);
+#undef BLUB_CORRECT
         h->bricks_premarked = mark;
     }
     else if (step_done)
@@ -1233,6 +1239,12 @@ int blub_fluid_set_pcg_schedule(blub_fluid* h, int mode) {
     return BLUB_OK;
 }
 int blub_fluid_get_pcg_schedule(const blub_fluid* h) { return h ? h->pcg_schedule : BLUB_ERR_INVALID_ARGUMENT; }
+int blub_fluid_set_filter_mode(blub_fluid* h, int mode) {
+    if (!h || mode < BLUB_FILTER_SEPARABLE || mode > BLUB_FILTER_WEIGHTED8) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    h->filter_mode = mode;
+    return BLUB_OK;
+}
+int blub_fluid_get_filter_mode(const blub_fluid* h) { return h ? h->filter_mode : BLUB_ERR_INVALID_ARGUMENT; }
 int blub_fluid_read_scalar_log(blub_fluid* h, int which, float* out, int capacity, int* count_out) {
     REQUIRE_HANDLE(h);
     if (which < 0 || which > 1 || !count_out || (capacity > 0 && !out)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");

@@ -562,7 +562,31 @@ __device__ __forceinline__ float4 solid_point_clamp(const float4* __restrict__ s
     const int z = min(max((int)floorf(tz * (float)g.nz), 0), g.nz - 1);
     return solid[cidx(g, x, y, z)];
 }
-template <class Fetch>
+// What Vulkan leaves to the implementation is the ARITHMETIC of the linear filter (spec 16.8.3 gives the weighted sum, hardware evaluates it with
+// fixed-point weights).  FILTER selects it (blub_fluid_set_filter_mode; the three evaluations of the shim that runs the reference's shaders, oracle/glsl/):
+//   0 separable : lerps along x, then y, then z in f32 (what the oracle does; the default)
+//   1 weighted  : the spec's formula in f32, tau = (1-a)(1-b)(1-g) t000 + a(1-b)(1-g) t100 + ..., summed in that order
+//   2 weighted8 : the same with the weights a, b, g truncated to 8 fractional bits (a real sampler: the reference wgpu path on a GPU)
+// each bit-exact against the shim in the same mode (tests/test_gpu_vs_ref.py).
+template <int FILTER>
+__device__ __forceinline__ float trilinear_combine(float t000, float t100, float t010, float t110, float t001, float t101, float t011, float t111, float a, float b, float c) {
+    if (FILTER == 0) {
+        const float c00 = mixf(t000, t100, a), c10 = mixf(t010, t110, a), c01 = mixf(t001, t101, a), c11 = mixf(t011, t111, a);
+        return mixf(mixf(c00, c10, b), mixf(c01, c11, b), c);
+    }
+    if (FILTER == 2) { a = floorf(a * 256.0f) / 256.0f; b = floorf(b * 256.0f) / 256.0f; c = floorf(c * 256.0f) / 256.0f; }
+    const float na = 1.0f - a, nb = 1.0f - b, nc = 1.0f - c;
+    float acc = na * nb * nc * t000;
+    acc = acc + a * nb * nc * t100;
+    acc = acc + na * b * nc * t010;
+    acc = acc + a * b * nc * t110;
+    acc = acc + na * nb * c * t001;
+    acc = acc + a * nb * c * t101;
+    acc = acc + na * b * c * t011;
+    acc = acc + a * b * c * t111;
+    return acc;
+}
+template <int FILTER = 0, class Fetch>
 __device__ __forceinline__ float trilinear_clamp(const Grid& g, Fetch fetch, float tx, float ty, float tz) {
     const float ux = tx * (float)g.nx - 0.5f, uy = ty * (float)g.ny - 0.5f, uz = tz * (float)g.nz - 0.5f;
     const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
@@ -571,15 +595,14 @@ __device__ __forceinline__ float trilinear_clamp(const Grid& g, Fetch fetch, flo
     const int xa = min(max(x0, 0), g.nx - 1), xb = min(max(x0 + 1, 0), g.nx - 1);
     const int ya = min(max(y0, 0), g.ny - 1), yb = min(max(y0 + 1, 0), g.ny - 1);
     const int za = min(max(z0, 0), g.nz - 1), zb = min(max(z0 + 1, 0), g.nz - 1);
-    const float c00 = mixf(fetch(xa, ya, za), fetch(xb, ya, za), fx), c10 = mixf(fetch(xa, yb, za), fetch(xb, yb, za), fx);
-    const float c01 = mixf(fetch(xa, ya, zb), fetch(xb, ya, zb), fx), c11 = mixf(fetch(xa, yb, zb), fetch(xb, yb, zb), fx);
-    return mixf(mixf(c00, c10, fy), mixf(c01, c11, fy), fz);
+    return trilinear_combine<FILTER>(fetch(xa, ya, za), fetch(xb, ya, za), fetch(xa, yb, za), fetch(xb, yb, za), fetch(xa, ya, zb), fetch(xb, ya, zb), fetch(xa, yb, zb), fetch(xb, yb, zb), fx, fy, fz);
 }
 // The same filter for an f32 volume with the x-pairs fetched as ONE 8-byte load each (4-byte aligned): the two x-texels of a
 // pair are neighbours in memory, so the eight scattered 4-byte loads become four 8-byte ones (the particle kernels are
 // issue-bound on the memory pipe: profiles/r01_pmc_sq_sparse_bench.csv, k_correct).  Same values, same arithmetic.
 typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float2_a4 ld_pair_o(const float* base, uint32_t cell) { return *reinterpret_cast<const float2_a4*>(reinterpret_cast<const char*>(base) + cell * 4u); }   // 32-bit offset from a uniform base (see ld4o)
+template <int FILTER = 0>
 __device__ __forceinline__ float trilinear_clamp_f32(const Grid& g, const float* __restrict__ V, float tx, float ty, float tz) {
     const float ux = tx * (float)g.nx - 0.5f, uy = ty * (float)g.ny - 0.5f, uz = tz * (float)g.nz - 0.5f;
     const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
@@ -596,8 +619,7 @@ __device__ __forceinline__ float trilinear_clamp_f32(const Grid& g, const float*
     };
     float a0, a1, b0, b1, c0, c1, d0, d1;
     pair(ya, za, a0, a1); pair(yb, za, b0, b1); pair(ya, zb, c0, c1); pair(yb, zb, d0, d1);
-    const float c00 = mixf(a0, a1, fx), c10 = mixf(b0, b1, fx), c01 = mixf(c0, c1, fx), c11 = mixf(d0, d1, fx);
-    return mixf(mixf(c00, c10, fy), mixf(c01, c11, fy), fz);
+    return trilinear_combine<FILTER>(a0, a1, b0, b1, c0, c1, d0, d1, fx, fy, fz);
 }
 // advect_particles.comp:139-148 / density_projection_correct_particles.comp:51-60 (Q12: literal)
 __device__ __forceinline__ void truncate_step(const float* orig, const float* move, float* dir, float& max_step) {
@@ -615,6 +637,7 @@ __device__ __forceinline__ void truncate_step(const float* orig, const float* mo
 // =================================================================================================================
 // A1: advect_particles.comp:35-194 (G2P + APIC rows + RK4-in-cell + wall handling + marker / density list)
 // =================================================================================================================
+template <int FILTER = 0>
 __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, float dt, float4* __restrict__ pos, float4* __restrict__ pvx,
                                                 float4* __restrict__ pvy, float4* __restrict__ pvz, const float* __restrict__ vx,
                                                 const float* __restrict__ vy, const float* __restrict__ vz, const float4* __restrict__ solid,
@@ -704,9 +727,9 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
             if (solid) {
                 auto sw = [&](int ax, int ay, int az) -> float { return solid[cidx(g, ax, ay, az)].w; };
                 const float push[3] = {
-                    trilinear_clamp(g, sw, tc[0] - inv[0], tc[1], tc[2]) - trilinear_clamp(g, sw, tc[0] + inv[0], tc[1], tc[2]),
-                    trilinear_clamp(g, sw, tc[0], tc[1] - inv[1], tc[2]) - trilinear_clamp(g, sw, tc[0], tc[1] + inv[1], tc[2]),
-                    trilinear_clamp(g, sw, tc[0], tc[1], tc[2] - inv[2]) - trilinear_clamp(g, sw, tc[0], tc[1], tc[2] + inv[2])};
+                    trilinear_clamp<FILTER>(g, sw, tc[0] - inv[0], tc[1], tc[2]) - trilinear_clamp<FILTER>(g, sw, tc[0] + inv[0], tc[1], tc[2]),
+                    trilinear_clamp<FILTER>(g, sw, tc[0], tc[1] - inv[1], tc[2]) - trilinear_clamp<FILTER>(g, sw, tc[0], tc[1] + inv[1], tc[2]),
+                    trilinear_clamp<FILTER>(g, sw, tc[0], tc[1], tc[2] - inv[2]) - trilinear_clamp<FILTER>(g, sw, tc[0], tc[1], tc[2] + inv[2])};
 #pragma unroll
                 for (int k = 0; k < 3; ++k) mv[k] += push[k] * (dt * 50.0f);
             } else {
@@ -750,6 +773,7 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
 // =================================================================================================================
 // step_done_host / step_number: the run-ahead throttle of blub_fluid_step (a counter in pinned host memory; this is the last kernel of a
 // step, and its last workgroup is dispatched when nearly all others have retired -- the throttle needs no more than that)
+template <int FILTER = 0>
 __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles, float4* __restrict__ pos, const int8_t* __restrict__ marker,
                                                  const float* __restrict__ vx, const float* __restrict__ vy, const float* __restrict__ vz,
                                                  volatile uint32_t* step_done_host, uint32_t step_number,
@@ -770,7 +794,7 @@ __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles,
 #pragma unroll
         for (int k = 0; k < 3; ++k) o[k] = fmaxf(0.0f, op[k] - (k == c ? 0.5f : 0.0f));
         const float* V = vel[c];
-        ch[c] = trilinear_clamp_f32(g, V, o[0] * inv[0], o[1] * inv[1], o[2] * inv[2]);
+        ch[c] = trilinear_clamp_f32<FILTER>(g, V, o[0] * inv[0], o[1] * inv[1], o[2] * inv[2]);
     }
     float np[3] = {op[0] + ch[0], op[1] + ch[1], op[2] + ch[2]};
     bool outside = false;

@@ -170,6 +170,8 @@ def load_library():
         "blub_fluid_set_pcg_schedule": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_pcg_schedule": (C.c_int, [vp]),
         "blub_fluid_last_solve_path": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "blub_fluid_set_filter_mode": (C.c_int, [vp, C.c_int]),
+        "blub_fluid_get_filter_mode": (C.c_int, [vp]),
         "blub_fluid_read_scalar_log": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
         "blub_fluid_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
@@ -441,6 +443,15 @@ class HybridFluid:
 
     def pcg_schedule(self):
         return ("reference", "single_reduction")[int(self._L.blub_fluid_get_pcg_schedule(self._h))]
+
+    FILTER_MODES = {"separable": 0, "weighted": 1, "weighted8": 2}
+
+    def set_filter_mode(self, mode):
+        """Arithmetic of the trilinear filter in R3 / A1's push-out: "separable" (default) | "weighted" | "weighted8" (include/blubhip.h)."""
+        _check(self._L, self._L.blub_fluid_set_filter_mode(self._h, self.FILTER_MODES[mode]))
+
+    def filter_mode(self):
+        return {v: k for k, v in self.FILTER_MODES.items()}[int(self._L.blub_fluid_get_filter_mode(self._h))]
 
     def last_solve_path(self, which):
         """(schedule, mapping) the most recently enqueued solve `which` ACTUALLY ran (include/blubhip.h: blub_fluid_last_solve_path): the selected

@@ -282,6 +282,16 @@ int blub_fluid_get_pcg_schedule(const blub_fluid* h);
  * sequence of the LOD0 reading.  Either pointer may be NULL.  BLUB_ERR_INVALID_ARGUMENT before the first solve.  (Round-4 ADVICE: a drop-in caller
  * must be able to tell which rounding of the recurrence produced a pressure field.) */
 int blub_fluid_last_solve_path(const blub_fluid* h, int which, int* schedule, int* mapping);
+/* Arithmetic of the hardware trilinear filter the reference samples with in density_projection_correct_particles.comp:32-40 (R3: the position change) and
+ * advect_particles.comp:155-163 (A1: the push out of a solid).  Vulkan leaves it to the implementation; the three evaluations the shim that runs the
+ * reference's own shaders offers (oracle/glsl/), each reproduced BIT FOR BIT by the engine in the same mode (tests/test_gpu_vs_ref.py):
+ *   BLUB_FILTER_SEPARABLE (default): f32 lerps along x, y, z -- what the oracle evaluates;
+ *   BLUB_FILTER_WEIGHTED: the weighted sum of Vulkan 1.2 16.8.3 in f32 (<= 4e-6 cells from SEPARABLE);
+ *   BLUB_FILTER_WEIGHTED8: the same with 8-bit filter weights -- what a real sampler does, i.e. the closest to "the reference wgpu path on the host's own
+ *     GPU" (<= 3e-3 cells at p99.9 from SEPARABLE in R3).  A quirk switch like the preconditioner reading: it changes results, not speed. */
+enum { BLUB_FILTER_SEPARABLE = 0, BLUB_FILTER_WEIGHTED = 1, BLUB_FILTER_WEIGHTED8 = 2 };
+int blub_fluid_set_filter_mode(blub_fluid* h, int mode);
+int blub_fluid_get_filter_mode(const blub_fluid* h);
 /* Diagnostic (blub_fluid_set_tuning "pcg_scalar_log" 1 switches it on): the scalars of the most recent single-reduction solve `which`, 4 floats per
  * iteration i -- {gamma_i = r.u, delta_i = w.u, max|r_i|, alpha_i} exactly as K(i) reduced them from the partial array (pressure_solver.rs:654-723 keeps
  * the same quantities in its 16-float control buffer).  *count_out = iterations that ran (<= 1024); at most `capacity` entries are copied.  Every slab of

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    config.addinivalue_line("markers", "slow: tens of seconds of CPU (still part of the default CPU suite)")
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -59,6 +59,11 @@ def step_fixture():
         rec = S.run_step_recording(r)
         out["s0_%s/advect/particles" % flt] = rec["advect/particles"]
         out["s0_%s/correct/particles_pos" % flt] = rec["correct/particles_pos"]
+        # (round 5: what `correct` reads in this mode -- the marker after advection and the position-change volumes -- so that an engine with the same
+        #  filter arithmetic can be held to correct/particles_pos bit for bit, tests/test_gpu_vs_ref.py)
+        out["s0_%s/advect/marker" % flt] = rec["advect/marker"]
+        for v in ("vel_x", "vel_y", "vel_z"):
+            out["s0_%s/position_change/%s" % (flt, v)] = rec["position_change/" + v]
     np.savez_compressed(os.path.join(HERE, "ref_step_64x16x32.npz"), **out)
 
 
@@ -125,7 +130,91 @@ def freerun_fixture():
     np.savez_compressed(os.path.join(HERE, "ref_freerun_64x16x32.npz"), **out)
 
 
+def caps_fixture():
+    """Lists beyond the 12- / 32-entry caps of the gathers in a reproducible insertion order (tests/ref_scenarios.py: caps_scene): every recorded array of
+    step 0 up to the density gather."""
+    sc = S.caps_scene()
+    n = len(sc["pos"])
+    ok_p2g = [S.lists_are_wave_local(sc["pos"], off, sc["dim"]) for off in ((1.0, 0.5, 0.5), (0.5, 1.0, 0.5), (0.5, 0.5, 1.0))]
+    assert all(o[0] for o in ok_p2g) and max(o[1] for o in ok_p2g) == 64, ok_p2g
+    out = dict(provenance(), dim=sc["dim"], dt=np.float32(S.DT), gravity=sc["gravity"], solid=sc["solid"], pos_in=sc["pos"], vx_in=sc["vx"], vy_in=sc["vy"], vz_in=sc["vz"])
+    r = RefFluid(*sc["dim"], n + 64)
+    S.configure(r, sc, is_ref=True)
+    r.set_modes(filter="separable")
+    rec = S.run_step_recording(r, stages=S.STAGES[:S.STAGES.index("density_gather") + 1])
+    adv = rec["advect/particles"].view(np.float32)
+    ok_den = S.lists_are_wave_local(adv[:, :3], (0.5, 0.5, 0.5), sc["dim"])
+    assert ok_den[0] and ok_den[1] == 64, ok_den      # the density lists (built from the ADVECTED positions) are still wave-local, the longest holds 64
+    for k, v in rec.items():
+        out["s0/" + k] = v
+    np.savez_compressed(os.path.join(HERE, "ref_caps_64x16x32.npz"), **out)
+
+
+def full_size_scene(name="dam_halfhalf"):
+    """A BASELINE scene at its full size as the backends take it: grid dimension, seeded particles (the oracle's restatement of add_fluid_cube; the
+    product's generator equals it bit for bit, tests/test_host_abi.py), gravity in grid units.  No solids (the shipped fluid-only scenes)."""
+    import json
+    from oracle.oracle import Oracle
+    cfg = json.load(open(os.path.join(ROOT, "scenes", name + ".json")))
+    fl = cfg["fluid"]
+    dim = (int(fl["grid_dimension"]["x"]), int(fl["grid_dimension"]["y"]), int(fl["grid_dimension"]["z"]))
+    scale = np.float32(fl["grid_to_world_scale"])
+    o = Oracle(dim[0], dim[1], dim[2], int(fl["max_num_particles"]))
+    for c in fl["fluid_cubes"]:
+        mn = np.float32([c["min"][k] for k in "xyz"]) / scale
+        mx = np.float32([c["max"][k] for k in "xyz"]) / scale
+        o.add_fluid_cube(mn, mx)
+    pos = o.get_particles()[0][:, :3].copy()
+    g = np.float32([cfg["gravity"][k] for k in "xyz"]) / scale      # scene/mod.rs:139
+    return dim, pos, g
+
+
+def fullsize_fixture(name="dam_halfhalf"):
+    """Round-4 review, item 4a: a reference-shader fixture at a BASELINE size.  Step 0 of scenes/dam_halfhalf.json (128 x 64 x 64, 1 218 672 particles,
+    the reference's default solver configuration) through the reference's own shaders, stage by stage -- minutes of CPU, so only the SHA-256 of
+    every recorded array is kept (plus the solver statistics and two planes of the final pressure for eyeballing).  The oracle must reproduce every
+    hash (tests/test_oracle_vs_ref.py, slow), which carries the pin to the full-size arrays the engine is compared with on the GPU."""
+    import time
+    dim, pos, g = full_size_scene(name)
+    n = len(pos)
+    out = dict(provenance(), scene=np.array(name), dim=np.array(dim), dt=np.float32(S.DT), gravity=g, num_particles=np.int64(n), pos_in_sha=np.array(sha(pos)))
+    r = RefFluid(dim[0], dim[1], dim[2], n + 64)
+    r.set_gravity_grid(g)
+    for w in (0, 1):
+        r.set_solver_config(w, error_tolerance=0.1, max_num_iterations=32, error_check_frequency=4)
+    r.set_modes(precond="zero", filter="separable")
+    r.binning_enabled = False
+    r.set_particles(pos)
+    for step in range(2):      # step 0 stage by stage, step 1 chained behind it
+        keys, hashes = [], []
+        for st in S.STAGES:
+            t0 = time.time()
+            r.run_stage(st, S.DT)
+            for what in S.STAGE_OUTPUTS[st]:
+                a = S.capture(r, what)
+                keys.append("%s/%s" % (st, what)); hashes.append(sha(a))
+                if what.startswith("stats"):
+                    out["s%d/%s/%s" % (step, st, what)] = a
+            print("step %d %s: %.1f s" % (step, st, time.time() - t0), flush=True)
+        r.step_counter += 1
+        out["s%d/keys" % step] = np.array(keys)
+        out["s%d/sha" % step] = np.array(hashes)
+    pv = r.read_volume("pressure_velocity")
+    out["s0/pressure_velocity_planes"] = np.stack([pv[dim[2] // 4], pv[dim[2] // 2]])
+    np.savez_compressed(os.path.join(HERE, "ref_fullsize_%s.npz" % name), **out)
+
+
 if __name__ == "__main__":
+    if "fullsize" in sys.argv[1:] or "caps" in sys.argv[1:] or "step" in sys.argv[1:]:      # (single fixtures: fullsize = the BASELINE-size one -- minutes)
+        if ref_fluid.build(force=False) is None:
+            sys.exit("the reference checkout is not available: cannot regenerate the reference fixtures")
+        if "fullsize" in sys.argv[1:]:
+            fullsize_fixture()
+        if "caps" in sys.argv[1:]:
+            caps_fixture()
+        if "step" in sys.argv[1:]:
+            step_fixture()
+        sys.exit(0)
     if ref_fluid.build(force="freerun" not in sys.argv[1:]) is None:
         sys.exit("the reference checkout is not available: cannot regenerate the reference fixtures")
     if "freerun" not in sys.argv[1:]:      # (`make_ref_golden.py freerun`: only the free-running fixture)

@@ -54,6 +54,69 @@ def step_scene(seed=2024, dim=STEP_DIM, solids=True):
     return dict(dim=np.array(dim), pos=pos, vx=vel[0], vy=vel[1], vz=vel[2], solid=solid, gravity=np.array([0.0, -981.0, 0.0], np.float32))
 
 
+CAPS_COUNTS = (64, 40, 33, 32, 20, 13, 12, 5)
+
+
+def caps_scene(seed=77, dim=STEP_DIM):
+    """Lists LONGER than the caps of the two gathers -- 12 rounds in P2G (transfer_gather_velocity.comp:61), 32 in the density gather
+    (density_projection_gather_error.comp:69) -- in an insertion order an engine can reproduce.  WHICH particles a longer list keeps is the order
+    of the atomic exchanges: ascending particle index in the shim, a race on a GPU -- except for particles of ONE wavefront, which insert together.
+    So the particles come in blocks of 64 consecutive indices; block k puts n_k of them (n_k cycles through 64, 40, 33, 32, 20, 13, 12, 5) into
+    cell c_k of a blob and the other 64 - n_k into cell d_k of a second blob, all at c + f with f in (0.62, 0.92)^3: every one of the four dual
+    cells of a particle (three staggered P2G lists, the density list) is then the same for the whole sub-block, every list lives inside one block
+    of 64, and the small fall of one step (g dt^2 = 0.07 cells) keeps the density dual cell.  Small random velocities and APIC rows that differ from
+    particle to particle (sigma 0.5 cells / s: 0.004 cells per step), so that WHICH 12 of a 64-entry list enter a face's average shows in the result
+    at the 1e-1 level; no solids."""
+    rng = np.random.default_rng(seed)
+    a = np.stack(np.meshgrid(np.arange(3, 11), np.arange(3, 8), np.arange(4, 10), indexing="ij"), -1).reshape(-1, 3)        # 240 cells
+    b = np.stack(np.meshgrid(np.arange(30, 38), np.arange(3, 8), np.arange(14, 20), indexing="ij"), -1).reshape(-1, 3)      # 240 cells
+    pos = []
+    for k in range(len(a)):
+        n = CAPS_COUNTS[k % len(CAPS_COUNTS)]
+        f = 0.62 + 0.30 * rng.random((64, 3))
+        cell = np.where((np.arange(64) < n)[:, None], a[k][None, :], b[k][None, :])
+        pos.append(cell + f)
+    pos = np.concatenate(pos).astype(np.float32)
+    vel = []
+    for c in range(3):
+        rows = np.zeros((len(pos), 4), np.float32)
+        rows[:, :3] = (rng.standard_normal((len(pos), 3)) * 0.2).astype(np.float32)
+        rows[:, 3] = (rng.standard_normal(len(pos)) * 0.5).astype(np.float32)
+        vel.append(rows)
+    return dict(dim=np.array(dim), pos=pos, vx=vel[0], vy=vel[1], vz=vel[2], solid=np.zeros(tuple(dim[::-1]) + (4,), np.float32),
+                gravity=np.array([0.0, -981.0, 0.0], np.float32))
+
+
+def sequential_lists(pos, offset, dim):
+    """The linked lists a SEQUENTIAL insertion in ascending particle index leaves (the shim's order, transfer_build_linkedlist.comp:25:
+    next = atomicExchange(head, i + 1) - 1): (heads volume [z, y, x] uint32 with index + 1, next per particle uint32, 0xFFFFFFFF = end)."""
+    c = np.floor(pos[:, :3].astype(np.float32) - np.float32(offset)).astype(np.int64)
+    nx, ny, nz = (int(v) for v in dim)
+    inb = (c >= 0).all(1) & (c[:, 0] < nx) & (c[:, 1] < ny) & (c[:, 2] < nz)
+    key = (c[:, 2] * ny + c[:, 1]) * nx + c[:, 0]
+    heads = np.zeros(nx * ny * nz, np.uint32)
+    nxt = np.full(len(pos), 0xFFFFFFFF, np.uint32)
+    idx = np.nonzero(inb)[0]
+    order = idx[np.argsort(key[idx], kind="stable")]          # by cell, ascending index inside a cell
+    k = key[order]
+    first = np.ones(len(order), bool); first[1:] = k[1:] != k[:-1]
+    last = np.ones(len(order), bool); last[:-1] = k[1:] != k[:-1]
+    nxt[order[~first]] = order[np.nonzero(~first)[0] - 1].astype(np.uint32)
+    heads[k[last]] = (order[last] + 1).astype(np.uint32)
+    return heads.reshape(nz, ny, nx), nxt
+
+
+def lists_are_wave_local(pos, offset, dim):
+    """every dual cell floor(pos - offset) holds particles of ONE block of 64 consecutive indices only"""
+    c = np.floor(pos[:, :3].astype(np.float32) - np.float32(offset)).astype(np.int64)
+    key = (c[:, 2] * int(dim[1]) + c[:, 1]) * int(dim[0]) + c[:, 0]
+    blk = np.arange(len(pos)) // 64
+    order = np.argsort(key, kind="stable")
+    k, b = key[order], blk[order]
+    same = k[1:] == k[:-1]
+    return bool(np.all(b[1:][same] == b[:-1][same])), np.bincount(np.unique(key, return_inverse=True)[1]).max()
+
+
 def configure(backend, scene, precond="zero", max_iter=32, tol=0.1, freq=4, is_ref=False):
     backend.set_gravity_grid(scene["gravity"])
     for w in (0, 1):

@@ -128,10 +128,31 @@ def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
         # (no monotonicity claim: with this smooth right-hand side and the z = r/d^2 preconditioner max|r| first grows --
         #  the CPU oracle shows 217 / 75 / 94 / 77 after 4 / 8 / 16 / 24 iterations at 128^3 -- CG minimises the A-norm of the error)
         if n == 128:
-            # max|r| of this UNCONVERGED iterate is a rounding amplifier: the oracle reports 76.57 with f64 dot products and 92.60 with f32
-            # ones (Oracle.set_dot_mode, nothing else changed) -- the engine's f32 trees are a third rounding (measured: 71.5 on the brick
-            # mapping, 73.7 with the single-reduction schedule), so the statement is an envelope of that width
-            assert abs(np.abs(r[fluid]).max() - 76.57) < 20.0
+            # max|r| of this UNCONVERGED iterate is a rounding amplifier (the oracle reports 76.57 with f64 dot products and 92.60 with f32 ones, the
+            # engine's f32 trees 71.5 - 73.7): an envelope around it says nothing (round-4 review, item 4d: the +-20 assertion that stood here).  What CG
+            # minimises is the energy phi(p) = p.Ap / 2 - b.p (the A-norm of the error up to a constant), and THAT is insensitive to the rounding of the
+            # dots: the engine's iterate must reach the energy of the oracle's 24th iterate (f64 dots) to 1e-4 -- a solver that lost an iteration, dropped
+            # a neighbour term or used a wrong alpha anywhere would miss it by percents.
+            from oracle.oracle import Oracle
+            o = Oracle(n, n, n, 16)
+            o.set_quirks(precond="zero", binning="off")
+            o.write_volume("marker", marker)
+            o.write_volume("residual", b)
+            o.write_volume("pressure_velocity", np.zeros_like(b))
+            o.reset_pressure_cleared(0, True)
+            o.set_solver_config(0, error_tolerance=0.0, max_num_iterations=24, error_check_frequency=4)
+            o.run_stage("solve_velocity", util.DT)
+            po = o.read_volume("pressure_velocity").astype(np.float64)
+
+            def energy(q):
+                Aq = np.zeros_like(q)
+                for axis in range(3):
+                    for sft in (-1, 1):
+                        Aq -= np.roll(q, sft, axis) * np.roll(fluid, sft, axis)
+                Aq = (Aq + diag * q) * fluid
+                return 0.5 * float((q * Aq).sum()) - float((b.astype(np.float64) * q).sum())
+            e_engine, e_oracle = energy(p), energy(po)
+            assert e_oracle < 0 and abs(e_engine - e_oracle) <= 1e-4 * abs(e_oracle), (mapping, e_engine, e_oracle)
         # linearity: solving 2b from the same start gives 2p (CG is scale invariant)
         h.write_volume("residual", 2 * b)
         h.mark_pressure_initialised(0, False)

@@ -61,7 +61,7 @@ def step_fx():
 def test_reference_fixtures_are_current():
     """The fixtures name the shader sources and the recipe they were made from; where the reference is present they must still match."""
     ref_shaders = "/root/reference/shader"
-    for name in ("ref_step_64x16x32.npz", "ref_pcg_32x64x16.npz", "ref_binning_64x16x32.npz", "ref_freerun_64x16x32.npz"):
+    for name in ("ref_step_64x16x32.npz", "ref_pcg_32x64x16.npz", "ref_binning_64x16x32.npz", "ref_freerun_64x16x32.npz", "ref_caps_64x16x32.npz", "ref_fullsize_dam_halfhalf.npz"):
         fx = np.load(os.path.join(GOLD, name))
         listed = dict(line.split("  ")[::-1] for line in str(fx["shader_sha256"]).strip().split("\n"))
         assert len(listed) >= 28 and "simulation/transfer_gather_velocity.comp" in listed
@@ -90,6 +90,55 @@ def test_every_stage_of_a_step_matches_the_reference_shaders_bit_for_bit(step_fx
     c = sc["pos"].astype(int)
     assert (sc["solid"][c[:, 2], c[:, 1], c[:, 0], 3] > 0).sum() > 100, "no particle starts inside a solid voxel (escape path)"
     assert rec["solve_velocity/stats0"][1] >= 4 and rec["solve_density/stats1"][1] >= 4
+
+
+def test_lists_beyond_the_gather_caps_match_the_reference_shaders_bit_for_bit():
+    """Round-4 review, item 4b: P2G lists of up to 64 entries against the 12-round cap (transfer_gather_velocity.comp:61), density lists of up to 64
+    against the 32-round cap (density_projection_gather_error.comp:69) -- the reference's shaders decide which particles take part (the first 12 / 32
+    from the head: the LAST inserted), the oracle has to keep the same ones."""
+    fx = dict(np.load(os.path.join(GOLD, "ref_caps_64x16x32.npz")))
+    sc = scene_from_fixture(fx)
+    o = Oracle(*sc["dim"], len(sc["pos"]) + 64)
+    S.configure(o, sc)
+    stages = S.STAGES[:S.STAGES.index("density_gather") + 1]
+    rec = S.run_step_recording(o, float(fx["dt"]), stages=stages)
+    assert set("s0/" + k for k in rec) == set(k for k in fx if k.startswith("s0/"))
+    for k, v in rec.items():
+        assert_bits(k, v, fx["s0/" + k])
+    # the scene does what it was built for: list lengths beyond both caps, every list inside one block of 64 consecutive particles
+    for off in ((1.0, 0.5, 0.5), (0.5, 1.0, 0.5), (0.5, 0.5, 1.0)):
+        local, longest = S.lists_are_wave_local(sc["pos"], off, sc["dim"])
+        assert local and longest == 64
+    adv = rec["advect/particles"].view(np.float32)
+    local, longest = S.lists_are_wave_local(adv[:, :3], (0.5, 0.5, 0.5), sc["dim"])
+    assert local and longest == 64
+    # ... and the caps bite: the density of a cell whose list holds 64 particles counts 32 of them (rho <= 32 there; all 64 would give ~40)
+    assert np.abs(rec["density_gather/residual@fluid"]).max() > 0
+
+
+@pytest.mark.slow
+def test_a_full_size_step_matches_the_reference_shaders_hash_for_hash():
+    """Round-4 review, item 4a: scenes/dam_halfhalf.json (128 x 64 x 64, 1 218 672 particles -- BASELINE configs[1]) through the reference's own shaders,
+    two chained steps, every recorded array as a SHA-256 (tests/golden/ref_fullsize_dam_halfhalf.npz; make_ref_golden.py fullsize).  The oracle in the
+    reference's literal reduction order reproduces every hash: the pin reaches the full-size arrays the engine is compared with on the GPU
+    (tests/test_gpu_vs_ref.py::test_full_size_step...)."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_ref_golden as G
+    fx = dict(np.load(os.path.join(GOLD, "ref_fullsize_dam_halfhalf.npz")))
+    dim, pos, g = G.full_size_scene(str(fx["scene"]))
+    assert tuple(fx["dim"]) == dim and len(pos) == int(fx["num_particles"]) and sha(pos) == str(fx["pos_in_sha"])
+    o = Oracle(dim[0], dim[1], dim[2], len(pos) + 64)
+    o.set_gravity_grid(g)
+    o.set_quirks(precond="zero", binning="off")
+    o.set_dot_mode(2)
+    o.set_particles(pos)
+    for step in range(2):
+        want = dict(zip(fx["s%d/keys" % step], fx["s%d/sha" % step]))
+        for st in S.STAGES:
+            o.run_stage(st, float(fx["dt"]))
+            for what in S.STAGE_OUTPUTS[st]:
+                assert sha(S.capture(o, what)) == want["%s/%s" % (st, what)], "step %d %s/%s differs from the reference's shaders" % (step, st, what)
+        o.step_counter = o.step_counter + 1
 
 
 def test_three_chained_steps_match_the_reference_shaders_bit_for_bit(step_fx):
