@@ -131,8 +131,9 @@ def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
             # max|r| of this UNCONVERGED iterate is a rounding amplifier (the oracle reports 76.57 with f64 dot products and 92.60 with f32 ones, the
             # engine's f32 trees 71.5 - 73.7): an envelope around it says nothing (round-4 review, item 4d: the +-20 assertion that stood here).  What CG
             # minimises is the energy phi(p) = p.Ap / 2 - b.p (the A-norm of the error up to a constant), and THAT is insensitive to the rounding of the
-            # dots: the engine's iterate must reach the energy of the oracle's 24th iterate (f64 dots) to 1e-4 -- a solver that lost an iteration, dropped
-            # a neighbour term or used a wrong alpha anywhere would miss it by percents.
+            # dots: the engine's iterate must reach the energy of the oracle's 24th iterate (f64 dots) to 5e-4 (measured: < 1e-4 with the reference's
+            # order of operations, 1.8e-4 with the single-reduction recurrence) -- a solver that lost an iteration, dropped a neighbour term or used a
+            # wrong alpha anywhere would miss it by percents.
             from oracle.oracle import Oracle
             o = Oracle(n, n, n, 16)
             o.set_quirks(precond="zero", binning="off")
@@ -152,7 +153,8 @@ def test_pcg_full_grid_solution_satisfies_the_linear_system(n, mapping):
                 Aq = (Aq + diag * q) * fluid
                 return 0.5 * float((q * Aq).sum()) - float((b.astype(np.float64) * q).sum())
             e_engine, e_oracle = energy(p), energy(po)
-            assert e_oracle < 0 and abs(e_engine - e_oracle) <= 1e-4 * abs(e_oracle), (mapping, e_engine, e_oracle)
+            print("energy after 24 iterations, %s: engine %.8g oracle %.8g (relative difference %.3g)" % (mapping, e_engine, e_oracle, abs(e_engine - e_oracle) / abs(e_oracle)))
+            assert e_oracle < 0 and abs(e_engine - e_oracle) <= 5e-4 * abs(e_oracle), (mapping, e_engine, e_oracle)
         # linearity: solving 2b from the same start gives 2p (CG is scale invariant)
         h.write_volume("residual", 2 * b)
         h.mark_pressure_initialised(0, False)
