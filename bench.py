@@ -330,23 +330,67 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
         torch.cuda.synchronize()
         if active:
             group.synchronize()
+    def all_agree_ok(local_ok):
+        """collective: did every rank get through without a (recoverable) transport error?"""
+        flag = torch.tensor([0.0 if local_ok else 1.0], device=ctl)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return float(flag.item()) == 0.0
+
+    def guarded(fn):
+        """A timed-out wait of the direct transport (BLUB_ERR_COMM: a peer seconds late) is recoverable in place; anything else is not."""
+        try:
+            fn()
+            return True
+        except blub_amd.BlubError as e:
+            if e.status != -8 or transport != "direct":
+                raise
+            sys.stderr.write("rank %d: %s\n" % (rank, e))
+            return False
+    res["recovered_in_place"] = 0
     try:
-        for _ in range(warmup):
+        if active and transport == "direct":
+            group.set_checkpoint_interval(int(os.environ.get("BLUB_BENCH_CHECKPOINT_INTERVAL", "16")))      # (one pass over the particles + pressure every 16th step)
+        attempts = 0
+        stall = os.environ.get("BLUB_BENCH_STALL", "").split(":") if os.environ.get("BLUB_BENCH_STALL") else None      # "rank:step:seconds"
+        while True:
+            def window():
+                for _ in range(warmup):
+                    if active:
+                        group.step(dt)
+                if transport == "direct" and os.environ.get("BLUB_BENCH_FAIL_DIRECT"):      # (test hook: the second attempt over RCCL)
+                    raise RuntimeError("injected failure of the direct transport")
+                if active:
+                    group.synchronize()
+            ok_w = guarded(window)
+            dist.barrier()
+            torch.cuda.synchronize()
+            fluid0 = group.local_fluid(0) if active else None
+            it0 = fluid0.total_solver_iterations() if active else 0
+            t0 = time.perf_counter()
+
+            def timed():
+                for k in range(steps):
+                    if stall and attempts == 0 and rank == int(stall[0]) and k == int(stall[1]):      # (test hook: this rank falls seconds behind once)
+                        time.sleep(float(stall[2]))
+                    if active:
+                        group.step(dt)
+                if active:
+                    group.synchronize()
+            ok_t = guarded(timed) if ok_w else False
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            if all_agree_ok(ok_w and ok_t):
+                break
+            attempts += 1
+            if attempts > 2 or transport != "direct":
+                raise RuntimeError("the direct transport timed out again after %d in-place recoveries" % (attempts - 1))
+            # round-4 review, item 5: one late peer must not end in `value: null` -- every rank goes back to the newest checkpoint all of them hold and
+            # the window is run again from there
             if active:
-                group.step(dt)
-        if transport == "direct" and os.environ.get("BLUB_BENCH_FAIL_DIRECT"):      # (test hook: the second attempt over RCCL)
-            raise RuntimeError("injected failure of the direct transport")
-        barrier()
-        fluid0 = group.local_fluid(0) if active else None
-        it0 = fluid0.total_solver_iterations() if active else 0
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            if active:
-                group.step(dt)
-        if active:
-            group.synchronize()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+                back = group.recover_over_torch_distributed()
+                if rank == 0:
+                    sys.stderr.write("bench.py: a wait of the direct transport timed out; recovered in place to step %d, running the window again\n" % back)
+            res["recovered_in_place"] = attempts
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         res["elapsed"] = float(t.item())
@@ -423,7 +467,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
                        "slab_cuts": res["cuts"], "slab_cuts_mode": res["cuts_mode"]},
             "fluid_bricks_per_rank": res["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": res["fluid_bricks_per_rank_uniform_cuts"],
             "pcg_iters_per_step": res["pcg_iters_per_step"], "transport_ops_per_step": res["transport_ops_per_step"],
-            "transport": res["transport"], "direct_transport_probe": probe, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "roofline": None, "cpu_baseline": None}
+            "transport": res["transport"], "recovered_in_place": res["recovered_in_place"], "direct_transport_probe": probe, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "roofline": None, "cpu_baseline": None}
     # ---- secondary: the size the decomposition is for (BASELINE configs[4]): corner_dams_512, strong scaling over the same ranks.  A failure or stall
     # here costs only this object: the primary result above is printed either way.
     secondary = None

@@ -317,6 +317,41 @@ __global__ __launch_bounds__(256) void k_slab_push_particles(SlabParticlePush up
     }
 }
 
+// ---- checkpoints of the restartable state (round 5: in-place recovery of a group after a timed-out wait of the direct transport) --------------------
+// What survives a step: the particles (position + three APIC rows), the two pressure volumes (warm starts), the counts.  A generation
+// is only ever written while the slab's time-out mark is clear, so every generation a slab holds was taken before its first failed wait.
+struct SlabCheckpoint { float4* part[4]; float* pressure[2]; uint32_t* n; uint32_t* step; };      // device buffers of ONE generation
+__global__ __launch_bounds__(256) void k_slab_checkpoint(SlabCheckpoint ck, const float4* __restrict__ pos, const float4* __restrict__ vx, const float4* __restrict__ vy,
+                                                         const float4* __restrict__ vz, const float* __restrict__ p0, const float* __restrict__ p1, uint32_t vol_quads,
+                                                         const uint32_t* __restrict__ n_dev, uint32_t n_host, const uint32_t* __restrict__ dir_error, uint32_t step) {
+    if (dir_error && __hip_atomic_load(dir_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // (uniform) never overwrite a good generation with a doubtful state
+    const uint32_t n = n_dev ? n_dev[0] : n_host;
+    const float4* src[4] = {pos, vx, vy, vz};
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ck.part[k][i] = src[k][i];
+    }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < vol_quads; i += gridDim.x * 256) {
+        reinterpret_cast<float4*>(ck.pressure[0])[i] = reinterpret_cast<const float4*>(p0)[i];
+        reinterpret_cast<float4*>(ck.pressure[1])[i] = reinterpret_cast<const float4*>(p1)[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ck.n[0] = n; *ck.step = step; }
+}
+__global__ __launch_bounds__(256) void k_slab_restore(SlabCheckpoint ck, float4* __restrict__ pos, float4* __restrict__ vx, float4* __restrict__ vy, float4* __restrict__ vz,
+                                                      float* __restrict__ p0, float* __restrict__ p1, uint32_t vol_quads, uint32_t* __restrict__ n_dev) {
+    const uint32_t n = ck.n[0];
+    float4* dst[4] = {pos, vx, vy, vz};
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k][i] = ck.part[k][i];
+    }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < vol_quads; i += gridDim.x * 256) {
+        reinterpret_cast<float4*>(p0)[i] = reinterpret_cast<const float4*>(ck.pressure[0])[i];
+        reinterpret_cast<float4*>(p1)[i] = reinterpret_cast<const float4*>(ck.pressure[1])[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_dev) { n_dev[0] = n; n_dev[1] = 0u; n_dev[2] = 0u; }
+}
+
 // Dot products across slabs: every slab's PCG kernels write their per-block partials into segment `rank` of a gather array
 // of nranks x SLAB_NP entries; after the segments have been exchanged (p2p, see slab_gather) the unchanged consumer kernels
 // re-reduce all nranks x SLAB_NP partials in the same fixed order on every slab => identical scalars and identical

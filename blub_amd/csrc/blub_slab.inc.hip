@@ -72,6 +72,11 @@ struct blub_slab_group {
     std::vector<uint32_t*> flags, blocks_done, dir_error;   // [local slab]: flag words (one per source rank), finished-workgroup counter, time-out marker
     uint32_t flag_seq = 0;                          // exchanges issued so far (the same number on every rank)
     blubk::SlabFlagList push_flags{};               // flags the pending batched push raises
+    // ---- checkpoints / in-place recovery (round 5): two generations of the restartable state per local slab, taken every `ck_interval` steps
+    uint32_t ck_interval = 0;
+    std::vector<blubk::SlabCheckpoint> ck[2];       // [generation][local slab]
+    std::vector<void*> ck_allocs;
+    uint32_t* ck_step_host = nullptr;               // pinned: [generation][local slab] step numbers as read back by blub_slab_group_checkpoints
 };
 
 namespace blub {
@@ -920,6 +925,7 @@ static void slab_group_destroy(blub_slab_group* G) {
     if (G->stream) (void)hipStreamSynchronize(G->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     for (void* m : G->ipc_opened) (void)hipIpcCloseMemHandle(m);
+    for (void* a : G->ck_allocs) F(a);
     for (auto& ar : G->arena) F(ar.base);
     for (auto h : G->slabs) { h->n_dev = nullptr; destroy(h); }
     if (G->rec_host) (void)hipHostFree(G->rec_host);
@@ -932,6 +938,37 @@ static void slab_group_destroy(blub_slab_group* G) {
     if (G->comm) (void)ncclCommDestroy(G->comm);   // (nullptr after an abort)
     if (G->stream) (void)hipStreamDestroy(G->stream);
     delete G;
+}
+
+// One generation of the restartable state of every local slab (see blub_slab.hip.h: SlabCheckpoint); generation = (step / interval) & 1
+static int slab_checkpoint_alloc(blub_slab_group* G) {
+    if (!G->ck[0].empty()) return BLUB_OK;
+    for (int gen = 0; gen < 2; ++gen)
+        for (auto h : G->slabs) {
+            blubk::SlabCheckpoint c{};
+            for (int k = 0; k < 4; ++k) { HIP_TRY(hipMalloc((void**)&c.part[k], (size_t)G->capacity * sizeof(float4))); G->ck_allocs.push_back(c.part[k]); }
+            for (int k = 0; k < 2; ++k) { HIP_TRY(hipMalloc((void**)&c.pressure[k], h->vol_cells * sizeof(float))); G->ck_allocs.push_back(c.pressure[k]); }
+            HIP_TRY(hipMalloc((void**)&c.n, 4 * sizeof(uint32_t))); G->ck_allocs.push_back(c.n);
+            HIP_TRY(hipMalloc((void**)&c.step, sizeof(uint32_t))); G->ck_allocs.push_back(c.step);
+            HIP_TRY(hipMemsetAsync(c.step, 0xFF, sizeof(uint32_t), G->stream));      // 0xFFFFFFFF: no generation yet
+            HIP_TRY(hipMemsetAsync(c.n, 0, 4 * sizeof(uint32_t), G->stream));
+            G->ck[gen].push_back(c);
+        }
+    return BLUB_OK;
+}
+static int slab_checkpoint(blub_slab_group* G) {
+    int rc = slab_checkpoint_alloc(G);
+    if (rc != BLUB_OK) return rc;
+    const uint32_t step = G->slabs[0]->step_counter;
+    const int gen = (int)((step / G->ck_interval) & 1u);
+    for (size_t i = 0; i < G->slabs.size(); ++i) {
+        blub_fluid* h = G->slabs[i];
+        // (host-side counts are exact until the first asynchronous exchange replaced them by bounds; the device copy is current either way once uploaded)
+        hipLaunchKernelGGL(blubk::k_slab_checkpoint, dim3(1024), dim3(256), 0, G->stream, G->ck[gen][i], (const float4*)h->pos, (const float4*)h->pvel[0], (const float4*)h->pvel[1],
+                           (const float4*)h->pvel[2], (const float*)(h->pressure[0] + h->vol_first), (const float*)(h->pressure[1] + h->vol_first), (uint32_t)(h->vol_cells / 4),
+                           (const uint32_t*)h->n_dev, h->num_particles, (const uint32_t*)G->dir_error[i], step);
+    }
+    return BLUB_OK;
 }
 
 // z-range of slab `index` of `nranks`: whole bricks, as even as possible
@@ -1219,6 +1256,64 @@ int blub_slab_balanced_cuts(const uint32_t grid_dim[3], uint32_t n, const float*
         for (int r = 0; r < num_slabs; ++r) { double b = 0.0; for (int l = first[(size_t)r]; l < first[(size_t)r + 1]; ++l) b += bricks[(size_t)l]; fluid_bricks_out[r] = (uint32_t)b; }
     return BLUB_OK;
 }
+// ---- checkpoints and in-place recovery (direct transport) ----------------------------------------------------------------------------------------
+int blub_slab_group_set_checkpoint_interval(blub_slab_group* g, uint32_t every_n_steps) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    g->ck_interval = every_n_steps;
+    return every_n_steps ? blub::slab_checkpoint_alloc(g) : BLUB_OK;
+}
+int blub_slab_group_checkpoints(blub_slab_group* g, uint32_t steps_out[2]) {
+    if (!g || !steps_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    steps_out[0] = steps_out[1] = 0xFFFFFFFFu;
+    if (g->ck[0].empty()) return BLUB_OK;
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    for (int gen = 0; gen < 2; ++gen) {
+        // a generation counts only if EVERY local slab holds the same step (they are written together; a slab whose time-out mark was set skipped it)
+        uint32_t common = 0xFFFFFFFFu; bool first = true;
+        for (auto& c : g->ck[gen]) {
+            uint32_t v = 0xFFFFFFFFu;
+            HIP_TRY(hipMemcpy(&v, c.step, sizeof v, hipMemcpyDeviceToHost));
+            if (first) { common = v; first = false; } else if (v != common) common = 0xFFFFFFFFu;
+        }
+        steps_out[gen] = common;
+    }
+    return BLUB_OK;
+}
+int blub_slab_group_exchange_sequence(const blub_slab_group* g, uint32_t* seq_out) {
+    if (!g || !seq_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    *seq_out = g->flag_seq;
+    return BLUB_OK;
+}
+// Collective (every rank, the same arguments), after EVERY rank has drained its stream (blub_slab_group_synchronize -- which reports and clears the
+// time-out -- then a barrier of the caller's control plane): back to the checkpoint of `step`, exchange sequence numbers restarted at `sequence_base`
+// (larger than any number a rank has issued: the ranks stopped at different points of the step that failed).
+int blub_slab_group_restore(blub_slab_group* g, uint32_t step, uint32_t sequence_base) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted: a group on the RCCL transport cannot be recovered in place");
+    uint32_t have[2];
+    { int rc = blub_slab_group_checkpoints(g, have); if (rc != BLUB_OK) return rc; }
+    int gen = -1;
+    for (int k = 0; k < 2; ++k) if (have[k] == step && step != 0xFFFFFFFFu) gen = k;
+    if (gen < 0) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "no checkpoint of that step is held (blub_slab_group_checkpoints)");
+    for (size_t i = 0; i < g->slabs.size(); ++i) {
+        blub_fluid* h = g->slabs[i];
+        HIP_TRY(hipMemsetAsync(g->dir_error[i], 0, sizeof(uint32_t), g->stream));
+        hipLaunchKernelGGL(blubk::k_slab_restore, dim3(1024), dim3(256), 0, g->stream, g->ck[gen][i], h->pos, h->pvel[0], h->pvel[1], h->pvel[2],
+                           h->pressure[0] + h->vol_first, h->pressure[1] + h->vol_first, (uint32_t)(h->vol_cells / 4), h->n_dev);
+        h->step_counter = step; h->num_ghost = 0; h->all_touched = true; h->bricks_premarked = false; h->have_last_counts = false;
+        h->pressure_initialised[0] = h->pressure_initialised[1] = true;      // (the checkpoint holds them as they were: zero if no solve had run)
+        HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, g->stream));
+        h->stats_pending[0].clear(); h->stats_pending[1].clear(); h->stats_dt[0].clear(); h->stats_dt[1].clear();      // samples of the abandoned steps never land
+    }
+    for (auto& H : g->hist) H = blub_slab_group::Hist();
+    g->cnt_pending = false; g->ctrl_host_valid[0] = g->ctrl_host_valid[1] = false;
+    g->copies.n = 0; g->push_flags.n = 0; g->push_flags.n_ack = 0;
+    g->flag_seq = sequence_base ? sequence_base : 1u;
+    return blub::slab_refresh_counts(g);      // (drains the stream; exact counts back on the host)
+}
 int blub_slab_group_cuts(const blub_slab_group* g, int32_t* cuts_out) {
     if (!g || !cuts_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
     for (int r = 0; r <= g->nranks; ++r) cuts_out[r] = r == g->nranks ? std::min(g->cuts[(size_t)r], g->slabs[0]->g.nz) : g->cuts[(size_t)r];
@@ -1310,6 +1405,7 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
     if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
+    if (g->ck_interval && g->slabs[0]->step_counter % g->ck_interval == 0) { const int rck = blub::slab_checkpoint(g); if (rck != BLUB_OK) return rck; }
     const int rc = blub::slab_step(g, dt);
     if (rc != BLUB_OK && g->rccl && g->comm) {
         // A rank that leaves the lock-step sequence (buffer overflow, a failed HIP / RCCL call) must not leave its peers blocked inside

@@ -652,6 +652,8 @@ class SlabGroup:
                 ("blub_slab_group_create_local_ex", C.c_int, [C.POINTER(_FluidDesc), C.c_int, vp, C.c_uint32, C.POINTER(vp)]),
                 ("blub_slab_group_create_rccl_ex", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, vp, C.c_uint32, C.POINTER(vp)]),
                 ("blub_slab_group_cuts", C.c_int, [vp, vp]),
+                ("blub_slab_group_set_checkpoint_interval", C.c_int, [vp, C.c_uint32]), ("blub_slab_group_checkpoints", C.c_int, [vp, vp]),
+                ("blub_slab_group_exchange_sequence", C.c_int, [vp, C.POINTER(C.c_uint32)]), ("blub_slab_group_restore", C.c_int, [vp, C.c_uint32, C.c_uint32]),
                 ("blub_slab_group_destroy", None, [vp]), ("blub_slab_group_num_local", C.c_int, [vp]),
                 ("blub_slab_group_local_fluid", vp, [vp, C.c_int]), ("blub_slab_group_local_range", C.c_int, [vp, C.c_int, vp, vp]),
                 ("blub_slab_group_set_particles", C.c_int, [vp, C.c_uint32, vp, vp, vp, vp]), ("blub_slab_group_num_particles", C.c_uint32, [vp]),
@@ -769,6 +771,55 @@ class SlabGroup:
             return False
         self.set_transport("direct")
         return True
+
+    # ---- checkpoints and in-place recovery (include/blubhip.h: blub_slab_group_set_checkpoint_interval ... _restore) ----
+    def set_checkpoint_interval(self, every_n_steps):
+        _check(self._L, self._L.blub_slab_group_set_checkpoint_interval(self._g, int(every_n_steps)))
+
+    def checkpoints(self):
+        """step numbers of the (up to two) checkpoint generations this rank holds; blocks"""
+        out = (C.c_uint32 * 2)()
+        _check(self._L, self._L.blub_slab_group_checkpoints(self._g, out))
+        return sorted(int(v) for v in out if int(v) != 0xFFFFFFFF)
+
+    def exchange_sequence(self):
+        v = C.c_uint32()
+        _check(self._L, self._L.blub_slab_group_exchange_sequence(self._g, C.byref(v)))
+        return int(v.value)
+
+    def restore(self, step, sequence_base):
+        _check(self._L, self._L.blub_slab_group_restore(self._g, int(step), int(sequence_base)))
+
+    def recover(self, all_gather, barrier):
+        """In-place recovery after a timed-out wait of the direct transport (a peer seconds late): COLLECTIVE -- every rank calls it, whether or not it saw
+        the error itself.  `all_gather(obj) -> [obj of rank 0, ...]` and `barrier()` are the caller's control plane.  Returns the step the group is back
+        at (the newest checkpoint every rank holds): the caller steps on from there.  Raises if no common checkpoint exists."""
+        try:
+            self.synchronize()          # drains the stream (every wait is bounded); reports the time-out once and clears the mark
+        except BlubError as e:
+            if e.status != -8:          # BLUB_ERR_COMM is what we are here for
+                raise
+        info = all_gather((self.checkpoints(), self.exchange_sequence()))
+        common = set(info[0][0])
+        for steps, _ in info[1:]:
+            common &= set(steps)
+        if not common:
+            raise BlubError(-8, "no checkpoint generation is held by every rank: %s" % [i[0] for i in info])
+        step = max(common)
+        base = (max(seq for _, seq in info) + 1024) & 0x7FFFFFFF or 1
+        barrier()                       # nobody rewrites its state while a peer's kernels may still be storing into it
+        self.restore(step, base)
+        barrier()
+        return step
+
+    def recover_over_torch_distributed(self):
+        import torch.distributed as dist
+
+        def all_gather(obj):
+            out = [None] * dist.get_world_size()
+            dist.all_gather_object(out, obj)
+            return out
+        return self.recover(all_gather, dist.barrier)
 
     def close(self):
         if getattr(self, "_g", None):

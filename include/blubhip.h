@@ -397,6 +397,21 @@ int blub_slab_group_create_rccl_ex(const blub_fluid_desc* desc, int rank, int nu
  * blub_fluid_set_particles takes them) -- the contiguous partition of the brick layers that minimises the heaviest slab, every slab at least
  * `min_layers` brick layers thick (>= 1).  cuts_out: num_slabs + 1 planes; fluid_bricks_out (may be NULL): FLUID bricks per slab at these positions. */
 int blub_slab_balanced_cuts(const uint32_t grid_dim[3], uint32_t num_particles, const float* pos_ll, int num_slabs, int min_layers, int32_t* cuts_out, uint32_t* fluid_bricks_out);
+/* ---- checkpoints and in-place recovery of a group on the DIRECT transport (round 5) ----
+ * A bounded wait for a peer that runs out (a peer seconds late, or gone) used to end the group: every later wait gives up at once, the data stepped since is
+ * invalid, and the caller had to tear the job down.  With an interval > 0 every local slab copies its restartable state -- particles, the two pressure
+ * volumes, the counts (everything else is scratch) -- into one of two device-side generations at the start of every `every_n_steps`-th
+ * step, and only while its time-out mark is clear: every generation a rank holds predates its first failed wait.  Recovery, by the caller over its own
+ * control plane (blub_amd.SlabGroup.recover_over_torch_distributed is the worked example; tests/test_gpu_multirank.py injects a 10-second stall):
+ *   1. every rank: blub_slab_group_synchronize (drains the stream; reports BLUB_ERR_COMM once and clears the mark);
+ *   2. all-gather blub_slab_group_checkpoints and blub_slab_group_exchange_sequence; pick the newest step EVERY rank holds -- a generation taken after
+ *      some rank's failure is missing on that rank -- and a sequence base above every rank's number;  3. barrier;
+ *   4. every rank: blub_slab_group_restore(step, base);  5. barrier; step on (replaying from `step`).
+ * Cost of a generation: one pass over 64 B per particle + 8 B per held cell (~40 us for the metric's scene), amortised over the interval. */
+int blub_slab_group_set_checkpoint_interval(blub_slab_group* g, uint32_t every_n_steps);      /* 0 = off (default); every rank the same value */
+int blub_slab_group_checkpoints(blub_slab_group* g, uint32_t steps_out[2]);                    /* step numbers of the two generations, 0xFFFFFFFF = none; blocks */
+int blub_slab_group_exchange_sequence(const blub_slab_group* g, uint32_t* seq_out);
+int blub_slab_group_restore(blub_slab_group* g, uint32_t step, uint32_t sequence_base);
 /* The cut planes a group was created with (num_slabs + 1 values, the last one = nz). */
 int blub_slab_group_cuts(const blub_slab_group* g, int32_t* cuts_out);
 void blub_slab_group_destroy(blub_slab_group* g);
