@@ -1292,7 +1292,7 @@ int blub_slab_group_exchange_sequence(const blub_slab_group* g, uint32_t* seq_ou
 int blub_slab_group_restore(blub_slab_group* g, uint32_t step, uint32_t sequence_base) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
-    if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted: a group on the RCCL transport cannot be recovered in place");
+    if (g->rccl && !g->direct) return blub::set_error(BLUB_ERR_UNSUPPORTED, "in-place recovery is for the direct transport (a failed RCCL operation aborts the communicator)");
     uint32_t have[2];
     { int rc = blub_slab_group_checkpoints(g, have); if (rc != BLUB_OK) return rc; }
     int gen = -1;
@@ -1404,10 +1404,10 @@ int blub_slab_group_step(blub_slab_group* g, float dt) {
     if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
-    if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
+    if (g->rccl && !g->direct && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
     if (g->ck_interval && g->slabs[0]->step_counter % g->ck_interval == 0) { const int rck = blub::slab_checkpoint(g); if (rck != BLUB_OK) return rck; }
     const int rc = blub::slab_step(g, dt);
-    if (rc != BLUB_OK && g->rccl && g->comm) {
+    if (rc != BLUB_OK && g->rccl && g->comm && !g->direct) {      // (the direct transport does not use the communicator after creation: its failures are recoverable in place)
         // A rank that leaves the lock-step sequence (buffer overflow, a failed HIP / RCCL call) must not leave its peers blocked inside
         // their next grouped send / receive: aborting the communicator makes their pending operations fail, so every rank returns an error.
         const std::string keep = blub::g_last_error;
@@ -1478,7 +1478,7 @@ int blub_slab_group_run_stages(blub_slab_group* g, float dt, int first, int last
     if (!g || first < 0 || last >= blub::SS_COUNT || first > last) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
     if (!(dt > 0.0f)) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "simulation delta must be > 0");
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
-    if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
+    if (g->rccl && !g->direct && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
     return blub::slab_step(g, dt, first, last);
 }
 uint64_t blub_slab_group_transport_ops(const blub_slab_group* g) { return g ? g->comm_ops : 0; }
