@@ -250,7 +250,7 @@ def shared_device_queue_limit(world):
     hardware queues; beyond the device's queue slots the scheduler rotates them on a timer, and kernels that spin on words another process' kernels
     write (the direct transport) only make progress when the timer fires.  GPU_MAX_HW_QUEUES must be in the environment before the HIP runtime
     starts, i.e. before `import torch` (profiles/r05_multiproc_direct.jsonl: what it changes)."""
-    if world <= 1 or os.environ.get("GPU_MAX_HW_QUEUES"):
+    if world <= 1:
         return None
     try:
         nodes = "/sys/class/kfd/kfd/topology/nodes"
@@ -261,10 +261,14 @@ def shared_device_queue_limit(world):
     except OSError:
         return None
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if gpus and local_world > gpus and os.environ.get("GPU_MAX_HW_QUEUES"):
+        os.environ["BLUB_BENCH_SHARED_DEVICE"] = "1"      # (the caller chose the queue limit itself)
+        return None
     if gpus and local_world > gpus:
         # measured with 4 processes on one MI355X (profiles/r05_multiproc_direct.jsonl): the runtime's default of 4 hardware queues per process and 2 both
         # run the direct transport at the same speed (984 / 987 steps/s); with ONE queue per process a flag wait times out (the run falls back to RCCL)
         os.environ["GPU_MAX_HW_QUEUES"] = "2"
+        os.environ["BLUB_BENCH_SHARED_DEVICE"] = "1"
         return "2"
     return None
 
@@ -293,21 +297,30 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
         # Cut planes: every rank holds the same particles here, so every rank derives the same cuts.  Weighted (default): every slab starts with
         # about 1/N of the FLUID bricks (round-4 review: uniform cuts of the metric's scene leave six of eight ranks without fluid).
         uniform = [blub_amd.SlabGroup.slab_range(dim[2], world, i)[0] for i in range(world)] + [dim[2]]
-        cuts_mode = os.environ.get("BLUB_BENCH_CUTS", "weighted")
-        cuts = blub_amd.SlabGroup.balanced_cuts(dim, pos, world)[0] if cuts_mode == "weighted" else uniform
+        # dynamic (default): weighted at t = 0, then blub_slab_group_rebalance every BLUB_BENCH_REBALANCE_EVERY (16) steps INSIDE the timed loop -- cuts
+        # balanced for t = 0 go stale within ~30 steps of a dam break (profiles/r05_slab_cuts_uniform_vs_weighted.jsonl); the slabs then hold the whole grid
+        cuts_mode = os.environ.get("BLUB_BENCH_CUTS", "dynamic" if scaling == "strong" else "uniform")
+        dynamic = cuts_mode == "dynamic"
+        rebalance_every = int(os.environ.get("BLUB_BENCH_REBALANCE_EVERY", "16"))
+        cuts = blub_amd.SlabGroup.balanced_cuts(dim, pos, world)[0] if cuts_mode in ("weighted", "dynamic") else uniform
         res.update(grid=list(dim), particles=P, dt=dt, cuts=list(cuts), cuts_mode=cuts_mode,
                    fluid_bricks_per_rank=blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos, cuts),
                    fluid_bricks_per_rank_uniform_cuts=blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos, uniform))
         # capacity per slab: the whole particle set (strong scaling: a slab may come to own all of it)
         if transport == "loopback":
             if rank == 0:
-                group = blub_amd.SlabGroup(dim, P + 64, local=world, device=dev, cuts=cuts, memory=memory)
+                group = blub_amd.SlabGroup(dim, P + 64, local=world, device=dev, cuts=cuts, memory=memory, movable_cuts=dynamic)
         else:
-            group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev, cuts=cuts, memory=memory)
+            group = blub_amd.SlabGroup.from_torch_distributed(dim, P + 64, device=dev, cuts=cuts, memory=memory, movable_cuts=dynamic)
         if group is not None and transport == "direct":
             # peer-mapped slabs over hipIpc, kernels store into the neighbours' memory themselves (after the probe, or forced)
             if not group.connect_direct_over_torch_distributed():
                 sys.stderr.write("rank %d: hipIpc mapping unavailable on some rank; staying on the RCCL transport\n" % rank)
+        if group is not None and os.environ.get("BLUB_BENCH_SHARED_DEVICE"):
+            # (development box: several ranks on one GPU -- the one-launch brick-list build waits for co-resident workgroups of ITS process and sits out its
+            #  bound while another process holds the CUs; the two-kernel build has no such wait)
+            for i in range(group.num_local()):
+                group.local_fluid(i).set_tuning("bricks_two_kernel_build", 1)
         if group is not None:
             group.set_gravity_grid(gravity)
             if args.pcg_schedule != "default":
@@ -347,6 +360,16 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
             sys.stderr.write("rank %d: %s\n" % (rank, e))
             return False
     res["recovered_in_place"] = 0
+    res["recuts"] = 0
+    counter = [0]
+
+    def one_step():
+        # (a re-balance is part of stepping this domain on N GPUs: it sits inside the timed loop, one host synchronisation every `rebalance_every` steps)
+        if active and dynamic and counter[0] % rebalance_every == 0 and counter[0] > 0:
+            res["recuts"] += int(group.rebalance(min_layers=2))
+        counter[0] += 1
+        if active:
+            group.step(dt)
     try:
         if active and transport == "direct":
             group.set_checkpoint_interval(int(os.environ.get("BLUB_BENCH_CHECKPOINT_INTERVAL", "16")))      # (one pass over the particles + pressure every 16th step)
@@ -355,8 +378,7 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
         while True:
             def window():
                 for _ in range(warmup):
-                    if active:
-                        group.step(dt)
+                    one_step()
                 if transport == "direct" and os.environ.get("BLUB_BENCH_FAIL_DIRECT"):      # (test hook: the second attempt over RCCL)
                     raise RuntimeError("injected failure of the direct transport")
                 if active:
@@ -372,8 +394,7 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
                 for k in range(steps):
                     if stall and attempts == 0 and rank == int(stall[0]) and k == int(stall[1]):      # (test hook: this rank falls seconds behind once)
                         time.sleep(float(stall[2]))
-                    if active:
-                        group.step(dt)
+                    one_step()
                 if active:
                     group.synchronize()
             ok_t = guarded(timed) if ok_w else False
@@ -402,7 +423,7 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
             group.synchronize()
             res.update(pcg_iters_per_step=round((it1 - it0) / steps, 2), transport_ops_per_step=round(group.transport_ops() - ops0, 1),
                        transport=group.transport_description(), transport_kind=group.transport(),
-                       particles_per_local_slab=[group.local_fluid(i).num_particles() for i in range(group.num_local())])
+                       particles_per_local_slab=[group.local_fluid(i).num_particles() for i in range(group.num_local())], cuts_at_end=group.cuts())
         dist.barrier()
     finally:
         if active:
@@ -464,7 +485,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             "scaling": args.scaling if transport != "loopback" else args.scaling + "-emulated-on-one-gpu", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": res["workload"], "grid": res["grid"], "particles": res["particles"], "dt": res["dt"], "solver": "tol 0.1 / 32 it / check 4", "rebinning": 60,
                        "parallelism": parallelism, "pcg_schedule": args.pcg_schedule if args.pcg_schedule != "default" else "single_reduction (library default)",
-                       "slab_cuts": res["cuts"], "slab_cuts_mode": res["cuts_mode"]},
+                       "slab_cuts": res["cuts"], "slab_cuts_mode": res["cuts_mode"], "slab_cuts_at_end": res.get("cuts_at_end"), "recuts_in_run": res["recuts"]},
             "fluid_bricks_per_rank": res["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": res["fluid_bricks_per_rank_uniform_cuts"],
             "pcg_iters_per_step": res["pcg_iters_per_step"], "transport_ops_per_step": res["transport_ops_per_step"],
             "transport": res["transport"], "recovered_in_place": res["recovered_in_place"], "direct_transport_probe": probe, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "roofline": None, "cpu_baseline": None}
@@ -490,7 +511,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             if r2["active"]:
                 secondary = {"workload": r2["workload"], "grid": r2["grid"], "particles": r2["particles"], "value": round(s_steps / r2["elapsed"], 3), "unit": "steps/s",
                              "ms_per_step": round(r2["elapsed"] / s_steps * 1e3, 4), "steps": s_steps, "warmup": s_warm, "single_gpu_reference": "bench.py --scene corner_dams_512 (profiles/r04_other_scenes.txt: 298 steps/s)",
-                             "slab_cuts": r2["cuts"], "fluid_bricks_per_rank": r2["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": r2["fluid_bricks_per_rank_uniform_cuts"],
+                             "slab_cuts": r2["cuts"], "slab_cuts_at_end": r2.get("cuts_at_end"), "recuts_in_run": r2["recuts"], "fluid_bricks_per_rank": r2["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": r2["fluid_bricks_per_rank_uniform_cuts"],
                              "pcg_iters_per_step": r2["pcg_iters_per_step"], "transport_ops_per_step": r2["transport_ops_per_step"], "transport": r2["transport"]}
         except Exception as e:
             secondary = {"workload": "corner_dams_512", "error": "%s: %s" % (type(e).__name__, str(e)[:300])}

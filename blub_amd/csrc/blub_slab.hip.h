@@ -352,6 +352,15 @@ __global__ __launch_bounds__(256) void k_slab_restore(SlabCheckpoint ck, float4*
     if (blockIdx.x == 0 && threadIdx.x == 0 && n_dev) { n_dev[0] = n; n_dev[1] = 0u; n_dev[2] = 0u; }
 }
 
+// FLUID bricks of the own range per brick layer (blub_slab_group_rebalance): hist[layer] += 1 for every entry of the fluid list (hist zeroed by the caller)
+__global__ __launch_bounds__(256) void k_slab_layer_histogram(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, float* __restrict__ hist) {
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        int bx, by, bz; brick_coords(bg, list[i], bx, by, bz);
+        atomicAdd(hist + bz, 1.0f);      // (integers below 2^24: exact, order-independent)
+    }
+}
+
 // Dot products across slabs: every slab's PCG kernels write their per-block partials into segment `rank` of a gather array
 // of nranks x SLAB_NP entries; after the segments have been exchanged (p2p, see slab_gather) the unchanged consumer kernels
 // re-reduce all nranks x SLAB_NP partials in the same fixed order on every slab => identical scalars and identical

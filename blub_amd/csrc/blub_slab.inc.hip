@@ -22,6 +22,9 @@ struct blub_slab_group {
     int device = 0;
     uint32_t capacity = 0;            // particle capacity of every slab and of the transfer buffers
     int mem_mode = 0;                 // BLUB_SLAB_MEMORY_*: what the exportable regions were allocated with
+    bool full_volumes = false;        // every slab holds the whole grid (BLUB_SLAB_FULL_VOLUMES): the precondition of blub_slab_group_recut
+    float* layer_hist = nullptr;      // device, nranks x layers: FLUID bricks per brick layer, one segment per rank (blub_slab_group_rebalance)
+    float* layer_hist_host = nullptr; // pinned
     std::vector<int> cuts;            // nranks + 1 cut planes (multiples of the brick depth): slab r owns [cuts[r], cuts[r + 1]); uniform unless the caller passed its own
     std::vector<int> vol_z0_of; std::vector<size_t> vol_first_of;   // per rank: first plane its volumes hold / that plane's first cell (blub_fluid::vol_z0, vol_first)
     struct Extra {
@@ -926,6 +929,8 @@ static void slab_group_destroy(blub_slab_group* G) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     for (void* m : G->ipc_opened) (void)hipIpcCloseMemHandle(m);
     for (void* a : G->ck_allocs) F(a);
+    F(G->layer_hist);
+    if (G->layer_hist_host) (void)hipHostFree(G->layer_hist_host);
     for (auto& ar : G->arena) F(ar.base);
     for (auto h : G->slabs) { h->n_dev = nullptr; destroy(h); }
     if (G->rec_host) (void)hipHostFree(G->rec_host);
@@ -1021,6 +1026,119 @@ static int slab_partition_layers(const std::vector<double>& w, int nranks, int m
     return BLUB_OK;
 }
 
+
+// ---- moving the cut planes of a running group (round 5; review "missing" 6) -----------------------------------------------------------------------
+// Precondition: BLUB_SLAB_FULL_VOLUMES (every slab holds every plane: nothing is reallocated, only ownership moves).  Every new cut lies strictly between
+// its old neighbours, so state only moves between ADJACENT slabs: the planes of the two pressure volumes (warm starts) that change owner travel like halo
+// planes, the particles through one ordinary migration exchange against the new ranges.  Everything else is scratch -- the brick
+// bookkeeping is range-independent (k_bricks_build filters its work lists by the own range at every build).  Collective, between steps.
+static int slab_recut(blub_slab_group* G, const std::vector<int>& nc) {
+    const int S = (int)G->slabs.size();
+    blub_fluid* h0 = G->slabs[0];
+    const size_t pb = (size_t)h0->g.nx * h0->g.ny * sizeof(float);
+    int rc = slab_refresh_counts(G);      // drains the stream; exact counts on the host (the synchronous exchange below takes them as exact)
+    if (rc != BLUB_OK) return rc;
+    // (1) pressure planes that change owner.  Cut r separates slab r - 1 (below) from slab r (above).
+    auto moved = [&](int r, int* src, int* dst, int* za, int* zb) {
+        const int o = G->cuts[(size_t)r], n = nc[(size_t)r];
+        if (n == o) return false;
+        if (n > o) { *src = r; *dst = r - 1; *za = o; *zb = n; } else { *src = r - 1; *dst = r; *za = n; *zb = o; }
+        *zb = std::min(*zb, h0->g.nz);
+        return *zb > *za;
+    };
+    G->comm_ops += 1;
+    if (G->direct) G->flag_seq = seq_after(G->flag_seq);
+    if (G->rccl && !G->direct) NCCL_TRY(ncclGroupStart());
+    std::vector<uint32_t> wait_mask((size_t)S, 0u);
+    for (int r = 1; r < G->nranks; ++r) {
+        int src, dst, za, zb;
+        if (!moved(r, &src, &dst, &za, &zb)) continue;
+        const size_t off = (size_t)za * pb, bytes = (size_t)(zb - za) * pb;
+        const bool src_local = rank_local(G, src), dst_local = rank_local(G, dst);
+        for (int w = 0; w < 2; ++w) {
+            if (src_local) {
+                const int i = src - G->first;
+                char* mine = (char*)G->slabs[i]->pressure[w];
+                if (G->direct) {
+                    // (whole planes in pieces of < 4 GiB; the push kernel's copies are 32-bit sized)
+                    for (size_t at = 0; at < bytes; at += (size_t)1 << 30) {
+                        const size_t len = std::min(bytes - at, (size_t)1 << 30);
+                        if ((rc = slab_copy(G, (char*)peer_vol(G, i, dst, mine, sizeof(float)) + off + at, mine + off + at, len)) != BLUB_OK) return rc;
+                    }
+                    push_flag_to(G, i, dst);
+                } else if (dst_local) {
+                    HIP_TRY(hipMemcpyAsync((char*)G->slabs[dst - G->first]->pressure[w] + off, mine + off, bytes, hipMemcpyDeviceToDevice, G->stream));
+                } else NCCL_TRY(ncclSend(mine + off, bytes, ncclChar, dst, G->comm, G->stream));
+            }
+            if (dst_local && !src_local) {
+                const int i = dst - G->first;
+                if (G->direct) wait_mask[(size_t)i] |= 1u << src;
+                else NCCL_TRY(ncclRecv((char*)G->slabs[i]->pressure[w] + off, bytes, ncclChar, src, G->comm, G->stream));
+            }
+        }
+    }
+    if (G->rccl && !G->direct) NCCL_TRY(ncclGroupEnd());
+    if (G->direct) {
+        // (every slab takes part in the flag round of this sequence number, whether or not it moves planes: the acknowledgement handshake is symmetric)
+        for (int i = 0; i < S; ++i) { if (has_up(G, i)) push_flag_to(G, i, G->first + i + 1); if (has_down(G, i)) push_flag_to(G, i, G->first + i - 1); }
+        if ((rc = slab_copy_flush(G)) != BLUB_OK) return rc;
+        for (int i = 0; i < S; ++i) if ((rc = slab_wait(G, i, neighbour_mask(G, i))) != BLUB_OK) return rc;
+    }
+    // (2) the new ranges, then ONE migration exchange against them (synchronous variant: no message-size history applies to a re-cut)
+    G->cuts = nc;
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        h->slab_z0 = nc[(size_t)G->first + i]; h->slab_z1 = nc[(size_t)G->first + i + 1];
+        h->have_last_counts = false;
+    }
+    // the ghost planes of the two pressure volumes at the NEW interfaces (the next solves start from p with its halo: pressure_init.comp:50-83)
+    for (int w = 0; w < 2; ++w)
+        if ((rc = slab_halo(G, {[w](blub_fluid* h) { return (void*)h->pressure[w]; }}, 4)) != BLUB_OK) return rc;
+    const bool was_direct = G->direct;
+    G->direct = false;      // (the synchronous exchange speaks device copies / RCCL; a multi-process direct group still holds its communicator)
+    rc = slab_exchange_particles(G, XFER_MIGRATE);
+    G->direct = was_direct;
+    if (rc != BLUB_OK) return rc;
+    for (auto& H : G->hist) H = blub_slab_group::Hist();
+    G->cnt_pending = false;
+    for (int k = 0; k < G->nranks; ++k) G->cnt_host[k] = 0.0f;      // (the gathered brick counts belong to the old ranges)
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    return BLUB_OK;
+}
+// FLUID bricks per brick layer of the whole domain, the same array on every rank: every local slab counts its own layers, the segments are gathered
+static int slab_layer_histogram(blub_slab_group* G, std::vector<double>& hist) {
+    blub_fluid* h0 = G->slabs[0];
+    const int L = h0->bg.nbz, S = (int)G->slabs.size();
+    if (!G->layer_hist) {
+        HIP_TRY(hipMalloc((void**)&G->layer_hist, (size_t)S * G->nranks * L * sizeof(float)));
+        HIP_TRY(hipHostMalloc((void**)&G->layer_hist_host, (size_t)G->nranks * L * sizeof(float)));
+    }
+    // one array of nranks x L per local slab (segment r = rank r's counts), gathered with the group's own transport
+    HIP_TRY(hipMemsetAsync(G->layer_hist, 0, (size_t)S * G->nranks * L * sizeof(float), G->stream));
+    for (int i = 0; i < S; ++i) {
+        blub_fluid* h = G->slabs[i];
+        float* mine = G->layer_hist + ((size_t)i * G->nranks + (size_t)(G->first + i)) * L;
+        hipLaunchKernelGGL(blubk::k_slab_layer_histogram, dim3(64), dim3(256), 0, G->stream, h->bg, (const uint32_t*)h->list_fluid, (const uint32_t*)&h->counts->n_fluid, mine);
+    }
+    const bool was_direct = G->direct;
+    if (G->direct && (int)G->slabs.size() != G->nranks) G->direct = false;      // (between processes the histogram is not inside an exportable region: RCCL carries it)
+    float* base = G->layer_hist;
+    const int nr = G->nranks;
+    int rc = G->direct ? BLUB_OK : slab_gather(G, [base, nr, L](int i) { return base + (size_t)i * nr * L; }, L);
+    if (G->direct) {      // local group: plain copies between the local arrays
+        for (int sidx = 0; sidx < S && rc == BLUB_OK; ++sidx)
+            for (int d = 0; d < S && rc == BLUB_OK; ++d)
+                if (d != sidx) HIP_TRY(hipMemcpyAsync(base + ((size_t)d * nr + sidx) * L, base + ((size_t)sidx * nr + sidx) * L, (size_t)L * sizeof(float), hipMemcpyDeviceToDevice, G->stream));
+    }
+    G->direct = was_direct;
+    if (rc != BLUB_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(G->layer_hist_host, G->layer_hist, (size_t)nr * L * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    hist.assign((size_t)L, 0.0);
+    for (int r = 0; r < nr; ++r) for (int l = 0; l < L; ++l) hist[(size_t)l] += G->layer_hist_host[(size_t)r * L + l];
+    return BLUB_OK;
+}
+
 // RCCL transport of the PCG partials, chosen by measurement on the hardware at hand (the two candidates cannot be ranked
 // on the 1-GPU development box): per candidate, 30 rounds of what one PCG iteration issues; the slowest rank's time decides
 // (all-reduced, so every rank picks the same mode).  blub_slab_group_set_gather_mode overrides.
@@ -1076,6 +1194,8 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     if (!d || !out || nranks < 1 || nlocal < 1 || first < 0 || first + nlocal > nranks || nlocal > 8) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad slab group arguments");
     *out = nullptr;
     if ((int)((d->nz + BZ - 1) / BZ) < nranks) return set_error(BLUB_ERR_INVALID_ARGUMENT, "more slabs than brick layers in z");
+    const bool full_volumes = (mem_mode & BLUB_SLAB_FULL_VOLUMES) != 0;      // every slab holds every plane: the cut planes may move later (blub_slab_group_recut)
+    mem_mode &= ~(uint32_t)BLUB_SLAB_FULL_VOLUMES;
     if (mem_mode > BLUB_SLAB_MEMORY_UNCACHED) return set_error(BLUB_ERR_INVALID_ARGUMENT, "bad slab memory mode");
     std::vector<int> cut_planes;
     { int rcc = slab_cuts((int)d->nz, nranks, cuts, cut_planes); if (rcc != BLUB_OK) return rcc; }
@@ -1088,7 +1208,7 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
     if (!G) return set_error(BLUB_ERR_OUT_OF_MEMORY, "host allocation failed");
     G->nranks = nranks; G->first = first; G->device = dev; G->capacity = std::max<uint32_t>(d->max_num_particles, 1);
     G->rccl = nccl_id != nullptr;
-    G->cuts = cut_planes; G->mem_mode = (int)mem_mode;
+    G->cuts = cut_planes; G->mem_mode = (int)mem_mode; G->full_volumes = full_volumes || nranks == 1;
     int rc = BLUB_OK;
     if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) { delete G; return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     blub_fluid_desc dd = *d; dd.device = dev;
@@ -1103,7 +1223,10 @@ static int slab_group_create(const blub_fluid_desc* d, int nranks, int first, in
         G->vol_z0_of[(size_t)r] = za; G->vol_first_of[(size_t)r] = (size_t)d->nx * d->ny * (size_t)za;
         vol_planes = std::max(vol_planes, zb - za);
     }
-    if (nranks == 1) vol_planes = 0;      // (whole grid)
+    if (nranks == 1 || full_volumes) {    // (whole grid: 8.5 GiB per rank at 512^3 -- of 288)
+        vol_planes = 0;
+        std::fill(G->vol_z0_of.begin(), G->vol_z0_of.end(), 0); std::fill(G->vol_first_of.begin(), G->vol_first_of.end(), (size_t)0);
+    }
     for (int i = 0; i < nlocal && rc == BLUB_OK; ++i) {
         blub_fluid* h = nullptr;
         rc = create(&dd, &h, G->stream, G->vol_z0_of[(size_t)first + i], vol_planes, (int)mem_mode);
@@ -1313,6 +1436,56 @@ int blub_slab_group_restore(blub_slab_group* g, uint32_t step, uint32_t sequence
     g->copies.n = 0; g->push_flags.n = 0; g->push_flags.n_ack = 0;
     g->flag_seq = sequence_base ? sequence_base : 1u;
     return blub::slab_refresh_counts(g);      // (drains the stream; exact counts back on the host)
+}
+int blub_slab_group_recut(blub_slab_group* g, const int32_t* new_cuts) {
+    if (!g || !new_cuts) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    if (!g->full_volumes) return blub::set_error(BLUB_ERR_UNSUPPORTED, "moving the cut planes needs a group created with BLUB_SLAB_FULL_VOLUMES");
+    if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
+    std::vector<int> nc;
+    { int rc = blub::slab_cuts(g->slabs[0]->g.nz, g->nranks, new_cuts, nc); if (rc != BLUB_OK) return rc; }
+    for (int r = 1; r < g->nranks; ++r)
+        if (nc[(size_t)r] <= g->cuts[(size_t)r - 1] || nc[(size_t)r] >= g->cuts[(size_t)r + 1])
+            return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "a cut plane may only move strictly between its old neighbours (state moves between adjacent slabs only): re-cut in several steps");
+    if (nc == g->cuts) return BLUB_OK;
+    return blub::slab_recut(g, nc);
+}
+// Collective.  FLUID bricks per brick layer are counted on the device and gathered; every rank derives the same balanced cuts (the partition of
+// blub_slab_balanced_cuts), limited to what one re-cut may move, and the group re-cuts when that lowers the heaviest slab's share by more than 5 %.
+// *changed (may be NULL): 1 if the cuts moved.  One host synchronisation: call it every few dozen steps, not every step.
+int blub_slab_group_rebalance(blub_slab_group* g, int min_layers, int* changed) {
+    if (!g) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null handle");
+    if (changed) *changed = 0;
+    if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
+    if (!g->full_volumes) return blub::set_error(BLUB_ERR_UNSUPPORTED, "moving the cut planes needs a group created with BLUB_SLAB_FULL_VOLUMES");
+    if (g->nranks == 1) return BLUB_OK;
+    std::vector<double> bricks;
+    { int rc = blub::slab_layer_histogram(g, bricks); if (rc != BLUB_OK) return rc; }
+    const int L = (int)bricks.size();
+    double total = 0.0; for (double v : bricks) total += v;
+    std::vector<double> w = bricks;
+    const double eps = std::max(1.0, total) / (double)L * 0.02;
+    for (auto& v : w) v += eps;
+    std::vector<int> first;
+    { int rc = blub::slab_partition_layers(w, g->nranks, min_layers, first); if (rc != BLUB_OK) return rc; }
+    std::vector<int32_t> nc((size_t)g->nranks + 1);
+    auto load = [&](const std::vector<int>& cuts) { double mx = 0.0; for (int r = 0; r < g->nranks; ++r) { double a = 0.0; for (int l = cuts[(size_t)r] / blubk::BZ; l < std::min(L, cuts[(size_t)r + 1] / blubk::BZ); ++l) a += w[(size_t)l]; mx = std::max(mx, a); } return mx; };
+    std::vector<int> target((size_t)g->nranks + 1);
+    for (int r = 0; r <= g->nranks; ++r) target[(size_t)r] = first[(size_t)r] * blubk::BZ;
+    // one re-cut moves a cut strictly inside its old neighbours' slabs: clamp towards the target (the next call continues)
+    std::vector<int> next = g->cuts;
+    for (int r = 1; r < g->nranks; ++r) {
+        const int lo = std::max(g->cuts[(size_t)r - 1], next[(size_t)r - 1]) + blubk::BZ * std::max(1, min_layers), hi = g->cuts[(size_t)r + 1] - blubk::BZ;
+        next[(size_t)r] = std::max(lo, std::min(hi, target[(size_t)r]));
+    }
+    for (int r = g->nranks - 1; r >= 1; --r)      // (keep every slab at least min_layers thick from above too)
+        next[(size_t)r] = std::min(next[(size_t)r], next[(size_t)r + 1] - blubk::BZ * std::max(1, min_layers));
+    for (int r = 1; r < g->nranks; ++r) if (next[(size_t)r] <= g->cuts[(size_t)r - 1] || next[(size_t)r] >= g->cuts[(size_t)r + 1] || next[(size_t)r] <= next[(size_t)r - 1]) return BLUB_OK;      // (no legal move)
+    if (next == g->cuts || load(next) > 0.95 * load(g->cuts)) return BLUB_OK;
+    for (int r = 0; r <= g->nranks; ++r) nc[(size_t)r] = r == g->nranks ? g->slabs[0]->g.nz : next[(size_t)r];
+    int rc = blub_slab_group_recut(g, nc.data());
+    if (rc == BLUB_OK && changed) *changed = 1;
+    return rc;
 }
 int blub_slab_group_cuts(const blub_slab_group* g, int32_t* cuts_out) {
     if (!g || !cuts_out) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "null argument");

@@ -641,7 +641,8 @@ class SlabGroup:
 
     MEMORY_MODES = {"coarse": 0, "fine_grained": 1, "uncached": 2}      # include/blubhip.h: BLUB_SLAB_MEMORY_*
 
-    def __init__(self, grid_dimension, max_num_particles, local=None, rank=None, world=None, unique_id=None, device=-1, binning="fixed", cuts=None, memory="coarse"):
+    def __init__(self, grid_dimension, max_num_particles, local=None, rank=None, world=None, unique_id=None, device=-1, binning="fixed", cuts=None, memory="coarse",
+                 movable_cuts=False):
         self._L = load_library()
         L = self._L
         vp = C.c_void_p
@@ -652,6 +653,7 @@ class SlabGroup:
                 ("blub_slab_group_create_local_ex", C.c_int, [C.POINTER(_FluidDesc), C.c_int, vp, C.c_uint32, C.POINTER(vp)]),
                 ("blub_slab_group_create_rccl_ex", C.c_int, [C.POINTER(_FluidDesc), C.c_int, C.c_int, vp, vp, C.c_uint32, C.POINTER(vp)]),
                 ("blub_slab_group_cuts", C.c_int, [vp, vp]),
+                ("blub_slab_group_recut", C.c_int, [vp, vp]), ("blub_slab_group_rebalance", C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
                 ("blub_slab_group_set_checkpoint_interval", C.c_int, [vp, C.c_uint32]), ("blub_slab_group_checkpoints", C.c_int, [vp, vp]),
                 ("blub_slab_group_exchange_sequence", C.c_int, [vp, C.POINTER(C.c_uint32)]), ("blub_slab_group_restore", C.c_int, [vp, C.c_uint32, C.c_uint32]),
                 ("blub_slab_group_destroy", None, [vp]), ("blub_slab_group_num_local", C.c_int, [vp]),
@@ -682,10 +684,10 @@ class SlabGroup:
         if cut_arr is not None and cut_arr.shape != (self.num_slabs + 1,):
             raise ValueError("cuts must hold num_slabs + 1 planes")
         if local is not None:
-            _check(L, L.blub_slab_group_create_local_ex(C.byref(d), int(local), _ptr(cut_arr), self.MEMORY_MODES[memory], C.byref(self._g)))
+            _check(L, L.blub_slab_group_create_local_ex(C.byref(d), int(local), _ptr(cut_arr), self.MEMORY_MODES[memory] | (0x100 if movable_cuts else 0), C.byref(self._g)))
         else:
             buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
-            _check(L, L.blub_slab_group_create_rccl_ex(C.byref(d), int(rank), int(world), buf, _ptr(cut_arr), self.MEMORY_MODES[memory], C.byref(self._g)))
+            _check(L, L.blub_slab_group_create_rccl_ex(C.byref(d), int(rank), int(world), buf, _ptr(cut_arr), self.MEMORY_MODES[memory] | (0x100 if movable_cuts else 0), C.byref(self._g)))
 
     @staticmethod
     def unique_id():
@@ -731,20 +733,34 @@ class SlabGroup:
         edges[-1] = (nz + 3) // 4
         return [int(((layer >= edges[r]) & (layer < edges[r + 1])).sum()) for r in range(len(cuts) - 1)]
 
+    def recut(self, cuts):
+        """COLLECTIVE, between steps, groups created with movable_cuts=True: move the cut planes (each strictly between its old neighbours);
+        include/blubhip.h: blub_slab_group_recut"""
+        a = np.ascontiguousarray(cuts, np.int32)
+        if a.shape != (self.num_slabs + 1,):
+            raise ValueError("cuts must hold num_slabs + 1 planes")
+        _check(self._L, self._L.blub_slab_group_recut(self._g, _ptr(a)))
+
+    def rebalance(self, min_layers=1):
+        """COLLECTIVE: re-cut towards equal FLUID bricks per slab if that helps (include/blubhip.h: blub_slab_group_rebalance); True if the cuts moved"""
+        ch = C.c_int(0)
+        _check(self._L, self._L.blub_slab_group_rebalance(self._g, int(min_layers), C.byref(ch)))
+        return bool(ch.value)
+
     def cuts(self):
         out = np.zeros(self.num_slabs + 1, np.int32)
         _check(self._L, self._L.blub_slab_group_cuts(self._g, _ptr(out)))
         return [int(c) for c in out]
 
     @staticmethod
-    def from_torch_distributed(grid_dimension, max_num_particles, device=-1, binning="fixed", cuts=None, memory="coarse"):
+    def from_torch_distributed(grid_dimension, max_num_particles, device=-1, binning="fixed", cuts=None, memory="coarse", movable_cuts=False):
         """One slab per rank of the default process group; rank 0's RCCL id is broadcast (works over gloo or nccl)."""
         import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
         payload = [SlabGroup.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(payload, src=0)
-        return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning, cuts=cuts, memory=memory)
+        return SlabGroup(grid_dimension, max_num_particles, rank=rank, world=world, unique_id=payload[0], device=device, binning=binning, cuts=cuts, memory=memory, movable_cuts=movable_cuts)
 
     def connect_direct_over_torch_distributed(self):
         """DIRECT transport between the ranks of the default process group: every rank's hipIpc handles are all-gathered over the control plane,

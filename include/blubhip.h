@@ -390,7 +390,10 @@ int blub_slab_group_create_rccl(const blub_fluid_desc* desc, int rank, int num_r
  *   BLUB_SLAB_MEMORY_FINE_GRAINED / _UNCACHED = hipExtMallocWithFlags(hipDeviceMallocFinegrained / hipDeviceMallocUncached): the documented way to share
  *   memory between agents while kernels run; cost on one device: profiles/r05_slab_memory_modes.jsonl.  bench.py's probe (blub_amd/direct_probe.py)
  *   tries COARSE first, then FINE_GRAINED, then falls back to RCCL.  Every rank passes the same mode. */
-enum { BLUB_SLAB_MEMORY_COARSE = 0, BLUB_SLAB_MEMORY_FINE_GRAINED = 1, BLUB_SLAB_MEMORY_UNCACHED = 2 };
+enum { BLUB_SLAB_MEMORY_COARSE = 0, BLUB_SLAB_MEMORY_FINE_GRAINED = 1, BLUB_SLAB_MEMORY_UNCACHED = 2,
+       /* OR-ed into memory_mode: every slab allocates the WHOLE grid (1.2 GiB at 256^3, 8.5 GiB at 512^3 -- of 288) instead of its own planes + 8 on either
+        * side, so that the cut planes can move while the group runs (blub_slab_group_recut / _rebalance) */
+       BLUB_SLAB_FULL_VOLUMES = 0x100 };
 int blub_slab_group_create_local_ex(const blub_fluid_desc* desc, int num_slabs, const int32_t* cuts, uint32_t memory_mode, blub_slab_group** out);
 int blub_slab_group_create_rccl_ex(const blub_fluid_desc* desc, int rank, int num_ranks, const void* unique_id_128, const int32_t* cuts, uint32_t memory_mode, blub_slab_group** out);
 /* Host only: cut planes that give every slab about the same number of FLUID bricks for the given particle positions (16-byte records, as
@@ -412,7 +415,17 @@ int blub_slab_group_set_checkpoint_interval(blub_slab_group* g, uint32_t every_n
 int blub_slab_group_checkpoints(blub_slab_group* g, uint32_t steps_out[2]);                    /* step numbers of the two generations, 0xFFFFFFFF = none; blocks */
 int blub_slab_group_exchange_sequence(const blub_slab_group* g, uint32_t* seq_out);
 int blub_slab_group_restore(blub_slab_group* g, uint32_t step, uint32_t sequence_base);
-/* The cut planes a group was created with (num_slabs + 1 values, the last one = nz). */
+/* ---- moving the cut planes of a running group (round 5) ----
+ * Cuts balanced for the particles at t = 0 go stale: the metric's dam break spreads over all of z within ~100 steps (profiles/r05_slab_cuts_uniform_vs_weighted.jsonl).
+ * blub_slab_group_recut: COLLECTIVE, between steps, groups created with BLUB_SLAB_FULL_VOLUMES.  Every new cut plane must lie strictly between its two old
+ *   neighbours -- state then only moves between ADJACENT slabs: the planes of the two pressure volumes that change owner travel like halo planes, the
+ *   particles through one ordinary migration exchange against the new ranges; everything else is scratch.  One host synchronisation.
+ * blub_slab_group_rebalance: COLLECTIVE.  FLUID bricks per brick layer are counted on the device and gathered, every rank derives the same balanced cuts
+ *   (the partition of blub_slab_balanced_cuts, every slab >= min_layers brick layers), clamped to what ONE re-cut may move, and the group re-cuts if that
+ *   lowers the heaviest slab's share of the FLUID bricks by more than 5 %.  *changed (may be NULL) = 1 if the cuts moved.  Call it every few dozen steps. */
+int blub_slab_group_recut(blub_slab_group* g, const int32_t* new_cuts);
+int blub_slab_group_rebalance(blub_slab_group* g, int min_layers, int* changed);
+/* The cut planes of a group (num_slabs + 1 values, the last one = nz). */
 int blub_slab_group_cuts(const blub_slab_group* g, int32_t* cuts_out);
 void blub_slab_group_destroy(blub_slab_group* g);
 int blub_slab_group_num_local(const blub_slab_group* g);

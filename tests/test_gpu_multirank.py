@@ -205,7 +205,7 @@ def test_bench_gpus_2_runs_the_slab_path(tmp_path, transport):
             pr = d["direct_transport_probe"]
             assert pr["passed"] is True and pr["detail"] == "ok" and pr["slab_memory"] == ("fine_grained" if fine else "coarse"), pr
             assert ("fine-grained memory" if fine else "coarse-grained memory") in d["transport"], d["transport"]
-        assert len(d["fluid_bricks_per_rank"]) == 2 and min(d["fluid_bricks_per_rank"]) > 0 and d["config"]["slab_cuts_mode"] == "weighted", d
+        assert len(d["fluid_bricks_per_rank"]) == 2 and min(d["fluid_bricks_per_rank"]) > 0 and d["config"]["slab_cuts_mode"] == "dynamic", d
     else:
         assert "rccl, 2 ranks" in d["transport"] and d["transport_ops_per_step"] > 0
 

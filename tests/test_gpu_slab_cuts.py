@@ -137,6 +137,104 @@ def test_read_and_write_volume_of_a_slab_whose_plane_count_equals_nz():
         group.close()
 
 
+@pytest.mark.parametrize("transport", ["direct", "host"])
+def test_moving_the_cut_planes_of_a_running_group(transport):
+    """blub_slab_group_recut (round 5): four slabs that hold the whole grid (movable_cuts), two steps on (0, 12, 24, 36, 48), the cut planes move to
+    (0, 8, 28, 40, 48) -- pressure planes and particles change owner between adjacent slabs --, two more steps: the group stays on the single domain's
+    trajectory, every slab holds exactly the particles of its NEW range, no particle is lost, and a cut that would jump over its neighbour is refused."""
+    import blub_amd
+    from tests.test_gpu_parity import _match_particles
+    dim = (32, 32, 48)
+    pos, vel = _blob(dim, (6, 8, 6), (26, 20, 42))
+    cfg = dict(error_tolerance=0.0, max_num_iterations=120, error_check_frequency=8)
+    single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
+    group = blub_amd.SlabGroup(dim, pos.shape[0], local=4, binning="off", cuts=(0, 12, 24, 36, 48), movable_cuts=True)
+    group.set_transport(transport)
+    for f in [single] + [group.local_fluid(i) for i in range(4)]:
+        f.set_tuning("pcg1_max_iterations", 1000)
+    try:
+        for f in (single, group):
+            f.set_gravity_grid((0.0, -981.0, 0.0))
+            f.set_particles(pos, *vel)
+            for w in (0, 1):
+                f.set_solver_config(w, **cfg)
+        for step in range(4):
+            if step == 2:
+                with pytest.raises(blub_amd.BlubError):
+                    group.recut((0, 24, 28, 40, 48))          # cut 1 would land ON old cut 2
+                before = group.num_particles()
+                group.recut((0, 8, 28, 40, 48))
+                assert group.cuts() == [0, 8, 28, 40, 48] and [group.local_range(i) for i in range(4)] == [(0, 8), (8, 28), (28, 40), (40, 48)]
+                assert group.num_particles() == before == pos.shape[0]
+            single.step(util.DT)
+            group.step(util.DT)
+            ps = single.get_particles()[0][:, :3].astype(np.float64)
+            pgl = group.get_particles()[0]
+            d = _match_particles(pgl[:, :3].astype(np.float64), ps)
+            q = (np.median(d), np.quantile(d, 0.99), np.quantile(d, 0.999), d.max())
+            print("step %d (%s, cuts %s): median %.3g p99 %.3g p99.9 %.3g max %.3g" % ((step, transport, group.cuts()) + q))
+            bounds = (3e-5, 4e-4, 1.5e-3, 3e-3) if step == 0 else (2e-4, 3e-3, 3e-2, 0.1)
+            for a, b in zip(q, bounds):
+                assert a <= b, (step, q, bounds)
+            off = 0
+            for i in range(4):
+                z0, z1 = group.local_range(i)
+                n = group.local_fluid(i).num_particles()
+                z = pgl[off:off + n, 2]
+                off += n
+                assert np.all(z >= z0) and np.all(z < z1), (step, i)
+        for w in (0, 1):
+            st = [group.local_fluid(i).solver_stats(w) for i in range(4)]
+            assert all(x == st[0] for x in st)
+    finally:
+        single.close()
+        group.close()
+
+
+def test_rebalancing_follows_the_fluid():
+    """blub_slab_group_rebalance: corner_dams_128 (the metric's scene family at 128^3) as 8 slabs with UNIFORM cuts -- six slabs start without fluid --, a
+    re-balance every 8 steps for 64 steps (the dams collapse and spread over z).  The cuts move, every slab ends up with fluid, the heaviest slab's share of
+    the FLUID bricks stays below twice the mean, no particle is lost, and the body of water stays the single domain's (centre of mass, occupancy)."""
+    import blub_amd
+    from blub_amd import slab_scene
+    cfg = blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", "corner_dams_128.json")).config
+    dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, 1)
+    pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
+    single = blub_amd.HybridFluid(dim, len(pos) + 64)
+    group = blub_amd.SlabGroup(dim, len(pos) + 64, local=8, movable_cuts=True)
+    try:
+        for f in (single, group):
+            f.set_gravity_grid(gravity)
+            f.set_particles(pos)
+        cuts0 = group.cuts()
+        history, moves = [cuts0], 0
+        for step in range(64):
+            if step % 8 == 0:
+                if group.rebalance(min_layers=1):
+                    moves += 1
+                    history.append(group.cuts())
+            single.step(util.DT)
+            group.step(util.DT)
+        assert group.num_particles() == len(pos)
+        bricks = [group.local_fluid(i).brick_counts()["fluid"] for i in range(8)]
+        print("rebalance: %d moves, cuts %s -> %s, FLUID bricks per slab at the end %s" % (moves, cuts0, group.cuts(), bricks))
+        print("rebalance: the cuts on the way: %s" % history)
+        assert moves >= 2 and any(h != cuts0 for h in history)      # (the final cuts may well be the uniform ones again: the water ends up spread over all of z)
+        assert history[1][1] < cuts0[1] and history[1][-2] > cuts0[-2]      # the first move pulls the outer cuts towards the two dams
+        assert min(bricks) > 0 and max(bricks) <= 2.0 * sum(bricks) / 8.0, bricks
+        ps = single.get_particles()[0][:, :3].astype(np.float64)
+        pg = group.get_particles()[0][:, :3].astype(np.float64)
+        com = np.abs(ps.mean(0) - pg.mean(0)).max()
+        hs = np.histogramdd(ps, bins=(16, 16, 16), range=[(0, dim[0]), (0, dim[1]), (0, dim[2])])[0]
+        hg = np.histogramdd(pg, bins=(16, 16, 16), range=[(0, dim[0]), (0, dim[1]), (0, dim[2])])[0]
+        l1 = np.abs(hs - hg).sum() / len(pos)
+        print("rebalance: centre of mass apart by %.3g cells, occupancy histogram L1 %.3g" % (com, l1))
+        assert com < 0.3 and l1 < 0.25      # (64 free-running steps of loosely converged solves: the statistical comparison of tests/test_gpu_fullsize.py)
+    finally:
+        single.close()
+        group.close()
+
+
 def test_balanced_cuts_of_the_metric_scene_give_every_slab_fluid():
     """scenes/corner_dams_256.json (the configuration the metric is quoted on): uniform cuts into 8 leave six slabs without a FLUID brick; the balanced
     cuts give every slab an eighth.  One step of the group (direct transport) on those cuts: the PCG statistics of every slab agree with each other and

@@ -5,7 +5,9 @@ a GPU per slab would see is bounded from below by the BUSIEST slab, so this tool
 (blub_fluid_profile_*), the GPU-busy microseconds per step of every slab: max = the critical path of a perfectly overlapped group, sum = what this one
 GPU executes.  Round-4 review, item 1a: uniform cuts of the metric's scene leave six of eight slabs without fluid -- two ranks carry everything.
 
-usage: python tools/slab_cuts_bench.py [scene] [slabs] [steps] [warmup] [uniform|weighted] [coarse|fine_grained|uncached] [direct|host]"""
+cuts_mode "dynamic": weighted cuts at t = 0, then blub_slab_group_rebalance every REBALANCE_EVERY (16) steps -- slabs that hold the whole grid.
+
+usage: python tools/slab_cuts_bench.py [scene] [slabs] [steps] [warmup] [uniform|weighted|dynamic] [coarse|fine_grained|uncached] [direct|host]"""
 import json
 import os
 import sys
@@ -24,17 +26,25 @@ def main(scene="corner_dams_256", slabs=8, steps=60, warmup=10, cuts_mode="weigh
     dim, scale, gravity, cubes, maxp = slab_scene.weak_scaling_scene(cfg, 1)
     pos = slab_scene.seed_scene_particles(dim, maxp, cubes)
     uniform = [blub_amd.SlabGroup.slab_range(dim[2], slabs, i)[0] for i in range(slabs)] + [dim[2]]
-    cuts = blub_amd.SlabGroup.balanced_cuts(dim, pos, slabs)[0] if cuts_mode == "weighted" else uniform
-    g = blub_amd.SlabGroup(dim, len(pos) + 64, local=slabs, cuts=cuts, memory=memory)
+    cuts = blub_amd.SlabGroup.balanced_cuts(dim, pos, slabs)[0] if cuts_mode in ("weighted", "dynamic") else uniform
+    dynamic = cuts_mode == "dynamic"
+    every = int(os.environ.get("REBALANCE_EVERY", "16"))
+    g = blub_amd.SlabGroup(dim, len(pos) + 64, local=slabs, cuts=cuts, memory=memory, movable_cuts=dynamic)
+    moves = [0]
+
+    def step_once(k):
+        if dynamic and k % every == 0 and g.rebalance(min_layers=2):
+            moves[0] += 1
+        g.step(dt)
     g.set_gravity_grid(gravity)
     g.set_transport(transport)
     g.set_particles(pos)
-    for _ in range(warmup):
-        g.step(dt)
+    for k in range(warmup):
+        step_once(k)
     g.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        g.step(dt)
+    for k in range(steps):
+        step_once(warmup + k)
     g.synchronize()
     wall = (time.perf_counter() - t0) / steps
     counts = [g.local_fluid(i).num_particles() for i in range(slabs)]
@@ -44,9 +54,10 @@ def main(scene="corner_dams_256", slabs=8, steps=60, warmup=10, cuts_mode="weigh
     for f in fl:
         f.profile_reset()
         f.profile_enable(True)
-    for _ in range(steps):
-        g.step(dt)
+    for k in range(steps):
+        step_once(warmup + steps + k)
     g.synchronize()
+    cuts_end = g.cuts()
     busy, solve = [], []
     for f in fl:
         pr = f.profile_read()
@@ -55,7 +66,7 @@ def main(scene="corner_dams_256", slabs=8, steps=60, warmup=10, cuts_mode="weigh
         solve.append(sum(v["total_ms"] for k, v in pr.items() if k.startswith("pcg")) * 1e3 / steps)
     it = fl[0].total_solver_iterations()
     g.close()
-    print(json.dumps({"scene": scene, "slabs_on_one_gpu": slabs, "cuts_mode": cuts_mode, "cuts": cuts, "memory": memory, "transport": transport, "steps": steps, "warmup": warmup,
+    print(json.dumps({"scene": scene, "slabs_on_one_gpu": slabs, "cuts_mode": cuts_mode, "cuts": cuts, "cuts_at_end": cuts_end, "rebalance_every": every if dynamic else None, "recuts": moves[0], "memory": memory, "transport": transport, "steps": steps, "warmup": warmup,
                       "fluid_bricks_per_slab_at_t0": blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos, cuts), "fluid_bricks_per_slab_at_end": bricks_end, "particles_per_slab_at_end": counts,
                       "wall_ms_per_step_all_slabs_on_one_gpu": round(wall * 1e3, 3),
                       "gpu_busy_us_per_step_per_slab": [round(b, 1) for b in busy], "pcg_us_per_step_per_slab": [round(b, 1) for b in solve],
