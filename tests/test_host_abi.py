@@ -43,6 +43,30 @@ def test_integration_md_ffi_block_is_generated_from_the_header():
     assert sorted(names) == declared_functions()
 
 
+def test_no_reference_shader_text_is_tracked():
+    """oracle/_ref/ (the reference's shader text turned into C++ by oracle/glsl/build_ref.sh, and the library built from it) is a build product: git-ignored,
+    never in history (round-4 review, hygiene).  Where this is a git checkout: nothing under oracle/_ref is tracked and no tracked file carries a line that
+    only the reference's shaders have."""
+    import subprocess
+    try:
+        tracked = subprocess.run(["git", "ls-files"], cwd=ROOT, capture_output=True, text=True, timeout=30)
+    except (OSError, subprocess.TimeoutExpired):
+        pytest.skip("git is not available")
+    if tracked.returncode != 0:
+        pytest.skip("not a git checkout")
+    files = tracked.stdout.split()
+    assert files and not [f for f in files if f.startswith("oracle/_ref/")]
+    assert "oracle/_ref/" in open(os.path.join(ROOT, ".gitignore")).read()
+    ref = "/root/reference/shader/simulation/transfer_gather_velocity.comp"
+    if os.path.exists(ref):
+        lines = [l.strip() for l in open(ref) if len(l.strip()) > 60][:8]      # long, characteristic lines of one of the reference's shaders
+        assert lines
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".md", ".sh", ".c")):
+                text = open(os.path.join(ROOT, f), errors="replace").read()
+                assert not any(l in text for l in lines), "%s contains shader text of the reference" % f
+
+
 def test_scene_json_matches_reference_schema(tmp_path):
     s = blub_amd.Scene.parse(path=os.path.join(ROOT, "scenes", "double_dam.json")).config
     assert list(s.grid_dimension) == [128, 64, 64] and s.max_num_particles == 2000000 and s.num_fluid_cubes == 2
