@@ -320,7 +320,7 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
             # (development box: several ranks on one GPU -- the one-launch brick-list build waits for co-resident workgroups of ITS process and sits out its
             #  bound while another process holds the CUs; the two-kernel build has no such wait)
             for i in range(group.num_local()):
-                group.local_fluid(i).set_tuning("bricks_two_kernel_build", 1)
+                group.local_fluid(i).set_tuning("spin_free", 1)
         if group is not None:
             group.set_gravity_grid(gravity)
             if args.pcg_schedule != "default":

@@ -1284,6 +1284,10 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "fuse_divergence") h->fuse_divergence = std::max(0, std::min(2, value));
     else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);
     else if (k == "bricks_two_kernel_build") h->two_kernel_build = value != 0;
+    else if (k == "spin_free") {      // no kernel of a step waits for co-resident workgroups any more: the two-kernel list build, every PCG iteration launched (no persistent tail)
+        h->two_kernel_build = value != 0;
+        h->use_tail = value == 0 && h->tail_grid >= 8;
+    }
     else if (k == "pcg1_max_iterations") h->pcg1_max_iterations = std::max(0, value);
     else if (k == "pcg_scalar_log") {
         HIP_TRY(hipStreamSynchronize(h->stream));

@@ -315,6 +315,9 @@ int blub_fluid_read_scalar_log(blub_fluid* h, int which, float* out, int capacit
  * "p2g_compact" -1|0|1 (default -1): 1 = the P2G gather compacts each tile's non-empty lists, 0 = one lane per list cell (same results bit for
  *   bit), -1 = chosen per step from the particles per FLUID brick.
  * "bricks_two_kernel_build" 0|1: build the brick lists with the two-kernel scan that grids with more 1024-brick blocks than CUs use.
+ * "spin_free" 0|1: 1 = no kernel of blub_fluid_step waits for co-resident workgroups (two-kernel list build, no persistent PCG tail).  The default (0) uses two
+ *   such kernels -- each with a bounded wait whose time-out is sticky, reported and survivable (BLUB_ERR_DEVICE, then this mode by itself) -- because they are
+ *   worth 3 % of the metric (1 481-1 486 against 1 434-1 443 steps/s, profiles/r05_spin_free_cost.txt); a shared, partitioned or preemptible device should set it.
  * Unknown names: BLUB_ERR_INVALID_ARGUMENT. */
 int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value);
 /* Upper bound on the steps the host may enqueue ahead of the GPU (default 4, further limited so that < ~700 kernel launches are queued; 0 = unbounded). blub_fluid_step blocks
