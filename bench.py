@@ -20,8 +20,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILES = {256: os.path.join("profiles", "r04_pmc_dense_pcg_256.json"),   # FETCH_SIZE / WRITE_SIZE captures of the dense PCG benchmark (tools/dense_pmc.sh),
-             512: os.path.join("profiles", "r04_pmc_dense_pcg_512.json")}   # stamped with the hash of the sources they were taken from
+PMC_FILES = {256: os.path.join("profiles", "r05_pmc_dense_pcg_256.json"),   # FETCH_SIZE / WRITE_SIZE captures of the dense PCG benchmark (tools/dense_pmc.sh),
+             512: os.path.join("profiles", "r05_pmc_dense_pcg_512.json")}   # stamped with the hash of the sources they were taken from
 
 
 def algorithmic_bytes(kernel, F, P, A, Fb):

@@ -16,6 +16,8 @@ timeout 600 python bench.py > ${o}_bench_${ver}.log 2>&1; grep '^{' ${o}_bench_$
 ( cd /tmp && export TMPDIR=/tmp && rm -rf $root/gpurun_out/_sq && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $root/gpurun_out/_sq -o p -- python $root/bench.py --dense-only --dense-size 256 > $root/gpurun_out/_sq.log 2>&1 )
 python tools/pmc_summary.py gpurun_out/_sq > ${o}_${ver}_pmc_sq_dense_pcg_256.csv; rm -rf gpurun_out/_sq
 for tr in direct host; do for n in 2 4 8; do python tools/slab_loopback_bench.py corner_dams_256 $n 60 5 single_reduction 1 $tr; done; done > ${o}_${ver}_slab_loopback.jsonl 2>${o}_slab.err
+# (round 5) strong scaling of ONE domain on one GPU: uniform / weighted / dynamic cuts, per-slab GPU-busy time
+for m in uniform weighted dynamic; do timeout 300 python tools/slab_cuts_bench.py corner_dams_256 8 60 10 $m coarse direct; done > ${o}_${ver}_slab_cuts.jsonl 2>>${o}_slab.err
 bash tools/dense_sweep.sh 256 256:16 512:16 512:32 1024:16 1024:32 > ${o}_${ver}_dense_sweep.txt 2>&1
 bash tools/dense_sweep.sh 512 512:16 512:32 1024:32 >> ${o}_${ver}_dense_sweep.txt 2>&1
 bash tools/headline_pmc.sh ${o}_${ver}_pmc_headline > /dev/null 2>&1
