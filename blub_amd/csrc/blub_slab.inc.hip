@@ -1027,6 +1027,7 @@ static int slab_partition_layers(const std::vector<double>& w, int nranks, int m
 }
 
 
+static int slab_checkpoint(blub_slab_group* G);
 // ---- moving the cut planes of a running group (round 5; review "missing" 6) -----------------------------------------------------------------------
 // Precondition: BLUB_SLAB_FULL_VOLUMES (every slab holds every plane: nothing is reallocated, only ownership moves).  Every new cut lies strictly between
 // its old neighbours, so state only moves between ADJACENT slabs: the planes of the two pressure volumes (warm starts) that change owner travel like halo
@@ -1102,6 +1103,12 @@ static int slab_recut(blub_slab_group* G, const std::vector<int>& nc) {
     for (auto& H : G->hist) H = blub_slab_group::Hist();
     G->cnt_pending = false;
     for (int k = 0; k < G->nranks; ++k) G->cnt_host[k] = 0.0f;      // (the gathered brick counts belong to the old ranges)
+    // checkpoint generations taken under the OLD ranges would put particles and pressure planes back where they no longer belong: drop them and, if
+    // checkpoints are in use, take a fresh generation of the re-cut state right away
+    if (!G->ck[0].empty()) {
+        for (int gen = 0; gen < 2; ++gen) for (auto& c : G->ck[gen]) HIP_TRY(hipMemsetAsync(c.step, 0xFF, sizeof(uint32_t), G->stream));
+        if (G->ck_interval && (rc = slab_checkpoint(G)) != BLUB_OK) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(G->stream));
     return BLUB_OK;
 }

@@ -191,6 +191,47 @@ def test_moving_the_cut_planes_of_a_running_group(transport):
         group.close()
 
 
+def test_a_checkpoint_taken_before_a_recut_is_not_restored():
+    """Checkpoint generations belong to the cut planes they were taken under: a re-cut drops them and takes a fresh one, so a restore after a re-cut goes
+    back to the re-cut state (same step), never to particles and pressure planes laid out for the old ranges."""
+    import blub_amd
+    from tests.test_gpu_parity import _match_particles
+    dim = (32, 32, 48)
+    pos, vel = _blob(dim, (6, 8, 6), (26, 20, 42))
+    cfg = dict(error_tolerance=0.0, max_num_iterations=60, error_check_frequency=8)
+    single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
+    group = blub_amd.SlabGroup(dim, pos.shape[0], local=4, binning="off", cuts=(0, 12, 24, 36, 48), movable_cuts=True)
+    try:
+        for f in (single, group):
+            f.set_gravity_grid((0.0, -981.0, 0.0))
+            f.set_particles(pos, *vel)
+            for w in (0, 1):
+                f.set_solver_config(w, **cfg)
+        group.set_checkpoint_interval(2)
+        for _ in range(3):
+            single.step(util.DT)
+            group.step(util.DT)
+        assert group.checkpoints() == [0, 2]
+        group.recut((0, 8, 28, 40, 48))
+        assert group.checkpoints() == [3]                       # the generations of the old ranges are gone, one of the re-cut state (step 3) exists
+        single.step(util.DT)
+        group.step(util.DT)                                      # step 3 (no generation: 3 % 2 != 0)
+        group.synchronize()
+        group.restore(3, group.exchange_sequence() + 1024)      # back to the re-cut state ...
+        group.step(util.DT)                                      # ... and step 3 again
+        assert group.num_particles() == pos.shape[0] and group.cuts() == [0, 8, 28, 40, 48]
+        d = _match_particles(group.get_particles()[0][:, :3].astype(np.float64), single.get_particles()[0][:, :3].astype(np.float64))
+        q = (np.median(d), np.quantile(d, 0.99), np.quantile(d, 0.999), d.max())
+        print("restore after a re-cut, step 4: median %.3g p99 %.3g p99.9 %.3g max %.3g" % q)
+        for a, b in zip(q, (2e-4, 3e-3, 3e-2, 0.1)):
+            assert a <= b, q
+        with pytest.raises(blub_amd.BlubError):
+            group.restore(2, group.exchange_sequence() + 1024)   # the generation of step 2 belonged to the old cuts
+    finally:
+        single.close()
+        group.close()
+
+
 def test_rebalancing_follows_the_fluid():
     """blub_slab_group_rebalance: corner_dams_128 (the metric's scene family at 128^3) as 8 slabs with UNIFORM cuts -- six slabs start without fluid --, a
     re-balance every 8 steps for 64 steps (the dams collapse and spread over z).  The cuts move, every slab ends up with fluid, the heaviest slab's share of
