@@ -79,7 +79,6 @@ struct blub_slab_group {
     uint32_t ck_interval = 0;
     std::vector<blubk::SlabCheckpoint> ck[2];       // [generation][local slab]
     std::vector<void*> ck_allocs;
-    uint32_t* ck_step_host = nullptr;               // pinned: [generation][local slab] step numbers as read back by blub_slab_group_checkpoints
 };
 
 namespace blub {
@@ -1050,7 +1049,6 @@ static int slab_recut(blub_slab_group* G, const std::vector<int>& nc) {
     G->comm_ops += 1;
     if (G->direct) G->flag_seq = seq_after(G->flag_seq);
     if (G->rccl && !G->direct) NCCL_TRY(ncclGroupStart());
-    std::vector<uint32_t> wait_mask((size_t)S, 0u);
     for (int r = 1; r < G->nranks; ++r) {
         int src, dst, za, zb;
         if (!moved(r, &src, &dst, &za, &zb)) continue;
@@ -1071,11 +1069,8 @@ static int slab_recut(blub_slab_group* G, const std::vector<int>& nc) {
                     HIP_TRY(hipMemcpyAsync((char*)G->slabs[dst - G->first]->pressure[w] + off, mine + off, bytes, hipMemcpyDeviceToDevice, G->stream));
                 } else NCCL_TRY(ncclSend(mine + off, bytes, ncclChar, dst, G->comm, G->stream));
             }
-            if (dst_local && !src_local) {
-                const int i = dst - G->first;
-                if (G->direct) wait_mask[(size_t)i] |= 1u << src;
-                else NCCL_TRY(ncclRecv((char*)G->slabs[i]->pressure[w] + off, bytes, ncclChar, src, G->comm, G->stream));
-            }
+            if (dst_local && !src_local && !G->direct)      // (direct: the flag round below covers both neighbours of every slab)
+                NCCL_TRY(ncclRecv((char*)G->slabs[dst - G->first]->pressure[w] + off, bytes, ncclChar, src, G->comm, G->stream));
         }
     }
     if (G->rccl && !G->direct) NCCL_TRY(ncclGroupEnd());
