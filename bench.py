@@ -252,13 +252,14 @@ def shared_device_queue_limit(world):
     starts, i.e. before `import torch` (profiles/r05_multiproc_direct.jsonl: what it changes)."""
     if world <= 1:
         return None
+    # (the GPUs THIS job can see -- not the host's: a container's kfd topology lists every GPU of the machine.  Asked in a child process: the answer must be
+    #  known before this process makes its first HIP call, which is when the runtime reads GPU_MAX_HW_QUEUES)
+    import subprocess
     try:
-        nodes = "/sys/class/kfd/kfd/topology/nodes"
-        gpus = 0
-        for n in os.listdir(nodes):
-            props = dict(l.split()[:2] for l in open(os.path.join(nodes, n, "properties")) if len(l.split()) >= 2)
-            gpus += int(props.get("simd_count", "0")) > 0
-    except OSError:
+        out = subprocess.run([sys.executable, "-c", "import ctypes; h = ctypes.CDLL('libamdhip64.so'); n = ctypes.c_int(0); h.hipGetDeviceCount(ctypes.byref(n)); print(n.value)"],
+                             capture_output=True, text=True, timeout=60)
+        gpus = int(out.stdout.strip() or "0")
+    except (OSError, ValueError, subprocess.TimeoutExpired):
         return None
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     if gpus and local_world > gpus and os.environ.get("GPU_MAX_HW_QUEUES"):
@@ -510,7 +511,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             r2 = slab_run(args, torch, dist, rank, world, dev, ctl, transport, "corner_dams_512", s_steps, s_warm, "strong", memory)
             if r2["active"]:
                 secondary = {"workload": r2["workload"], "grid": r2["grid"], "particles": r2["particles"], "value": round(s_steps / r2["elapsed"], 3), "unit": "steps/s",
-                             "ms_per_step": round(r2["elapsed"] / s_steps * 1e3, 4), "steps": s_steps, "warmup": s_warm, "single_gpu_reference": "bench.py --scene corner_dams_512 (profiles/r04_other_scenes.txt: 298 steps/s)",
+                             "ms_per_step": round(r2["elapsed"] / s_steps * 1e3, 4), "steps": s_steps, "warmup": s_warm, "single_gpu_reference": "bench.py --scene corner_dams_512 (profiles/r05_other_scenes.txt: 302 steps/s)",
                              "slab_cuts": r2["cuts"], "slab_cuts_at_end": r2.get("cuts_at_end"), "recuts_in_run": r2["recuts"], "fluid_bricks_per_rank": r2["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": r2["fluid_bricks_per_rank_uniform_cuts"],
                              "pcg_iters_per_step": r2["pcg_iters_per_step"], "transport_ops_per_step": r2["transport_ops_per_step"], "transport": r2["transport"]}
         except Exception as e:
