@@ -1363,8 +1363,9 @@ int blub_slab_balanced_cuts(const uint32_t grid_dim[3], uint32_t n, const float*
     if (nbz < num_slabs) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "more slabs than brick layers in z");
     std::vector<uint8_t> mark((size_t)nbx * nby * nbz, 0);
     for (uint32_t i = 0; i < n; ++i) {
-        const int x = (int)pos_ll[4 * (size_t)i], y = (int)pos_ll[4 * (size_t)i + 1], z = (int)pos_ll[4 * (size_t)i + 2];
-        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+        const float fx = pos_ll[4 * (size_t)i], fy = pos_ll[4 * (size_t)i + 1], fz = pos_ll[4 * (size_t)i + 2];
+        if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)nx && fy < (float)ny && fz < (float)nz)) continue;      // (also: NaN)
+        const int x = (int)fx, y = (int)fy, z = (int)fz;
         mark[((size_t)(z / blubk::BZ) * nby + (size_t)(y / blubk::BY)) * nbx + (size_t)(x / blubk::BX)] = 1;
     }
     std::vector<double> w((size_t)nbz, 0.0);

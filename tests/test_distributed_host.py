@@ -103,6 +103,10 @@ def test_balanced_cuts_share_out_the_fluid_bricks():
     assert cuts == [0, 16, 32, 48, 64] and bricks == [0, 0, 0, 0]
     with pytest.raises(blub_amd.BlubError):
         blub_amd.SlabGroup.balanced_cuts((64, 64, 16), pos[:10], 8)          # more slabs than brick layers
+    # positions outside the grid -- or not numbers at all -- carry no weight
+    odd = np.array([[np.nan, 1, 1, 0], [5.5, 5.5, 5.5, 0], [1e30, 2, 2, 0], [-3, 2, 2, 0], [np.inf, 2, 2, 0]], np.float32)
+    cuts, bricks = blub_amd.SlabGroup.balanced_cuts((64, 64, 64), odd, 4)
+    assert sum(bricks) == 1 and cuts[0] == 0 and cuts[-1] == 64
 
 
 @pytest.mark.parametrize("cuts", [(4, 32, 64), (0, 30, 64), (0, 32, 32), (0, 32, 60), (0, 40, 32)])
