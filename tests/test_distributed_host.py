@@ -117,6 +117,96 @@ def test_bad_cut_planes_are_rejected_before_anything_is_allocated(cuts):
     assert e.value.status == -1, str(e.value)          # BLUB_ERR_INVALID_ARGUMENT (not BLUB_ERR_NO_DEVICE: the cuts are checked first)
 
 
+RECOVER_WORKER = textwrap.dedent("""
+    import os, sys
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    import blub_amd
+    from blub_amd.hybrid_fluid import BlubError
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% sys.argv[1], rank=int(sys.argv[2]), world_size=2)
+    rank = dist.get_rank()
+
+    class Stub(blub_amd.SlabGroup):
+        # the collective LOGIC of SlabGroup.recover without a device: which generation is restored, with which sequence base
+        def __init__(self, held, seq, fail_sync):
+            self.held, self.seq, self.fail_sync, self.restored = held, seq, fail_sync, None
+        def synchronize(self):
+            if self.fail_sync:
+                self.fail_sync = False
+                raise BlubError(-8, "direct transport: a wait for a peer's flag timed out")
+        def checkpoints(self):
+            return sorted(self.held)
+        def exchange_sequence(self):
+            return self.seq
+        def restore(self, step, base):
+            self.restored = (step, base)
+        def close(self):
+            pass
+
+    # rank 0 failed at step 30 (holds the generations of steps 0 -> overwritten, 16; skipped 32), rank 1 ran on and took a generation at step 32
+    g = Stub(held=[16, 0] if rank == 0 else [16, 32], seq=7012 if rank == 0 else 7345, fail_sync=(rank == 0))
+    step = g.recover_over_torch_distributed()
+    assert step == 16 and g.restored == (16, 7345 + 1024), (step, g.restored)      # the newest generation BOTH hold; a base above every rank's number
+    # no common generation: every rank raises (and nobody restores)
+    g = Stub(held=[0] if rank == 0 else [16, 32], seq=1, fail_sync=False)
+    try:
+        g.recover_over_torch_distributed()
+        raise SystemExit("expected an error")
+    except BlubError as e:
+        assert e.status == -8 and g.restored is None
+    # an error other than the time-out is not swallowed
+    class Broken(Stub):
+        def synchronize(self):
+            raise BlubError(-4, "device error")
+    try:
+        Broken([0], 1, False).recover_over_torch_distributed()
+        raise SystemExit("expected an error")
+    except BlubError as e:
+        assert e.status == -4
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %%d ok" %% rank)
+""")
+
+
+def test_recovery_picks_the_newest_generation_every_rank_holds(tmp_path):
+    """blub_amd.SlabGroup.recover (in-place recovery of a z-slab group, include/blubhip.h) over a 2-rank gloo group with the device calls stubbed:
+    the newest checkpoint BOTH ranks hold is restored -- a generation a rank took after its peer's failure is missing on the peer --, the sequence
+    numbers restart above every rank's, no common generation is an error on every rank, other errors pass through."""
+    script = tmp_path / "recover_worker.py"
+    script.write_text(RECOVER_WORKER % ROOT)
+    port = str(33500 + os.getpid() % 2000)
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "rank %d ok" % r in o
+
+
+def test_layer_partition_properties():
+    """blub_slab_balanced_cuts on random particle clouds (host only): valid cut planes, every particle-bearing brick counted once, the heaviest slab never
+    heavier than under uniform cuts, min_layers honoured."""
+    import numpy as np
+    import blub_amd
+    rng = np.random.default_rng(11)
+    for trial in range(25):
+        dim = (int(rng.integers(2, 9)) * 16, int(rng.integers(2, 9)) * 8, int(rng.integers(8, 40)) * 4)
+        n = int(rng.integers(1, 4000))
+        centre = rng.random(3) * np.array(dim)
+        pos = (centre + rng.standard_normal((n, 3)) * np.array(dim) * rng.uniform(0.02, 0.4)).astype(np.float32)
+        slabs = int(rng.integers(1, min(8, dim[2] // 4) + 1))
+        ml = int(rng.integers(1, max(1, dim[2] // 4 // slabs) + 1))
+        cuts, bricks = blub_amd.SlabGroup.balanced_cuts(dim, pos, slabs, ml)
+        assert cuts[0] == 0 and cuts[-1] == dim[2] and all(c % 4 == 0 for c in cuts) and all(b - a >= 4 * ml for a, b in zip(cuts, cuts[1:])), (dim, slabs, ml, cuts)
+        inside = ((pos >= 0) & (pos < np.array(dim, np.float32))).all(1)
+        assert bricks == blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos[inside], cuts)
+        uniform = [blub_amd.SlabGroup.slab_range(dim[2], slabs, i)[0] for i in range(slabs)] + [dim[2]]
+        if ml == 1:
+            assert max(bricks) <= max(blub_amd.SlabGroup.fluid_bricks_per_slab(dim, pos[inside], uniform)) + 1, (cuts, bricks, uniform)
+
+
 PROBE_WORKER = textwrap.dedent("""
     import os, sys
     import torch.distributed as dist
