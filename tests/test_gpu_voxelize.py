@@ -200,10 +200,13 @@ def test_scene_with_a_moving_solid_matches_oracle():
         f.close()
 
 
-def test_moving_solid_in_a_z_slab_group_matches_single_domain():
+@pytest.mark.parametrize("recut", [False, True])
+def test_moving_solid_in_a_z_slab_group_matches_single_domain(recut):
     """The voxelised solid straddles the interface of two z-slabs (every slab voxelises the meshes in global coordinates);
     the group must stay inside the engine's run-to-run noise envelope of the single-domain run (see
-    test_gpu_parity.py::test_z_slab_decomposition_matches_single_domain for the envelope)."""
+    test_gpu_parity.py::test_z_slab_decomposition_matches_single_domain for the envelope).  recut: slabs that hold the whole grid, the cut plane moves from
+    z = 16 to z = 12 after the second step -- through the moving solid: the solid volume is every slab's own (voxelised in global coordinates), only the
+    pressure planes and the particles change owner (blub_slab_group_recut)."""
     import blub_amd
     from scipy.spatial import cKDTree
     scene = blub_amd.Scene(text=json.dumps(SCENE))
@@ -211,7 +214,7 @@ def test_moving_solid_in_a_z_slab_group_matches_single_domain():
     single = scene.fluid()
     dim = single.grid_dimension()
     pos0 = single.get_particles()[0]
-    group = blub_amd.SlabGroup(dim, 40000, local=2)
+    group = blub_amd.SlabGroup(dim, 40000, local=2, movable_cuts=recut)
     try:
         mesh_p, mesh_i = blub_amd.load_obj(os.path.join(scene.models_dir, "unit_cube.obj"))
         group.set_meshes(mesh_p, mesh_i)
@@ -229,6 +232,9 @@ def test_moving_solid_in_a_z_slab_group_matches_single_domain():
             total += DELTA_NS
             d = blub_amd.mesh_desc_at_time(scene.config, 0, total, DELTA_NS)
             d.index_begin, d.index_end = 0, len(mesh_i)
+            if recut and step == 3:
+                group.recut((0, 12, 32))
+                assert group.cuts() == [0, 12, 32]
             group.voxelize([d])
             group.step(util.DT)
             ps = single.get_particles()[0][:, :3].astype(np.float64)
