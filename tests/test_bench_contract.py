@@ -31,3 +31,24 @@ def test_committed_bench_line_has_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
+
+
+def test_committed_multi_gpu_lines_carry_the_cut_planes_and_the_secondary():
+    """`bench.py --gpus N` lines captured on the GPU box (N processes on its one GPU, tools/multiproc_direct_bench.sh): the contract keys, the cut planes and
+    FLUID bricks per rank (round-4 review, item 1a), the recovery counter and -- strong scaling of the default scene -- the corner_dams_512 secondary (1d)."""
+    path = os.path.join(ROOT, "profiles", "r05_multiproc_direct.jsonl")
+    lines = [json.loads(l) for l in open(path) if l.startswith("{")]
+    assert len(lines) >= 6
+    with_secondary = [d for d in lines if d.get("secondary") and "value" in d["secondary"]]
+    assert with_secondary, "no captured line carries a completed secondary run"
+    for d in lines:
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "fluid_bricks_per_rank", "transport", "transport_ops_per_step"):
+            assert k in d, k
+        assert d["n_gpus"] >= 2 and d["scaling"] == "strong" and len(d["fluid_bricks_per_rank"]) == d["n_gpus"]
+        cuts = d["config"]["slab_cuts"]
+        assert cuts[0] == 0 and cuts[-1] == d["config"]["grid"][2] and len(cuts) == d["n_gpus"] + 1 and all(c % 4 == 0 for c in cuts)
+        if d["config"]["slab_cuts_mode"] != "uniform":
+            assert min(d["fluid_bricks_per_rank"]) > 0                      # weighted cuts: nobody starts without fluid
+    s2 = with_secondary[-1]["secondary"]
+    assert s2["grid"] == [512, 512, 512] and s2["particles"] == 8065008 and s2["value"] > 0 and len(s2["fluid_bricks_per_rank"]) == with_secondary[-1]["n_gpus"]
