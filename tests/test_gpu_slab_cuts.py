@@ -191,6 +191,58 @@ def test_moving_the_cut_planes_of_a_running_group(transport):
         group.close()
 
 
+def test_random_legal_recuts_keep_the_trajectory():
+    """Ten steps with a RANDOM legal re-cut in front of every step (each cut strictly between its old neighbours, slabs down to one brick layer, slabs
+    that own no particle at all): particle count conserved, ownership exact after every re-cut, and the group stays inside the free-running envelope of the
+    single domain -- a re-cut moves owners, never the physics."""
+    import blub_amd
+    from tests.test_gpu_parity import _match_particles
+    dim = (32, 32, 48)
+    pos, vel = _blob(dim, (6, 8, 6), (26, 20, 42))
+    cfg = dict(error_tolerance=0.0, max_num_iterations=60, error_check_frequency=8)
+    rng = np.random.default_rng(2025)
+    single = blub_amd.HybridFluid(dim, pos.shape[0], binning="off")
+    group = blub_amd.SlabGroup(dim, pos.shape[0], local=5, binning="off", movable_cuts=True)
+    try:
+        for f in (single, group):
+            f.set_gravity_grid((0.0, -981.0, 0.0))
+            f.set_particles(pos, *vel)
+            for w in (0, 1):
+                f.set_solver_config(w, **cfg)
+        seen = set()
+        for step in range(10):
+            old = group.cuts()
+            new = list(old)
+            for r in range(1, 5):      # a new cut anywhere strictly between the OLD neighbours, and above the new cut below it
+                lo, hi = max(old[r - 1], new[r - 1]) + 4, old[r + 1] - 4
+                if lo <= hi:
+                    new[r] = int(rng.integers(lo // 4, hi // 4 + 1)) * 4
+            group.recut(new)
+            assert group.cuts() == new
+            seen.add(tuple(new))
+            single.step(util.DT)
+            group.step(util.DT)
+            assert group.num_particles() == pos.shape[0]
+            pgl = group.get_particles()[0]
+            off = 0
+            for i in range(5):
+                z0, z1 = group.local_range(i)
+                n = group.local_fluid(i).num_particles()
+                z = pgl[off:off + n, 2]
+                off += n
+                assert np.all(z >= z0) and np.all(z < z1), (step, i, (z0, z1))
+        d = _match_particles(pgl[:, :3].astype(np.float64), single.get_particles()[0][:, :3].astype(np.float64))
+        q = (np.median(d), np.quantile(d, 0.99), np.quantile(d, 0.999), d.max())
+        print("ten random re-cuts (%d distinct cut sets, thinnest slab %d planes): median %.3g p99 %.3g p99.9 %.3g max %.3g" % (
+            (len(seen), min(b - a for c in seen for a, b in zip(c, c[1:]))) + q))
+        assert len(seen) >= 8
+        for a, b in zip(q, (4e-4, 6e-3, 5e-2, 0.3)):       # (ten free-running steps of 60-iteration solves: twice the later-step envelope of the three-step tests)
+            assert a <= b, q
+    finally:
+        single.close()
+        group.close()
+
+
 def test_a_checkpoint_taken_before_a_recut_is_not_restored():
     """Checkpoint generations belong to the cut planes they were taken under: a re-cut drops them and takes a fresh one, so a restore after a re-cut goes
     back to the re-cut state (same step), never to particles and pressure planes laid out for the old ranges."""
