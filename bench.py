@@ -108,7 +108,7 @@ def dense_pcg_benchmark(n=256, iterations=32, tuning=None, repeats=1):
             "iter_bytes_fused": fused, "iter_frac_fused": round(fused / (iter_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernels": out}
 
 
-def transfer_microbenchmark(n=256, seed=1234):
+def transfer_microbenchmark(n=256, seed=1234, tune=()):
     """M4 of BASELINE.md / SURVEY 8(d): n^3 grid, 8 jittered particles in every interior cell of the lower half, smooth
     velocity field; the transfer kernels (list building + P2G gathers), advection and the density gather are timed per
     kernel class with HIP events, with the particles in random order and again after the engine's own binning pass."""
@@ -129,6 +129,9 @@ def transfer_microbenchmark(n=256, seed=1234):
         vel.append(rows)
     dt = blub_amd.default_simulation_delta()
     h = blub_amd.HybridFluid((n, n, n), P)
+    for kv in tune:
+        k_, v_ = kv.split("=")
+        h.set_tuning(k_, int(v_))
     h.set_gravity_grid((0.0, -9.81 * n / 1.28, 0.0))
     h.set_particles(pos, *vel)
     del pos, vel, cells
@@ -580,7 +583,7 @@ def main():
         print(json.dumps(res))
         return
     if args.transfer_only:
-        print(json.dumps(transfer_microbenchmark(256)))
+        print(json.dumps(transfer_microbenchmark(256, tune=args.tune)))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

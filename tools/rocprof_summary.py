@@ -5,7 +5,7 @@ import sys
 import numpy as np
 
 
-def main(db_path, out_path=None, steps_marker="k_build_lists"):
+def main(db_path, out_path=None, steps_marker="k_correct"):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
     rows = list(cur.execute("select name, start, end from kernels order by start"))
