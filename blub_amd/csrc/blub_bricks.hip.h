@@ -21,11 +21,6 @@ constexpr int BX = 16, BY = 8, BZ = 4;        // brick extent in cells (x fastes
 static_assert(BX == 16 && BY == 8 && BZ == 4, "k_advect (blub_kernels.hip.h) marks FLUID bricks with these extents as shifts");
 constexpr int BRICK_THREADS = 128;            // one thread per quad (4 x-consecutive cells)
 constexpr uint32_t STALE_BIT = 0x80000000u;
-// Entry allocators of the run lists (k_reset_bricks): a single cursor would see one atomic per brick with particles on ONE address (~11 ns each,
-// MI355X_MICROARCH.md "dequeue": 1 200 bricks = 14 us of a 6 us kernel), so the workgroups spread over RUN_SHARDS cursors, each with its own
-// region of the entry array sized twice its fair share; a brick that does not fit its shard's region takes its entries from the overflow region
-// behind them (cursor RUN_SHARDS), which alone could hold every entry.
-constexpr int RUN_SHARDS = 32, RUN_SHARD_STRIDE = 32;      // (cursors 128 bytes apart; slot RUN_SHARDS + 1 is the allocator of the particle re-sort, k_resort_scan)
 
 struct BrickGeom {
     Grid g;
@@ -149,10 +144,10 @@ __global__ __launch_bounds__(1024) void k_bricks_classify(BrickGeom bg, int phas
 __global__ __launch_bounds__(1024) void k_bricks_scatter(BrickGeom bg, const uint8_t* __restrict__ brick_flags, const uint4* __restrict__ block_counts, int nblocks,
                                                          uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
                                                          uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq,
-                                                         uint8_t* __restrict__ brick_fluid_to_clear, BrickCounts* __restrict__ host_snapshot, uint32_t* __restrict__ run_cursor) {
+                                                         uint8_t* __restrict__ brick_fluid_to_clear, BrickCounts* __restrict__ host_snapshot, uint32_t* __restrict__ resort_cursor) {
     __shared__ uint32_t sm[17];
     __shared__ uint32_t base[4], total[4];
-    if (run_cursor && blockIdx.x == 0 && threadIdx.x <= RUN_SHARDS + 1) run_cursor[threadIdx.x * RUN_SHARD_STRIDE] = 0;      // bump allocators of the run lists: empty before the reset kernel's scan (k_reset_bricks)
+    if (resort_cursor && blockIdx.x == 0 && threadIdx.x == 0) *resort_cursor = 0;      // bump allocator of the particle re-sort (k_resort_scan): empty after every list build
     if (threadIdx.x < 64) {   // one wave sums the block counts: lanes stride over the blocks in order
         uint32_t before[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};
         for (int k = threadIdx.x; k < nblocks; k += 64) {
@@ -205,12 +200,12 @@ __global__ __launch_bounds__(1024) void k_bricks_build(BrickGeom bg, int phase, 
                                                        uint8_t* __restrict__ brick_active, uint8_t* __restrict__ brick_touched, uint32_t* block_counts4 /* 4 per block */,
                                                        uint32_t* block_ready, uint32_t* __restrict__ list_fluid, uint32_t* __restrict__ list_active,
                                                        uint32_t* __restrict__ list_reset, BrickCounts* __restrict__ counts, uint32_t seq, BrickCounts* __restrict__ host_snapshot,
-                                                       uint32_t* __restrict__ sticky_timeout, uint32_t* __restrict__ run_cursor) {
+                                                       uint32_t* __restrict__ sticky_timeout, uint32_t* __restrict__ resort_cursor) {
     __shared__ uint32_t sm[17];
     __shared__ uint32_t base[4], total[4];
     __shared__ uint32_t wtot[16];
     __shared__ int timed_out;
-    if (run_cursor && blockIdx.x == 0 && threadIdx.x <= RUN_SHARDS + 1) run_cursor[threadIdx.x * RUN_SHARD_STRIDE] = 0;      // bump allocators of the run lists: empty before the reset kernel's scan (k_reset_bricks)
+    if (resort_cursor && blockIdx.x == 0 && threadIdx.x == 0) *resort_cursor = 0;      // bump allocator of the particle re-sort (k_resort_scan): empty after every list build
     const int b = blockIdx.x * 1024 + threadIdx.x;
     const int nblocks = gridDim.x;
     uint32_t fl = 0;
@@ -326,27 +321,44 @@ __global__ __launch_bounds__(256) void k_resort_count(BrickGeom bg, uint32_t num
     const uint32_t r = wave_group_rank(wave_group_add(counters, key, mine), mine);
     if (live) ranks[i] = r;
 }
+constexpr int RESORT_GROUP = 4;      // FLUID bricks per workgroup and allocation: the allocator is ONE address (~11 ns per atomic, MI355X_MICROARCH.md "dequeue")
 __global__ __launch_bounds__(BRICK_THREADS) void k_resort_scan(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                uint32_t* __restrict__ counters, uint32_t* __restrict__ starts, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t wave_tot[2], base_of;
+    __shared__ uint32_t wave_tot[RESORT_GROUP][2], base_of[RESORT_GROUP];
     const uint32_t n = *count;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t i = blockIdx.x; i <= n; i += gridDim.x) {
-        if (i == n) {      // the bucket outside the grid
-            if (threadIdx.x == 0) { const uint32_t k = (uint32_t)bg.nb * (BX * BY * BZ), c = counters[k]; starts[k] = c ? atomicAdd(cursor, c) : 0u; counters[k] = 0; }
-            continue;
+    for (uint32_t i0 = blockIdx.x * RESORT_GROUP; i0 <= n; i0 += gridDim.x * RESORT_GROUP) {
+        uint4 q[RESORT_GROUP]; uint32_t s[RESORT_GROUP], inc[RESORT_GROUP]; size_t at[RESORT_GROUP];
+#pragma unroll
+        for (int k = 0; k < RESORT_GROUP; ++k) {
+            const bool valid = i0 + k < n;
+            at[k] = valid ? (size_t)list[i0 + k] * (BX * BY * BZ) + 4 * threadIdx.x : 0;
+            q[k] = valid ? *reinterpret_cast<const uint4*>(counters + at[k]) : make_uint4(0, 0, 0, 0);
+            s[k] = q[k].x + q[k].y + q[k].z + q[k].w;
+            inc[k] = wave_inclusive_scan(s[k]);
+            if (lane == 63) wave_tot[k][wave] = inc[k];
         }
-        const size_t at = (size_t)list[i] * (BX * BY * BZ) + 4 * threadIdx.x;
-        const uint4 q = *reinterpret_cast<const uint4*>(counters + at);
-        const uint32_t s = q.x + q.y + q.z + q.w, inc = wave_inclusive_scan(s);
-        if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
-        if (threadIdx.x == 0) { const uint32_t tot = wave_tot[0] + wave_tot[1]; base_of = tot ? atomicAdd(cursor, tot) : 0u; }
+        if (threadIdx.x == 0) {
+            uint32_t tot[RESORT_GROUP], sum = 0;
+#pragma unroll
+            for (int k = 0; k < RESORT_GROUP; ++k) { tot[k] = wave_tot[k][0] + wave_tot[k][1]; sum += tot[k]; }
+            const bool outside_here = n - i0 < (uint32_t)RESORT_GROUP;       // this group holds list position n: it also places the bucket outside the grid
+            const uint32_t ko = (uint32_t)bg.nb * (BX * BY * BZ), co = outside_here ? counters[ko] : 0u;
+            uint32_t b0 = (sum + co) ? atomicAdd(cursor, sum + co) : 0u;
+#pragma unroll
+            for (int k = 0; k < RESORT_GROUP; ++k) { base_of[k] = b0; b0 += tot[k]; }
+            if (outside_here) { starts[ko] = b0; counters[ko] = 0; }
+        }
         __syncthreads();
-        const uint32_t f0 = base_of + (wave ? wave_tot[0] : 0u) + inc - s;
-        *reinterpret_cast<uint4*>(starts + at) = make_uint4(f0, f0 + q.x, f0 + q.x + q.y, f0 + q.x + q.y + q.z);
-        if (s) *reinterpret_cast<uint4*>(counters + at) = make_uint4(0, 0, 0, 0);
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RESORT_GROUP; ++k) {
+            if (i0 + k >= n) continue;
+            const uint32_t f0 = base_of[k] + (wave ? wave_tot[k][0] : 0u) + inc[k] - s[k];
+            *reinterpret_cast<uint4*>(starts + at[k]) = make_uint4(f0, f0 + q[k].x, f0 + q[k].x + q[k].y, f0 + q[k].x + q[k].y + q[k].z);
+            if (s[k]) *reinterpret_cast<uint4*>(counters + at[k]) = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();      // (the next group of this workgroup reuses wave_tot / base_of)
     }
 }
 __global__ __launch_bounds__(256) void k_resort_move(BrickGeom bg, uint32_t num_particles, const float4* __restrict__ pos, const uint32_t* __restrict__ pid,
@@ -391,74 +403,27 @@ __device__ __forceinline__ uint32_t static_marker_quad(const Grid& g, const floa
 }
 // T1 (+T3) over the reset list: marker := static pattern, list heads := 0; stale bricks additionally get velocity and
 // pressure volumes zeroed (what the reference's dense D2 / pressure_init / R2 passes would have written there).
-// R.cursor != nullptr (the transfer's reset): the SCAN of the run lists (blub_kernels.hip.h) rides along -- the brick's 512 counters per component
-// become {first entry, entries} behind a base from the bump allocator R.cursor[c] (one atomic per brick and component; the order of the bricks in
-// the entry arrays is whatever the atomics make it, the order inside a brick is cell order), the counters are zeroed for the next count, and
-// R.brick_base[c][brick] says whether the brick holds entries at all (RUN_EMPTY: its run cells are not written and must not be read).
-struct RunScan { uint32_t* counts[3]; uint2* runs[3]; uint32_t* brick_base; uint32_t* cursor; uint32_t nb, shard_capacity; };
 __global__ __launch_bounds__(BRICK_THREADS) void k_reset_bricks(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                                 const float4* __restrict__ solid, int8_t* __restrict__ marker,
                                                                 uint32_t* __restrict__ ll0, uint32_t* __restrict__ ll1, uint32_t* __restrict__ ll2,
                                                                 float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz,
-                                                                float* __restrict__ p0, float* __restrict__ p1, RunScan R) {
-    __shared__ uint32_t wave_tot[3][2], base_of[3];
+                                                                float* __restrict__ p0, float* __restrict__ p1) {
     const uint32_t n = *count;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t e = list[i];
         int x0, y, z;
-        const bool valid = brick_quad(bg, e & ~STALE_BIT, threadIdx.x, x0, y, z);
-        const int base = valid ? cidx(bg.g, x0, y, z) : 0;
-        uint4 q[3]; uint32_t inc[3];
-        if (R.cursor) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) q[c] = valid ? *reinterpret_cast<const uint4*>(R.counts[c] + base) : make_uint4(0, 0, 0, 0);
+        if (!brick_quad(bg, e & ~STALE_BIT, threadIdx.x, x0, y, z)) continue;
+        const int base = cidx(bg.g, x0, y, z);
+        *reinterpret_cast<uint32_t*>(marker + base) = static_marker_quad(bg.g, solid, base, x0, y, z);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        if (ll0) *reinterpret_cast<uint4*>(ll0 + base) = z4;
+        if (ll1) *reinterpret_cast<uint4*>(ll1 + base) = z4;
+        if (ll2) *reinterpret_cast<uint4*>(ll2 + base) = z4;
+        if ((e & STALE_BIT) && vx) {
+            const float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(vx + base) = f0; *reinterpret_cast<float4*>(vy + base) = f0; *reinterpret_cast<float4*>(vz + base) = f0;
+            *reinterpret_cast<float4*>(p0 + base) = f0; *reinterpret_cast<float4*>(p1 + base) = f0;
         }
-        if (valid) {
-            *reinterpret_cast<uint32_t*>(marker + base) = static_marker_quad(bg.g, solid, base, x0, y, z);
-            const uint4 z4 = make_uint4(0, 0, 0, 0);
-            if (ll0) *reinterpret_cast<uint4*>(ll0 + base) = z4;
-            if (ll1) *reinterpret_cast<uint4*>(ll1 + base) = z4;
-            if (ll2) *reinterpret_cast<uint4*>(ll2 + base) = z4;
-            if ((e & STALE_BIT) && vx) {
-                const float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(vx + base) = f0; *reinterpret_cast<float4*>(vy + base) = f0; *reinterpret_cast<float4*>(vz + base) = f0;
-                *reinterpret_cast<float4*>(p0 + base) = f0; *reinterpret_cast<float4*>(p1 + base) = f0;
-            }
-        }
-        if (!R.cursor) continue;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            inc[c] = wave_inclusive_scan(q[c].x + q[c].y + q[c].z + q[c].w);
-            if (lane == 63) wave_tot[c][wave] = inc[c];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {      // the brick's entries of the three components in ONE allocation
-            const uint32_t t0 = wave_tot[0][0] + wave_tot[0][1], t1 = wave_tot[1][0] + wave_tot[1][1], t2 = wave_tot[2][0] + wave_tot[2][1], tot = t0 + t1 + t2;
-            uint32_t b0 = 0;
-            if (tot) {
-                const uint32_t shard = blockIdx.x % RUN_SHARDS;
-                b0 = atomicAdd(R.cursor + shard * RUN_SHARD_STRIDE, tot);
-                if (b0 + tot <= R.shard_capacity) b0 += shard * R.shard_capacity;
-                else b0 = RUN_SHARDS * R.shard_capacity + atomicAdd(R.cursor + RUN_SHARDS * RUN_SHARD_STRIDE, tot);
-            }
-            const uint32_t bc[3] = {t0 ? b0 : RUN_EMPTY, t1 ? b0 + t0 : RUN_EMPTY, t2 ? b0 + t0 + t1 : RUN_EMPTY};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { base_of[c] = bc[c]; R.brick_base[(size_t)c * R.nb + (e & ~STALE_BIT)] = bc[c]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t b0 = base_of[c];
-            if (b0 == RUN_EMPTY || !valid) continue;
-            const uint32_t s = q[c].x + q[c].y + q[c].z + q[c].w;
-            const uint32_t f0 = b0 + (wave ? wave_tot[c][0] : 0u) + inc[c] - s, f1 = f0 + q[c].x, f2 = f1 + q[c].y, f3 = f2 + q[c].z;
-            uint4* const ro = reinterpret_cast<uint4*>(R.runs[c] + base);
-            ro[0] = make_uint4(f0, q[c].x, f1, q[c].y);
-            ro[1] = make_uint4(f2, q[c].z, f3, q[c].w);
-            if (s) *reinterpret_cast<uint4*>(R.counts[c] + base) = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();      // (the next brick of this workgroup reuses wave_tot / base_of)
     }
 }
 // Dense variant (creation, new solid voxels): every cell gets the static pattern.
@@ -494,36 +459,12 @@ constexpr int GP_STRIDE = 768;
 struct GatherPartialsV { float2 part[8][GP_STRIDE]; };     // [corner][list cell] {sum w*d, sum w}: 48 KiB
 struct GatherPartialsD { float part[8][GP_STRIDE]; };      // [corner][list cell] sum w: 24 KiB
 
-// the two sample coordinates per axis a list reaches: faces d and d + 1 (:20, sample = face + 0.5 (+ 0.5 along COMP))
-struct GatherSamples { float sx0, sx1, sy0, sy1, sz0, sz1; };
-template <int COMP>
-__device__ __forceinline__ GatherSamples gather_samples(int gx, int gy, int gz) {
-    GatherSamples S;
-    S.sx0 = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f); S.sx1 = (float)(gx + 1) + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
-    S.sy0 = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f); S.sy1 = (float)(gy + 1) + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
-    S.sz0 = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f); S.sz1 = (float)(gz + 1) + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
-    return S;
-}
-// one particle of a list into the list's eight partial sums (p: position, r: its velocity row of this component)
-__device__ __forceinline__ void gather_add(const GatherSamples& S, const float4& p, const float4& r, float (&v)[8], float (&ws)[8]) {
-    const float tx[2] = {S.sx0 - p.x, S.sx1 - p.x}, ty[2] = {S.sy0 - p.y, S.sy1 - p.y}, tz[2] = {S.sz0 - p.z, S.sz1 - p.z};   // :20
-    const float ox[2] = {satf(1.0f - fabsf(tx[0])), satf(1.0f - fabsf(tx[1]))};
-    const float oy[2] = {satf(1.0f - fabsf(ty[0])), satf(1.0f - fabsf(ty[1]))};
-    const float oz[2] = {satf(1.0f - fabsf(tz[0])), satf(1.0f - fabsf(tz[1]))};
-    const float ax[2] = {r.x * tx[0], r.x * tx[1]}, ay[2] = {r.y * ty[0], r.y * ty[1]}, az[2] = {r.z * tz[0], r.z * tz[1]};
-    const float rw = r.w * 1.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
-        const float w = ox[kx] * oy[ky] * oz[kz];                                    // :22
-        const float d = ((ax[kx] + ay[ky]) + az[kz]) + rw;                           // :24
-        v[k] += w * d;
-        ws[k] += w;
-    }
-}
 template <int COMP>
 __device__ __forceinline__ void gather_walk(const GatherNode* __restrict__ nodes, uint32_t cur, int gx, int gy, int gz, float (&v)[8], float (&ws)[8]) {      // nodes: component COMP's array
-    const GatherSamples S = gather_samples<COMP>(gx, gy, gz);
+    // the two sample coordinates per axis this list reaches: faces d and d + 1 (:20, sample = face + 0.5 (+ 0.5 along COMP))
+    const float sx0 = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f), sx1 = (float)(gx + 1) + 0.5f + (COMP == 0 ? 0.5f : 0.0f);
+    const float sy0 = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f), sy1 = (float)(gy + 1) + 0.5f + (COMP == 1 ? 0.5f : 0.0f);
+    const float sz0 = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f), sz1 = (float)(gz + 1) + 0.5f + (COMP == 2 ? 0.5f : 0.0f);
     // one hop = the two halves of ONE 32-byte node (k_build_lists): {position, link}, {row}
     const float4* nd = reinterpret_cast<const float4*>(nodes);
     float4 p = nd[2 * (size_t)cur], r = nd[2 * (size_t)cur + 1];
@@ -532,7 +473,20 @@ __device__ __forceinline__ void gather_walk(const GatherNode* __restrict__ nodes
         const bool has_n = nxt != INVALID_LL && round + 1 < GATHER_CAP_V;
         float4 pn = p, rn = r; uint32_t nn = INVALID_LL;
         if (has_n) { pn = nd[2 * (size_t)nxt]; rn = nd[2 * (size_t)nxt + 1]; nn = __float_as_uint(pn.w); }   // next node in flight during the arithmetic
-        gather_add(S, p, r, v, ws);
+        const float tx[2] = {sx0 - p.x, sx1 - p.x}, ty[2] = {sy0 - p.y, sy1 - p.y}, tz[2] = {sz0 - p.z, sz1 - p.z};   // :20
+        const float ox[2] = {satf(1.0f - fabsf(tx[0])), satf(1.0f - fabsf(tx[1]))};
+        const float oy[2] = {satf(1.0f - fabsf(ty[0])), satf(1.0f - fabsf(ty[1]))};
+        const float oz[2] = {satf(1.0f - fabsf(tz[0])), satf(1.0f - fabsf(tz[1]))};
+        const float ax[2] = {r.x * tx[0], r.x * tx[1]}, ay[2] = {r.y * ty[0], r.y * ty[1]}, az[2] = {r.z * tz[0], r.z * tz[1]};
+        const float rw = r.w * 1.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
+            const float w = ox[kx] * oy[ky] * oz[kz];                                    // :22
+            const float d = ((ax[kx] + ay[ky]) + az[kz]) + rw;                           // :24
+            v[k] += w * d;
+            ws[k] += w;
+        }
         if (!has_n) break;
         p = pn; r = rn; nxt = nn;
     }
@@ -719,125 +673,6 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_velocity3_s(BrickGeom bg,
     if (comp == 0) gather_velocity_sparse_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes + (size_t)0 * a.node_stride, a.out[0], a.gravity_dt[0]);
     else if (comp == 1) gather_velocity_sparse_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes + (size_t)1 * a.node_stride, a.out[1], a.gravity_dt[1]);
     else gather_velocity_sparse_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes + (size_t)2 * a.node_stride, a.out[2], a.gravity_dt[2]);
-}
-
-// ---- T4 over RUN lists (blub_kernels.hip.h: count / scan / scatter): the default ---------------------------------------------------------
-// A list is a contiguous piece of the entry array ({position, particle}, most recent insertion LAST), the lists of a brick row follow each other.
-// The tile's lists are staged through LDS GR_R entries at a time -- pass p holds entries p GR_R .. p GR_R + GR_R - 1 of EVERY list, counted from
-// its head, in a fixed slot (list cell x GR_R + entry): no prefix sums, no searching.  Lane s of the staging loop fetches slot s: GR_R
-// consecutive lanes read consecutive addresses, neighbouring cells neighbouring lists -- a wave-wide load touches a handful of lines, where a
-// linked-list hop touched 64 --, then the velocity row of THAT particle; nothing depends on an earlier hop.  The faces then run the reference's
-// own loop (transfer_gather_velocity.comp:59-98) out of LDS: round i takes the i-th element of the face's eight lists, own list first -- the
-// same additions in the same ORDER as the shader's, every lane busy.  At most GATHER_CAP_V / GR_R passes, fewer when the tile's lists are short.
-#ifndef BLUB_GR_R
-#define BLUB_GR_R 3
-#endif
-constexpr int GR_R = BLUB_GR_R;                                    // entries of a list per pass (x 765 lists x 32 bytes = 72 KiB of LDS: two workgroups per CU)
-constexpr int GR_THREADS = 512;                            // one thread per face; the 765 list cells are covered in two strides
-constexpr int GR_SLOTS = GT_N * GR_R;
-struct GatherRunArgs3 { const uint2* runs[3]; const float4* rows[3]; float* out[3]; float gravity_dt[3]; const uint32_t* brick_base; const float4* entries; uint32_t nb; int ablate; };
-struct GatherRunShared {
-    float4 pe[GR_SLOTS], row[GR_SLOTS];                    // staged entries of this pass: {position, particle}, that particle's velocity row
-    uint32_t first[GT_N + 3];                              // list cell -> first entry of its (capped) list in the entry array
-    uint8_t len[GT_N + 3];                                 // ... and its length, <= GATHER_CAP_V
-};
-template <int COMP>
-__device__ __forceinline__ void gather_velocity_run_body(GatherRunShared& sh, uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg, const uint32_t* __restrict__ list,
-                                                         const uint32_t* __restrict__ count, const int8_t* __restrict__ marker, const uint2* __restrict__ runs,
-                                                         const uint32_t* __restrict__ brick_base, const float4* __restrict__ entries, const float4* __restrict__ rows,
-                                                         float* __restrict__ out, float gravity_dt, int ablate) {
-    const Grid g = bg.g;
-    const int tid = threadIdx.x;
-    const int fx = tid & 15, fy = (tid >> 4) & 7, fz = tid >> 7;                               // this thread's face of the brick
-    const int tc = (fx + 1) + (fy + 1) * GT_X + (fz + 1) * GT_X * GT_Y;                         // ... and its own list cell in the tile
-    const uint32_t n = *count;
-    for (uint32_t i = first_brick; i < n; i += brick_stride) {
-        const uint32_t b = list[i];
-        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
-        {   // the tile's lists lie in this brick and its seven negative neighbours: none of them holds an entry => nothing to do (uniform: no barrier)
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int qx = bx - (k & 1), qy = by - ((k >> 1) & 1), qz = bz - (k >> 2);
-                if (qx >= 0 && qy >= 0 && qz >= 0) any = any || brick_base[(qz * bg.nby + qy) * bg.nbx + qx] != RUN_EMPTY;
-            }
-            if (!any) continue;
-        }
-        const int ox0 = bx * BX - 1, oy0 = by * BY - 1, oz0 = bz * BZ - 1;                     // grid coordinates of tile cell 0 (:41)
-        __syncthreads();                // (the previous brick's faces are done with first / len and the staged entries)
-        uint32_t longest = 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = tid + GR_THREADS * j;
-            if (c >= GT_N) continue;
-            const int gx = ox0 + c % GT_X, gy = oy0 + (c / GT_X) % GT_Y, gz = oz0 + c / (GT_X * GT_Y);
-            uint32_t ln = 0, lfirst = 0;
-            if (inb(g, gx, gy, gz) && brick_base[brick_of_cell(bg, gx, gy, gz)] != RUN_EMPTY) {
-                const uint2 r = runs[cidx(g, gx, gy, gz)];
-                ln = r.y < (uint32_t)GATHER_CAP_V ? r.y : (uint32_t)GATHER_CAP_V;               // :61 -- the list's most recent entries
-                lfirst = r.x + r.y - ln;
-            }
-            sh.first[c] = lfirst; sh.len[c] = (uint8_t)ln;
-            longest = ln > longest ? ln : longest;
-        }
-        // (every thread learns the longest list of the tile: the number of passes)
-        int passes = 0;
-#pragma unroll
-        for (int q = 0; q < GATHER_CAP_V / GR_R; ++q) passes += __syncthreads_or(longest > (uint32_t)(q * GR_R)) ? 1 : 0;
-        if (passes == 0) continue;      // no particle anywhere in the tile: no face of this brick touches a FLUID cell, nothing is written
-        // the face: its sample point and the lengths of its eight lists (4 bits each), in the reference's order (:87-93): own cell, then the seven negative neighbours
-        const int gx = bx * BX + fx, gy = by * BY + fy, gz = bz * BZ + fz;
-        const float sx = (float)gx + 0.5f + (COMP == 0 ? 0.5f : 0.0f), sy = (float)gy + 0.5f + (COMP == 1 ? 0.5f : 0.0f), sz = (float)gz + 0.5f + (COMP == 2 ? 0.5f : 0.0f);   // :20
-        uint32_t lens = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lens |= (uint32_t)sh.len[tc - (k & 1) - ((k >> 1) & 1) * GT_X - (k >> 2) * GT_X * GT_Y] << (4 * k);
-        float val = 0.0f, wsum = 0.0f;
-        for (int p = 0; p < passes; ++p) {
-            if (p) __syncthreads();     // the faces are done with the previous pass's entries
-#pragma unroll
-            for (int m = 0; m < (GR_SLOTS + GR_THREADS - 1) / GR_THREADS; ++m) {
-                const int s = tid + GR_THREADS * m;
-                if (s >= GR_SLOTS) continue;
-                const int c = s / GR_R, e = p * GR_R + s % GR_R, ln = sh.len[c];
-                if (e >= ln) continue;
-                const float4 pe = entries[sh.first[c] + (uint32_t)(ln - 1 - e)];              // entry e counted from the head
-                sh.pe[s] = pe;
-                sh.row[s] = (ablate & 1) ? pe : rows[__float_as_uint(pe.w)];
-            }
-            __syncthreads();
-            if (ablate & 2) continue;
-#pragma unroll
-            for (int jj = 0; jj < GR_R; ++jj) {                                                  // :61 round p GR_R + jj ...
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {                                                    // :87-93 ... of the eight lists
-                    if ((int)((lens >> (4 * k)) & 15u) <= p * GR_R + jj) continue;
-                    const int s = (tc - (k & 1) - ((k >> 1) & 1) * GT_X - (k >> 2) * GT_X * GT_Y) * GR_R + jj;
-                    add_particle(val, wsum, sh.pe[s], sh.row[s], sx, sy, sz);
-                }
-            }
-        }
-        if (!inb(g, gx, gy, gz)) continue;
-        const int mA = (int)marker[cidx(g, gx, gy, gz)];
-        const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
-        if (mA == CELL_FLUID || mB == CELL_FLUID) {                                              // :50
-            float o = 0.0f;
-            if (mA != CELL_SOLID && mB != CELL_SOLID) {                                          // :51
-                o = val;
-                if (wsum > 0.0f) o /= wsum;                                                      // :117-119
-                o += gravity_dt;                                                                 // :120
-            }
-            out[cidx(g, gx, gy, gz)] = o;                                                        // (:121-124: 0 with exactly one solid side)
-        }
-    }
-}
-__global__ __launch_bounds__(GR_THREADS) void k_gather_velocity3_r(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
-                                                                   const int8_t* __restrict__ marker, GatherRunArgs3 a) {
-    __shared__ GatherRunShared sh;
-    uint32_t slot, slots; int comp;
-    gather3_block_role(slot, slots, comp);
-    if (comp == 0) gather_velocity_run_body<0>(sh, slot, slots, bg, list, count, marker, a.runs[0], a.brick_base + (size_t)0 * a.nb, a.entries, a.rows[0], a.out[0], a.gravity_dt[0], a.ablate);
-    else if (comp == 1) gather_velocity_run_body<1>(sh, slot, slots, bg, list, count, marker, a.runs[1], a.brick_base + (size_t)1 * a.nb, a.entries, a.rows[1], a.out[1], a.gravity_dt[1], a.ablate);
-    else gather_velocity_run_body<2>(sh, slot, slots, bg, list, count, marker, a.runs[2], a.brick_base + (size_t)2 * a.nb, a.entries, a.rows[2], a.out[2], a.gravity_dt[2], a.ablate);
 }
 
 // R1 in the same formulation (density_projection_gather_error.comp:41-198): samples are cell centres, the list cap is 32

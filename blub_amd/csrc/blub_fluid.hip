@@ -80,6 +80,13 @@ struct blub_fluid {
     // z-slab groups without host synchronisation (blub_slab.inc.hip): the particle counts live on the device ({own, ghost}); num_particles /
     // num_ghost are then the BOUNDS launch grids are sized for, and the exact values only come back on request (slab_refresh_counts)
     uint32_t* n_dev = nullptr;
+    // internal re-sort of the particles (blub_bricks.hip.h "internal re-sort"): every `resort_every` steps, at the binning point of blub_fluid_step
+    int resort_every = 8;                     // blub_fluid_set_tuning "resort_every": 0 = never (the particle order only changes with the reference's rebinning)
+    uint32_t *pid = nullptr, *pid_tmp = nullptr;          // internal slot -> canonical particle index (allocated with the tables, on the first re-sort)
+    uint32_t *resort_counters = nullptr, *resort_starts = nullptr, *resort_ranks = nullptr;   // brick-major tables (nb x 512 + 4 entries), a rank per particle
+    uint32_t* resort_cursor = nullptr;        // bump allocator of k_resort_scan (zeroed by every brick list build)
+    bool order_internal = false;              // the particle arrays are NOT in the caller's order (pid is not the identity)
+    uint32_t resorts_done = 0;
     bool bricks_premarked = false;            // brick_fluid already holds the marks of the current particle positions (set and consumed inside stage_advect)
     float gravity[3] = {0, 0, 0};
     int device = 0;
@@ -92,23 +99,8 @@ struct blub_fluid {
     uint32_t step_counter = 0;
     // particles (hybrid_fluid.rs:114-122)
     float4 *pos = nullptr, *pos_tmp = nullptr, *pvel[3] = {nullptr, nullptr, nullptr};
-    blubk::GatherNode* nodes = nullptr;       // linked-list form of the P2G lists ("p2g_runs" = 0; allocated on first use): 3 x 32 bytes per particle, what the list walks read (written by k_build_lists); component c at nodes + c * node_stride
+    blubk::GatherNode* nodes = nullptr;       // 3 x 32 bytes per particle: what the P2G list walks read (written by k_build_lists); component c at nodes + c * node_stride
     uint32_t node_stride = 0;
-    // run form of the three P2G lists (blub_kernels.hip.h "lists as RUNS"; the default): counters and {first, entries} per dual cell, ranks and 16-byte entries per particle and component
-    int p2g_runs = 0;                         // blub_fluid_set_tuning "p2g_runs": 1 = runs, 0 = linked lists + gather nodes
-    uint32_t* lcount[3] = {nullptr, nullptr, nullptr}; uint32_t* lcount_alloc[3] = {nullptr, nullptr, nullptr};
-    uint2* lrun[3] = {nullptr, nullptr, nullptr}; uint2* lrun_alloc[3] = {nullptr, nullptr, nullptr};
-    uint32_t *run_ranks = nullptr, *run_brick_base = nullptr, *run_cursor = nullptr;
-    float4* run_entries = nullptr;
-    uint32_t run_capacity = 0, run_shard_capacity = 0;   // entries: RUN_SHARDS regions of run_shard_capacity + an overflow region of 3 x max particles (blub_bricks.hip.h)
-    int gather_ablate = 0;                    // measurement hook ("p2g_gather_ablate")
-    // internal re-sort of the particles (blub_bricks.hip.h "internal re-sort"): every `resort_every` steps, at the binning point of blub_fluid_step
-    int resort_every = 8;                     // blub_fluid_set_tuning "resort_every": 0 = never (the particle order only changes with the reference's rebinning)
-    uint32_t *pid = nullptr, *pid_tmp = nullptr;          // internal slot -> canonical particle index (allocated with the tables, on the first re-sort)
-    uint32_t *resort_counters = nullptr, *resort_starts = nullptr;   // brick-major tables, nb x 512 + 4 entries
-    bool order_internal = false;              // the particle arrays are NOT in the caller's order (pid is not the identity)
-    uint32_t resorts_done = 0;
-    bool lists_counted = false;               // the counters / ranks of the CURRENT particle positions exist (k_correct of the previous step left them: stage_correct); consumed by stage_transfer
     // volumes (hybrid_fluid.rs:142-154; pressure_solver.rs:104-108, 332-351)
     int8_t* marker = nullptr;
     uint32_t* ll[3] = {nullptr, nullptr, nullptr};
@@ -329,27 +321,20 @@ static int build_lists(blub_fluid* h, int phase) {
     if (nblk <= h->num_cus && !h->two_kernel_build) {      // every block co-resident: classification and scatter in ONE launch (k_bricks_build)
         hipLaunchKernelGGL(k_bricks_build, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, h->brick_fluid, h->brick_active,
                            h->brick_touched, reinterpret_cast<uint32_t*>(h->brick_block_counts), h->brick_block_ready, h->list_fluid, h->list_active, h->list_reset, h->counts,
-                           h->counts_seq, h->counts_host_dev + (h->counts_seq % COUNTS_RING), &(h->counts_host_dev + COUNTS_RING)->pad0, h->run_cursor);
+                           h->counts_seq, h->counts_host_dev + (h->counts_seq % COUNTS_RING), &(h->counts_host_dev + COUNTS_RING)->pad0, h->resort_cursor);
         if (phase == COMPACT_STEP_A) h->all_touched = false;
         return BLUB_OK;
     }
     hipLaunchKernelGGL(k_bricks_classify, dim3(nblk), dim3(1024), 0, h->stream, h->bg, phase, all_touched, h->slab_z0 / BZ, h->slab_z1 / BZ, (const uint8_t*)h->brick_fluid, h->brick_active,
                        h->brick_touched, h->brick_flags, h->brick_block_counts);
     hipLaunchKernelGGL(k_bricks_scatter, dim3(nblk), dim3(1024), 0, h->stream, h->bg, (const uint8_t*)h->brick_flags, (const uint4*)h->brick_block_counts, nblk,
-                       h->list_fluid, h->list_active, h->list_reset, h->counts, h->counts_seq, h->brick_fluid, h->counts_host_dev + (h->counts_seq % COUNTS_RING), h->run_cursor);
+                       h->list_fluid, h->list_active, h->list_reset, h->counts, h->counts_seq, h->brick_fluid, h->counts_host_dev + (h->counts_seq % COUNTS_RING), h->resort_cursor);
     if (phase == COMPACT_STEP_A) h->all_touched = false;
     return BLUB_OK;
 }
 static int build_lists_from_particles(blub_fluid* h, int phase) { return build_lists(h, phase); }
 // particles were changed from outside a step (or a stage ran on its own): marks a kernel left for the next list build are void
-static int drop_list_counts(blub_fluid* h) {      // ... and so are the list counters k_correct left for the next transfer (all zero again: the next transfer counts by itself)
-    if (!h->lists_counted) return BLUB_OK;
-    h->lists_counted = false;
-    for (int c = 0; c < 3; ++c) HIP_TRY(hipMemsetAsync(h->lcount_alloc[c], 0, h->vol_cells * sizeof(uint32_t), h->stream));
-    return BLUB_OK;
-}
 static int drop_brick_marks(blub_fluid* h) {
-    { int rc = drop_list_counts(h); if (rc != BLUB_OK) return rc; }
     if (!h->bricks_premarked) return BLUB_OK;
     h->bricks_premarked = false;
     HIP_TRY(hipMemsetAsync(h->brick_fluid, 0, (size_t)h->bg.nb, h->stream));
@@ -407,53 +392,21 @@ static ListGrids list_grids(blub_fluid* h) {
 }
 
 // ---- stages ------------------------------------------------------------------------------------------------------
-static RunLists run_lists(const blub_fluid* h) {
-    RunLists L;
-    for (int c = 0; c < 3; ++c) { L.counts[c] = h->lcount[c]; L.runs[c] = h->lrun[c]; }
-    L.ranks = h->run_ranks; L.entries = h->run_entries; L.stride = h->node_stride; L.capacity = h->run_capacity;
-    return L;
-}
-static int ensure_gather_nodes(blub_fluid* h) {      // linked-list form only
-    if (h->nodes) return BLUB_OK;
-    return dev_alloc_zero(h->stream, &h->nodes, 3 * (size_t)h->node_stride);
-}
 static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-833
-    const bool runs = h->p2g_runs != 0;
-    const uint32_t np_all = h->num_particles + h->num_ghost;
-    int rc;
-    if (!runs && ((rc = drop_list_counts(h)) != BLUB_OK || (rc = ensure_gather_nodes(h)) != BLUB_OK)) return rc;      // (counters a run-form step left behind, should the form be switched between two steps)
-    // run form: count (unless the previous step's k_correct did), scan inside the reset kernel, scatter, gather
-    if (runs && np_all && !h->lists_counted)
-        LAUNCH(h, KC_BUILD_LISTS, k_count_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, (const float4*)h->pos, run_lists(h), (const uint32_t*)h->n_dev, N_ALL);
-    h->lists_counted = false;
-    if ((rc = build_lists_from_particles(h, COMPACT_STEP_A)) != BLUB_OK) return rc;
+    int rc = build_lists_from_particles(h, COMPACT_STEP_A);
+    if (rc != BLUB_OK) return rc;
     const ListGrids lg = list_grids(h);
-    RunScan R{};
-    if (runs) { for (int c = 0; c < 3; ++c) { R.counts[c] = h->lcount[c]; R.runs[c] = h->lrun[c]; } R.brick_base = h->run_brick_base; R.cursor = h->run_cursor; R.nb = (uint32_t)h->bg.nb; R.shard_capacity = h->run_shard_capacity; }
-    // (run form inside a step: nobody reads the linked-list volume before the advection's own reset clears it; the stage hook shows the x lists in it)
-    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(lg.reset), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker,
-           (!runs || h->standalone_stage) ? h->ll[0] : (uint32_t*)nullptr, runs ? (uint32_t*)nullptr : h->ll[1], runs ? (uint32_t*)nullptr : h->ll[2],
-           h->vel[0], h->vel[1], h->vel[2], h->pressure[0], h->pressure[1], R);
-    if (np_all) {
-        if (runs)
-            LAUNCH(h, KC_BUILD_LISTS, k_scatter_entries, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, (const float4*)h->pos, h->marker, run_lists(h), (int)(h->solid == nullptr), (const uint32_t*)h->n_dev, N_ALL);
-        else
-            LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, h->marker,
-                   h->ll[0], h->ll[1], h->ll[2], (const float4*)h->pvel[0], (const float4*)h->pvel[1], (const float4*)h->pvel[2], h->nodes, h->node_stride, (int)(h->solid == nullptr), (int)h->standalone_stage, (const uint32_t*)h->n_dev, N_ALL);
-    }
-    const dim3 ggrid(3 * ((lg.active + 7) / 8) * 8);
-    if (runs) {
-        GatherRunArgs3 a;
-        for (int c = 0; c < 3; ++c) { a.runs[c] = h->lrun[c]; a.rows[c] = h->pvel[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
-        a.brick_base = h->run_brick_base; a.entries = h->run_entries; a.nb = (uint32_t)h->bg.nb; a.ablate = h->gather_ablate;
-        LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_r, ggrid, dim3(GR_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker, a);
-        // stage hook: the x lists as heads + links (BLUB_VOLUME_LINKED_LIST, particles_position_ll), derived from the runs the gather just used
-        if (h->standalone_stage && np_all)
-            LAUNCH(h, KC_COPY, k_runs_to_links, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, run_lists(h), h->ll[0], (const uint32_t*)h->n_dev, N_ALL);
-    } else {
+    LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(lg.reset), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0], h->ll[1], h->ll[2],
+           h->vel[0], h->vel[1], h->vel[2], h->pressure[0], h->pressure[1]);
+    const uint32_t np_all = h->num_particles + h->num_ghost;
+    if (np_all)
+        LAUNCH(h, KC_BUILD_LISTS, k_build_lists, dim3(particle_blocks(np_all)), dim3(256), h->g, np_all, h->pos, h->marker,
+               h->ll[0], h->ll[1], h->ll[2], (const float4*)h->pvel[0], (const float4*)h->pvel[1], (const float4*)h->pvel[2], h->nodes, h->node_stride, (int)(h->solid == nullptr), (int)h->standalone_stage, (const uint32_t*)h->n_dev, N_ALL);
+    {
         GatherArgs3 a;
         for (int c = 0; c < 3; ++c) { a.heads[c] = h->ll[c]; a.out[c] = h->vel[c]; a.gravity_dt[c] = h->gravity[c] * dt; }
         a.node_stride = h->node_stride;
+        const dim3 ggrid(3 * ((lg.active + 7) / 8) * 8);
         // Which of the two (bit-identical) gathers: the compacting one wins while a FLUID brick holds particles in a minority of its cells (headline scene: ~750
         // particles per FLUID brick, 69 against 76 us), one lane per list cell when the bricks are full (M4: ~4000 per brick, 3.7 against 4.1 ms).
         // Decided from the newest brick counts that have landed -- a speed choice only.
@@ -738,6 +691,7 @@ static int ensure_resort_tables(blub_fluid* h) {
     if (rc == BLUB_OK) rc = dev_alloc_zero(h->stream, &h->pid_tmp, P);
     if (rc == BLUB_OK) rc = dev_alloc_zero(h->stream, &h->resort_counters, T);
     if (rc == BLUB_OK) rc = dev_alloc_zero(h->stream, &h->resort_starts, T);
+    if (rc == BLUB_OK) rc = dev_alloc_zero(h->stream, &h->resort_ranks, P);
     if (rc != BLUB_OK) return rc;
     hipLaunchKernelGGL(k_iota, dim3(particle_blocks((uint32_t)P)), dim3(256), 0, h->stream, 0u, (uint32_t)P, h->pid);
     return BLUB_OK;
@@ -751,10 +705,9 @@ static int stage_resort(blub_fluid* h) {      // the fluid brick list of this st
     int rc = ensure_resort_tables(h);
     if (rc != BLUB_OK) return rc;
     const uint32_t n = h->num_particles;
-    uint32_t* const cursor = h->run_cursor + (RUN_SHARDS + 1) * RUN_SHARD_STRIDE;      // (zeroed by the list build of this step's transfer)
-    LAUNCH(h, KC_BIN_COUNT, k_resort_count, dim3(particle_blocks(n)), dim3(256), h->bg, n, (const float4*)h->pos, h->resort_counters, h->run_ranks);
-    LAUNCH(h, KC_BIN_SCAN, k_resort_scan, dim3(list_grids(h).fluid + 1), dim3(BRICK_THREADS), h->bg, LIST(h, fluid), h->resort_counters, h->resort_starts, cursor);
-    LAUNCH(h, KC_BIN_REWRITE, k_resort_move, dim3(particle_blocks(n)), dim3(256), h->bg, n, (const float4*)h->pos, (const uint32_t*)h->pid, (const uint32_t*)h->run_ranks,
+    LAUNCH(h, KC_BIN_COUNT, k_resort_count, dim3(particle_blocks(n)), dim3(256), h->bg, n, (const float4*)h->pos, h->resort_counters, h->resort_ranks);
+    LAUNCH(h, KC_BIN_SCAN, k_resort_scan, dim3(list_grids(h).fluid / RESORT_GROUP + 1), dim3(BRICK_THREADS), h->bg, LIST(h, fluid), h->resort_counters, h->resort_starts, h->resort_cursor);      // (the cursor was zeroed by the list build of this step's transfer)
+    LAUNCH(h, KC_BIN_REWRITE, k_resort_move, dim3(particle_blocks(n)), dim3(256), h->bg, n, (const float4*)h->pos, (const uint32_t*)h->pid, (const uint32_t*)h->resort_ranks,
            (const uint32_t*)h->resort_starts, h->pos_tmp, h->pid_tmp);
     std::swap(h->pos, h->pos_tmp); std::swap(h->pid, h->pid_tmp);
     h->order_internal = true; h->resorts_done += 1;
@@ -765,8 +718,6 @@ static int stage_resort(blub_fluid* h) {      // the fluid brick list of this st
 static int restore_canonical_order(blub_fluid* h) {
     if (!h->order_internal) return BLUB_OK;
     h->order_internal = false;
-    int rc = drop_list_counts(h);      // (ranks are per internal slot)
-    if (rc != BLUB_OK) return rc;
     const uint32_t n = h->num_particles;
     if (n) {
         ProfScope ps(h, KC_COPY);
@@ -793,7 +744,7 @@ static int stage_advect_particles(blub_fluid* h, float dt, bool insert_lists, bo
     // mark_bricks: the list build that follows takes its FLUID bricks from this kernel's marks (brick_fluid is all zero here, see build_lists)
     // the reset list (active + stale bricks of this step, own AND ghost bricks) is a superset of the active list
     LAUNCH(h, KC_RESET_BRICKS, k_reset_bricks, dim3(list_grids(h).reset), dim3(BRICK_THREADS), h->bg, LIST(h, reset), (const float4*)h->solid, h->marker, h->ll[0],
-           (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, RunScan{});
+           (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     if (h->num_particles) {
 #define BLUB_ADVECT(F) LAUNCH(h, KC_ADVECT, k_advect<F>, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, dt, h->pos, h->pvel[0], h->pvel[1], h->pvel[2], \
                h->vel[0], h->vel[1], h->vel[2], h->solid, h->marker, insert_lists ? h->ll[0] : (uint32_t*)nullptr, \
@@ -823,18 +774,13 @@ static int stage_position_change(blub_fluid* h, float dt) {   // :960-967
 // list build after advection consumed and cleared it), one launch less per step; every entry point that changes particles drops the marks.
 static int stage_correct(blub_fluid* h, bool step_done = false) {   // :969-973
     const bool mark = step_done && h->num_ghost == 0;
-    // ... and it enters the particles into the next step's P2G lists (run form: counters + ranks, k_correct<.., true>)
-    const bool count = mark && h->p2g_runs != 0 && h->n_dev == nullptr;
     if (h->num_particles) {
-#define BLUB_CORRECT(F, C) LAUNCH(h, KC_CORRECT, (k_correct<F, C>), dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2], \
+#define BLUB_CORRECT(F) LAUNCH(h, KC_CORRECT, k_correct<F>, dim3(particle_blocks(h->num_particles)), dim3(256), h->g, h->num_particles, h->pos, h->marker, h->vel[0], h->vel[1], h->vel[2], \
                step_done ? (volatile uint32_t*)h->steps_done_dev : (volatile uint32_t*)nullptr, h->steps_enqueued + 1u, mark ? h->brick_fluid : (uint8_t*)nullptr, h->bg.nbx, h->bg.nby, \
-               run_lists(h), (const uint32_t*)h->n_dev, N_OWN)
-#define BLUB_CORRECT_F(F) do { if (count) BLUB_CORRECT(F, true); else BLUB_CORRECT(F, false); } while (0)
-        if (h->filter_mode == BLUB_FILTER_WEIGHTED) BLUB_CORRECT_F(1); else if (h->filter_mode == BLUB_FILTER_WEIGHTED8) BLUB_CORRECT_F(2); else BLUB_CORRECT_F(0);
-#undef BLUB_CORRECT_F
+               (const uint32_t*)h->n_dev, N_OWN)
+        if (h->filter_mode == BLUB_FILTER_WEIGHTED) BLUB_CORRECT(1); else if (h->filter_mode == BLUB_FILTER_WEIGHTED8) BLUB_CORRECT(2); else BLUB_CORRECT(0);
 #undef BLUB_CORRECT
         h->bricks_premarked = mark;
-        h->lists_counted = count;
     }
     else if (step_done)
         hipLaunchKernelGGL(k_step_done, dim3(1), dim3(1), 0, h->stream, (volatile uint32_t*)h->steps_done_dev, h->steps_enqueued + 1u);
@@ -880,9 +826,7 @@ static void destroy(blub_fluid* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->solid_alloc); F(h->scan_totals);
-    for (int c = 0; c < 3; ++c) { F(h->lcount_alloc[c]); F(h->lrun_alloc[c]); }
-    F(h->run_ranks); F(h->run_entries); F(h->run_brick_base); F(h->run_cursor);
-    F(h->pid); F(h->pid_tmp); F(h->resort_counters); F(h->resort_starts);
+    F(h->pid); F(h->pid_tmp); F(h->resort_counters); F(h->resort_starts); F(h->resort_ranks); F(h->resort_cursor);
     for (auto p : h->vol_owned) F(p);
     for (auto p : h->cgbuf_alloc) F(p);
     F(h->brick_flags); F(h->brick_block_counts); F(h->brick_block_ready); F(h->brick_fluid); F(h->brick_active); F(h->brick_touched); F(h->list_fluid); F(h->list_active); F(h->list_reset); F(h->counts);
@@ -966,14 +910,8 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { destroy(h); return set_error(BLUB_ERR_DEVICE, "hipStreamCreate failed"); }
     A(dev_alloc_zero(h->stream, &h->pos, P)); A(dev_alloc_zero(h->stream, &h->pos_tmp, P));
     for (int c = 0; c < 3; ++c) A(dev_alloc_zero(h->stream, &h->pvel[c], P));
-    h->node_stride = (uint32_t)P;
-    h->run_shard_capacity = (uint32_t)((6 * P + RUN_SHARDS - 1) / RUN_SHARDS); h->run_capacity = h->run_shard_capacity * RUN_SHARDS + (uint32_t)(3 * P);
-    if (9 * (uint64_t)P + RUN_SHARDS >= (1ull << 32)) A(set_error(BLUB_ERR_UNSUPPORTED, "max_num_particles too large for 32-bit list entries"));
-    A(dev_alloc_zero(h->stream, &h->run_ranks, 3 * P)); A(dev_alloc_zero(h->stream, &h->run_entries, (size_t)h->run_capacity)); A(dev_alloc_zero(h->stream, &h->run_cursor, (size_t)(RUN_SHARDS + 2) * RUN_SHARD_STRIDE));
-    for (int c = 0; c < 3; ++c) {      // per-cell state of the run lists: outside the volume slab (never exchanged between slabs), indexed like a volume
-        A(dev_alloc_zero(h->stream, &h->lcount_alloc[c], h->vol_cells)); A(dev_alloc_zero(h->stream, &h->lrun_alloc[c], h->vol_cells));
-        if (rc == BLUB_OK) { h->lcount[c] = h->lcount_alloc[c] - h->vol_first; h->lrun[c] = h->lrun_alloc[c] - h->vol_first; }
-    }
+    A(dev_alloc_zero(h->stream, &h->nodes, 3 * P)); h->node_stride = (uint32_t)P;
+    A(dev_alloc_zero(h->stream, &h->resort_cursor, 4));
     if (d->volume_shift_kib != 0xFFFFFFFFu) {      // (0xFFFFFFFF: one allocation per volume)
         h->slab_shift = (size_t)(d->volume_shift_kib ? d->volume_shift_kib : 64u) * 1024u;
         const size_t per = ((h->vol_cells * 4 + 0x1FFFFFull) & ~0x1FFFFFull) + 0x400000ull;      // 2 MiB alignment + up to 2 MiB of shift
@@ -1022,7 +960,6 @@ static int create(const blub_fluid_desc* d, blub_fluid** out, hipStream_t shared
     A(dev_alloc_zero(h->stream, &h->counts, 1));
     A(dev_alloc_zero(h->stream, &h->brick_flags, (size_t)bg.nb)); A(dev_alloc_zero(h->stream, &h->brick_block_counts, (size_t)(bg.nb + 1023) / 1024));
     A(dev_alloc_zero(h->stream, &h->brick_block_ready, (size_t)(bg.nb + 1023) / 1024));
-    if (rc == BLUB_OK) { if (hipMalloc((void**)&h->run_brick_base, 3 * (size_t)bg.nb * sizeof(uint32_t)) != hipSuccess) rc = set_error(BLUB_ERR_OUT_OF_MEMORY, "hipMalloc failed"); else (void)hipMemsetAsync(h->run_brick_base, 0xFF, 3 * (size_t)bg.nb * sizeof(uint32_t), h->stream); }      // RUN_EMPTY everywhere
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) h->num_cus = 0;
     if (rc == BLUB_OK) {
         void* hp = nullptr;
@@ -1414,8 +1351,6 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "list_launch_grid") h->list_grid_forced = value;
     else if (k == "fuse_divergence") h->fuse_divergence = std::max(0, std::min(2, value));
     else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);
-    else if (k == "p2g_runs") h->p2g_runs = value != 0;
-    else if (k == "p2g_gather_ablate") h->gather_ablate = value;
     else if (k == "resort_every") h->resort_every = std::max(0, value);
     else if (k == "bricks_two_kernel_build") h->two_kernel_build = value != 0;
     else if (k == "spin_free") {      // no kernel of a step waits for co-resident workgroups any more: the two-kernel list build, every PCG iteration launched (no persistent tail)

@@ -104,28 +104,9 @@ __device__ __forceinline__ uint32_t wave_list_insert(uint32_t* __restrict__ head
     return is_first ? old_of_group - 1u : prev_particle;
 }
 
-// ---- lists as RUNS (round 6: the steady-state form of the three P2G lists) --------------------------------------------------------------
-// A linked list makes the gather a chain of dependent, fully divergent 64-byte misses (one per hop: ~8 CU-cycles per hop whatever the occupancy,
-// docs/DESIGN_rounds_1-3.md 5c) and its construction an exchange per particle and list.  The same lists as a counting sort:
-//   count   : every particle adds itself to its dual cell's counter and keeps the value it found -- its RANK in the list = its position in the
-//             reference's insertion order (transfer_build_linkedlist.comp:25: the exchange order; here per wave in lane order, like wave_list_insert);
-//             inside blub_fluid_step this rides in k_correct, the last writer of a position
-//   scan    : k_reset_bricks turns the 512 counters of a brick into offsets behind a base it takes from a bump allocator (one atomic per brick and
-//             component) and zeroes the counters: run[c][cell] = {first entry, entries}
-//   scatter : k_scatter_entries writes {position, particle} at run.first + rank -- 16 bytes per particle and component, no atomics
-// A list is then ONE contiguous piece of memory, most recent insertion last; the lists of a brick row follow each other.  The gather
-// (k_gather_velocity3_r, blub_bricks.hip.h) fetches them with coalesced loads, stages them in LDS and walks them there, head first as before.
-constexpr uint32_t RUN_EMPTY = 0xFFFFFFFFu;      // brick_base[c][brick]: no entry of component c's lists lies in this brick (its run[] cells are not current)
-
-// dual cell of component c's list a position belongs to (transfer_build_linkedlist.comp:17-19), -1 outside the grid
-__device__ __forceinline__ int dual_key(const Grid& g, float px, float py, float pz, int c) {
-    const int dx = (int)(px - (c == 0 ? 1.0f : 0.5f)), dy = (int)(py - (c == 1 ? 1.0f : 0.5f)), dz = (int)(pz - (c == 2 ? 1.0f : 0.5f));
-    return inb(g, dx, dy, dz) ? cidx(g, dx, dy, dz) : -1;
-}
-// Wave-aggregated counting insertion: the lanes of a wave that share a list take consecutive ranks in lane order behind ONE atomic add (the group
-// search of wave_list_insert).  In three parts so that a particle's three insertions have their atomics in flight together: the group's lanes
-// (wave_group), the add by its first lane (wave_group_add: the counter's old value, valid in that lane), the rank (wave_group_rank).  key < 0: no
-// insertion.  All 64 lanes must call these.
+// Wave-aggregated COUNTING insertion (the particle re-sort, blub_bricks.hip.h): the lanes of a wave that share a key take consecutive ranks in lane
+// order behind ONE atomic add -- the group search of wave_list_insert.  In three parts: the group's lanes (wave_group), the add by its first lane
+// (wave_group_add: the counter's old value, valid in that lane), the rank (wave_group_rank).  key < 0: no insertion.  All 64 lanes must call these.
 __device__ __forceinline__ unsigned long long wave_group(int key) {
     unsigned long long remaining = ~0ull, mine = 0ull;
     while (remaining) {
@@ -143,82 +124,6 @@ __device__ __forceinline__ uint32_t wave_group_add(uint32_t* __restrict__ counts
 __device__ __forceinline__ uint32_t wave_group_rank(uint32_t base, unsigned long long mine) {
     const int lane = threadIdx.x & 63;
     return (uint32_t)__shfl((int)base, __builtin_ctzll(mine), 64) + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
-}
-// the three insertions of one particle (dummy lanes: live = false)
-__device__ __forceinline__ void wave_count3(const Grid& g, uint32_t* const (&counts)[3], bool live, float px, float py, float pz, uint32_t (&rank)[3]) {
-    int key[3]; unsigned long long mine[3]; uint32_t base[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { key[c] = live ? dual_key(g, px, py, pz, c) : -1; mine[c] = wave_group(key[c]); }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) base[c] = wave_group_add(counts[c], key[c], mine[c]);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rank[c] = wave_group_rank(base[c], mine[c]);
-}
-struct RunLists {            // what the count / scatter side of the run lists needs (component c: counts[c], runs[c], ranks + c * stride, entries + c * stride)
-    uint32_t* counts[3];     // u32 per dual cell, all zero between a scan and the next count
-    uint2* runs[3];          // {first entry, entries} per dual cell, current inside bricks whose brick_base is not RUN_EMPTY
-    uint32_t* ranks;         // 3 x stride
-    float4* entries;         // {position, particle index}: ONE array for the three components (a brick's entries are allocated together: k_reset_bricks), `capacity` entries
-    uint32_t stride, capacity;
-};
-// the three counts of a particle (stand-alone: stage calls, slabs with ghost particles, after the particles were changed from outside)
-__global__ __launch_bounds__(256) void k_count_lists(Grid g, uint32_t num_particles, const float4* __restrict__ pos, RunLists L,
-                                                     const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
-    num_particles = particle_count(num_particles, n_dev, n_sel);
-    if (blockIdx.x * 256u >= num_particles) return;      // (uniform)
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < num_particles;                 // no early return: the wave-level insertion needs every lane
-    const float4 p = live ? pos[i] : make_float4(-8.f, -8.f, -8.f, 0.f);
-    uint32_t rank[3];
-    wave_count3(g, L.counts, live, p.x, p.y, p.z, rank);
-    if (live) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) L.ranks[(size_t)c * L.stride + i] = rank[c];
-    }
-}
-// T2 (marker) + the scatter: transfer_build_linkedlist.comp:10-26 with the lists as runs
-__global__ __launch_bounds__(256) void k_scatter_entries(Grid g, uint32_t num_particles, const float4* __restrict__ pos, int8_t* __restrict__ marker, RunLists L,
-                                                         int no_solid_voxels, const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
-    num_particles = particle_count(num_particles, n_dev, n_sel);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= num_particles) return;
-    const float4 p = pos[i];
-    uint32_t rk[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rk[c] = L.ranks[(size_t)c * L.stride + i];
-    const int x = (int)p.x, y = (int)p.y, z = (int)p.z;
-    if (inb(g, x, y, z)) {
-        const int cc = cidx(g, x, y, z);
-        // without solid voxels only the domain shell is SOLID: an interior cell is marked without reading the marker first
-        const bool interior = no_solid_voxels && x > 0 && y > 0 && z > 0 && x < g.nx - 1 && y < g.ny - 1 && z < g.nz - 1;
-        if (interior || marker[cc] != CELL_SOLID) marker[cc] = CELL_FLUID;
-    }
-    const float4 e = make_float4(p.x, p.y, p.z, __uint_as_float(i));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int key = dual_key(g, p.x, p.y, p.z, c);
-        if (key < 0) continue;
-        const uint32_t dst = L.runs[c][key].x + rk[c];
-        if (dst < L.capacity) L.entries[dst] = e;      // (always true for counts and ranks of THESE positions; a guard against a caller's misuse, not a path)
-    }
-}
-// Stage hook only (blub_fluid_run_stage): the x lists in the reference's own form -- heads in the linked-list volume, links in particles_position_ll
-// (transfer_build_linkedlist.comp:25-26) -- derived from the runs the gather used: a run read backwards IS the list (head = its last entry).
-__global__ __launch_bounds__(256) void k_runs_to_links(Grid g, uint32_t num_particles, float4* __restrict__ pos, RunLists L, uint32_t* __restrict__ heads,
-                                                       const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
-    num_particles = particle_count(num_particles, n_dev, n_sel);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= num_particles) return;
-    const float4 p = pos[i];
-    const int key = dual_key(g, p.x, p.y, p.z, 0);
-    uint32_t link = INVALID_LL;
-    if (key >= 0) {
-        const uint2 r = L.runs[0][key];
-        const uint32_t rk = L.ranks[i];
-        if (rk > 0u) link = __float_as_uint(L.entries[r.x + rk - 1u].w);
-        if (rk + 1u == r.y) heads[key] = i + 1u;
-    }
-    reinterpret_cast<uint32_t*>(pos)[4 * (size_t)i + 3] = link;
 }
 
 // Gather nodes: what one hop of a P2G list walk reads, in ONE 32-byte piece -- {position, link of component c's list, velocity row c}.  One array of
@@ -890,22 +795,18 @@ __global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, 
 // =================================================================================================================
 // step_done_host / step_number: the run-ahead throttle of blub_fluid_step (a counter in pinned host memory; this is the last kernel of a
 // step, and its last workgroup is dispatched when nearly all others have retired -- the throttle needs no more than that)
-// COUNT (inside blub_fluid_step, no ghost particles): the kernel is the last writer of a position, so it also enters the particle into the three
-// P2G lists of the NEXT step -- counts and ranks of the run lists (wave_list_count), which are all the next step's transfer needs besides a scan
-// and a scatter: no pass over the particles re-reads positions to build lists.
-template <int FILTER = 0, bool COUNT = false>
+template <int FILTER = 0>
 __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles, float4* __restrict__ pos, const int8_t* __restrict__ marker,
                                                  const float* __restrict__ vx, const float* __restrict__ vy, const float* __restrict__ vz,
                                                  volatile uint32_t* step_done_host, uint32_t step_number,
-                                                 uint8_t* __restrict__ brick_fluid, int nbx, int nby, RunLists L, const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
+                                                 uint8_t* __restrict__ brick_fluid, int nbx, int nby, const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
     if (step_done_host && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *step_done_host = step_number;
     num_particles = particle_count(num_particles, n_dev, n_sel);
     const uint32_t pi = blockIdx.x * 256 + threadIdx.x;
-    if (COUNT ? blockIdx.x * 256u >= num_particles : pi >= num_particles) return;      // (COUNT: uniform -- the wave-level insertion needs every lane)
-    const bool live = pi < num_particles;
+    if (pi >= num_particles) return;
     const float gs[3] = {(float)g.nx, (float)g.ny, (float)g.nz};
     const float inv[3] = {1.0f / gs[0], 1.0f / gs[1], 1.0f / gs[2]};
-    const float4 p0 = live ? pos[pi] : make_float4(1.5f, 1.5f, 1.5f, 0.0f);
+    const float4 p0 = pos[pi];
     const float op[3] = {p0.x, p0.y, p0.z};
     const float* vel[3] = {vx, vy, vz};
     float ch[3];
@@ -934,18 +835,10 @@ __global__ __launch_bounds__(256) void k_correct(Grid g, uint32_t num_particles,
 #pragma unroll
         for (int k = 0; k < 3; ++k) { np[k] = op[k] + dir[k] * ms; np[k] = clampf(np[k], 1.001f, gs[k] - 1.001f); }
     }
-    if (live) pos[pi] = make_float4(np[0], np[1], np[2], p0.w);
-    if (live && brick_fluid) {   // what k_bricks_mark_particles would do for the next step's first list build (16 x 8 x 4 bricks, see k_advect)
+    pos[pi] = make_float4(np[0], np[1], np[2], p0.w);
+    if (brick_fluid) {   // what k_bricks_mark_particles would do for the next step's first list build (16 x 8 x 4 bricks, see k_advect)
         const int x = (int)np[0], y = (int)np[1], z = (int)np[2];
         if (inb(g, x, y, z)) brick_fluid[((z >> 2) * nby + (y >> 3)) * nbx + (x >> 4)] = 1;
-    }
-    if (COUNT) {
-        uint32_t rank[3];
-        wave_count3(g, L.counts, live, np[0], np[1], np[2], rank);
-        if (live) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) L.ranks[(size_t)c * L.stride + pi] = rank[c];
-        }
     }
 }
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+root=${GRAFT_REPO_ROOT:-$(pwd)}; cd $root; mkdir -p gpurun_out
+o=gpurun_out/r06_g
+timeout 1500 python -m pytest tests/test_gpu_vs_ref.py tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_abi.py tests/test_gpu_baseline_parity.py -m gpu -q -x --maxfail=5 > ${o}_tests.log 2>&1; tail -4 ${o}_tests.log
+for t in "resort_every=0" "resort_every=4" "resort_every=8"; do
+  timeout 300 python bench.py --no-cpu-baseline --no-dense-pcg --no-other-schedule --no-fast-forward --tune $t > ${o}_bench.log 2>&1
+  grep '^{' ${o}_bench.log | tail -1 > ${o}_bench.json
+  python - <<P
+import json
+d=json.load(open("${o}_bench.json"))
+u=d["kernel_breakdown"]["us_per_step"]
+print("$t value", d["value"], {k: u.get(k) for k in ("gather_velocity","build_lists","correct","reset_bricks","advect","density_gather","bin_count","bin_scan","bin_rewrite")}, "sum", d["kernel_breakdown"]["sum_us_per_step"])
+P
+done
+for lib in "" p6; do
+if [ -n "$lib" ]; then export BLUBHIP_LIB=$root/blub_amd/libblubhip_$lib.so; else unset BLUBHIP_LIB; fi
+timeout 900 python bench.py --transfer-only 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+for k in ('after_binning',):
+    print('lib=$lib', k, {q: (v['avg_us'], v['frac']) for q,v in d[k].items() if isinstance(v, dict)})
+"
+done
