@@ -56,6 +56,13 @@ __device__ __forceinline__ bool brick_quad(const BrickGeom& bg, uint32_t b, int 
     return x0 < bg.g.nx && y < bg.g.ny && z < bg.g.nz;
 }
 
+// XCD-contiguous order for kernels that loop over a brick list: workgroup b runs on XCD b % 8 (observed dispatch order, a speed hint only -- any
+// placement is correct), and every kernel starts with cold L2s, so list position j -> (j % 8) * ceil(n / 8) + j / 8 hands XCD k the contiguous
+// range [k n / 8, (k + 1) n / 8) of the list: x-neighbouring bricks (consecutive in the list, sharing 64-byte sectors of every row they touch and
+// each other's halo cells) meet in ONE L2 instead of being fetched by up to four.  Loop j over [0, list_slots(n)) with a stride that is a multiple of 8.
+__device__ __forceinline__ uint32_t list_slots(uint32_t n) { return (n + 7u) & ~7u; }
+__device__ __forceinline__ bool list_slot(uint32_t j, uint32_t n, uint32_t& i) { i = (j & 7u) * ((n + 7u) >> 3) + (j >> 3); return i < n; }
+
 // ---- list construction ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bricks_mark_particles(BrickGeom bg, uint32_t num_particles, const float4* __restrict__ pos, uint8_t* __restrict__ brick_fluid,
                                                                const uint32_t* __restrict__ n_dev, uint32_t n_sel) {
@@ -409,7 +416,9 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_reset_bricks(BrickGeom bg, co
                                                                 float* __restrict__ vx, float* __restrict__ vy, float* __restrict__ vz,
                                                                 float* __restrict__ p0, float* __restrict__ p1) {
     const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    for (uint32_t j = blockIdx.x; j < list_slots(n); j += gridDim.x) {
+        uint32_t i;
+        if (!list_slot(j, n, i)) continue;
         const uint32_t e = list[i];
         int x0, y, z;
         if (!brick_quad(bg, e & ~STALE_BIT, threadIdx.x, x0, y, z)) continue;
@@ -685,7 +694,9 @@ __global__ __launch_bounds__(768) void k_density_gather_p(BrickGeom bg, const ui
     const bool live = tid < GT_N;
     const int lx = tid % GT_X, ly = (tid / GT_X) % GT_Y, lz = tid / (GT_X * GT_Y);
     const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    for (uint32_t j = blockIdx.x; j < list_slots(n); j += gridDim.x) {
+        uint32_t i;
+        if (!list_slot(j, n, i)) continue;
         const uint32_t b = list[i];
         int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int gx = bx * BX + lx - 1, gy = by * BY + ly - 1, gz = bz * BZ + lz - 1;
@@ -740,7 +751,9 @@ __global__ __launch_bounds__(768) void k_density_gather_p(BrickGeom bg, const ui
 // ---- quad-vectorised element-wise grid kernels over brick lists -------------------------------------------------------
 #define BRICK_LOOP_BEGIN(bg, list, count)                                                     \
     const uint32_t _n = *(count);                                                             \
-    for (uint32_t _i = blockIdx.x; _i < _n; _i += gridDim.x) {                                \
+    for (uint32_t _j = blockIdx.x; _j < list_slots(_n); _j += gridDim.x) {                    \
+        uint32_t _i;                                                                          \
+        if (!list_slot(_j, _n, _i)) continue;                                                 \
         int x0, y, z;                                                                         \
         if (!brick_quad((bg), (list)[_i] & ~STALE_BIT, threadIdx.x, x0, y, z)) continue;      \
         const int base = cidx((bg).g, x0, y, z);
@@ -908,7 +921,10 @@ __global__ __launch_bounds__(BRICK_THREADS) void k_extrapolate_b(BrickGeom bg, c
     const uint32_t n = *count;
     const int plane = g.nx * g.ny;
     int parity = 0;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x, parity ^= 1) {
+    for (uint32_t j = blockIdx.x; j < list_slots(n); j += gridDim.x) {
+        uint32_t i;
+        if (!list_slot(j, n, i)) continue;
+        parity ^= 1;
         const uint32_t b = list[i] & ~STALE_BIT;
         int bx, by, bz; brick_coords(bg, b, bx, by, bz);
         const int tx0 = bx * BX - 4, ty0 = by * BY - 1, tz0 = bz * BZ - 1;     // tile origin (x is dword aligned)

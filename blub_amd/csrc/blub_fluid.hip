@@ -386,7 +386,7 @@ static ListGrids list_grids(blub_fluid* h) {
     if (h->list_grid_forced > 0) { lg.fluid = lg.active = lg.reset = std::min(h->list_grid_forced, h->bg.nb); return lg; }
     BrickCounts bc; bool have = false;
     if (latest_counts(h, false, &bc, &have) != BLUB_OK || !have) return lg;      // (an error is reported by the solve stage, which asks too)
-    auto sz = [&](uint32_t n) { return (int)std::min<uint32_t>((uint32_t)h->bg.nb, std::max<uint32_t>(256u, n + n / 8u + 16u)); };
+    auto sz = [&](uint32_t n) { return (int)std::min<uint32_t>(((uint32_t)h->bg.nb + 7u) & ~7u, (std::max<uint32_t>(256u, n + n / 8u + 16u) + 7u) & ~7u); };      // (a multiple of 8: list_slot's XCD-contiguous order)
     lg.fluid = sz(bc.n_fluid); lg.active = sz(bc.n_active); lg.reset = sz(bc.n_reset);
     return lg;
 }
