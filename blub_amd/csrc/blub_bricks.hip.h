@@ -684,6 +684,135 @@ __global__ __launch_bounds__(GS_THREADS) void k_gather_velocity3_s(BrickGeom bg,
     else gather_velocity_sparse_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes + (size_t)2 * a.node_stride, a.out[2], a.gravity_dt[2]);
 }
 
+// ---- T4, list-centric (round 6; single domains, well-filled bricks): every list is walked ONCE ----------------------------------------------------------------
+// The kernels above give every brick the lists of its tile (own 16 x 8 x 4 cells + the negative halo, 765 cells): a halo list is walked by
+// two to eight bricks, 1.49 x the hops, and a hop -- two divergent 16-byte accesses per lane -- is what the walk is bound by (one L1 -> L2
+// request per hop at ~7 cycles per request and CU; profiles/r06_pmc_dam_halfhalf_highres_*.csv).  Here a brick walks its OWN 512 lists only.
+// Their partial sums reach the 17 x 9 x 5 faces own cell + {0,1}^3 (the REGION: the brick's own faces and one layer on the POSITIVE sides);
+// per region face the kernel adds up the partials it holds, in the reference's list order (:87-93).  Faces whose eight lists all lie in
+// this brick (region coordinates >= 1 and inside the brick: 315 of 512) are finished here; the sums of the others -- own faces that also
+// take part in a negative neighbour's lists, and the positive layer, which belongs to the neighbours -- go to a scratch array, stamped with
+// the sequence number of this step's list build, and k_gather_finish3 adds up to eight of them per boundary face: own brick first, then
+// the negative neighbours in the order of their lists.  Only the ASSOCIATION of a boundary face's sum changes (per-brick subtotals).
+struct GatherHalo { float2* sums; uint32_t* stamp; uint32_t seq, nb; };      // sums[(c nb + brick) 765 + region face], stamp[c nb + brick] = seq: the brick wrote sums this step
+struct GatherOwnShared { float2 part[8][BX * BY * BZ]; };                      // [corner][own list cell]: 32 KiB
+__device__ __forceinline__ float2 region_sum(const float2 (&part)[8][BX * BY * BZ], int fx, int fy, int fz) {
+    float2 S = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int lx = fx - (k & 1), ly = fy - ((k >> 1) & 1), lz = fz - (k >> 2);
+        if ((unsigned)lx < (unsigned)BX && (unsigned)ly < (unsigned)BY && (unsigned)lz < (unsigned)BZ) { const float2 q = part[k][lx + BX * (ly + BY * lz)]; S.x += q.x; S.y += q.y; }
+    }
+    return S;
+}
+__device__ __forceinline__ bool region_interior(int fx, int fy, int fz) { return fx >= 1 && fx < BX && fy >= 1 && fy < BY && fz >= 1 && fz < BZ; }
+// the value of a face from its sums (transfer_gather_velocity.comp:50-51, 117-124)
+template <int COMP>
+__device__ __forceinline__ void gather_finish_face(const Grid& g, const int8_t* __restrict__ marker, float* __restrict__ out, float gravity_dt, int gx, int gy, int gz, float2 S) {
+    if (!inb(g, gx, gy, gz)) return;
+    const int mA = (int)marker[cidx(g, gx, gy, gz)];
+    const int mB = mk(marker, g, gx + (COMP == 0), gy + (COMP == 1), gz + (COMP == 2));
+    if (mA == CELL_FLUID || mB == CELL_FLUID) {                                                  // :50
+        float o = 0.0f;
+        if (mA != CELL_SOLID && mB != CELL_SOLID) {                                              // :51
+            o = S.x;
+            if (S.y > 0.0f) o /= S.y;                                                            // :117-119
+            o += gravity_dt;                                                                     // :120
+        }
+        out[cidx(g, gx, gy, gz)] = o;                                                            // (:121-124: 0 with exactly one solid side)
+    }
+}
+template <int COMP>
+__device__ __forceinline__ void gather_region_out(const GatherOwnShared& sh, const BrickGeom& bg, uint32_t b, int bx, int by, int bz, const int8_t* __restrict__ marker,
+                                                  float* __restrict__ out, float gravity_dt, float2* __restrict__ sums, int nthreads) {
+    for (int r = threadIdx.x; r < GT_N; r += nthreads) {
+        const int fx = r % GT_X, fy = (r / GT_X) % GT_Y, fz = r / (GT_X * GT_Y);
+        const float2 S = region_sum(sh.part, fx, fy, fz);
+        if (region_interior(fx, fy, fz)) gather_finish_face<COMP>(bg.g, marker, out, gravity_dt, bx * BX + fx, by * BY + fy, bz * BZ + fz, S);
+        else sums[(size_t)b * GT_N + r] = S;
+    }
+}
+// one lane per own list cell (512 threads): the counterpart of k_gather_velocity3_p
+template <int COMP>
+__device__ __forceinline__ void gather_velocity_own_body(GatherOwnShared& sh, uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg, const uint32_t* __restrict__ list,
+                                                         const uint32_t* __restrict__ count, const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,
+                                                         const GatherNode* __restrict__ nodes, float* __restrict__ out, float gravity_dt, float2* __restrict__ sums,
+                                                         uint32_t* __restrict__ stamp, uint32_t seq) {
+    const Grid g = bg.g;
+    const int tid = threadIdx.x, lx = tid % BX, ly = (tid / BX) % BY, lz = tid / (BX * BY);
+    const uint32_t n = *count;
+    for (uint32_t i = first_brick; i < n; i += brick_stride) {
+        const uint32_t b = list[i];
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
+        const int gx = bx * BX + lx, gy = by * BY + ly, gz = bz * BZ + lz;
+        const uint32_t cur = inb(g, gx, gy, gz) ? heads[cidx(g, gx, gy, gz)] - 1u : INVALID_LL;
+        // (the barrier also separates the previous brick's reads of the partials from this brick's writes)
+        if (!__syncthreads_or(cur != INVALID_LL)) continue;      // none of the brick's own lists holds a particle: it has nothing to add to any face
+        float v[8], ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = 0.0f; ws[k] = 0.0f; }
+        if (cur != INVALID_LL) gather_walk<COMP>(nodes, cur, gx, gy, gz, v, ws);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh.part[k][tid] = make_float2(v[k], ws[k]);
+        if (tid == 0) stamp[b] = seq;
+        __syncthreads();
+        gather_region_out<COMP>(sh, bg, b, bx, by, bz, marker, out, gravity_dt, sums, BX * BY * BZ);
+    }
+}
+struct GatherOwnArgs3 { const uint32_t* heads[3]; float* out[3]; float gravity_dt[3]; uint32_t node_stride; GatherHalo halo; };
+__global__ __launch_bounds__(BX * BY * BZ) void k_gather_velocity3_po(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                                      const int8_t* __restrict__ marker, const GatherNode* __restrict__ nodes, GatherOwnArgs3 a) {
+    __shared__ GatherOwnShared sh;
+    uint32_t slot, slots; int comp;
+    gather3_block_role(slot, slots, comp);
+    float2* const sums = a.halo.sums + (size_t)comp * a.halo.nb * GT_N;
+    uint32_t* const stamp = a.halo.stamp + (size_t)comp * a.halo.nb;
+    if (comp == 0) gather_velocity_own_body<0>(sh, slot, slots, bg, list, count, marker, a.heads[0], nodes + (size_t)0 * a.node_stride, a.out[0], a.gravity_dt[0], sums, stamp, a.halo.seq);
+    else if (comp == 1) gather_velocity_own_body<1>(sh, slot, slots, bg, list, count, marker, a.heads[1], nodes + (size_t)1 * a.node_stride, a.out[1], a.gravity_dt[1], sums, stamp, a.halo.seq);
+    else gather_velocity_own_body<2>(sh, slot, slots, bg, list, count, marker, a.heads[2], nodes + (size_t)2 * a.node_stride, a.out[2], a.gravity_dt[2], sums, stamp, a.halo.seq);
+}
+// The faces on the three negative sides of a brick (197 of 512): own sums + those of the (up to seven) negative neighbours whose positive layer they lie in.
+template <int COMP>
+__device__ __forceinline__ void gather_finish_body(uint32_t first_brick, uint32_t brick_stride, const BrickGeom& bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                   const int8_t* __restrict__ marker, float* __restrict__ out, float gravity_dt, const float2* __restrict__ sums,
+                                                   const uint32_t* __restrict__ stamp, uint32_t seq) {
+    const uint32_t n = *count;
+    for (uint32_t i = first_brick; i < n; i += brick_stride) {
+        const uint32_t b = list[i];
+        int bx, by, bz; brick_coords(bg, b, bx, by, bz);
+        uint32_t live = 0;              // bit d: brick - d (d in {0,1}^3) exists and wrote sums this step
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int qx = bx - (d & 1), qy = by - ((d >> 1) & 1), qz = bz - (d >> 2);
+            if (qx >= 0 && qy >= 0 && qz >= 0 && stamp[(qz * bg.nby + qy) * bg.nbx + qx] == seq) live |= 1u << d;
+        }
+        if (!live) continue;            // (uniform) no particle near any face of this brick
+        for (int f = threadIdx.x; f < BX * BY * BZ; f += blockDim.x) {
+            const int fx = f % BX, fy = (f / BX) % BY, fz = f / (BX * BY);
+            if (region_interior(fx, fy, fz)) continue;
+            float2 S = make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
+                if (!((live >> d) & 1u) || (dx && fx) || (dy && fy) || (dz && fz)) continue;
+                const uint32_t q = (uint32_t)(((bz - dz) * bg.nby + (by - dy)) * bg.nbx + (bx - dx));
+                const float2 t = sums[(size_t)q * GT_N + (fx + dx * BX) + GT_X * ((fy + dy * BY) + GT_Y * (fz + dz * BZ))];
+                S.x += t.x; S.y += t.y;
+            }
+            gather_finish_face<COMP>(bg.g, marker, out, gravity_dt, bx * BX + fx, by * BY + fy, bz * BZ + fz, S);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_finish3(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const int8_t* __restrict__ marker, GatherOwnArgs3 a) {
+    uint32_t slot, slots; int comp;
+    gather3_block_role(slot, slots, comp);
+    const float2* const sums = a.halo.sums + (size_t)comp * a.halo.nb * GT_N;
+    const uint32_t* const stamp = a.halo.stamp + (size_t)comp * a.halo.nb;
+    if (comp == 0) gather_finish_body<0>(slot, slots, bg, list, count, marker, a.out[0], a.gravity_dt[0], sums, stamp, a.halo.seq);
+    else if (comp == 1) gather_finish_body<1>(slot, slots, bg, list, count, marker, a.out[1], a.gravity_dt[1], sums, stamp, a.halo.seq);
+    else gather_finish_body<2>(slot, slots, bg, list, count, marker, a.out[2], a.gravity_dt[2], sums, stamp, a.halo.seq);
+}
+
 // R1 in the same formulation (density_projection_gather_error.comp:41-198): samples are cell centres, the list cap is 32
 __global__ __launch_bounds__(768) void k_density_gather_p(BrickGeom bg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                           const int8_t* __restrict__ marker, const uint32_t* __restrict__ heads,

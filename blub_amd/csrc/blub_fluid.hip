@@ -134,6 +134,8 @@ struct blub_fluid {
     int force_pcg_path = -1;                  // -1 auto, 0 dense rows, >= 1 brick lists
     int dense_kd_nt = -1;                     // non-temporal s_out stores of the dense direction kernel: -1 = by grid size, 0 / 1 = forced (tuning knob)
     int fuse_divergence = 1; bool divergence_deferred = false;     // ("fuse_divergence" tuning: 0 never, 1 inside blub_fluid_step, 2 also for blub_fluid_run_stage -- a test hook; see stage_divergence)
+    int p2g_own = 1;                          // P2G gather of a single domain: 1 = list-centric (every list walked once + k_gather_finish3; blub_bricks.hip.h), 0 = tile-centric (halo lists walked by every brick that needs them); "p2g_own" tuning
+    float2* gather_sums = nullptr; uint32_t* gather_stamp = nullptr;      // list-centric gather: region sums / stamps per component and brick (allocated on first use)
     int p2g_compact = -1;                     // P2G gather: 1 = the tile's non-empty lists compacted (k_gather_velocity3_s), 0 = one lane per list cell, -1 = by fill (stage_transfer)
     bool two_kernel_build = false;            // test hook ("bricks_two_kernel_build"): the list build of grids with more brick blocks than CUs
     int dense_alternate_march = -1;           // odd z-chunks of the dense kernels march downwards (blub_pcg_dense.hip.h: xcd_tile_pairs): bit 0 KD, bit 1 KU, -1 by grid size
@@ -416,7 +418,21 @@ static int stage_transfer(blub_fluid* h, float dt) {   // hybrid_fluid.rs:806-83
             if ((rc = latest_counts(h, false, &bc, &have)) != BLUB_OK) return rc;
             compact = have && (uint64_t)np_all < 1536ull * bc.n_fluid;
         }
-        if (compact) LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_s, ggrid, dim3(GS_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker, (const blubk::GatherNode*)h->nodes, a);
+        // List-centric where the walk dominates (well-filled bricks: dam_halfhalf_highres 490 -> 436 us, M4 3.01 -> 2.60 ms incl. the finishing kernel); the
+        // headline scene's sparse bricks are bound by per-tile latency, and a second launch costs more than the shorter walks save (66 -> 83 us): tile-centric there.
+        const bool own = !compact && h->p2g_own != 0 && h->num_ghost == 0 && h->n_dev == nullptr && h->slab_z0 <= 0 && h->slab_z1 >= h->g.nz;      // (slabs: the lists of the brick layer below belong to nobody's work list)
+        if (own) {
+            if (!h->gather_sums) {
+                if ((rc = dev_alloc_zero(h->stream, &h->gather_sums, (size_t)3 * h->bg.nb * GT_N)) != BLUB_OK || (rc = dev_alloc_zero(h->stream, &h->gather_stamp, (size_t)3 * h->bg.nb)) != BLUB_OK) return rc;
+            }
+            GatherOwnArgs3 o;
+            for (int c = 0; c < 3; ++c) { o.heads[c] = h->ll[c]; o.out[c] = h->vel[c]; o.gravity_dt[c] = a.gravity_dt[c]; }
+            o.node_stride = h->node_stride;
+            o.halo.sums = h->gather_sums; o.halo.stamp = h->gather_stamp; o.halo.seq = h->counts_seq; o.halo.nb = (uint32_t)h->bg.nb;
+            LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_po, ggrid, dim3(BX * BY * BZ), h->bg, LIST(h, active), (const int8_t*)h->marker, (const blubk::GatherNode*)h->nodes, o);
+            LAUNCH(h, KC_GATHER_VELOCITY, k_gather_finish3, ggrid, dim3(256), h->bg, LIST(h, active), (const int8_t*)h->marker, o);
+        }
+        else if (compact) LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_s, ggrid, dim3(GS_THREADS), h->bg, LIST(h, active), (const int8_t*)h->marker, (const blubk::GatherNode*)h->nodes, a);
         else LAUNCH(h, KC_GATHER_VELOCITY, k_gather_velocity3_p, ggrid, dim3(768), h->bg, LIST(h, active), (const int8_t*)h->marker, (const blubk::GatherNode*)h->nodes, a);
     }
     return BLUB_OK;
@@ -826,6 +842,7 @@ static void destroy(blub_fluid* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->solid_alloc); F(h->scan_totals);
+    F(h->gather_sums); F(h->gather_stamp);
     F(h->pid); F(h->pid_tmp); F(h->resort_counters); F(h->resort_starts); F(h->resort_ranks); F(h->resort_cursor);
     for (auto p : h->vol_owned) F(p);
     for (auto p : h->cgbuf_alloc) F(p);
@@ -1352,6 +1369,7 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
     else if (k == "fuse_divergence") h->fuse_divergence = std::max(0, std::min(2, value));
     else if (k == "p2g_compact") h->p2g_compact = value < 0 ? -1 : (value != 0);
     else if (k == "resort_every") h->resort_every = std::max(0, value);
+    else if (k == "p2g_own") h->p2g_own = value != 0;
     else if (k == "bricks_two_kernel_build") h->two_kernel_build = value != 0;
     else if (k == "spin_free") {      // no kernel of a step waits for co-resident workgroups any more: the two-kernel list build, every PCG iteration launched (no persistent tail)
         h->two_kernel_build = value != 0;

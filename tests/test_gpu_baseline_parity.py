@@ -219,8 +219,11 @@ def test_three_free_running_steps_stay_inside_the_oracles_own_rounding_envelope(
     0.386 vs 1.387 (density, step 2), pressure fields 0.5 % / 4.5 % apart in relative L2, particles median 3e-4 / p99 1.6e-3 /
     max 0.24 cells.  The reference's own f32 tree reductions are a third rounding of the same kind.  Hence: step 0's velocity
     solve within 1 %; afterwards the engine's max|r| must lie within 2.5x of the interval spanned by TWO oracles stepped beside it -- f64 and
-    f32 dot products, nothing else changed -- i.e. the envelope is measured at run time instead of being a fixed factor (a fixed 4x was
-    exceeded once in round 3: 0.337 against 0.075 for the density solve of step 1, the quantity that is carried by single cells);
+    f32 dot products, nothing else changed -- i.e. the envelope is measured at run time instead of being a fixed factor.  The DENSITY solve's
+    max|r| is carried by single cells and is bimodal from run to run on the very same binary (the order of the list atomics decides: step 1 of
+    corner_dams_256 measured 0.072, 0.078, 0.122, 0.232, 0.264 in five runs of round 6, 0.337 once in round 3, oracles 0.075 / 0.084), so for
+    that solve the sharp statement is the FIELD: its pressure within 2 % relative L2 of the oracle's (measured 0.2-0.3 % in all of those runs;
+    the bound was 15 %), and max|r| only within 5x of the oracles' interval;
     iteration counts may only differ while both sides hover at the tolerance, velocity pressure within 5 % (density 15 %) relative L2,
     centre of mass and occupancy histogram close."""
     from oracle.oracle import Oracle
@@ -248,7 +251,8 @@ def test_three_free_running_steps_stay_inside_the_oracles_own_rounding_envelope(
                 assert len(hist) == step + 1
                 if step == 0 and w == 0:
                     assert s.iteration_count == io and abs(s.error - eo) <= 0.01 * eo, (s, io, eo)
-                assert min(eo, eo32) / 2.5 < s.error < max(eo, eo32) * 2.5, (step, w, s, io, eo, eo32)
+                env = 2.5 if w == 0 else 5.0
+                assert min(eo, eo32) / env < s.error < max(eo, eo32) * env, (step, w, s, io, eo, eo32)
                 if s.iteration_count != io:
                     assert max(s.error, eo) < 0.4, (step, w, s, io, eo)       # both hover around the tolerance of 0.1
                 # A solve that stops at an earlier check than the other side's leaves a visibly different iterate (7 % measured) and
@@ -257,7 +261,7 @@ def test_three_free_running_steps_stay_inside_the_oracles_own_rounding_envelope(
                 if s.iteration_count != io:
                     same_schedule = False
                 if same_schedule:
-                    assert rel_l2 < (0.05 if w == 0 else 0.15), (step, w, rel_l2)
+                    assert rel_l2 < (0.05 if w == 0 else 0.02), (step, w, rel_l2)
         # permutation-invariant particle metrics after three steps (binning orders differ inside a cell)
         a, b = h.get_particles()[0][:, :3].astype(np.float64), o.get_particles()[0][:, :3].astype(np.float64)
         assert a.shape == b.shape
