@@ -368,11 +368,31 @@ def test_balanced_cuts_of_the_metric_scene_give_every_slab_fluid():
         pg = group.get_particles()[0][:, :3].astype(np.float64)
         from scipy.spatial import cKDTree
         d = cKDTree(ps).query(pg, k=1, workers=-1)[0]
-        print("corner_dams_256, 8 balanced slabs vs single after 3 steps (loose default solves): median %.3g p99 %.3g max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
-        # (three free-running steps of LOOSELY converged solves: a convergence decision that falls the other way -- 20 against 24 iterations -- moves the
-        #  median from ~1e-4 to ~5e-3 cells; both modes have been measured, run to run (3.5e-5 ... 7e-4 in six runs, 4.7e-3 in the seventh).  The tight
-        #  statements are the fixed-iteration tests.)
-        assert np.median(d) < 2e-2 and np.quantile(d, 0.99) < 0.1
+        # diagnostic only: three free-running steps of LOOSELY converged solves are bimodal from run to run (a convergence decision that falls the other way --
+        # 20 against 24 iterations -- moves the median from ~1e-4 to ~5e-3 cells: 3.5e-5 ... 7e-4 in six runs, 4.7e-3 in the seventh); the bound is below
+        print("corner_dams_256, 8 balanced slabs vs single after 3 steps (loose default solves; diagnostic): median %.3g p99 %.3g max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
+    finally:
+        single.close()
+        group.close()
+    # The trajectory statement, with both solves CONVERGED (as tests/golden/ref_freerun does: nothing amplifies the order of the list atomics, so the bimodality
+    # is gone and the bound can catch a regression of the cut / exchange path): the same three steps, particle by particle.
+    single = blub_amd.HybridFluid(dim, len(pos) + 64, binning="off")
+    group = blub_amd.SlabGroup(dim, len(pos) + 64, local=8, cuts=cuts, binning="off")
+    try:
+        for f in (single, group):
+            f.set_gravity_grid(gravity)
+            f.set_particles(pos)
+            for w in (0, 1):
+                f.set_solver_config(w, error_tolerance=1e-4, max_num_iterations=400, error_check_frequency=8)
+        for step in range(3):
+            single.step(util.DT)
+            group.step(util.DT)
+        assert group.num_particles() == len(pos)
+        ps = single.get_particles()[0][:, :3].astype(np.float64)
+        pg = group.get_particles()[0][:, :3].astype(np.float64)
+        d = cKDTree(ps).query(pg, k=1, workers=-1)[0]
+        print("corner_dams_256, 8 balanced slabs vs single after 3 steps (converged solves): median %.3g p99 %.3g max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
+        assert np.median(d) <= 2e-4 and np.quantile(d, 0.99) <= 5e-3
     finally:
         single.close()
         group.close()
