@@ -365,13 +365,15 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
             return False
     res["recovered_in_place"] = 0
     res["recuts"] = 0
-    counter = [0]
-
     def one_step():
-        # (a re-balance is part of stepping this domain on N GPUs: it sits inside the timed loop, one host synchronisation every `rebalance_every` steps)
-        if active and dynamic and counter[0] % rebalance_every == 0 and counter[0] > 0:
-            res["recuts"] += int(group.rebalance(min_layers=2))
-        counter[0] += 1
+        # (a re-balance is part of stepping this domain on N GPUs: it sits inside the timed loop, one host synchronisation every `rebalance_every` steps.
+        #  The cadence follows the GROUP's step counter, which an in-place recovery puts back to the same restored step on every rank -- a per-process
+        #  counter of loop iterations ran apart when the ranks left a failed window at different iterations, and the collective re-balance with it:
+        #  round-5 ADVICE.)
+        if active and dynamic:
+            at = group.local_fluid(0).step_counter
+            if at > 0 and at % rebalance_every == 0:
+                res["recuts"] += int(group.rebalance(min_layers=2))
         if active:
             group.step(dt)
     try:

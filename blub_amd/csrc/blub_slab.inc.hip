@@ -1445,6 +1445,9 @@ int blub_slab_group_recut(blub_slab_group* g, const int32_t* new_cuts) {
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
     if (!g->full_volumes) return blub::set_error(BLUB_ERR_UNSUPPORTED, "moving the cut planes needs a group created with BLUB_SLAB_FULL_VOLUMES");
     if (g->rccl && !g->comm) return blub::set_error(BLUB_ERR_COMM, "the group's communicator was aborted after an earlier failure");
+    // a multi-process direct group: what follows are UNBOUNDED collective operations -- a rank whose peer has already left the step loop after a time-out
+    // must not enter them (round-5 ADVICE): drain the stream and report a pending time-out first (BLUB_ERR_COMM: recoverable in place, like in a step)
+    if (g->direct && g->rccl) { int rc0 = blub_slab_group_synchronize(g); if (rc0 != BLUB_OK) return rc0; }
     std::vector<int> nc;
     { int rc = blub::slab_cuts(g->slabs[0]->g.nz, g->nranks, new_cuts, nc); if (rc != BLUB_OK) return rc; }
     for (int r = 1; r < g->nranks; ++r)
@@ -1462,6 +1465,7 @@ int blub_slab_group_rebalance(blub_slab_group* g, int min_layers, int* changed) 
     if (hipSetDevice(g->device) != hipSuccess) return blub::set_error(BLUB_ERR_DEVICE, "hipSetDevice failed");
     if (!g->full_volumes) return blub::set_error(BLUB_ERR_UNSUPPORTED, "moving the cut planes needs a group created with BLUB_SLAB_FULL_VOLUMES");
     if (g->nranks == 1) return BLUB_OK;
+    if (g->direct && g->rccl) { int rc0 = blub_slab_group_synchronize(g); if (rc0 != BLUB_OK) return rc0; }      // (see blub_slab_group_recut)
     std::vector<double> bricks;
     { int rc = blub::slab_layer_histogram(g, bricks); if (rc != BLUB_OK) return rc; }
     const int L = (int)bricks.size();

@@ -810,19 +810,25 @@ class SlabGroup:
         """In-place recovery after a timed-out wait of the direct transport (a peer seconds late): COLLECTIVE -- every rank calls it, whether or not it saw
         the error itself.  `all_gather(obj) -> [obj of rank 0, ...]` and `barrier()` are the caller's control plane.  Returns the step the group is back
         at (the newest checkpoint every rank holds): the caller steps on from there.  Raises if no common checkpoint exists."""
+        failure = None
         try:
             self.synchronize()          # drains the stream (every wait is bounded); reports the time-out once and clears the mark
         except BlubError as e:
-            if e.status != -8:          # BLUB_ERR_COMM is what we are here for
-                raise
-        info = all_gather((self.checkpoints(), self.exchange_sequence()))
+            if e.status != -8:          # BLUB_ERR_COMM is what we are here for; anything else is raised COLLECTIVELY below (round-5 ADVICE: a rank
+                failure = "%d: %s" % (e.status, e)      # that raised here left its peers blocked in the all-gather until the caller's watchdog fired)
+        info = all_gather((self.checkpoints() if failure is None else [], self.exchange_sequence() if failure is None else 0, failure))
+        failed = [(r, i[2]) for r, i in enumerate(info) if i[2] is not None]
+        if failed:
+            raise BlubError(-4, "in-place recovery impossible: rank(s) %s report an error that is not a transport time-out" % failed)
         common = set(info[0][0])
-        for steps, _ in info[1:]:
+        for steps, _, _ in info[1:]:
             common &= set(steps)
         if not common:
             raise BlubError(-8, "no checkpoint generation is held by every rank: %s" % [i[0] for i in info])
         step = max(common)
-        base = (max(seq for _, seq in info) + 1024) & 0x7FFFFFFF or 1
+        # above every rank's number, over the full 32 bits (waits compare by signed DIFFERENCE and the counter skips 0 on wrap: a 31-bit mask made the new
+        # base SMALLER than stale flags once a counter had passed 2^31 -- round-5 ADVICE)
+        base = (max(seq for _, seq, _ in info) + 1024) & 0xFFFFFFFF or 1
         barrier()                       # nobody rewrites its state while a peer's kernels may still be storing into it
         self.restore(step, base)
         barrier()

@@ -414,7 +414,7 @@ int blub_slab_balanced_cuts(const uint32_t grid_dim[3], uint32_t num_particles, 
  *      some rank's failure is missing on that rank -- and a sequence base above every rank's number;  3. barrier;
  *   4. every rank: blub_slab_group_restore(step, base);  5. barrier; step on (replaying from `step`).
  * Cost of a generation: one pass over 64 B per particle + 8 B per held cell (~40 us for the metric's scene), amortised over the interval. */
-int blub_slab_group_set_checkpoint_interval(blub_slab_group* g, uint32_t every_n_steps);      /* 0 = off (default); every rank the same value */
+int blub_slab_group_set_checkpoint_interval(blub_slab_group* g, uint32_t every_n_steps);      /* 0 = off (default); every rank the same value.  Between PROCESSES use >= 4: a rank that was only late keeps writing generations for a step or two before it sees a mark, and with 1 - 2 it could replace both generations its peers still hold in common */
 int blub_slab_group_checkpoints(blub_slab_group* g, uint32_t steps_out[2]);                    /* step numbers of the two generations, 0xFFFFFFFF = none; blocks */
 int blub_slab_group_exchange_sequence(const blub_slab_group* g, uint32_t* seq_out);
 int blub_slab_group_restore(blub_slab_group* g, uint32_t step, uint32_t sequence_base);
