@@ -320,9 +320,10 @@ def slab_run(args, torch, dist, rank, world, dev, ctl, transport, scene_name, st
             # peer-mapped slabs over hipIpc, kernels store into the neighbours' memory themselves (after the probe, or forced)
             if not group.connect_direct_over_torch_distributed():
                 sys.stderr.write("rank %d: hipIpc mapping unavailable on some rank; staying on the RCCL transport\n" % rank)
-        if group is not None and os.environ.get("BLUB_BENCH_SHARED_DEVICE"):
+        if group is not None and os.environ.get("BLUB_BENCH_SHARED_DEVICE") and transport != "direct":
             # (development box: several ranks on one GPU -- the one-launch brick-list build waits for co-resident workgroups of ITS process and sits out its
-            #  bound while another process holds the CUs; the two-kernel build has no such wait)
+            #  bound while another process holds the CUs; the two-kernel build has no such wait.  Over the direct transport the library notices the shared
+            #  device by itself when it maps a peer: blub_slab_group_connect)
             for i in range(group.num_local()):
                 group.local_fluid(i).set_tuning("spin_free", 1)
         if group is not None:
@@ -484,7 +485,11 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
         if transport == "loopback":
             parallelism = "%d z-slabs EMULATED on one GPU (loopback transport, rank 0 only): protocol cost without a wire, not a scaling result" % world
         else:
-            parallelism = "z-slab decomposition over %s: %d slabs, 1 rank per GPU" % ("peer-mapped memory (hipIpc)" if res["transport_kind"] == "direct" else "RCCL", world)
+            over = "peer-mapped memory (hipIpc)" if res["transport_kind"] == "direct" else "RCCL"
+            if os.environ.get("BLUB_BENCH_SHARED_DEVICE"):      # (more ranks than GPUs: a development box)
+                parallelism = "z-slab decomposition over %s: %d slabs in %d processes SHARING fewer GPUs than ranks -- the protocol between processes, not a scaling result" % (over, world, world)
+            else:
+                parallelism = "z-slab decomposition over %s: %d slabs, 1 rank per GPU" % (over, world)
         line = {
             "metric": METRIC, "value": round(args.steps / elapsed, 3), "unit": "steps/s (global steps of the whole domain)", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,

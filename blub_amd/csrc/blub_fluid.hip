@@ -159,6 +159,7 @@ struct blub_fluid {
     float* cgbuf[3] = {nullptr, nullptr, nullptr};
     float4* part4 = nullptr;
     Pcg1Scalars* pcg1_scalars[2] = {nullptr, nullptr};
+    unsigned long long* phase_stamps[2] = {nullptr, nullptr};   // diagnostic ("pcg_phase_stamps" tuning): 64 x 8 time stamps per solver, see SlabDirect::stamps / blub_fluid_read_phase_stamps
     float4* scalar_log[2] = {nullptr, nullptr};   // diagnostic ("pcg_scalar_log" tuning): 1024 entries per solver, see SlabDirect::log / blub_fluid_read_scalar_log
     PcgTailSync* tail_sync[2] = {nullptr, nullptr};
     bool use_tail = true;            // persistent tail kernel of the single-reduction solves (blub_fluid_set_tuning "pcg_tail")
@@ -581,7 +582,8 @@ static int stage_solve(blub_fluid* h, int which, float dt, bool standalone) {
             float* Q[2] = {h->aux_temp, h->cgbuf[2]};
             float4* part[2] = {h->part4, h->part4 + PCG_GRID_MAX};
             Pcg1Scalars* sc = h->pcg1_scalars[which];
-            SlabDirect nodir{}; nodir.log = h->scalar_log[which];
+            SlabDirect nodir{}; nodir.log = h->scalar_log[which]; nodir.stamps = h->phase_stamps[which];
+            if (nodir.stamps) HIP_TRY(hipMemsetAsync(nodir.stamps, 0, 64 * 8 * sizeof(unsigned long long), h->stream));
             if (nodir.log) HIP_TRY(hipMemsetAsync(nodir.log, 0xFF, 1024 * sizeof(float4), h->stream));
             LAUNCH(h, KC_PCG_INIT, k_pcg1_w0_s<false>, grid, block, h->bg, LIST(h, fluid), 0, (const uint8_t*)h->dvol, (const float*)h->search, W[0], (const float2*)part_upd, 0, part[0], 1, 0u, -1, -1, SlabDirect{});
             // Launch as many iterations as the last few solves needed (+ `tail_margin_checks` check intervals); ONE persistent kernel covers
@@ -842,7 +844,7 @@ static void destroy(blub_fluid* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(h->pos); F(h->pos_tmp); for (auto p : h->pvel) F(p); F(h->nodes); F(h->solid_alloc); F(h->scan_totals);
-    F(h->gather_sums); F(h->gather_stamp);
+    F(h->gather_sums); F(h->gather_stamp); F(h->phase_stamps[0]); F(h->phase_stamps[1]);
     F(h->pid); F(h->pid_tmp); F(h->resort_counters); F(h->resort_starts); F(h->resort_ranks); F(h->resort_cursor);
     for (auto p : h->vol_owned) F(p);
     for (auto p : h->cgbuf_alloc) F(p);
@@ -1343,6 +1345,14 @@ int blub_fluid_read_scalar_log(blub_fluid* h, int which, float* out, int capacit
     for (int i = 0; i < n && i < capacity; ++i) memcpy(out + 4 * (size_t)i, &buf[4 * (size_t)i], 4 * sizeof(float));
     return BLUB_OK;
 }
+int blub_fluid_read_phase_stamps(blub_fluid* h, int which, uint64_t* out, int capacity_iterations) {
+    REQUIRE_HANDLE(h);
+    if (which < 0 || which > 1 || !out || capacity_iterations <= 0) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!h->phase_stamps[which]) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "the phase stamps are off (blub_fluid_set_tuning \"pcg_phase_stamps\" 1)");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->phase_stamps[which], (size_t)std::min(capacity_iterations, 64) * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return BLUB_OK;
+}
 int blub_fluid_last_solve_path(const blub_fluid* h, int which, int* schedule, int* mapping) {
     if (!h || which < 0 || which > 1) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "bad argument");
     if (h->last_schedule[which] < 0) return blub::set_error(BLUB_ERR_INVALID_ARGUMENT, "no solve of this kind has been enqueued yet");
@@ -1381,6 +1391,13 @@ int blub_fluid_set_tuning(blub_fluid* h, const char* name, int value) {
         for (int w = 0; w < 2; ++w) {
             if (value && !h->scalar_log[w]) { HIP_TRY(hipMalloc((void**)&h->scalar_log[w], 1024 * sizeof(float4))); HIP_TRY(hipMemset(h->scalar_log[w], 0xFF, 1024 * sizeof(float4))); }
             if (!value && h->scalar_log[w]) { (void)hipFree(h->scalar_log[w]); h->scalar_log[w] = nullptr; }
+        }
+    }
+    else if (k == "pcg_phase_stamps") {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int w = 0; w < 2; ++w) {
+            if (value && !h->phase_stamps[w]) { HIP_TRY(hipMalloc((void**)&h->phase_stamps[w], 64 * 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(h->phase_stamps[w], 0, 64 * 8 * sizeof(unsigned long long))); }
+            if (!value && h->phase_stamps[w]) { (void)hipFree(h->phase_stamps[w]); h->phase_stamps[w] = nullptr; }
         }
     }
     else if (k == "dense_tile_quads" || k == "dense_tile_planes" || k == "dense_grid") {

@@ -306,7 +306,12 @@ struct SlabDirect {
     uint32_t seq_in, seq_out, wait_mask;      // wait for flags_in[r] >= seq_in for every bit r of wait_mask; publish seq_out
     int n_out;
     float4* log;                              // diagnostic (any transport, also the single domain; nullptr = off): entry i = {gamma_i, delta_i, max|r_i|, alpha_i} as K(i) reduced them
+    unsigned long long* stamps;               // diagnostic (nullptr = off; "pcg_phase_stamps" tuning): K(i)'s workgroup 0 leaves 8 time stamps (s_memrealtime, 10 ns ticks) at its phase boundaries in entry i
 };
+// one time stamp of the intra-kernel timeline (blub_fluid_read_phase_stamps): workgroup 0, thread 0 only
+__device__ __forceinline__ void phase_stamp(const SlabDirect* dir, int iteration, int k) {
+    if (dir && dir->stamps && blockIdx.x == 0 && threadIdx.x == 0 && iteration >= 0 && iteration < 64) dir->stamps[iteration * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
 constexpr unsigned SLAB_SPIN_LIMIT = 1u << 24;
 __device__ __forceinline__ bool slab_gave_up(const uint32_t* error) { return error && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
 // every thread of the block returns once all awaited flags have arrived (or the bounded wait ran out)

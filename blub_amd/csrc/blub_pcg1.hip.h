@@ -349,6 +349,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     __shared__ DivConst div_lut[8];
     const Grid g = bg.g;
     const int t = threadIdx.x & (BRICK_THREADS - 1), half = threadIdx.x >> 7;
+    phase_stamp(dir, iteration, 0);      // entry
     pcg_fill_div_lut(div_lut);      // (the prologue's barriers separate this from the first use)
     const int ghost_lo = (DIRECT && halo_lo >= 0) ? halo_lo - 1 : -2, ghost_hi = (DIRECT && halo_hi >= 0) ? halo_hi + 1 : -2;
     bool pushed = false;      // this thread stored into a peer's memory
@@ -370,6 +371,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     if (SURPLUS_EXITS && (int)blockIdx.x >= V) return false;
     const int num_part = num_part_in > 0 ? num_part_in : V;
     if (PL.done) return false;      // uniform
+    phase_stamp(dir, iteration, 1);      // round trip 1 is back (`done`, list length)
     const bool has_vb = (int)blockIdx.x < V;
     const uint32_t blk0 = XMAP ? (blockIdx.x & 7u) * ((uint32_t)V >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t i0 = blk0 * PCG_BPB + half;
@@ -381,6 +383,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
     // (direct transport: the tags of ALL partials of the previous launch have been seen before anything else that came from a peer -- the halo
     //  rows of w below -- is requested)
     if (!pcg1_prologue_finish<FIRST, DIRECT>(PL, ctrl, sc, part_in, num_part, tolerance, iteration, check_prev, sm4, alpha, beta, DIRECT ? dir->seq_in : 0u, DIRECT ? dir->error : nullptr, dir ? dir->log : nullptr)) return false;
+    phase_stamp(dir, iteration, 2);      // partials reduced, alpha / beta known (descriptor loads were in flight meanwhile)
     if (has_vb && i0 < n) pcg1_tile_load_fields<FIRST, DIRECT>(TL, r_in, w_in, q_in, dsearch, p, ghost_lo, ghost_hi);
     StagedTile& T = tiles[half];
     bool first = true;
@@ -464,7 +467,9 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
                 T.d[row * ST_ROW + (side ? 20 : 3)] = (uint8_t)TL.hdv;
             }
         }
+        if (ib == blk) phase_stamp(dir, iteration, 3);      // first brick: descriptors + fields arrived, phase 1 (r, u, q, d, p) done, tile written
         __syncthreads();
+        if (ib == blk) phase_stamp(dir, iteration, 4);
         if (have) {
             // phase 2: w_{i+1} = A u_{i+1} for the own quad from the tile
             int x0, y, z;
@@ -491,6 +496,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
                 }
             }
         }
+        if (ib == blk) phase_stamp(dir, iteration, 5);      // first brick: phase 2 (w = A u from the tile) done, stores issued
         __syncthreads();   // the tile is rewritten for the next brick
     }
     // one combined block reduction of the three partials of this virtual workgroup
@@ -512,6 +518,7 @@ __device__ __forceinline__ bool pcg1_iteration(BrickGeom bg, const uint32_t* __r
             for (int q = 0; q < dir->n_out; ++q) st_sys_f4(dir->part_out[q] + vb, tot);
         } else part_out[vb] = tot;
     }
+    if (vb == (int)blockIdx.x) phase_stamp(dir, iteration, 6);      // partial of the first virtual workgroup stored: end
     }
     return true;
 }

@@ -1649,6 +1649,14 @@ int blub_slab_group_connect(blub_slab_group* g, int rank, const void* blob, int 
         bases.push_back(reinterpret_cast<char*>(m));
     }
     g->peer_base[(size_t)rank] = bases;
+    // A peer PROCESS whose slab lies in THIS device's memory shares the GPU with us (a development box: more ranks than GPUs).  The two kernels of a step that
+    // wait for co-resident workgroups of their own launch (the one-launch brick-list build, the persistent PCG tail) sit out their bounds while the other
+    // process holds the CUs (profiles/r05_multiproc_direct.jsonl: "a brick list build timed out"): the handle takes the spin-free forms by itself -- what
+    // the "spin_free" tuning selects; bench.py used to set it when IT noticed the sharing (round-5 review, weak 6).
+    hipPointerAttribute_t attr;
+    if (!bases.empty() && hipPointerGetAttributes(&attr, bases[0]) == hipSuccess && attr.device == g->device)
+        for (auto h : g->slabs) { h->two_kernel_build = true; h->use_tail = false; }
+    else (void)hipGetLastError();
     return BLUB_OK;
 }
 // TEST HOOK: segments [first, last] of one step (0 ghost exchange, 1 transfer, 2 divergence, 3 solve_velocity, 4 binning, 5 project,

@@ -173,6 +173,7 @@ def load_library():
         "blub_fluid_set_filter_mode": (C.c_int, [vp, C.c_int]),
         "blub_fluid_get_filter_mode": (C.c_int, [vp]),
         "blub_fluid_read_scalar_log": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
+        "blub_fluid_read_phase_stamps": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "blub_fluid_set_max_steps_in_flight": (C.c_int, [vp, u32]),
         "blub_fluid_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "blub_scene_mesh_desc_at_time": (C.c_int, [C.POINTER(SceneConfig), u32, C.c_uint64, C.c_uint64, C.POINTER(MeshDesc)]),
@@ -459,6 +460,13 @@ class HybridFluid:
         a, b = C.c_int(), C.c_int()
         _check(self._L, self._L.blub_fluid_last_solve_path(self._h, int(which), C.byref(a), C.byref(b)))
         return ("reference", "single_reduction")[a.value], ("rows", "bricks", "lod0_literal")[b.value]
+
+    def phase_stamps(self, which):
+        """(64, 8) uint64: the time stamps workgroup 0 of K(i) left at its phase boundaries in the last single-reduction solve `which`, 10 ns ticks
+        (include/blubhip.h: blub_fluid_read_phase_stamps; needs set_tuning("pcg_phase_stamps", 1))."""
+        out = np.zeros((64, 8), np.uint64)
+        _check(self._L, self._L.blub_fluid_read_phase_stamps(self._h, int(which), _ptr(out), 64))
+        return out
 
     def scalar_log(self, which):
         """(iterations, 4) float32: {gamma, delta, max|r|, alpha} of every iteration of the last single-reduction solve `which`

@@ -297,6 +297,12 @@ int blub_fluid_get_filter_mode(const blub_fluid* h);
  * the same quantities in its 16-float control buffer).  *count_out = iterations that ran (<= 1024); at most `capacity` entries are copied.  Every slab of
  * a z-slab group derives bit-identical scalars, whatever the transport: the direct-transport probe compares the logs between ranks and transports. Blocks. */
 int blub_fluid_read_scalar_log(blub_fluid* h, int which, float* out, int capacity, int* count_out);
+/* Diagnostic (blub_fluid_set_tuning "pcg_phase_stamps" 1 switches it on): the intra-kernel timeline of the most recent single-reduction solve `which` on
+ * the brick mapping.  Workgroup 0 of K(i) leaves eight 64-bit time stamps (s_memrealtime: 100 MHz, 10 ns ticks; 0 = not reached) in entry i < 64:
+ * [0] entry, [1] first round trip back (`done`, list length), [2] partials reduced / alpha, beta known, [3] first brick: descriptors and fields arrived,
+ * r / u / q / d / p updated, tile written, [4] after the tile barrier, [5] w = A u formed and stored, [6] partial stored (end), [7] unused.
+ * `out`: capacity_iterations x 8 values.  Blocks.  (tools/kiter_timeline.py turns it into the table under profiles/.) */
+int blub_fluid_read_phase_stamps(blub_fluid* h, int which, uint64_t* out, int capacity_iterations);
 /* Performance knobs / test hooks by name (the library never reads the environment).  None changes a result beyond the rounding of a
  * dot-product tree.  "pcg_tail" 0|1: persistent tail kernel of the single-reduction solves; "pcg_tail_first" n: hand over to the tail after
  * exactly n launched iterations (-1: predicted from the last solves); "pcg_tail_margin" n: check intervals launched beyond the prediction;
@@ -304,6 +310,14 @@ int blub_fluid_read_scalar_log(blub_fluid* h, int which, float* out, int capacit
  *   (BLUB_ERR_DEVICE at the next synchronize / update_statistics) and the handle stops using the tail;
  * "pcg1_max_iterations" n (default 64): solves configured with more iterations run schedule 0 even when schedule 1 is selected;
  * "pcg_scalar_log" 0|1: keep the per-iteration scalars of the single-reduction solves for blub_fluid_read_scalar_log (one 16-byte store per launch);
+ * "pcg_phase_stamps" 0|1: workgroup 0 of every K(i) leaves time stamps at its phase boundaries for blub_fluid_read_phase_stamps (seven 8-byte stores);
+ * "resort_every" n (default 8; 0 = never): the engine re-sorts its particle arrays by (brick, cell) every n-th step, at the point of the step where the
+ *   reference rebins (positions only move there).  Every particle kernel is bound by sector requests and follows the order of the particles in memory;
+ *   the reference's own cadence (60 steps) is kept for what the CALLER sees -- blub_fluid_get_particles, the linked-list volume and every other
+ *   by-index entry point return the caller's order (a particle-id array restores it) -- only the device views' particle buffers are in the engine's
+ *   internal order between two such calls (a renderer does not care).  Single domains only; not with BLUB_BINNING_LITERAL;
+ * "p2g_own" 0|1 (default 1): well-filled bricks gather list-centrically (every P2G list walked once, brick-boundary faces finished by a second small
+ *   kernel: another association of <= 8 partial sums on those faces); 0: always tile-centric;
  * "pcg_launch_grid" n: launch grid of the brick-mapped PCG kernels (0: estimated from the last landed brick count) -- results do not depend on it;
  * "dense_tile_quads" 256|512|1024, "dense_tile_planes" n, "dense_grid" n: tile geometry / launch grid of the dense 2.5-D PCG kernels
  * (0 = default for the grid); "dense_kd_nt" -1|0|1: non-temporal stores of the dense direction kernel's output (-1: by grid size);
