@@ -20,8 +20,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILES = {256: os.path.join("profiles", "r05_pmc_dense_pcg_256.json"),   # FETCH_SIZE / WRITE_SIZE captures of the dense PCG benchmark (tools/dense_pmc.sh),
-             512: os.path.join("profiles", "r05_pmc_dense_pcg_512.json")}   # stamped with the hash of the sources they were taken from
+PMC_FILES = {256: os.path.join("profiles", "r06_pmc_dense_pcg_256.json"),   # FETCH_SIZE / WRITE_SIZE captures of the dense PCG benchmark (tools/dense_pmc.sh),
+             512: os.path.join("profiles", "r06_pmc_dense_pcg_512.json")}   # stamped with the hash of the sources they were taken from
 
 
 def algorithmic_bytes(kernel, F, P, A, Fb):
@@ -38,7 +38,7 @@ def algorithmic_bytes(kernel, F, P, A, Fb):
         "pcg_update": Fb + 20 * F,               # descriptor, s, p rw, r rw
         "pcg_iter": Fb + 40 * F,                 # single-reduction iteration: descriptor; r, w, q, d, p read and written
         "divergence_remove": 13 * A + 16 * F,
-        "extrapolate": A + 8 * F,
+        "extrapolate": 13 * A,                   # marker + the three velocity volumes over the active bricks (a brick-sparse D3 reads them to decide what to write; round-5 review: A + 8 F was too kind)
         "advect": 176 * P,
         "density_gather": 5 * Fb + 16 * P + 4 * F,
         "position_change": 13 * A + 4 * F,
@@ -156,7 +156,8 @@ def transfer_microbenchmark(n=256, seed=1234, tune=()):
         for k in ("build_lists", "gather_velocity", "advect", "density_gather", "reset_bricks"):
             if k not in prof:
                 continue
-            avg_ms = prof[k]["total_ms"] / prof[k]["launches"]
+            per = 2 if k == "reset_bricks" else 1      # (the transfer's and the advection's reset: two different launches, each moves its own bytes)
+            avg_ms = prof[k]["total_ms"] / per         # the CLASS per pass -- the list-centric gather is two launches (walk + finishing kernel) for ONE set of algorithmic bytes
             gbs = algorithmic_bytes(k, F, P, A, Fb) / (avg_ms * 1e-3) / 1e9
             res[k] = {"avg_us": round(avg_ms * 1e3, 1), "launches": prof[k]["launches"], "algorithmic_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         res["fluid_cells"] = F
@@ -521,7 +522,7 @@ def multi_gpu(args, torch, dist, rank, world, dev, ctl):
             r2 = slab_run(args, torch, dist, rank, world, dev, ctl, transport, "corner_dams_512", s_steps, s_warm, "strong", memory)
             if r2["active"]:
                 secondary = {"workload": r2["workload"], "grid": r2["grid"], "particles": r2["particles"], "value": round(s_steps / r2["elapsed"], 3), "unit": "steps/s",
-                             "ms_per_step": round(r2["elapsed"] / s_steps * 1e3, 4), "steps": s_steps, "warmup": s_warm, "single_gpu_reference": "bench.py --scene corner_dams_512 (profiles/r05_other_scenes.txt: 302 steps/s)",
+                             "ms_per_step": round(r2["elapsed"] / s_steps * 1e3, 4), "steps": s_steps, "warmup": s_warm, "single_gpu_reference": "bench.py --scene corner_dams_512 (profiles/r06_other_scenes.txt)",
                              "slab_cuts": r2["cuts"], "slab_cuts_at_end": r2.get("cuts_at_end"), "recuts_in_run": r2["recuts"], "fluid_bricks_per_rank": r2["fluid_bricks_per_rank"], "fluid_bricks_per_rank_uniform_cuts": r2["fluid_bricks_per_rank_uniform_cuts"],
                              "pcg_iters_per_step": r2["pcg_iters_per_step"], "transport_ops_per_step": r2["transport_ops_per_step"], "transport": r2["transport"]}
         except Exception as e:

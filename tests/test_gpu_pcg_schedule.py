@@ -420,7 +420,7 @@ def test_600_steps_of_both_schedules_have_the_same_statistics_and_no_residual_dr
     assert d[1] < 0.1 and d[0] < 0.05 * dim[0] and d[2] < 0.05 * dim[2], (pa.mean(0), pb.mean(0))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     import json
-    with open(os.path.join(ROOT, "gpurun_out", "r05_schedule_longrun_%s.json" % scene_name), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_schedule_longrun_%s.json" % scene_name), "w") as fh:
         json.dump({"scene": scene_name, "steps": 600, "statistics": report,
                    "residual_gap": {k: [list(map(float, x)) for x in out[k][1]] for k in out}}, fh, indent=1)
 
