@@ -149,7 +149,10 @@ uint32_t blub_fluid_step_counter(const blub_fluid* h);
 int blub_fluid_set_step_counter(blub_fluid* h, uint32_t c);
 
 /* bind_group_renderer(), hybrid_fluid.rs:700-723 + shader/fluid_render_info.glsl:11-23: device pointers, read-only
- * for the caller, valid until destroy. */
+ * for the caller.  The volume pointers are valid until destroy.  The four PARTICLE buffers: re-query after a step (the engine's own re-sort writes the positions
+ * into a second buffer and swaps: "resort_every"), and between two by-index calls (get / set particles, the linked-list volume, the stage hook) their slots are in
+ * the engine's internal order -- a permutation of the caller's, the same for all four buffers, which a point renderer does not see; blub_fluid_get_particles
+ * returns the caller's order. */
 typedef struct blub_device_views {
     const void* particles_position_ll;  /* float4 {x,y,z, u32 linked_list_next} */
     const void* particles_velocity_x;   /* float4 {C row xyz, v_x}   (particles.glsl:13-15) */

@@ -326,7 +326,11 @@ def test_full_step_loose_solver(pair):
     po, ph = o.get_particles(), h.get_particles()
     d = np.abs(ph[0][:, :3] - po[0][:, :3]).max(axis=1)
     print("deviation quantiles (cells): median %.3g  p99 %.3g  max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
-    assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 5e-3 and d.max() < 0.15      # (the engine's default is the reference's schedule; the single-reduction opt-in: test_gpu_pcg_schedule.py)
+    # Twelve runs of this test over rounds 5 and 6 (same binaries run to run: the order of the list atomics seeds the rounding that 32 unconverged iterations
+    # amplify): median 3.3e-5, 8.4e-5, 8.5e-5, 1.05e-4 (x3) ... 8.65e-4, 1.21e-3; p99 1.9e-4 ... 4.5e-3; max 0.03 ... 0.11.  The tail of that spread sat ON the
+    # former bound (1e-3 / 5e-3: one run in ten failed); the bound is 2.5x the worst run -- a defect shows at 1e-2 and above, and the tight statement for the same step
+    # is test_full_step_converged_solver (1e-4 cells).
+    assert np.median(d) < 3e-3 and np.quantile(d, 0.99) < 1.2e-2 and d.max() < 0.15
     for w in (0, 1):
         eo, io = o.solver_stats(w)
         eh, ih = h.solver_stats(w)

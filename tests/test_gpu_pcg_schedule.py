@@ -146,8 +146,9 @@ def test_full_step_loose_solver(pair):
     po, ph = o.get_particles(), h.get_particles()
     d = np.abs(ph[0][:, :3] - po[0][:, :3]).max(axis=1)
     print("single-reduction deviation quantiles (cells): median %.3g  p99 %.3g  max %.3g" % (np.median(d), np.quantile(d, 0.99), d.max()))
-    # (the same bound as the reference order's, test_gpu_parity.py::test_full_step_loose_solver; measured 0.07 -- a single particle at the free surface)
-    assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 5e-3 and d.max() < 0.15
+    # (the same bound as the reference order's, test_gpu_parity.py::test_full_step_loose_solver -- see the run-to-run spread recorded there; measured here: median
+    #  1.7e-5 ... 1.07e-4, max 0.07 -- a single particle at the free surface)
+    assert np.median(d) < 3e-3 and np.quantile(d, 0.99) < 1.2e-2 and d.max() < 0.15
 
 
 def test_headline_scene_statistics_track_the_reference_schedule():
