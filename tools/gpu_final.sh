@@ -13,6 +13,7 @@ bash tools/dense_pmc.sh 512 ${o}_${ver}_dense_pcg_512 > /dev/null 2>&1
 # the bench line again, now that the PMC captures of THIS code state exist (bench.py reads them from profiles/)
 mkdir -p profiles; for n in 256 512; do cp ${o}_${ver}_dense_pcg_${n}_pmc.json profiles/${tag}_pmc_dense_pcg_${n}.json; done
 timeout 600 python bench.py > ${o}_bench_${ver}.log 2>&1; grep '^{' ${o}_bench_${ver}.log | tail -1 > ${o}_bench_${ver}.json
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > ${o}_bench_${ver}_driver_window.log 2>&1; grep '^{' ${o}_bench_${ver}_driver_window.log | tail -1 > ${o}_bench_${ver}_driver_window.json
 ( cd /tmp && export TMPDIR=/tmp && rm -rf $root/gpurun_out/_sq && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $root/gpurun_out/_sq -o p -- python $root/bench.py --dense-only --dense-size 256 > $root/gpurun_out/_sq.log 2>&1 )
 python tools/pmc_summary.py gpurun_out/_sq > ${o}_${ver}_pmc_sq_dense_pcg_256.csv; rm -rf gpurun_out/_sq
 for tr in direct host; do for n in 2 4 8; do python tools/slab_loopback_bench.py corner_dams_256 $n 60 5 single_reduction 1 $tr; done; done > ${o}_${ver}_slab_loopback.jsonl 2>${o}_slab.err
