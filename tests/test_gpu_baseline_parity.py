@@ -145,8 +145,13 @@ def _every_stage_of_a_step(name, h, o, mid_run=False):
             util.assert_close(v, a, b, rel=1e-5)
             continue
         capped, n_long, longest = reach[c]
-        util.assert_close(v + " (faces of lists within the cap)", np.where(capped, 0, a), np.where(capped, 0, b), rel=1e-5)
-        bad = (np.abs(a.astype(np.float64) - b) > 1e-5 * np.maximum(1.0, np.abs(b))) & capped
+        # Faces of lists within the cap: the same products, added in another order (engine: per list, oracle: per round).  At step 0 the particles rest; here
+        # they move at tens of cells per second, so the order of a face's up to 96 additions is worth ~1e-5 in a bad case (measured over 10 runs: 0 or 1 of
+        # the ~10^6 written faces at 1.01e-5 .. 1.05e-5): util.assert_close_but_few.
+        util.assert_close_but_few(v + " (faces of lists within the cap)", np.where(capped, 0, a), np.where(capped, 0, b), rel=1e-5)
+        d = np.abs(a.astype(np.float64) - b)
+        tol = 1e-5 * np.maximum(1.0, np.abs(b))
+        bad = (d > tol) & capped
         print("%s mid-run %s: %d lists beyond the 12-entry cap (longest %d) reach %d faces; %d of those differ from the oracle's choice of 12 (%.2f %%)" % (
             name, v, n_long, longest, capped.sum(), bad.sum(), 100.0 * bad.sum() / max(1, capped.sum())))
         assert n_long > 1000      # (the state really exercises the cap; which 12 a longer list keeps is not comparable: 65 % of those faces differ, measured)

@@ -56,6 +56,17 @@ def copy_state(o, h, volumes=("marker", "linked_list") + tuple(FLOAT_VOLUMES)):
     h.step_counter = o.step_counter
 
 
+def assert_close_but_few(name, got, ref, rel=1e-5, few=8, factor=10.0):
+    """assert_close for sums whose ORDER of additions differs between the two sides while the particles move fast (a face of the P2G gather adds up to 96
+    products w * d; with |d| ~ 50 cells/s the order is worth ~1e-5 in a bad case, 3e-4 in the worst): `rel` for all but `few` values, factor * rel for all."""
+    got64 = np.asarray(got, np.float64)
+    ref64 = np.asarray(ref, np.float64)
+    over = np.abs(got64 - ref64) > rel * np.maximum(1.0, np.abs(ref64))
+    assert over.sum() <= few, "%s: %d values beyond %g (allowed: %d)" % (name, over.sum(), rel, few)
+    assert_close(name, got, ref, rel=factor * rel)
+    return int(over.sum())
+
+
 def assert_close(name, got, ref, rel=1e-5, abs_=None):
     """|got - ref| <= rel * max(1, |ref|)  (SURVEY 8c "stated tolerances", grid fields after one kernel)."""
     got = np.asarray(got, np.float64)
