@@ -306,6 +306,18 @@ class SimulationController {
         return steps;
     }
 
+    // the same two for a bare fluid (no static objects to animate): blub_fluid_step + update_statistics per step, synchronize per batch -- no callback in the loop
+    uint32_t fast_forward_steps(Duration simulation_jump_length, HybridFluid& fluid) {
+        uint32_t steps = 0;
+        check(blub_controller_fast_forward_steps_fluid(c_, (uint64_t)simulation_jump_length.count(), fluid.handle(), &steps));
+        return steps;
+    }
+    uint32_t frame_steps(HybridFluid& fluid) {
+        uint32_t steps = 0;
+        check(blub_controller_frame_steps_fluid(c_, fluid.handle(), &steps));
+        return steps;
+    }
+
   private:
     static blub_step_callbacks callbacks(Scene& scene) {
         blub_step_callbacks cb{};

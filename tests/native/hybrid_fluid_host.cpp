@@ -1,6 +1,7 @@
 // A host of the engine in a compiled language: the reference's main loop (main.rs: Scene::new, SimulationController::fast_forward_steps / frame_steps,
 // HybridFluid accessors) written against include/blub_hybrid_fluid.hpp -- no Python, no torch.  Built and run by tests/test_native_host.py.
 //   hybrid_fluid_host --host-only <scene.json>                 no GPU needed: scene parsing, the cube generator, and the NO_DEVICE error of the constructor
+//   hybrid_fluid_host --frames <frames> <positions.bin>        a fluid built by hand (HybridFluid::new, add_fluid_cube x 2, set_gravity_grid) driven frame by frame
 //   hybrid_fluid_host <scene.json> <steps> <positions.bin> [tuning=value ...]     fast-forwards `steps` simulation steps with solves of a fixed 120 iterations, writes the particle positions
 #include <cstdio>
 #include <cstdlib>
@@ -33,9 +34,42 @@ static int host_only(const char* scene_path) {
     return 0;
 }
 
+// main.rs's render loop without a renderer: on_frame_submitted (a fixed 1/60 s per frame, as start_recording_with_fixed_frame_length would give), frame_steps
+static int frames(int num_frames, const char* out_path) {
+    blub::HybridFluid fluid(blub::Extent3d{64, 48, 32}, 120000);
+    fluid.add_fluid_cube({2.0f, 2.0f, 2.0f}, {30.0f, 34.0f, 30.0f});
+    const uint32_t after_first = fluid.num_particles();
+    fluid.add_fluid_cube({40.0f, 2.0f, 4.0f}, {62.0f, 20.0f, 28.0f});      // (truncated at max_num_particles, like the reference)
+    fluid.set_gravity_grid({0.0f, -981.0f, 0.0f});
+    for (int which = 0; which < 2; ++which) {
+        auto cfg = which ? fluid.pressure_solver_config_density() : fluid.pressure_solver_config_velocity();
+        cfg->error_tolerance = 0.0f; cfg->max_num_iterations = 120; cfg->error_check_frequency = 8;
+    }
+    blub::SimulationController controller;
+    uint32_t steps = 0;
+    std::string per_frame;
+    for (int f = 0; f < num_frames; ++f) {
+        controller.on_frame_submitted(blub::Duration(16666667));
+        const uint32_t n = controller.frame_steps(fluid);
+        steps += n;
+        per_frame += (f ? ", " : "") + std::to_string(n);
+    }
+    fluid.synchronize();
+    fluid.update_statistics();
+    const std::vector<float> pos = fluid.particle_positions();
+    if (FILE* f = std::fopen(out_path, "wb")) { std::fwrite(pos.data(), sizeof(float), pos.size(), f); std::fclose(f); }
+    else { std::fprintf(stderr, "cannot write %s\n", out_path); return 1; }
+    std::printf("{\"steps_taken\": %u, \"steps_per_frame\": [%s], \"num_particles\": %u, \"after_first_cube\": %u, \"dropped\": %u, \"status\": %d, \"total_simulated_time_ns\": %lld, "
+                "\"total_render_time_ns\": %lld, \"steps_performed\": %u, \"stats_velocity\": %zu}\n",
+                steps, per_frame.c_str(), fluid.num_particles(), after_first, fluid.last_add_dropped(), (int)controller.status(), (long long)controller.total_simulated_time().count(),
+                (long long)controller.total_render_time().count(), controller.num_simulation_steps_performed(), fluid.pressure_solver_stats_velocity().size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
     try {
         if (argc == 3 && !std::strcmp(argv[1], "--host-only")) return host_only(argv[2]);
+        if (argc == 4 && !std::strcmp(argv[1], "--frames")) return frames(std::atoi(argv[2]), argv[3]);
         if (argc < 4) { std::fprintf(stderr, "usage: %s <scene.json> <steps> <positions.bin> [tuning=value ...] | --host-only <scene.json>\n", argv[0]); return 2; }
         const int steps = std::atoi(argv[2]);
         blub::Scene scene(argv[1]);
