@@ -664,8 +664,10 @@ __device__ __forceinline__ void truncate_step(const float* orig, const float* mo
 // =================================================================================================================
 // A1: advect_particles.comp:35-194 (G2P + APIC rows + RK4-in-cell + wall handling + marker / density list)
 // =================================================================================================================
+// (4 waves per SIMD: the kernel holds 143 registers at the compiler's free choice = 3 waves per SIMD; capped at 128 it spills 7 of them and runs 11 % faster -- it is
+//  bound by the latency of its 3 x 8 x 4 texel fetches: 32.5 -> 28.8 us per step on the headline scene, 329 -> 291 us at 10 M particles; 5 waves = 96 registers: slower)
 template <int FILTER = 0>
-__global__ __launch_bounds__(256) void k_advect(Grid g, uint32_t num_particles, float dt, float4* __restrict__ pos, float4* __restrict__ pvx,
+__global__ __launch_bounds__(256, 4) void k_advect(Grid g, uint32_t num_particles, float dt, float4* __restrict__ pos, float4* __restrict__ pvx,
                                                 float4* __restrict__ pvy, float4* __restrict__ pvz, const float* __restrict__ vx,
                                                 const float* __restrict__ vy, const float* __restrict__ vz, const float4* __restrict__ solid,
                                                 int8_t* __restrict__ marker, uint32_t* __restrict__ heads, uint8_t* __restrict__ brick_fluid,
