@@ -464,13 +464,22 @@ def test_divergence_left_after_the_pressure_projection_is_the_reported_residual(
     ENGINE's velocity volumes right after D2 (divergence_remove.comp), max|.| over FLUID cells -- held against (a) the engine's own
     statistic max|r| * dt of the solve that produced the pressure (in exact arithmetic they are the same number: r = b - A p), (b) the
     engine's residual volume cell by cell, (c) the same quantity of the oracle stepping the same particles."""
+    from oracle.oracle import Oracle
     scene, h, o = _pair_from_scene(name, binning="off")
+    # the same oracle with its dot products accumulated in f32: the free-running step below is held to the interval the TWO oracles span (the envelope test's rule)
+    nx_, ny_, nz_ = h.grid_dimension()
+    o32 = Oracle(nx_, ny_, nz_, h.num_particles() + 64)
+    o32.set_quirks(binning="off")
+    o32.set_dot_mode(1)
+    o32.set_gravity_grid(np.float32(list(scene.config.gravity)) / np.float32(scene.config.grid_to_world_scale))
+    o32.set_particles(h.get_particles()[0])
     try:
         h.particle_rebinning_step_frequency = 0
         for step in range(2):
             for st in ("transfer", "divergence", "solve_velocity", "project"):
                 h.run_stage(st, util.DT)
                 o.run_stage(st, util.DT)
+                o32.run_stage(st, util.DT)
             e_h, it_h = h.solver_stats(0)
             e_o, it_o = o.solver_stats(0)
             marker = h.read_volume("marker")
@@ -490,11 +499,15 @@ def test_divergence_left_after_the_pressure_projection_is_the_reported_residual(
             assert abs(dmax_o - e_o) <= 2e-4 * scale * util.DT + 1e-3 * e_o
             if step == 0:
                 assert it_h == it_o and abs(dmax - dmax_o) <= 0.02 * dmax_o, ((dmax, it_h), (dmax_o, it_o))
-            else:   # free-running: the envelope of tests above (an unconverged CG amplifies the rounding of its dots)
-                assert abs(it_h - it_o) <= 4 and 0.4 < dmax / dmax_o < 2.5
+            else:   # free-running: an unconverged CG amplifies the rounding of its dots -- dam_halfhalf: oracle 0.554 with f64 dots, 1.36 with f32 dots, engine 0.55 .. 1.41 from run to run
+                div_o32 = _divergence_d1(o32.read_volume("marker"), o32.read_volume("vel_x"), o32.read_volume("vel_y"), o32.read_volume("vel_z"))
+                dmax_o32 = float(np.abs(div_o32).max()) * util.DT
+                print("%s step %d: the oracle with f32 dot products: %.4g" % (name, step, dmax_o32))
+                assert abs(it_h - it_o) <= 4 and min(dmax_o, dmax_o32) / 2.5 < dmax < max(dmax_o, dmax_o32) * 2.5, (dmax, dmax_o, dmax_o32)
             for st in ("advect", "density_gather", "solve_density", "position_change", "correct"):
                 h.run_stage(st, util.DT)
                 o.run_stage(st, util.DT)
+                o32.run_stage(st, util.DT)
             h.step_counter = step + 1
             o.step_counter = step + 1
     finally:
