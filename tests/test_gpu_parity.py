@@ -335,7 +335,9 @@ def test_full_step_loose_solver(pair):
         eo, io = o.solver_stats(w)
         eh, ih = h.solver_stats(w)
         assert ih == io == 32
-        assert 0.5 < eh / eo < 2.0     # max|r| of an unconverged CG is not monotone (0.197, 0.175, 0.242, 0.140 at i = 8..20 here)
+        # max|r| of an unconverged CG is not monotone (0.197, 0.175, 0.242, 0.140 at i = 8..20 here); the density solve follows the engine's own advection of this step
+        # and is carried by single cells: the full-size tests' factor (tests/test_gpu_baseline_parity.py)
+        assert (0.5 < eh / eo < 2.0) if w == 0 else (0.25 < eh / eo < 4.0), (w, eh, eo)
 
 
 def test_convergence_decision_semantics(pair):
