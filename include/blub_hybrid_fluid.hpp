@@ -212,8 +212,10 @@ class Scene {
     }
     // :166-213: animate the models, voxelise them, step the fluid, poll the statistics.  The timer has already advanced by the step being taken when
     // Scene::step runs (timer.rs:124): total_simulated_time includes it.
-    void step(Duration simulation_delta) {
-        total_simulated_time_ += simulation_delta;
+    void step(Duration simulation_delta) { step(simulation_delta, total_simulated_time_ + simulation_delta); }
+    // ... with the clock of the caller's Timer, like the reference (`timer.total_simulated_time()`: the scene has no clock of its own there)
+    void step(Duration simulation_delta, Duration total_simulated_time) {
+        total_simulated_time_ = total_simulated_time;
         if (config_.num_static_objects) {
             if (!models_loaded_) load_models();
             std::vector<blub_mesh_desc> descs;
@@ -319,23 +321,25 @@ class SimulationController {
     }
 
   private:
-    static blub_step_callbacks callbacks(Scene& scene) {
+    struct StepContext { Scene* scene; Duration simulation_delta; };
+    blub_step_callbacks callbacks(Scene& scene) {
+        ctx_ = StepContext{&scene, simulation_delta()};
         blub_step_callbacks cb{};
-        cb.user = &scene;
+        cb.user = &ctx_;
         cb.step = [](void* user, float, uint64_t total_ns) -> int {
-            Scene& s = *static_cast<Scene*>(user);
+            StepContext& c = *static_cast<StepContext*>(user);
             try {
-                // (the controller's timer has advanced by the step being taken: the scene's clock follows it)
-                s.step(Duration((int64_t)total_ns) - s.total_simulated_time());
+                c.scene->step(c.simulation_delta, Duration((int64_t)total_ns));      // Scene::step(&timer, ...): the timer has advanced by the step being taken
             } catch (const Error& e) { return e.status; }
             return BLUB_OK;
         };
         cb.wait = [](void* user) -> int {
-            try { static_cast<Scene*>(user)->fluid_mut().synchronize(); } catch (const Error& e) { return e.status; }
+            try { static_cast<StepContext*>(user)->scene->fluid_mut().synchronize(); } catch (const Error& e) { return e.status; }
             return BLUB_OK;
         };
         return cb;
     }
+    StepContext ctx_{nullptr, Duration(0)};
     blub_controller* c_ = nullptr;
 };
 
