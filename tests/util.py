@@ -56,6 +56,13 @@ def copy_state(o, h, volumes=("marker", "linked_list") + tuple(FLOAT_VOLUMES)):
     h.step_counter = o.step_counter
 
 
+def max_but_three(d):
+    """The largest value of `d` once its three largest are set aside: trajectory comparisons hold their MAX column with it -- a single particle at the surface or a wall that
+    takes another branch of the wall handling moves by up to a cell whenever that happens (once in ~60 runs in two tests of round 6); callers hold d.max() to one cell."""
+    d = np.asarray(d).ravel()
+    return float(np.partition(d, len(d) - 4)[len(d) - 4]) if len(d) > 4 else float(d.max())
+
+
 def assert_close_but_few(name, got, ref, rel=1e-5, few=8, factor=10.0):
     """assert_close for sums whose ORDER of additions differs between the two sides while the particles move fast (a face of the P2G gather adds up to 96
     products w * d; with |d| ~ 50 cells/s the order is worth ~1e-5 in a bad case, 3e-4 in the worst): `rel` for all but `few` values, factor * rel for all."""
